@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING the reference on CPU.
+
+Runs only in the build container (needs /root/reference); nothing here travels to the GPU box except
+the .npz files it writes.  The reference's own tests pin nothing, so these vectors —
+outputs of the reference's Python (`pytorch/system/map.py`, `pytorch/network/*`) on seeded synthetic
+inputs — are what pins the oracle under /oracle.
+
+Stubs injected before import:
+  * `open3d`  — empty module (mesh container only, `map.py:6,521-543`)
+  * `numba`   — identity `jit` (`map.py:20`)
+  * `system.ext` — `groupby_sum` = index_add_ (stands in for `ext/indexing/indexing.cu:59-109`) and a
+    RECORDING `marching_cubes_interp` (the CUDA kernel cannot run here; the tuple it receives is the golden
+    vector for everything up to marching cubes)
+  * `torch.cuda.Stream/stream/synchronize` — no-ops (`map.py:232,625-626`)
+  * `np.product` — removed in NumPy 2 (`map.py:201,407`)
+
+Usage:  python tests/golden/make_golden.py            (writes *.npz next to this file)
+"""
+import contextlib
+import hashlib
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = Path("/root/reference/pytorch")
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REF))
+
+torch.manual_seed(0)
+np.product = np.prod  # noqa
+
+# ---- stubs -------------------------------------------------------------------------------------
+sys.modules["open3d"] = types.ModuleType("open3d")
+_numba = types.ModuleType("numba")
+_numba.jit = lambda f=None, **kw: (f if f is not None else (lambda g: g))
+sys.modules["numba"] = _numba
+
+RECORDED = {}
+
+
+def _groupby_sum(values, indices, C):
+    C = int(C)
+    s = torch.zeros((C, values.size(1)), dtype=torch.float32)
+    s.index_add_(0, indices, values)
+    c = torch.zeros((C,), dtype=torch.int32)
+    c.index_add_(0, indices, torch.ones_like(indices, dtype=torch.int32))
+    return [s, c]
+
+
+def _mc_record(indexer, valid_blocks, vec_batch_mapping, cube_sdf, cube_std, max_n, n_xyz, max_std):
+    RECORDED["mc_args"] = dict(indexer=indexer.clone(), valid_blocks=valid_blocks.clone(),
+                               vec_batch_mapping=vec_batch_mapping.clone(), cube_sdf=cube_sdf.clone(),
+                               cube_std=cube_std.clone(), max_n_triangles=int(max_n), n_xyz=list(n_xyz),
+                               max_std=float(max_std))
+    return (torch.zeros((0, 3, 3)), torch.zeros((0,), dtype=torch.long), torch.zeros((0, 3)))
+
+
+_ext = types.ModuleType("system.ext")
+_ext.groupby_sum = _groupby_sum
+_ext.marching_cubes_interp = _mc_record
+_system = types.ModuleType("system")
+_system.__path__ = [str(REF / "system")]
+_system.ext = _ext
+sys.modules["system"] = _system
+sys.modules["system.ext"] = _ext
+
+
+class _FakeStream:
+    def __init__(self, *a, **k):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+torch.cuda.Stream = _FakeStream
+torch.cuda.stream = lambda s: contextlib.nullcontext()
+torch.cuda.synchronize = lambda *a, **k: None
+
+from system import map as ref_map                     # noqa: E402  (the reference)
+from network import di_decoder, di_encoder, utility as ref_util   # noqa: E402
+from di_fusion_amd import synthetic as syn            # noqa: E402
+
+
+def load_reference_model():
+    hyper = json.loads((REF / "ckpt/default/hyper.json").read_text())
+    model = ref_util.Networks()
+    model.decoder = di_decoder.Model(hyper["code_length"], **hyper["network_specs"])
+    model.encoder = di_encoder.Model(**hyper["encoder_specs"])
+    model.decoder.load_state_dict(torch.load(REF / "ckpt/default/model_300.pth.tar", map_location="cpu")["model_state"])
+    model.encoder.load_state_dict(torch.load(REF / "ckpt/default/encoder_300.pth.tar", map_location="cpu")["model_state"])
+    model.eval()
+    return model, hyper
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def export_weights(model):
+    """Raw checkpoint tensors -> weights_default.npz (data, not code)."""
+    out = {}
+    for k, v in model.decoder.state_dict().items():
+        out["decoder." + k] = v.detach().cpu().numpy()
+    for k, v in model.encoder.state_dict().items():
+        out["encoder." + k] = v.detach().cpu().numpy()
+    np.savez_compressed(HERE / "weights_default.npz", **out)
+    print("weights:", len(out), "tensors")
+
+
+def golden_networks(model):
+    g = torch.Generator().manual_seed(7)
+    n = 384
+    lat = torch.randn((n, 29), generator=g) * 0.3
+    xyz = torch.rand((n, 3), generator=g) * 2.0 - 1.0
+    x = torch.cat([lat, xyz], 1)
+    with torch.no_grad():
+        sdf, std = model.decoder(x)
+    pts = torch.cat([torch.rand((n, 3), generator=g) * 2 - 1,
+                     torch.nn.functional.normalize(torch.randn((n, 3), generator=g), dim=1)], 1)
+    with torch.no_grad():
+        enc = model.encoder(pts)
+    lattices = {}
+    for r in (2, 4, 8):
+        a = -(r // 2) * (1. / r)
+        b = 1. + (r - 1) // 2 * (1. / r)
+        lattices[f"lattice_r{r}_default"] = ref_util.get_samples(r, torch.device("cpu")).numpy()
+        lattices[f"lattice_r{r}_ab"] = ref_util.get_samples(r, torch.device("cpu"), a=a, b=b).numpy()
+    # the lattices extract_mesh(resolution=4) really uses (map.py:640-646): R=8 and l=4 over [a,b], minus 0.5
+    a, b = -(4 // 2) * (1. / 4), 1. + (4 - 1) // 2 * (1. / 4)
+    lattices["extract_low_l4"] = (ref_util.get_samples(4, torch.device("cpu"), a=a, b=b) - 0.5).numpy()
+    lattices["extract_high_R8"] = (ref_util.get_samples(8, torch.device("cpu"), a=a, b=b) - 0.5).numpy()
+    # trilinear known answer (map.py:658-663)
+    low = torch.randn((5, 1, 4, 4, 4), generator=g)
+    up = torch.nn.functional.interpolate(low, mode="trilinear", size=(8, 8, 8), align_corners=True)
+    np.savez_compressed(HERE / "networks.npz", dec_x=x.numpy(), dec_sdf=sdf.numpy(), dec_std=std.numpy(),
+                        enc_x=pts.numpy(), enc_out=enc.numpy(), tri_low=low.numpy(), tri_up=up.numpy(), **lattices)
+    print("networks: decoder/encoder/lattices/trilinear saved")
+
+
+def map_state(m):
+    n = int(m.n_occupied)
+    idx = m.indexer.numpy()
+    nz = np.nonzero(idx != -1)[0]
+    return dict(n_occupied=np.int64(n), indexer_nz=nz.astype(np.int64), indexer_val=idx[nz].astype(np.int64),
+                latent_vecs_pos=m.latent_vecs_pos[:n].numpy().copy(),
+                voxel_obs_count=m.voxel_obs_count[:n].numpy().copy(),
+                latent_vecs=m.latent_vecs[:n].numpy().copy(),
+                capacity=np.int64(m.latent_vecs.size(0)),
+                updated_vec_id=m.mesh_cache.updated_vec_id.numpy().copy())
+
+
+def run_sequence(model, name, scene, cfg, intr, n_frames, deg_per_frame, store_inputs, store_cubes,
+                 probe=True, extract_every=1):
+    args = cfg.namespace()
+    m = ref_map.DenseIndexedMap(model, args, 29, torch.device("cpu"))
+    out = dict(n_frames=np.int64(n_frames), n_xyz=np.asarray(m.n_xyz, dtype=np.int64),
+               bound_min=np.asarray(cfg.bound_min, dtype=np.float64), voxel_size=np.float64(cfg.voxel_size),
+               deg_per_frame=np.float64(deg_per_frame),
+               intr=np.asarray([intr.fx, intr.fy, intr.cx, intr.cy, intr.width, intr.height], dtype=np.float64))
+    for f in range(n_frames):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg_per_frame)
+        out[f"f{f}_xyz_sha"] = np.asarray(sha(xyz.numpy()))
+        out[f"f{f}_nrm_sha"] = np.asarray(sha(nrm.numpy()))
+        out[f"f{f}_n_points"] = np.int64(xyz.size(0))
+        if store_inputs:
+            out[f"f{f}_xyz"] = xyz.numpy()
+            out[f"f{f}_nrm"] = nrm.numpy()
+        unq = m.integrate_keyframe(xyz, nrm)
+        out[f"f{f}_unq_mask"] = np.packbits(unq.numpy())
+        for k, v in map_state(m).items():
+            out[f"f{f}_int_{k}"] = v
+        if (f % extract_every) == 0:
+            RECORDED.clear()
+            _extract(m)
+            a = RECORDED["mc_args"]
+            out[f"f{f}_mc_valid_blocks"] = a["valid_blocks"].numpy()
+            out[f"f{f}_mc_vec_batch_mapping"] = a["vec_batch_mapping"].numpy()
+            out[f"f{f}_mc_B"] = np.int64(a["cube_sdf"].size(0))
+            out[f"f{f}_mc_cube_sdf_sha"] = np.asarray(sha(a["cube_sdf"].numpy()))
+            if store_cubes:
+                out[f"f{f}_mc_cube_sdf"] = a["cube_sdf"].numpy()
+                out[f"f{f}_mc_cube_std"] = a["cube_std"].numpy()
+            else:   # keep a strided subset of voxels so that large cases still pin values
+                sel = np.arange(0, a["cube_sdf"].size(0), max(1, a["cube_sdf"].size(0) // 64))
+                out[f"f{f}_mc_cube_sel"] = sel.astype(np.int64)
+                out[f"f{f}_mc_cube_sdf"] = a["cube_sdf"].numpy()[sel]
+                out[f"f{f}_mc_cube_std"] = a["cube_std"].numpy()[sel]
+        print(f"  {name} frame {f}: N={xyz.size(0)} kept={int(unq.sum())} n_occ={int(m.n_occupied)} "
+              f"B={int(out.get(f'f{f}_mc_B', -1))}")
+    if probe:
+        g = torch.Generator().manual_seed(11)
+        xyz, _ = syn.frame_points(scene, 0, intr, deg_per_frame=deg_per_frame)
+        sel = torch.randperm(xyz.size(0), generator=g)[:512]
+        q = xyz[sel] + (torch.rand((512, 3), generator=g) - 0.5) * cfg.voxel_size * 0.6
+        with torch.no_grad():
+            sdf, std, mask = m.get_sdf(q)
+        out["probe_xyz"] = q.numpy()
+        out["probe_sdf"] = sdf.numpy()
+        out["probe_std"] = std.numpy()
+        out["probe_mask"] = mask.numpy()
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"{name}: saved ({(HERE / f'{name}.npz').stat().st_size / 1e6:.2f} MB)")
+
+
+def _extract(m):
+    """`extract_mesh` up to the marching-cubes call; `_make_mesh_from_cache` needs open3d so the mesh-building
+    tail is cut off by making it a no-op (it runs after everything we record)."""
+    m._make_mesh_from_cache = lambda: None
+    return m.extract_mesh(4, int(4e6), max_std=0.15, extract_async=False, interpolate=True)
+
+
+def main():
+    model, hyper = load_reference_model()
+    export_weights(model)
+    golden_networks(model)
+
+    # S: tiny, inputs + full cubes stored.  80x60 image, 8^3 grid of 0.4 m voxels around a r=1.3 sphere.
+    intr_s = syn.Intrinsic().scaled(0.125)
+    run_sequence(model, "seq_small", syn.Scene(kind="sphere", radius=1.3),
+                 syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.4), intr_s,
+                 n_frames=3, deg_per_frame=20.0, store_inputs=True, store_cubes=True)
+    # M: 160x120 image, 16^3 grid, room scene with boxes, 4 frames with a large yaw so that new voxels,
+    # re-allocation (capacity doubling), the 600-count gate and the running average are all exercised.
+    intr_m = syn.Intrinsic().scaled(0.25)
+    run_sequence(model, "seq_room16", syn.default_room(),
+                 syn.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.4), intr_m,
+                 n_frames=4, deg_per_frame=15.0, store_inputs=False, store_cubes=False)
+    # C1 of BASELINE.json: one full 640x480 frame, 32^3 grid (0.1 m), camera inside a 1.5 m sphere.
+    scene, cfg = syn.config_c1()
+    run_sequence(model, "seq_c1", scene, cfg, syn.Intrinsic(), n_frames=1, deg_per_frame=0.5,
+                 store_inputs=False, store_cubes=False)
+
+
+if __name__ == "__main__":
+    main()
