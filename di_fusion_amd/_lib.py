@@ -1,0 +1,113 @@
+"""ctypes binding of libdifusion.so (the C ABI declared in include/difusion.h).
+
+There is no CPU fallback: every compute entry point of this package goes through this library and raises
+`RuntimeError` if it is missing or a call fails.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_uint8, c_void_p
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libdifusion.so"
+
+# counters (difusion.h)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT = range(12)
+C_COUNT = 16
+LATENT_DIM = 29
+
+ERRORS = {-1: "DIF_EINVAL (bad argument)", -2: "DIF_ELAUNCH (HIP launch/runtime failure)", -3: "DIF_ENOSPACE (workspace too small)"}
+
+
+class DifMap(Structure):
+    _fields_ = [("nx", c_int32), ("ny", c_int32), ("nz", c_int32),
+                ("bound_min", c_float * 3), ("voxel_size", c_float),
+                ("prune_min_vox_obs", c_int32), ("ignore_count_th", c_float), ("encoder_count_th", c_float),
+                ("capacity", c_int64),
+                ("indexer", c_void_p), ("latent_vecs", c_void_p), ("latent_vecs_pos", c_void_p),
+                ("voxel_obs_count", c_void_p), ("dirty", c_void_p), ("counters", c_void_p),
+                ("frame_count", c_void_p), ("grid_bits", c_void_p), ("vbm", c_void_p),
+                ("seg_start", c_void_p), ("seg_cnt", c_void_p), ("item_start", c_void_p)]
+
+
+class DifWeights(Structure):
+    _fields_ = [("enc_packed", c_void_p), ("enc_packed_floats", c_int64),
+                ("dec_packed", c_void_p), ("dec_packed_floats", c_int64)]
+
+
+class DifExtractBuffers(Structure):
+    _fields_ = [("max_voxels", c_int64), ("valid_blocks", c_void_p), ("occ_slot", c_void_p),
+                ("low_sdf", c_void_p), ("low_std", c_void_p), ("cube_sdf", c_void_p), ("cube_std", c_void_p),
+                ("refine_list", c_void_p), ("tri_count", c_void_p), ("tri_offset", c_void_p), ("block_tmp", c_void_p),
+                ("max_triangles", c_int64), ("triangles", c_void_p), ("triangle_flatten_id", c_void_p),
+                ("triangle_std", c_void_p)]
+
+
+# name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)
+SIGNATURES = {
+    "dif_version": (c_int32, []),
+    "dif_unproject": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
+    "dif_unproject_transform": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
+                                          c_float, c_float, POINTER(c_float), POINTER(c_float), c_void_p]),
+    "dif_compute_normal_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "dif_groupby_sum": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dif_integrate_workspace_bytes": (c_int64, [c_int64]),
+    "dif_integrate": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                c_int64, c_void_p]),
+    "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
+                              c_int32, c_int32, c_void_p]),
+    "dif_marching_cubes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                     c_void_p, c_int32, c_float, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dif_decode_rows": (c_int32, [POINTER(DifWeights), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "dif_encode_rows": (c_int32, [POINTER(DifWeights), c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_query_sdf": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dif_export_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p]),
+    "dif_merge_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_read_counters": (c_int32, [POINTER(DifMap), POINTER(c_int32), c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libdifusion.so; loud failure when it has not been built (`python __graft_entry__.py build`)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc, gfx950). di_fusion_amd has no CPU fallback.")
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"libdifusion: {what} failed: {ERRORS.get(rc, rc)}")
+
+
+def ptr(t) -> c_void_p:
+    """Device (or host) pointer of a torch tensor; None -> NULL."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr() -> c_void_p:
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("di_fusion_amd: tensors must live on the GPU (no CPU fallback); got a CPU tensor")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("di_fusion_amd: tensors must be contiguous")

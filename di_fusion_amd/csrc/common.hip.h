@@ -1,0 +1,168 @@
+// Shared device helpers for libdifusion (gfx950 / CDNA4 only: wave64, no CUDA compatibility paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/difusion.h"
+
+#define DIF_WAVE 64
+#define DIF_BLOCK 256
+#define DIF_INVALID_KEY 0x00FFFFFFu   // sort key of a (point, offset) pair that contributes to no voxel (24-bit keys)
+
+#define DIF_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return DIF_ELAUNCH; \
+    } while (0)
+
+namespace dif {
+
+struct Geo {
+    int nx, ny, nz;
+    float bx, by, bz, vs;
+};
+
+__host__ inline Geo geo_of(const dif_map_t* m) {
+    Geo g;
+    g.nx = m->nx; g.ny = m->ny; g.nz = m->nz;
+    g.bx = m->bound_min[0]; g.by = m->bound_min[1]; g.bz = m->bound_min[2];
+    g.vs = m->voxel_size;
+    return g;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// xn = (p - bound_min) / voxel_size : IEEE-754 correctly rounded subtraction and DIVISION (map.py:366-367).
+// The library is built with -ffp-contract=off; __fdiv_rn keeps the division exact even if fast-math flags leak in.
+__device__ __forceinline__ float normalize1(float p, float b, float vs) { return __fdiv_rn(__fsub_rn(p, b), vs); }
+
+// Voxel (i, i+1] owns xn: id = ceil(xn) - 1 (map.py:368).  Returns false for NaN / out-of-grid.
+__device__ __forceinline__ bool voxel_of(const Geo& g, float x, float y, float z, float& xnx, float& xny, float& xnz,
+                                         int& ix, int& iy, int& iz) {
+    xnx = normalize1(x, g.bx, g.vs);
+    xny = normalize1(y, g.by, g.vs);
+    xnz = normalize1(z, g.bz, g.vs);
+    float cx = ceilf(xnx), cy = ceilf(xny), cz = ceilf(xnz);
+    // NaN fails every comparison below
+    bool ok = (cx >= 1.0f) && (cy >= 1.0f) && (cz >= 1.0f) && (cx <= (float)g.nx) && (cy <= (float)g.ny) && (cz <= (float)g.nz);
+    ix = ok ? (int)cx - 1 : 0;
+    iy = ok ? (int)cy - 1 : 0;
+    iz = ok ? (int)cz - 1 : 0;
+    return ok;
+}
+
+__device__ __forceinline__ int linearize(const Geo& g, int ix, int iy, int iz) { return iz + g.nz * iy + (g.nz * g.ny) * ix; }
+
+__device__ __forceinline__ void unlinearize(const Geo& g, int lin, int& ix, int& iy, int& iz) {
+    ix = lin / (g.ny * g.nz);
+    iy = (lin / g.nz) % g.ny;
+    iz = lin % g.nz;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- wave / block primitives ---------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan across a 256-thread block.  `smem` must hold >= 8 ints.  Returns the exclusive prefix; total in `total`.
+__device__ __forceinline__ int block_excl_scan(int v, int* smem, int& total) {
+    int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = wave_incl_scan(v);
+    __syncthreads();                       // protect smem from the previous use
+    if (lane == 63) smem[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        int s = smem[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ int block_sum(int v, int* smem) {
+    int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < nw; ++w) tot += smem[w];
+    return tot;
+}
+
+// ---- generic ordered two-pass scan over n elements ------------------------------------------------------------
+// F provides:  __device__ int count(int i) const;   __device__ void emit(int i, int offset) const;
+//              __device__ void finish(int total) const;   (called once, by block 0 thread 0 of pass 2)
+// Element i gets offset = sum_{j<i} count(j).  Output order == index order => deterministic, sorted compaction.
+__device__ __forceinline__ void scan_range(int n, int& lo, int& hi) {
+    int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    per = (per + DIF_BLOCK - 1) / DIF_BLOCK * DIF_BLOCK;
+    long long l = (long long)blockIdx.x * per;
+    lo = l < n ? (int)l : n;
+    long long h = l + per;
+    hi = h < n ? (int)h : n;
+}
+
+template <class F>
+__global__ void __launch_bounds__(DIF_BLOCK) k_scan_pass1(F f, const int* n_ptr, int n_static, int* block_tot) {
+    __shared__ int smem[8];
+    int n = n_ptr ? *n_ptr : n_static;
+    int lo, hi;
+    scan_range(n, lo, hi);
+    int c = 0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += DIF_BLOCK) c += f.count(i);
+    int tot = block_sum(c, smem);
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+template <class F>
+__global__ void __launch_bounds__(DIF_BLOCK) k_scan_pass2(F f, const int* n_ptr, int n_static, const int* block_tot) {
+    __shared__ int smem[8];
+    int n = n_ptr ? *n_ptr : n_static;
+    int lo, hi;
+    scan_range(n, lo, hi);
+    int before = 0, all = 0;
+    for (int b = (int)threadIdx.x; b < (int)gridDim.x; b += DIF_BLOCK) {
+        int t = block_tot[b];
+        all += t;
+        if (b < (int)blockIdx.x) before += t;
+    }
+    int offset = block_sum(before, smem);
+    int total = block_sum(all, smem);
+    for (int base = lo; base < hi; base += DIF_BLOCK) {
+        int i = base + (int)threadIdx.x;
+        int c = (i < hi) ? f.count(i) : 0;
+        int chunk_total;
+        int ex = block_excl_scan(c, smem, chunk_total);
+        if (i < hi && c > 0) f.emit(i, offset + ex);
+        offset += chunk_total;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.finish(total);
+}
+
+inline int scan_blocks(int64_t n_upper) {
+    int64_t b = (n_upper + 4 * DIF_BLOCK - 1) / (4 * DIF_BLOCK);
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+template <class F>
+inline int launch_scan(F f, const int* n_ptr, int n_static, int64_t n_upper, int* block_tmp, hipStream_t s) {
+    int nb = scan_blocks(n_upper);
+    hipLaunchKernelGGL(k_scan_pass1<F>, dim3(nb), dim3(DIF_BLOCK), 0, s, f, n_ptr, n_static, block_tmp);
+    hipLaunchKernelGGL(k_scan_pass2<F>, dim3(nb), dim3(DIF_BLOCK), 0, s, f, n_ptr, n_static, (const int*)block_tmp);
+    return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+}
+
+}  // namespace dif

@@ -1,0 +1,1357 @@
+// libdifusion — MI355X (gfx950) kernels + C ABI for DI-Fusion's per-frame fusion path.  See include/difusion.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC difusion.hip -o libdifusion.so
+//
+// Every float expression whose rounding is observable in voxel ids or lattice coordinates is written with the
+// reference's operation order and compiled without FMA contraction; fmaf() is used only where the reference's own
+// CPU build fuses (trilinear upsample) or where the order is ours to choose (MLP accumulation = the MFMA's fmaf chain).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "common.hip.h"
+#include "mlp.hip.h"
+#include "mc_tables.inc"
+
+using namespace dif;
+
+namespace {
+
+constexpr int L = DIF_LATENT_DIM;     // 29
+constexpr int ITEM_ROWS = 256;        // gathered rows per encoder work item (8 MFMA tiles of 32 points)
+
+__device__ __constant__ int c_mc_edge_table[256];
+__device__ __constant__ signed char c_mc_tri_table[256][16];
+bool g_tables_uploaded[64] = {};
+
+int upload_tables() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DIF_ELAUNCH;
+    if (dev < 64 && g_tables_uploaded[dev]) return DIF_OK;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mc_edge_table), k_mc_edge_table, sizeof(k_mc_edge_table)) != hipSuccess) return DIF_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri_table), k_mc_tri_table, sizeof(k_mc_tri_table)) != hipSuccess) return DIF_ELAUNCH;
+    if (dev < 64) g_tables_uploaded[dev] = true;
+    return DIF_OK;
+}
+
+int num_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 64 && cus[dev]) return cus[dev];
+    hipDeviceProp_t p;
+    int n = 256;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+    if (dev < 64) cus[dev] = n;
+    return n;
+}
+
+inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+// =================================================================================================================
+// a1 / a2 : depth -> points  (ext/imgproc/imgproc.cu:5-44; utils/motion_util.py:322-327)
+// =================================================================================================================
+// One thread per pixel, threadIdx.x walks u (columns) => coalesced 4 B reads / 12 B writes (the reference walks rows).
+__global__ void __launch_bounds__(DIF_BLOCK) k_unproject(const float* __restrict__ depth, float* __restrict__ pc, int H, int W,
+                                                       float fx, float fy, float cx, float cy) {
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        float d = depth[i];
+        float x, y, z;
+        if (d == d) {
+            x = ((float)u - cx) / fx * d;       // (u - cx) / fx * d, imgproc.cu:18
+            y = ((float)v - cy) / fy * d;
+            z = d;
+        } else {
+            x = y = z = __builtin_nanf("");
+        }
+        pc[i * 3 + 0] = x; pc[i * 3 + 1] = y; pc[i * 3 + 2] = z;
+    }
+}
+
+struct Pose { float r[9]; float t[3]; };
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* __restrict__ depth, const float* __restrict__ ncam,
+                                                                 float* __restrict__ xyz, float* __restrict__ nrm, int H, int W,
+                                                                 float fx, float fy, float cx, float cy, Pose P) {
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        float d = depth[i];
+        const float qnan = __builtin_nanf("");
+        float ox = qnan, oy = qnan, oz = qnan, nx = qnan, ny = qnan, nz = qnan;
+        if (d == d) {
+            float x = ((float)u - cx) / fx * d;
+            float y = ((float)v - cy) / fy * d;
+            float z = d;
+            // ((r0*x + r1*y) + r2*z) + t, every op rounded (synthetic.transform_points states the same order)
+            ox = ((P.r[0] * x + P.r[1] * y) + P.r[2] * z) + P.t[0];
+            oy = ((P.r[3] * x + P.r[4] * y) + P.r[5] * z) + P.t[1];
+            oz = ((P.r[6] * x + P.r[7] * y) + P.r[8] * z) + P.t[2];
+            if (ncam) {
+                float a = ncam[i * 3 + 0], b = ncam[i * 3 + 1], c = ncam[i * 3 + 2];
+                nx = (P.r[0] * a + P.r[1] * b) + P.r[2] * c;
+                ny = (P.r[3] * a + P.r[4] * b) + P.r[5] * c;
+                nz = (P.r[6] * a + P.r[7] * b) + P.r[8] * c;
+            }
+        }
+        xyz[i * 3 + 0] = ox; xyz[i * 3 + 1] = oy; xyz[i * 3 + 2] = oz;
+        if (nrm) { nrm[i * 3 + 0] = nx; nrm[i * 3 + 1] = ny; nrm[i * 3 + 2] = nz; }
+    }
+}
+
+// ext/imgproc/imgproc.cu:98-141
+__global__ void __launch_bounds__(DIF_BLOCK) k_normal_weight(const float* __restrict__ pc, float* __restrict__ out, int H, int W) {
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        float* o = out + i * 4;
+        if (v < 1 || v > H - 2 || u < 1 || u > W - 2) { o[3] = -1.0f; continue; }
+        const float* c = pc + i * 3;
+        if (c[2] <= 1e-6) { o[3] = -1.0f; continue; }
+        const float* xp = pc + (i + 1) * 3; const float* xm = pc + (i - 1) * 3;
+        const float* yp = pc + (i + W) * 3; const float* ym = pc + (i - W) * 3;
+        if (xp[2] < 1e-6 || xm[2] < 1e-6 || yp[2] < 1e-6 || ym[2] < 1e-6) { o[3] = -1.0f; continue; }
+        float dxx = xp[0] - xm[0], dxy = xp[1] - xm[1], dxz = xp[2] - xm[2];
+        float dyx = yp[0] - ym[0], dyy = yp[1] - ym[1], dyz = yp[2] - ym[2];
+        float nx = dyy * dxz - dyz * dxy, ny = dyz * dxx - dyx * dxz, nz = dyx * dxy - dyy * dxx;   // cross(diff_y, diff_x)
+        float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        if (len < 1e-6) { o[3] = -1.0f; continue; }
+        nx /= len; ny /= len; nz /= len;
+        float theta = acosf(nz);
+        float td = theta / (0.5f * 3.14159f - theta);
+        float wgt = (0.0012f + 0.0019f * (c[2] - 0.4f) * (c[2] - 0.4f) + 0.0001f / sqrtf(c[2]) * td * td);
+        o[0] = nx; o[1] = ny; o[2] = nz; o[3] = 1.0f / wgt;
+    }
+}
+
+// =================================================================================================================
+// a9 : flat groupby_sum (ext/indexing/indexing.cu:59-109) — API parity entry; the map path uses the sorted reduction
+// =================================================================================================================
+__global__ void __launch_bounds__(DIF_BLOCK) k_groupby_sum(const float* __restrict__ values, const int64_t* __restrict__ idx, int64_t N,
+                                                         int Lw, float* __restrict__ sum, int* __restrict__ cnt, int64_t C) {
+    int64_t total = N * Lw;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = e / Lw;
+        int l = (int)(e - i * Lw);
+        int64_t g = idx[i];
+        if (g < 0 || g >= C) continue;
+        atomicAdd(sum + g * Lw + l, values[e]);
+        if (l == 0) atomicAdd(cnt + g, 1);
+    }
+}
+
+// =================================================================================================================
+// a3..a6 : voxel ids, prune, allocate   (map.py:366-387)
+// =================================================================================================================
+// K1: per-point voxel id + per-voxel point count of this frame.  Adjacent pixels mostly fall in the same voxel, so
+// equal-id runs inside a wave are aggregated with a ballot before touching memory (1 atomic per run, not per point).
+__global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* __restrict__ xyz, int64_t N, int* __restrict__ pt_lin,
+                                                         int* __restrict__ frame_count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // grid covers N rounded up to a wave
+    int lane = lane_id();
+    int lin = -2;                                                    // -2: beyond N, -1: invalid point
+    if (i < N) {
+        float xn, yn, zn; int ix, iy, iz;
+        bool ok = voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        lin = ok ? linearize(g, ix, iy, iz) : -1;
+        pt_lin[i] = lin;
+    }
+    int prev = __shfl_up(lin, 1);
+    bool head = (lane == 0) || (prev != lin);
+    unsigned long long heads = __ballot(head);
+    if (head && lin >= 0) {
+        unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        int run = above ? __ffsll((long long)above) : (64 - lane);
+        atomicAdd(frame_count + lin, run);
+    }
+}
+
+// K2: prune mask + candidate voxels.  mask[i] = count(voxel of i) > prune_min_vox_obs (map.py:375).  A kept point whose
+// voxel has no slot marks that voxel and its 6 clamped neighbours (if empty) in the bitmap (map.py:383-386).
+__global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, const int* __restrict__ pt_lin, int64_t N,
+                                                        const int* __restrict__ frame_count, const int64_t* __restrict__ indexer,
+                                                        uint8_t* __restrict__ unq_mask, uint32_t* __restrict__ bits,
+                                                        int* __restrict__ counters) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = lane_id();
+    int lin = (i < N) ? pt_lin[i] : -2;
+    bool keep = false;
+    if (lin >= 0) keep = (prune_min > 0) ? (frame_count[lin] > prune_min) : true;
+    if (i < N) unq_mask[i] = keep ? 1 : 0;
+    unsigned long long kept = __ballot(keep);
+    if (lane == 0 && kept) atomicAdd(counters + DIF_C_N_KEPT, __popcll(kept));
+    int prev = __shfl_up(lin, 1);
+    bool head = (lane == 0) || (prev != lin);
+    if (head && keep && indexer[lin] == -1) {
+        int ix, iy, iz;
+        unlinearize(g, lin, ix, iy, iz);
+        int cand[7];
+        cand[0] = lin;
+        cand[1] = linearize(g, clampi(ix - 1, 0, g.nx - 1), iy, iz);
+        cand[2] = linearize(g, clampi(ix + 1, 0, g.nx - 1), iy, iz);
+        cand[3] = linearize(g, ix, clampi(iy - 1, 0, g.ny - 1), iz);
+        cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
+        cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
+        cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            int v = cand[c];
+            if (indexer[v] != -1) continue;
+            uint32_t b = 1u << (v & 31);
+            if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
+        }
+    }
+}
+
+// K3: ordered compaction of the candidate bitmap -> slots n_occupied, n_occupied+1, ... in ASCENDING lin order
+// (torch.unique order, map.py:385-387, 310-319).  Clears the bitmap as it goes.
+struct AllocFunctor {
+    uint32_t* bits;
+    int64_t* indexer;
+    int64_t* pos;
+    int* counters;
+    int64_t capacity;
+    __device__ int count(int w) const { return __popc(bits[w]); }
+    __device__ void emit(int w, int offset) const {
+        uint32_t word = bits[w];
+        bits[w] = 0u;
+        int base = counters[DIF_C_N_OCCUPIED] + offset;
+        while (word) {
+            int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            int lin = w * 32 + b;
+            if (base < capacity) {
+                indexer[lin] = base;
+                pos[base] = lin;
+            }
+            ++base;
+        }
+    }
+    __device__ void finish(int total) const { counters[DIF_C_ALLOC_NEW] = total; }
+};
+
+// K4: (i) commit n_occupied += newly allocated (all pass-2 blocks of K3 have read the old value by now),
+// (ii) restore frame_count to zero, (iii) focus mask + 8-offset gather keys (map.py:389-433).
+// Key of pair (offset o, point i), stored at o*N + i (the reference's concatenation order): slot of the neighbour voxel
+// if that voxel is in the encode set {obs_count < encoder_count_th}, else DIF_INVALID_KEY.
+__device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
+                                                          const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
+                                                          const int64_t* __restrict__ indexer, const float* __restrict__ obs,
+                                                          uint32_t* __restrict__ pair_key, int* __restrict__ counters, int64_t capacity) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        int n = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
+        if (n > capacity) { n = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
+        counters[DIF_C_N_OCCUPIED] = n;
+    }
+    if (i >= N) return;
+    int lin = pt_lin[i];
+    uint32_t key[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) key[o] = DIF_INVALID_KEY;
+    if (lin >= 0) {
+        frame_count[lin] = 0;
+        if (unq_mask[i]) {
+            float xn, yn, zn; int ix, iy, iz;
+            voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+            // get_pruned_surface: own voxel in expand(encode set) <=> own voxel or an in-grid 6-neighbour is in the set
+            bool focus = in_encode_set(indexer[lin], obs, enc_th);
+            if (!focus && ix > 0) focus = in_encode_set(indexer[lin - g.ny * g.nz], obs, enc_th);
+            if (!focus && ix < g.nx - 1) focus = in_encode_set(indexer[lin + g.ny * g.nz], obs, enc_th);
+            if (!focus && iy > 0) focus = in_encode_set(indexer[lin - g.nz], obs, enc_th);
+            if (!focus && iy < g.ny - 1) focus = in_encode_set(indexer[lin + g.nz], obs, enc_th);
+            if (!focus && iz > 0) focus = in_encode_set(indexer[lin - 1], obs, enc_th);
+            if (!focus && iz < g.nz - 1) focus = in_encode_set(indexer[lin + 1], obs, enc_th);
+            if (focus) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;   // map.py:186-189
+                    int gx = clampi((int)(ceilf(xn + ox) - 1.0f), 0, g.nx - 1);                                   // map.py:422-424
+                    int gy = clampi((int)(ceilf(yn + oy) - 1.0f), 0, g.ny - 1);
+                    int gz = clampi((int)(ceilf(zn + oz) - 1.0f), 0, g.nz - 1);
+                    int64_t slot = indexer[linearize(g, gx, gy, gz)];
+                    if (in_encode_set(slot, obs, enc_th)) key[o] = (uint32_t)slot;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) pair_key[(int64_t)o * N + i] = key[o];
+}
+
+// K6: segment boundaries of the sorted keys -> seg_start / seg_cnt per slot; M = #valid rows.
+__global__ void __launch_bounds__(DIF_BLOCK) k_segments(const uint32_t* __restrict__ keys, int64_t n, int* __restrict__ seg_start,
+                                                      int* __restrict__ seg_cnt, int* __restrict__ counters) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t k = keys[j];
+        if (k == DIF_INVALID_KEY) {
+            if (j == 0) counters[DIF_C_M] = 0;
+            continue;
+        }
+        uint32_t kp = (j > 0) ? keys[j - 1] : 0xFFFFFFFFu;
+        uint32_t kn = (j + 1 < n) ? keys[j + 1] : DIF_INVALID_KEY;
+        if (kp != k) seg_start[k] = (int)j;
+        if (kn != k) {
+            // the start of this segment is needed for the count: find it through the start written by another thread
+            // is racy, so count = end - start is formed in k_items (which runs after this kernel); store the end here.
+            seg_cnt[k] = (int)(j + 1);                       // temporarily the segment END
+            if (kn == DIF_INVALID_KEY) counters[DIF_C_M] = (int)(j + 1);
+        }
+    }
+}
+
+// K7: per-slot encoder work items (ceil(cnt / ITEM_ROWS)), exclusive scan over slots, item -> slot table.
+struct ItemFunctor {
+    const int* seg_start;
+    int* seg_cnt;            // in: segment end (or 0); out (emit): row count
+    int* item_start;
+    int* item_slot;
+    int* counters;
+    int64_t max_items;
+    __device__ int count(int s) const {
+        int e = seg_cnt[s];
+        if (e <= 0) return 0;
+        int c = e - seg_start[s];
+        return (c + ITEM_ROWS - 1) / ITEM_ROWS;
+    }
+    __device__ void emit(int s, int offset) const {
+        int c = seg_cnt[s] - seg_start[s];
+        int n = (c + ITEM_ROWS - 1) / ITEM_ROWS;
+        if ((int64_t)offset + n > max_items) { seg_cnt[s] = 0; counters[DIF_C_OVERFLOW] = 4; return; }
+        seg_cnt[s] = c;
+        item_start[s] = offset;
+        for (int k = 0; k < n; ++k) item_slot[offset + k] = s;
+    }
+    __device__ void finish(int total) const { counters[DIF_C_ITEMS] = (total > max_items) ? (int)max_items : total; }
+};
+
+// =================================================================================================================
+// a7..a9 : gather + encoder (MFMA) + per-voxel sums
+// =================================================================================================================
+// Persistent: one 512-thread workgroup per CU keeps the 107 KB of packed encoder weights in LDS; each wave pulls work
+// items (slot, up to 256 sorted rows), runs 32-point tiles through the MFMA chain and accumulates the 29 output
+// features over the item's rows in registers; one fixed-order cross-lane reduction per item => deterministic partials.
+__global__ void __launch_bounds__(512, 2)
+k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
+         const uint32_t* __restrict__ sorted_val, const int* __restrict__ seg_start, const int* __restrict__ seg_cnt,
+         const int* __restrict__ item_start, const int* __restrict__ item_slot, const int* __restrict__ counters,
+         float* __restrict__ partial /* [items][32] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, ENC_FLOATS);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int n_items = counters[DIF_C_ITEMS];
+    for (int item = wave; item < n_items; item += nwaves) {
+        const int slot = item_slot[item];
+        const int chunk = item - item_start[slot];
+        const int row0 = seg_start[slot] + chunk * ITEM_ROWS;
+        const int row_end = min(seg_start[slot] + seg_cnt[slot], row0 + ITEM_ROWS);
+        f16v sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[r] = 0.0f;
+        for (int r0 = row0; r0 < row_end; r0 += 32) {
+            const int row = r0 + col;
+            const bool live = row < row_end;
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+            if (live) {
+                uint32_t v = sorted_val[row];
+                int o = 0;
+#pragma unroll
+                for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
+                int64_t i = (int64_t)v - (int64_t)o * N;
+                float xn = normalize1(xyz[i * 3 + 0], g.bx, g.vs);
+                float yn = normalize1(xyz[i * 3 + 1], g.by, g.vs);
+                float zn = normalize1(xyz[i * 3 + 2], g.bz, g.vs);
+                float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
+                float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
+                float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
+                float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
+                float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
+                float nxv = normal[i * 3 + 0], nyv = normal[i * 3 + 1], nzv = normal[i * 3 + 2];
+                x0 = half ? ry : rx;
+                x1 = half ? nxv : rz;
+                x2 = half ? nzv : nyv;
+            }
+            f16v out = encoder_tile(lds, x0, x1, x2, lane);
+            const float m = live ? 1.0f : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum[r] += out[r] * m;
+        }
+        // sum over the 32 points (lanes) of each half; fixed butterfly => deterministic
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = sum[r];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            sum[r] = v;
+        }
+        if (col == 0) {
+            float* p = partial + (int64_t)item * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[(r & 3) + 8 * (r >> 2) + 4 * half] = sum[r];
+        }
+    }
+}
+
+// a10: fusion update (map.py:448-452).  One 32-lane group per slot; partials summed in item order.
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const float* __restrict__ partial, const int* __restrict__ item_start, int* __restrict__ seg_cnt,
+                                                  float* __restrict__ latent, float* __restrict__ obs, uint8_t* __restrict__ dirty,
+                                                  int* __restrict__ counters) {
+    const int n_occ = counters[DIF_C_N_OCCUPIED];
+    const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
+    const int f = threadIdx.x & 31;
+    int updated = 0;
+    for (int s = grp; s < n_occ; s += ngrp) {
+        int cnt = seg_cnt[s];
+        if (cnt <= 0) continue;
+        int it0 = item_start[s], nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
+        if (f < L) {
+            float S = 0.0f;
+            for (int k = 0; k < nit; ++k) S += partial[(int64_t)(it0 + k) * 32 + f];
+            float w_old = obs[s];
+            float z_old = latent[(int64_t)s * L + f];
+            S = S + z_old * w_old;                           // map.py:449
+            float w_new = w_old + (float)cnt;                // map.py:450
+            latent[(int64_t)s * L + f] = S / w_new;          // map.py:451
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (f == 31) {                                       // after every lane of the group has read obs[s]
+            obs[s] = obs[s] + (float)cnt;
+            dirty[s] = 1;                                    // map.py:452
+            seg_cnt[s] = 0;
+            ++updated;
+        }
+    }
+    if (f == 31 && updated) atomicAdd(counters + DIF_C_C, updated);
+}
+
+// =================================================================================================================
+// a11 : extract — dirty list, confident neighbourhood, batch ids  (map.py:627-637)
+// =================================================================================================================
+struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> valid_blocks (lin ids), clears flags
+    uint8_t* dirty;
+    const int64_t* pos;
+    int64_t* valid_blocks;
+    int* counters;
+    int no_cache;
+    int64_t max_voxels;
+    __device__ int count(int s) const { return (no_cache || dirty[s]) ? 1 : 0; }
+    __device__ void emit(int s, int offset) const {
+        dirty[s] = 0;
+        if (offset < max_voxels) valid_blocks[offset] = pos[s];
+    }
+    __device__ void finish(int total) const {
+        if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 2; }
+        counters[DIF_C_K] = total;
+    }
+};
+
+// mark the confident voxels among each dirty voxel and its 6 allocated neighbours (map.py:628-631)
+__global__ void __launch_bounds__(DIF_BLOCK) k_mark_occupied(Geo g, float ignore_th, const int64_t* __restrict__ valid_blocks,
+                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
+                                                           uint32_t* __restrict__ bits, const int* __restrict__ counters) {
+    const int K = counters[DIF_C_K];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        int lin = (int)valid_blocks[k];
+        int ix, iy, iz;
+        unlinearize(g, lin, ix, iy, iz);
+        int cand[7];
+        cand[0] = lin;
+        cand[1] = linearize(g, clampi(ix - 1, 0, g.nx - 1), iy, iz);
+        cand[2] = linearize(g, clampi(ix + 1, 0, g.nx - 1), iy, iz);
+        cand[3] = linearize(g, ix, clampi(iy - 1, 0, g.ny - 1), iz);
+        cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
+        cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
+        cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            int v = cand[c];
+            int64_t slot = indexer[v];
+            if (slot < 0 || !(obs[slot] > ignore_th)) continue;
+            uint32_t b = 1u << (v & 31);
+            if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
+        }
+    }
+}
+
+struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm[slot] = b; clears the bitmap
+    uint32_t* bits;
+    const int64_t* indexer;
+    int32_t* occ_slot;
+    int32_t* vbm;
+    int* counters;
+    int64_t max_voxels;
+    __device__ int count(int w) const { return __popc(bits[w]); }
+    __device__ void emit(int w, int offset) const {
+        uint32_t word = bits[w];
+        bits[w] = 0u;
+        while (word) {
+            int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            int slot = (int)indexer[w * 32 + b];
+            if (offset < max_voxels) {
+                occ_slot[offset] = slot;
+                vbm[slot] = offset;
+            }
+            ++offset;
+        }
+    }
+    __device__ void finish(int total) const {
+        if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 3; }
+        counters[DIF_C_B] = total;
+        counters[DIF_C_VH] = 0;
+    }
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_reset_vbm(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm, const int* __restrict__ counters) {
+    const int B = counters[DIF_C_B];
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) vbm[occ_slot[b]] = -1;
+}
+
+// =================================================================================================================
+// a12..a14 : decoder over the per-voxel sample lattice, fast two-level refinement  (map.py:640-687)
+// =================================================================================================================
+struct Lattice {            // get_samples(res, a, b) - 0.5 (utility.py:129-149, map.py:645-646): fl(fl(i)*vsize) + a, then - 0.5
+    int res;
+    float vsize, a;
+    __device__ __forceinline__ float coord(int i) const { return ((float)i * vsize + a) - 0.5f; }
+};
+
+// decode mode: 0 = lattice (rows are (voxel b, sample s)), 1 = refine list, 2 = explicit rows, 3 = map point query
+struct DecodeArgs {
+    int mode;
+    const int* n_ptr;               // device row / voxel count (modes 0,1,3), or NULL
+    int64_t n_static;               // mode 2
+    Lattice lat;                    // modes 0,1
+    const int32_t* occ_slot;        // modes 0,1 : batch -> slot
+    const float* latent;            // modes 0,1,3
+    const int32_t* list;            // mode 1: b*R3+sb ; mode 3: point index
+    const float* rows;              // mode 2: (n,32)
+    const float* xyz;               // mode 3
+    const int64_t* indexer;         // mode 3
+    Geo geo;                        // mode 3
+    float* out_sdf;
+    float* out_std;
+    float sign;                     // -1 to store the negated sdf (map.py:687)
+};
+
+__global__ void __launch_bounds__(512, 2) k_decode(DecodeArgs A, const float* __restrict__ wblob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, DEC_LDS_FLOATS);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int res3 = A.lat.res * A.lat.res * A.lat.res;
+    const int tiles_per_voxel = (res3 + 31) / 32;
+    int64_t n_rows, n_tiles;
+    if (A.mode == 0) {
+        n_rows = (int64_t)(*A.n_ptr) * res3;
+        n_tiles = (int64_t)(*A.n_ptr) * tiles_per_voxel;
+    } else {
+        n_rows = A.n_ptr ? (int64_t)(*A.n_ptr) : A.n_static;
+        n_tiles = (n_rows + 31) / 32;
+    }
+    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+        bool live;
+        int64_t out_idx = 0;
+        const float* lat_row = nullptr;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        const float* row32 = nullptr;
+        if (A.mode == 0) {
+            int64_t b = tile / tiles_per_voxel;
+            int s = (int)(tile - b * tiles_per_voxel) * 32 + col;
+            live = s < res3;
+            if (live) {
+                int r = A.lat.res;
+                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
+                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+                out_idx = b * res3 + s;
+            }
+        } else if (A.mode == 1) {
+            int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) {
+                int e = A.list[row];
+                int b = e / res3, s = e - b * res3, r = A.lat.res;
+                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
+                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+                out_idx = e;
+            }
+        } else if (A.mode == 2) {
+            int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) { row32 = A.rows + row * 32; out_idx = row; }
+        } else {
+            int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) {
+                int64_t p = A.list[row];
+                float xn, yn, zn; int ix, iy, iz;
+                voxel_of(A.geo, A.xyz[p * 3 + 0], A.xyz[p * 3 + 1], A.xyz[p * 3 + 2], xn, yn, zn, ix, iy, iz);
+                px = (xn - (float)ix) - 0.5f; py = (yn - (float)iy) - 0.5f; pz = (zn - (float)iz) - 0.5f;      // map.py:575
+                lat_row = A.latent + A.indexer[linearize(A.geo, ix, iy, iz)] * L;
+                out_idx = row;
+            }
+        }
+        f16v xin;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int k = 2 * t + half;                     // natural k order of layer 0 (and of the skip input)
+            float v = 0.0f;
+            if (live) {
+                if (row32) v = row32[k];
+                else if (k < L) v = lat_row[k];
+                else v = (k == L) ? px : ((k == L + 1) ? py : pz);
+            }
+            xin[t] = v;
+        }
+        float sdf, sd;
+        decoder_tile(lds, wblob, xin, lane, sdf, sd);
+        if (live) {
+            if (half == 0) A.out_sdf[out_idx] = A.sign * sdf;
+            else A.out_std[out_idx] = sd;
+        }
+    }
+}
+
+// Trilinear x2 upsample (align_corners) of the low lattice + selection of samples to re-decode (map.py:655-667).
+// ATen CPU semantics (see oracle.trilinear_upsample_align_corners): per axis src = scale*j, i0 = int(src),
+// lam1 = src - i0, lam0 = 1 - lam1, two-tap value = fma(t0, lam0, t1*lam1), w innermost then h then d.
+__device__ __forceinline__ void tri_axis(int j, int l, float scale, int& i0, int& i1, float& w0, float& w1) {
+    float src = scale * (float)j;
+    i0 = min((int)src, l - 1);
+    i1 = i0 + ((i0 < l - 1) ? 1 : 0);
+    w1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
+    w0 = 1.0f - w1;
+}
+
+__device__ __forceinline__ float tri_sample(const float* __restrict__ low, int l, int x0, int x1, int y0, int y1, int z0, int z1,
+                                            float wx0, float wx1, float wy0, float wy1, float wz0, float wz1) {
+    // layout [x][y][z], z innermost ("w"), x outermost ("d")
+    float v00 = fmaf(low[(x0 * l + y0) * l + z0], wz0, low[(x0 * l + y0) * l + z1] * wz1);
+    float v01 = fmaf(low[(x0 * l + y1) * l + z0], wz0, low[(x0 * l + y1) * l + z1] * wz1);
+    float v10 = fmaf(low[(x1 * l + y0) * l + z0], wz0, low[(x1 * l + y0) * l + z1] * wz1);
+    float v11 = fmaf(low[(x1 * l + y1) * l + z0], wz0, low[(x1 * l + y1) * l + z1] * wz1);
+    float v0 = fmaf(v00, wy0, v01 * wy1);
+    float v1 = fmaf(v10, wy0, v11 * wy1);
+    return fmaf(v0, wx0, v1 * wx1);
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_upsample_mark(const float* __restrict__ low_sdf, const float* __restrict__ low_std, int l, int R,
+                                                           float* __restrict__ cube_sdf, float* __restrict__ cube_std,
+                                                           int32_t* __restrict__ refine_list, int* __restrict__ counters) {
+    const int B = counters[DIF_C_B];
+    const int R3 = R * R * R, l3 = l * l * l;
+    const int64_t n = (int64_t)B * R3;
+    const float scale = (float)(l - 1) / (float)(R - 1);
+    const int lane = lane_id();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_pad = (n + 63) / 64 * 64;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pad; e += stride) {
+        bool refine = false;
+        if (e < n) {
+            int b = (int)(e / R3), j = (int)(e - (int64_t)b * R3);
+            int jx = j / (R * R), jy = (j / R) % R, jz = j % R;
+            int x0, x1, y0, y1, z0, z1; float wx0, wx1, wy0, wy1, wz0, wz1;
+            tri_axis(jx, l, scale, x0, x1, wx0, wx1);
+            tri_axis(jy, l, scale, y0, y1, wy0, wy1);
+            tri_axis(jz, l, scale, z0, z1, wz0, wz1);
+            float s = tri_sample(low_sdf + (int64_t)b * l3, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+            float d = tri_sample(low_std + (int64_t)b * l3, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+            cube_sdf[e] = -s;
+            cube_std[e] = d;
+            refine = fabsf(s) < 0.05f;                       // map.py:667
+        }
+        unsigned long long m = __ballot(refine);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(counters + DIF_C_VH, __popcll(m));
+            base = __shfl(base, 0);
+            if (refine) refine_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)e;
+        }
+    }
+}
+
+// =================================================================================================================
+// a15 : sparse marching cubes with cross-voxel std-weighted blending (ext/marching_cubes/mc_interp_kernel.cu:7-320)
+// =================================================================================================================
+struct McArgs {
+    const int64_t* indexer; int nx, ny, nz;
+    const int64_t* valid_blocks; const int* K_ptr; int64_t K_static;
+    const int32_t* vbm; int64_t V;
+    const float* cube_sdf; const float* cube_std; int R;
+    float max_std;
+    int64_t max_triangles;
+    float* triangles; int64_t* tri_id; float* tri_std;
+    int32_t* tri_count; const int32_t* tri_offset;
+    int scale; float vs, bx, by, bz;
+};
+
+// batch index of voxel (bx,by,bz) or -1   (query_sdf_raw :13-24)
+__device__ __forceinline__ int mc_batch_of(const McArgs& a, int bx, int by, int bz) {
+    if ((unsigned)bx >= (unsigned)a.nx || (unsigned)by >= (unsigned)a.ny || (unsigned)bz >= (unsigned)a.nz) return -1;
+    int64_t vec = a.indexer[((int64_t)bx * a.ny + by) * a.nz + bz];
+    if (vec == -1 || vec >= a.V) return -1;
+    return a.vbm[vec];
+}
+
+// get_sdf (:34-185), STD_W_SDF branch: blend of the <=8 voxels whose cubes overlap corner `c` of voxel at nb[13].
+// nb: batch ids of the 3x3x3 neighbourhood (index (dx+1)*9 + (dy+1)*3 + (dz+1)).  Returns false => NaN (cell dropped).
+__device__ __forceinline__ bool mc_corner(const McArgs& a, const int* nb, int r, int cx, int cy, int cz, float& sdf, float& sd) {
+    const int R = a.R;
+    const int rbound = (r - 1) / 2, rstart = r / 2;
+    const float rmid = (float)r / 2.0f;
+    int c[3] = {cx, cy, cz};
+    int dm[3], dp[3], im[3], ip[3], zero[3];
+    float wm[3], wp[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (c[ax] <= rbound) {
+            dm[ax] = -1; im[ax] = c[ax] + rstart + r; dp[ax] = 0; ip[ax] = c[ax] + rstart;
+            wp[ax] = (float)c[ax] + rmid; wm[ax] = rmid - (float)c[ax];
+            zero[ax] = 1;
+        } else {
+            dm[ax] = 0; im[ax] = c[ax] + rstart; dp[ax] = 1; ip[ax] = c[ax] + rstart - r;
+            wp[ax] = (float)c[ax] - rmid; wm[ax] = rmid + (float)r - (float)c[ax];
+            zero[ax] = 0;
+        }
+        wm[ax] /= (float)r; wp[ax] /= (float)r;
+    }
+    const int zero_det = zero[0] * 4 + zero[1] * 2 + zero[2];
+    float ts = 0.0f, tw = 0.0f, tsd = 0.0f, twd = 0.0f;     // total_sdf.x, total_weight.x, total_sdf.y, total_weight.y
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sx = (k >> 2) & 1, sy = (k >> 1) & 1, sz = k & 1;
+        const int ddx = sx ? dp[0] : dm[0], ddy = sy ? dp[1] : dm[1], ddz = sz ? dp[2] : dm[2];
+        const int b = nb[(ddx + 1) * 9 + (ddy + 1) * 3 + (ddz + 1)];
+        float s = __builtin_nanf(""), d = 0.0f;
+        if (b >= 0) {
+            const int64_t off = (((int64_t)b * R + (sx ? ip[0] : im[0])) * R + (sy ? ip[1] : im[1])) * R + (sz ? ip[2] : im[2]);
+            s = a.cube_sdf[off];
+            d = a.cube_std[off];
+        }
+        const float w = (sx ? wp[0] : wm[0]) * (sy ? wp[1] : wm[1]) * (sz ? wp[2] : wm[2]);
+        if (s == s) {
+            ts += s * w * d; tw += w * d;
+            tsd += w * d;    twd += w;
+        } else if (zero_det == k) {
+            return false;
+        }
+    }
+    sdf = ts / tw;
+    sd = tsd / twd;
+    return sdf == sdf;
+}
+
+struct V4 { float x, y, z, w; };
+
+__device__ __forceinline__ V4 mc_interp(const float* p1, const float* p2, float s1, float s2, float v1, float v2) {   // sdf_interp :187-200
+    if (fabsf(0.0f - v1) < 1.0e-5f) return V4{p1[0], p1[1], p1[2], s1};
+    if (fabsf(0.0f - v2) < 1.0e-5f) return V4{p2[0], p2[1], p2[2], s2};
+    if (fabsf(v1 - v2) < 1.0e-5f) return V4{p1[0], p1[1], p1[2], s1};
+    float w2 = (0.0f - v1) / (v2 - v1);
+    float w1 = 1 - w2;
+    return V4{p1[0] * w1 + p2[0] * w2, p1[1] * w1 + p2[1] * w2, p1[2] * w1 + p2[2] * w2, s1 * w1 + s2 * w2};
+}
+
+// One wave per dirty voxel.  Phase 1: the (r+1)^3 blended corner values are computed ONCE into LDS (the reference
+// recomputes each corner for up to 8 cells).  Phase 2: lane = cell; EMIT=false counts the triangles that survive
+// max_std, EMIT=true writes them at tri_offset[k] + wave-prefix (canonical order: voxel, cell, table order).
+template <bool EMIT>
+__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int r = a.R / 2, r1 = r + 1, nc = r1 * r1 * r1, r3 = r * r * r;
+    const int lane = lane_id(), wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    float* c_sdf = lds + (size_t)wid * (2 * nc + 32);
+    float* c_std = c_sdf + nc;
+    int* nb = reinterpret_cast<int*>(c_std + nc);            // 27 (+pad)
+    const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
+    const float sbs = 1.0f / (float)r;
+    for (int64_t k = (int64_t)blockIdx.x * wpb + wid; k < K; k += (int64_t)gridDim.x * wpb) {
+        const int64_t vb = a.valid_blocks[k];
+        const int bx = (int)((vb / ((int64_t)a.ny * a.nz)) % a.nx), by = (int)((vb / a.nz) % a.ny), bz = (int)(vb % a.nz);
+        if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): nb[] visible to the whole wave
+        for (int c = lane; c < nc; c += 64) {
+            float s, d;
+            bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, s, d);
+            c_sdf[c] = ok ? s : __builtin_nanf("");
+            c_std[c] = ok ? d : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        int voxel_total = 0;
+        for (int s0 = 0; s0 < r3; s0 += 64) {
+            const int s = s0 + lane;
+            int ntri = 0;
+            V4 vl[12];
+            int cube_type = 0;
+            if (s < r3) {
+                const int rx = s / (r * r), ry = (s / r) % r, rz = s % r;
+                float val[8], sdv[8], pts[8][3];
+                bool dropped = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int dx = (q == 1 || q == 2 || q == 5 || q == 6), dy = (q == 2 || q == 3 || q == 6 || q == 7), dz = (q >= 4);
+                    const int ci = ((rx + dx) * r1 + (ry + dy)) * r1 + (rz + dz);
+                    val[q] = c_sdf[ci]; sdv[q] = c_std[ci];
+                    dropped |= !(val[q] == val[q]);
+                    pts[q][0] = (float)bx + (float)(rx + dx) * sbs;
+                    pts[q][1] = (float)by + (float)(ry + dy) * sbs;
+                    pts[q][2] = (float)bz + (float)(rz + dz) * sbs;
+                }
+                if (!dropped) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) cube_type |= (val[q] < 0.0f) ? (1 << q) : 0;
+                    const int edge_config = c_mc_edge_table[cube_type];
+                    if (edge_config) {
+                        const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+#pragma unroll
+                        for (int e = 0; e < 12; ++e)
+                            if (edge_config & (1 << e)) vl[e] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
+                        for (int i = 0; c_mc_tri_table[cube_type][i] != -1; i += 3) {
+                            float w0 = vl[c_mc_tri_table[cube_type][i]].w, w1 = vl[c_mc_tri_table[cube_type][i + 1]].w,
+                                  w2 = vl[c_mc_tri_table[cube_type][i + 2]].w;
+                            if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
+                            ++ntri;
+                        }
+                    } else {
+                        cube_type = 0;
+                    }
+                } else {
+                    cube_type = 0;
+                }
+            }
+            const int incl = wave_incl_scan(ntri);
+            const int chunk_total = __shfl(incl, 63);
+            if (EMIT && ntri > 0) {
+                int64_t t = (int64_t)a.tri_offset[k] + voxel_total + (incl - ntri);
+                for (int i = 0; c_mc_tri_table[cube_type][i] != -1; i += 3) {
+                    V4 v0 = vl[c_mc_tri_table[cube_type][i]], v1 = vl[c_mc_tri_table[cube_type][i + 1]], v2 = vl[c_mc_tri_table[cube_type][i + 2]];
+                    if (v0.w > a.max_std || v1.w > a.max_std || v2.w > a.max_std) continue;
+                    if (t < a.max_triangles) {
+                        V4 vv[3] = {v0, v1, v2};
+#pragma unroll
+                        for (int vi = 0; vi < 3; ++vi) {
+                            float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
+                            if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }   // map.py:698
+                            a.triangles[(t * 3 + vi) * 3 + 0] = x;
+                            a.triangles[(t * 3 + vi) * 3 + 1] = y;
+                            a.triangles[(t * 3 + vi) * 3 + 2] = z;
+                            a.tri_std[t * 3 + vi] = vv[vi].w;
+                        }
+                        a.tri_id[t] = vb;
+                    }
+                    ++t;
+                }
+            }
+            voxel_total += chunk_total;
+        }
+        if (!EMIT && lane == 0) a.tri_count[k] = voxel_total;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+struct TriScanFunctor {
+    const int32_t* tri_count;
+    int32_t* tri_offset;
+    int* counters;
+    __device__ int count(int k) const { return tri_count[k]; }
+    __device__ void emit(int k, int offset) const { tri_offset[k] = offset; }
+    __device__ void finish(int total) const { counters[DIF_C_T] = total; }
+};
+
+// =================================================================================================================
+// a17 : get_sdf — validity mask + ordered compaction of valid points  (map.py:565-573)
+// =================================================================================================================
+struct QueryFunctor {
+    Geo g;
+    float ignore_th;
+    const float* xyz;
+    const int64_t* indexer;
+    const float* obs;
+    uint8_t* mask;
+    int32_t* sel;
+    int* counters;
+    __device__ int count(int i) const {
+        float xn, yn, zn; int ix, iy, iz;
+        bool ok = voxel_of(g, xyz[(int64_t)i * 3 + 0], xyz[(int64_t)i * 3 + 1], xyz[(int64_t)i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        if (ok) {
+            int64_t slot = indexer[linearize(g, ix, iy, iz)];
+            ok = slot >= 0 && obs[slot] > ignore_th;
+        }
+        mask[i] = ok ? 1 : 0;
+        return ok ? 1 : 0;
+    }
+    __device__ void emit(int i, int offset) const { sel[offset] = i; }
+    __device__ void finish(int total) const { counters[DIF_C_QUERY_M] = total; }
+};
+
+// =================================================================================================================
+// multi-GPU merge helpers
+// =================================================================================================================
+__global__ void __launch_bounds__(DIF_BLOCK) k_export_records(const int64_t* __restrict__ pos, const float* __restrict__ obs,
+                                                            const float* __restrict__ latent, const int* __restrict__ counters,
+                                                            int32_t* __restrict__ rec, int64_t max_records) {
+    int n = counters[DIF_C_N_OCCUPIED];
+    if (n > max_records) n = (int)max_records;
+    const int64_t total = (int64_t)n * 32;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t s = e >> 5;
+        int f = (int)(e & 31);
+        int32_t out;
+        if (f == 0) out = (int32_t)(pos[s] & 0xFFFFFFFFll);
+        else if (f == 1) out = (int32_t)(pos[s] >> 32);
+        else if (f == 2) out = __float_as_int(obs[s]);
+        else out = __float_as_int(latent[s * L + (f - 3)] * obs[s]);
+        rec[e] = out;
+    }
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
+                                                        uint32_t* __restrict__ bits, int64_t grid) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lin = ((int64_t)(uint32_t)rec[i * 32]) | ((int64_t)rec[i * 32 + 1] << 32);
+        if (lin < 0 || lin >= grid) continue;
+        if (indexer[lin] == -1) atomicOr(bits + (lin >> 5), 1u << (lin & 31));
+    }
+}
+
+// records of one call carry distinct lin ids => plain read-modify-write, deterministic
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
+                                                         float* __restrict__ latent, float* __restrict__ obs, uint8_t* __restrict__ dirty,
+                                                         int* __restrict__ counters, int64_t grid, int64_t capacity) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int no = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
+        if (no > capacity) { no = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
+        counters[DIF_C_N_OCCUPIED] = no;
+        counters[DIF_C_ALLOC_NEW] = 0;
+    }
+    const int64_t total = n * 32;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = e >> 5;
+        int f = (int)(e & 31);
+        int64_t lin = ((int64_t)(uint32_t)rec[i * 32]) | ((int64_t)rec[i * 32 + 1] << 32);
+        if (lin < 0 || lin >= grid) continue;
+        int64_t s = indexer[lin];
+        if (s < 0) continue;
+        float w_r = __int_as_float(rec[i * 32 + 2]);
+        float w_old = obs[s];
+        float w_new = w_old + w_r;
+        if (f < L) {
+            float wz = __int_as_float(rec[i * 32 + 3 + f]);
+            float z = latent[s * L + f];
+            if (w_new > 0.0f) latent[s * L + f] = (z * w_old + wz) / w_new;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (f == 31) {
+            obs[s] = w_new;
+            if (w_r > 0.0f) dirty[s] = 1;
+        }
+    }
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+int dif_version(void) { return DIF_VERSION; }
+
+int dif_unproject(const float* depth, float* pc, int32_t H, int32_t W, float fx, float fy, float cx, float cy, void* stream) {
+    if (!depth || !pc || H <= 0 || W <= 0) return DIF_EINVAL;
+    hipLaunchKernelGGL(k_unproject, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth, pc, H, W, fx, fy, cx, cy);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_unproject_transform(const float* depth, const float* normal_cam, float* xyz_world, float* normal_world, int32_t H, int32_t W,
+                            float fx, float fy, float cx, float cy, const float* R, const float* t, void* stream) {
+    if (!depth || !xyz_world || !R || !t || H <= 0 || W <= 0) return DIF_EINVAL;
+    if ((normal_cam == nullptr) != (normal_world == nullptr)) return DIF_EINVAL;
+    Pose P;
+    for (int i = 0; i < 9; ++i) P.r[i] = R[i];
+    for (int i = 0; i < 3; ++i) P.t[i] = t[i];
+    hipLaunchKernelGGL(k_unproject_transform, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth, normal_cam,
+                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, int32_t W, void* stream) {
+    if (!pc || !normal_weight || H <= 0 || W <= 0) return DIF_EINVAL;
+    hipLaunchKernelGGL(k_normal_weight, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, pc, normal_weight, H, W);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_groupby_sum(const float* values, const int64_t* indices, int64_t N, int32_t Lw, float* sum, int32_t* count, int64_t C, void* stream) {
+    if (N < 0 || Lw <= 0 || C < 0 || (N > 0 && (!values || !indices || !sum || !count))) return DIF_EINVAL;
+    if (N == 0) return DIF_OK;
+    hipLaunchKernelGGL(k_groupby_sum, dim3(grid_for(N * Lw)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, values, indices, N, (int)Lw, sum, count, C);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+// ---- integrate ------------------------------------------------------------------------------------------------
+// workspace carve (all offsets 256-byte aligned)
+struct IntegrateWs {
+    int* pt_lin;            // [N]
+    uint32_t* key_in;       // [8N]
+    uint32_t* key_out;      // [8N]
+    uint32_t* val_out;      // [8N]
+    int* item_slot;         // [8N/ITEM_ROWS + N... ] bounded by M/ITEM_ROWS + C <= 8N/256 + 8N (loose) -> use 8N/16 + 4096... see below
+    float* partial;         // [max_items][32]
+    int* block_tmp;         // [4096]
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+    int64_t max_items;
+    int64_t total_bytes;
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int64_t max_items_for(int64_t N) {
+    // items = sum_s ceil(cnt_s / ITEM_ROWS) <= M/ITEM_ROWS + C with M <= 8N rows.  With pruning on, every kept point shares its
+    // voxel with > prune_min_vox_obs others, so the encoded voxels (26-neighbourhoods of those) number well under 2N; anything
+    // beyond the bound is dropped by ItemFunctor with DIF_C_OVERFLOW = 4.
+    return 8 * N / ITEM_ROWS + 2 * N + 64;
+}
+
+static int carve_integrate(int64_t N, void* base, IntegrateWs& ws) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    size_t sort_bytes = 0;
+    {
+        uint32_t* kn = nullptr;
+        rocprim::counting_iterator<uint32_t> vin(0);
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, kn, kn, vin, kn, (size_t)(8 * N), 0, 24, (hipStream_t)0);
+        if (e != hipSuccess) return DIF_ELAUNCH;
+    }
+    ws.max_items = max_items_for(N);
+    size_t o_lin = take((size_t)N * 4), o_kin = take((size_t)8 * N * 4), o_kout = take((size_t)8 * N * 4), o_vout = take((size_t)8 * N * 4);
+    size_t o_islot = take((size_t)ws.max_items * 4), o_part = take((size_t)ws.max_items * 32 * 4), o_tmp = take(4096 * 4);
+    size_t o_sort = take(sort_bytes + 256);
+    ws.total_bytes = (int64_t)off;
+    ws.sort_tmp_bytes = sort_bytes;
+    if (base) {
+        char* b = (char*)base;
+        ws.pt_lin = (int*)(b + o_lin); ws.key_in = (uint32_t*)(b + o_kin); ws.key_out = (uint32_t*)(b + o_kout); ws.val_out = (uint32_t*)(b + o_vout);
+        ws.item_slot = (int*)(b + o_islot); ws.partial = (float*)(b + o_part); ws.block_tmp = (int*)(b + o_tmp); ws.sort_tmp = (void*)(b + o_sort);
+    }
+    return DIF_OK;
+}
+
+int64_t dif_integrate_workspace_bytes(int64_t N) {
+    if (N <= 0) N = 1;
+    IntegrateWs ws;
+    if (carve_integrate(N, nullptr, ws) != DIF_OK) return -1;
+    return ws.total_bytes;
+}
+
+int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
+                  void* wsp, int64_t ws_bytes, void* stream_) {
+    if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0) return DIF_EINVAL;
+    if (N == 0) return DIF_OK;
+    if (!xyz || !normal || !unq_mask || !wsp) return DIF_EINVAL;
+    if (8 * N >= (int64_t)1 << 31 || map->capacity >= (int64_t)DIF_INVALID_KEY) return DIF_EINVAL;
+    const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
+    if (grid >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    IntegrateWs ws;
+    if (carve_integrate(N, wsp, ws) != DIF_OK) return DIF_ELAUNCH;
+    if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
+    Geo g = geo_of(map);
+    int* C = map->counters;
+    if (hipMemsetAsync(C + DIF_C_ALLOC_NEW, 0, sizeof(int) * 4, s) != hipSuccess) return DIF_ELAUNCH;          // ALLOC_NEW, M, C, ITEMS
+    if (hipMemsetAsync(C + DIF_C_N_KEPT, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
+    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK);
+
+    hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count);
+    hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
+                       (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, map->grid_bits, C);
+    DIF_CHECK_LAUNCH();
+    {
+        AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity};
+        int nwords = (int)((grid + 31) / 32);
+        if (launch_scan(f, nullptr, nwords, nwords, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
+                       (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
+                       ws.key_in, C, map->capacity);
+    DIF_CHECK_LAUNCH();
+    {
+        rocprim::counting_iterator<uint32_t> vin(0);
+        size_t tmp = ws.sort_tmp_bytes;
+        hipError_t e = rocprim::radix_sort_pairs(ws.sort_tmp, tmp, (const uint32_t*)ws.key_in, ws.key_out, vin, ws.val_out, (size_t)(8 * N), 0, 24, s);
+        if (e != hipSuccess) return DIF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k_segments, dim3(grid_for(8 * N)), dim3(DIF_BLOCK), 0, s, (const uint32_t*)ws.key_out, 8 * N, map->seg_start, map->seg_cnt, C);
+    DIF_CHECK_LAUNCH();
+    {
+        ItemFunctor f{map->seg_start, map->seg_cnt, map->item_start, ws.item_slot, C, ws.max_items};
+        if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    }
+    {
+        const size_t lds_bytes = (size_t)ENC_FLOATS * 4;
+        static bool attr_set[64] = {};
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (dev < 64 && !attr_set[dev]) {
+            if (hipFuncSetAttribute((const void*)k_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint32_t*)ws.val_out,
+                           (const int*)map->seg_start, (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot,
+                           (const int*)C, ws.partial);
+        DIF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, (const float*)ws.partial,
+                       (const int*)map->item_start, map->seg_cnt, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+// ---- decoder launches ------------------------------------------------------------------------------------------
+static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t tiles_upper, hipStream_t s) {
+    if (!w || !w->dec_packed || w->dec_packed_floats != DEC_FLOATS) return DIF_EINVAL;
+    const size_t lds_bytes = (size_t)DEC_LDS_FLOATS * 4;
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        attr_set[dev] = true;
+    }
+    int64_t blocks = (tiles_upper + 7) / 8;
+    if (blocks < 1) blocks = 1;
+    if (blocks > num_cus()) blocks = num_cus();
+    hipLaunchKernelGGL(k_decode, dim3((int)blocks), dim3(512), lds_bytes, s, A, w->dec_packed);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_decode_rows(const dif_weights_t* w, const float* rows, int64_t n, float* sdf, float* std_out, void* stream) {
+    if (n < 0 || (n > 0 && (!rows || !sdf || !std_out))) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    DecodeArgs A = {};
+    A.mode = 2; A.n_static = n; A.rows = rows; A.out_sdf = sdf; A.out_std = std_out; A.sign = 1.0f; A.lat.res = 1;
+    return launch_decode(A, w, (n + 31) / 32, (hipStream_t)stream);
+}
+
+// encoder on explicit rows: one work item per 256 rows, partial sums are not what we want here, so a dedicated small kernel
+namespace {
+__global__ void __launch_bounds__(512, 2) k_encode_rows(const float* __restrict__ wblob, const float* __restrict__ rows, int64_t n, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, ENC_FLOATS);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int64_t n_tiles = (n + 31) / 32;
+    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+        int64_t row = tile * 32 + col;
+        bool live = row < n;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (live) {
+            const float* p = rows + row * 6;
+            x0 = half ? p[1] : p[0];
+            x1 = half ? p[3] : p[2];
+            x2 = half ? p[5] : p[4];
+        }
+        f16v o = encoder_tile(lds, x0, x1, x2, lane);
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (f < L) out[row * L + f] = o[r];
+            }
+        }
+    }
+}
+}  // namespace
+
+int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float* out, void* stream) {
+    if (!w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || n < 0 || (n > 0 && (!rows || !out))) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    const size_t lds_bytes = (size_t)ENC_FLOATS * 4;
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)k_encode_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        attr_set[dev] = true;
+    }
+    int64_t blocks = ((n + 31) / 32 + 7) / 8;
+    if (blocks > num_cus()) blocks = num_cus();
+    hipLaunchKernelGGL(k_encode_rows, dim3((int)blocks), dim3(512), lds_bytes, (hipStream_t)stream, w->enc_packed, rows, n, out);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+// ---- marching cubes --------------------------------------------------------------------------------------------
+static int run_marching_cubes(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
+    if (upload_tables() != DIF_OK) return DIF_ELAUNCH;
+    const int r = a.R / 2, nc = (r + 1) * (r + 1) * (r + 1);
+    const size_t lds_bytes = (size_t)(DIF_BLOCK / 64) * (2 * nc + 32) * sizeof(float);
+    if (lds_bytes > 64 * 1024) return DIF_EINVAL;
+    const int blocks = grid_for(K_upper, DIF_BLOCK / 64, 8192);
+    a.tri_count = tri_count;
+    a.tri_offset = tri_offset;
+    hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+    DIF_CHECK_LAUNCH();
+    TriScanFunctor f{tri_count, tri_offset, counters};
+    if (launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_marching_cubes<true>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t nz, const int64_t* valid_blocks, int64_t K,
+                       const int32_t* vec_batch_mapping, int64_t V, const float* cube_sdf, const float* cube_std, int32_t R, float max_std,
+                       int64_t max_triangles, float* triangles, int64_t* triangle_flatten_id, float* triangle_std, int32_t* tri_count,
+                       int32_t* tri_offset, int32_t* block_tmp, int32_t* counters, void* stream) {
+    if (!indexer || !counters || !block_tmp || K < 0 || V < 0 || R < 2 || (R & 1) || max_triangles < 0) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 0) return hipMemsetAsync(counters + DIF_C_T, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+    if (!valid_blocks || !vec_batch_mapping || !cube_sdf || !cube_std || !triangles || !triangle_flatten_id || !triangle_std || !tri_count || !tri_offset)
+        return DIF_EINVAL;
+    McArgs a = {};
+    a.indexer = indexer; a.nx = nx; a.ny = ny; a.nz = nz; a.valid_blocks = valid_blocks; a.K_ptr = nullptr; a.K_static = K;
+    a.vbm = vec_batch_mapping; a.V = V; a.cube_sdf = cube_sdf; a.cube_std = cube_std; a.R = R; a.max_std = max_std;
+    a.max_triangles = max_triangles; a.triangles = triangles; a.tri_id = triangle_flatten_id; a.tri_std = triangle_std; a.scale = 0;
+    return run_marching_cubes(a, K, tri_count, tri_offset, block_tmp, counters, s);
+}
+
+// ---- extract ---------------------------------------------------------------------------------------------------
+int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
+                float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
+    if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
+    Geo g = geo_of(map);
+    int* C = map->counters;
+    const int r = resolution, R = 2 * r, l = r;               // fast two-level: low lattice l = R/2 (map.py:642-644)
+    const int R3 = R * R * R;
+    if (buf->max_voxels * (int64_t)R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    const double sample_a = -(double)(r / 2) * (1.0 / r), sample_b = 1.0 + (double)((r - 1) / 2) * (1.0 / r);   // map.py:640-641
+
+    {   // dirty slots -> valid_blocks
+        DirtyFunctor f{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels};
+        if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k_mark_occupied, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th,
+                       (const int64_t*)buf->valid_blocks, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, map->grid_bits, (const int*)C);
+    DIF_CHECK_LAUNCH();
+    {
+        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
+        int nwords = (int)((grid + 31) / 32);
+        if (launch_scan(f, nullptr, nwords, nwords, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    }
+    int rc;
+    if (fast) {
+        // low lattice decode (map.py:644-653)
+        DecodeArgs A = {};
+        A.mode = 0; A.n_ptr = C + DIF_C_B; A.occ_slot = buf->occ_slot; A.latent = map->latent_vecs;
+        A.lat.res = l; A.lat.a = (float)sample_a;
+        A.lat.vsize = (l > 1) ? (float)((sample_b - sample_a) / (l - 1)) : 0.0f;
+        A.out_sdf = buf->low_sdf; A.out_std = buf->low_std; A.sign = 1.0f;
+        rc = launch_decode(A, w, buf->max_voxels * ((l * l * l + 31) / 32), s);
+        if (rc != DIF_OK) return rc;
+        // upsample + threshold (map.py:655-667)
+        hipLaunchKernelGGL(k_upsample_mark, dim3(grid_for(buf->max_voxels * (int64_t)R3, DIF_BLOCK, 8192)), dim3(DIF_BLOCK), 0, s,
+                           (const float*)buf->low_sdf, (const float*)buf->low_std, l, R, buf->cube_sdf, buf->cube_std, buf->refine_list, C);
+        DIF_CHECK_LAUNCH();
+        // exact re-decode of the near-surface samples (map.py:668-679)
+        DecodeArgs Rf = {};
+        Rf.mode = 1; Rf.n_ptr = C + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
+        Rf.lat.res = R; Rf.lat.a = (float)sample_a; Rf.lat.vsize = (float)((sample_b - sample_a) / (R - 1));
+        Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
+        rc = launch_decode(Rf, w, buf->max_voxels * (int64_t)(R3 / 32), s);
+        if (rc != DIF_OK) return rc;
+    } else {
+        // every lattice sample decoded exactly (map.py:683-685), stored negated (map.py:687)
+        DecodeArgs A = {};
+        A.mode = 0; A.n_ptr = C + DIF_C_B; A.occ_slot = buf->occ_slot; A.latent = map->latent_vecs;
+        A.lat.res = R; A.lat.a = (float)sample_a; A.lat.vsize = (float)((sample_b - sample_a) / (R - 1));
+        A.out_sdf = buf->cube_sdf; A.out_std = buf->cube_std; A.sign = -1.0f;
+        rc = launch_decode(A, w, buf->max_voxels * (int64_t)((R3 + 31) / 32), s);
+        if (rc != DIF_OK) return rc;
+    }
+    // marching cubes (map.py:689-691)
+    McArgs a = {};
+    a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
+    a.vbm = map->vbm; a.V = map->capacity; a.cube_sdf = buf->cube_sdf; a.cube_std = buf->cube_std; a.R = R; a.max_std = max_std;
+    a.max_triangles = buf->max_triangles; a.triangles = buf->triangles; a.tri_id = buf->triangle_flatten_id; a.tri_std = buf->triangle_std;
+    a.scale = scale_vertices ? 1 : 0; a.vs = map->voxel_size; a.bx = map->bound_min[0]; a.by = map->bound_min[1]; a.bz = map->bound_min[2];
+    rc = run_marching_cubes(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s);
+    if (rc != DIF_OK) return rc;
+    hipLaunchKernelGGL(k_reset_vbm, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm, (const int*)C);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+// ---- get_sdf ---------------------------------------------------------------------------------------------------
+int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, uint8_t* mask, int32_t* sel, float* sdf,
+                  float* std_out, float* grad, int32_t* scratch, void* stream_) {
+    if (!map || !w || N < 0 || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    if (grad) return DIF_EINVAL;                              // analytic d sdf/d xyz: SURVEY.md section 8f-1, not built yet
+    hipStream_t s = (hipStream_t)stream_;
+    if (N == 0) return hipMemsetAsync(map->counters + DIF_C_QUERY_M, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+    if (!xyz || !mask || !sel || !sdf || !std_out || !scratch) return DIF_EINVAL;
+    Geo g = geo_of(map);
+    QueryFunctor f{g, map->ignore_count_th, xyz, map->indexer, map->voxel_obs_count, mask, sel, map->counters};
+    if (launch_scan(f, nullptr, (int)N, N, scratch, s) != DIF_OK) return DIF_ELAUNCH;
+    DecodeArgs A = {};
+    A.mode = 3; A.n_ptr = map->counters + DIF_C_QUERY_M; A.latent = map->latent_vecs; A.list = sel; A.xyz = xyz; A.indexer = map->indexer;
+    A.geo = g; A.out_sdf = sdf; A.out_std = std_out; A.sign = 1.0f; A.lat.res = 1;
+    return launch_decode(A, w, (N + 31) / 32, s);
+}
+
+// ---- multi-GPU merge -------------------------------------------------------------------------------------------
+int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, void* stream) {
+    if (!map || !records || max_records <= 0) return DIF_EINVAL;
+    hipLaunchKernelGGL(k_export_records, dim3(grid_for(max_records * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, (hipStream_t)stream,
+                       (const int64_t*)map->latent_vecs_pos, (const float*)map->voxel_obs_count, (const float*)map->latent_vecs,
+                       (const int*)map->counters, records, max_records);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t* scratch, void* stream_) {
+    if (!map || n < 0) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    if (!records || !scratch) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
+    if (hipMemsetAsync(map->counters + DIF_C_ALLOC_NEW, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, records, n, (const int64_t*)map->indexer, map->grid_bits, grid);
+    DIF_CHECK_LAUNCH();
+    AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, map->counters, map->capacity};
+    int nwords = (int)((grid + 31) / 32);
+    if (launch_scan(f, nullptr, nwords, nwords, scratch, s) != DIF_OK) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, records, n, (const int64_t*)map->indexer,
+                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_read_counters(const dif_map_t* map, int32_t* host_out, void* stream) {
+    if (!map || !host_out) return DIF_EINVAL;
+    if (hipMemcpyAsync(host_out, map->counters, sizeof(int32_t) * DIF_C_COUNT, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return DIF_ELAUNCH;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return DIF_ELAUNCH;
+    return DIF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""Fold and pack the DI-Fusion encoder/decoder weights for the MFMA kernels in `csrc/mlp.hip.h`.
+
+Folding (done once at load, float64 then cast to float32):
+  * decoder linears are `weight_norm`ed (reference `network/di_decoder.py:37-40`): W = g * v / ||v||_row;
+  * encoder 1x1 convs are followed by eval-mode BatchNorm (reference `utils/pt_util.py:76-127,193-206`):
+    W' = W * s, b' = beta - mean * s,  s = gamma / sqrt(var + 1e-5).
+
+Packing ("transposed chaining", see mlp.hip.h): each layer's weight matrix is the MFMA A operand.  For out-block `mb`
+(32 output features), k-group `g` (4 k-steps of the 32x32x2 MFMA) lane `l` stores a float4 whose component j is
+    W[mb*32 + (l & 31)][kmap(4g + j, l >> 5)]
+with
+    natural input (read from memory):   kmap(t, half) = 2t + half
+    D-fragment input (previous layer):  kmap(t, half) = 32*(t // 16) + (t%16 & 3) + 8*((t%16) >> 2) + 4*half
+so that register r of the previous layer's accumulator IS the B operand of k-step r.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+ENC_FLOATS = 27264
+DEC_LDS_FLOATS = 33508
+DEC_FLOATS = 49892
+
+
+def _frag_feature(r: int, half: int) -> int:
+    return (r & 3) + 8 * (r >> 2) + 4 * half
+
+
+def kmap_natural(t: int, half: int) -> int:
+    return 2 * t + half
+
+
+def kmap_dfrag(t: int, half: int) -> int:
+    return 32 * (t // 16) + _frag_feature(t % 16, half)
+
+
+def pack_A(W: np.ndarray, MB: int, KG: int, kmap) -> np.ndarray:
+    """W (M_out, K_in) -> (MB, KG, 64, 4) float32."""
+    M, K = W.shape
+    out = np.zeros((MB, KG, 64, 4), dtype=np.float32)
+    for mb in range(MB):
+        for g in range(KG):
+            for lane in range(64):
+                m = mb * 32 + (lane & 31)
+                if m >= M:
+                    continue
+                for j in range(4):
+                    k = kmap(4 * g + j, lane >> 5)
+                    if k is not None and 0 <= k < K:
+                        out[mb, g, lane, j] = W[m, k]
+    return out
+
+
+def pack_vec(b: np.ndarray, MB: int) -> np.ndarray:
+    """b (M_out,) -> (MB, 2, 16): the accumulator-fragment order of a per-feature vector."""
+    out = np.zeros((MB, 2, 16), dtype=np.float32)
+    for mb in range(MB):
+        for half in range(2):
+            for r in range(16):
+                f = mb * 32 + _frag_feature(r, half)
+                if f < b.shape[0]:
+                    out[mb, half, r] = b[f]
+    return out
+
+
+def fold_decoder(w: Dict[str, np.ndarray]):
+    Ws, bs = [], []
+    for i in range(5):
+        v = w[f"decoder.lin{i}.weight_v"].astype(np.float64)
+        g = w[f"decoder.lin{i}.weight_g"].astype(np.float64)
+        Ws.append((v * (g / np.linalg.norm(v, axis=1, keepdims=True))).astype(np.float32))
+        bs.append(w[f"decoder.lin{i}.bias"].astype(np.float32))
+    return Ws, bs, w["decoder.uncertainty_layer.weight"].astype(np.float32), w["decoder.uncertainty_layer.bias"].astype(np.float32)
+
+
+def fold_encoder(w: Dict[str, np.ndarray]):
+    Ws, bs = [], []
+    for i in range(3):
+        W = w[f"encoder.mlp.layer{i}.conv.weight"][:, :, 0].astype(np.float64)
+        gamma = w[f"encoder.mlp.layer{i}.normlayer.bn.weight"].astype(np.float64)
+        beta = w[f"encoder.mlp.layer{i}.normlayer.bn.bias"].astype(np.float64)
+        mean = w[f"encoder.mlp.layer{i}.normlayer.bn.running_mean"].astype(np.float64)
+        var = w[f"encoder.mlp.layer{i}.normlayer.bn.running_var"].astype(np.float64)
+        s = gamma / np.sqrt(var + 1e-5)
+        Ws.append((W * s[:, None]).astype(np.float32))
+        bs.append((beta - mean * s).astype(np.float32))
+    Ws.append(w["encoder.mlp.layer3.conv.weight"][:, :, 0].astype(np.float32))
+    bs.append(w["encoder.mlp.layer3.conv.bias"].astype(np.float32))
+    return Ws, bs
+
+
+def pack_encoder(w: Dict[str, np.ndarray]) -> np.ndarray:
+    Ws, bs = fold_encoder(w)
+    assert [x.shape for x in Ws] == [(32, 6), (64, 32), (256, 64), (29, 256)]
+    parts = [pack_A(Ws[0], 1, 1, kmap_natural), pack_vec(bs[0], 1),
+             pack_A(Ws[1], 2, 4, kmap_dfrag), pack_vec(bs[1], 2),
+             pack_A(Ws[2], 8, 8, kmap_dfrag), pack_vec(bs[2], 8),
+             pack_A(Ws[3], 1, 32, kmap_dfrag), pack_vec(bs[3], 1)]
+    blob = np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
+    assert blob.shape[0] == ENC_FLOATS, blob.shape
+    return blob
+
+
+def pack_decoder(w: Dict[str, np.ndarray]) -> np.ndarray:
+    Ws, bs, Wu, bu = fold_decoder(w)
+    assert [x.shape for x in Ws] == [(128, 32), (128, 128), (96, 128), (128, 128), (1, 128)]
+
+    def kmap_l3(t, half):       # input of lin3 = cat([h2 (96), x0 (32)])  (di_decoder.py:61-62)
+        return kmap_dfrag(t, half) if t < 48 else 96 + kmap_natural(t - 48, half)
+
+    parts = [pack_A(Ws[0], 4, 4, kmap_natural), pack_vec(bs[0], 4),
+             pack_A(Ws[1], 4, 16, kmap_dfrag), pack_vec(bs[1], 4),
+             pack_A(Ws[2], 3, 16, kmap_dfrag), pack_vec(bs[2], 3),
+             pack_vec(bs[3], 4),
+             pack_vec(Ws[4][0], 4), pack_vec(Wu[0], 4),
+             np.array([bs[4][0], bu[0], 0.0, 0.0], dtype=np.float32)]
+    lds = np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
+    assert lds.shape[0] == DEC_LDS_FLOATS, lds.shape
+    blob = np.concatenate([lds, pack_A(Ws[3], 4, 16, kmap_l3).reshape(-1)]).astype(np.float32)
+    assert blob.shape[0] == DEC_FLOATS, blob.shape
+    return blob

@@ -1,0 +1,86 @@
+"""Flat operator API of the reference's `pytorch/system/ext/__init__.py:15-44`, bound to libdifusion.so.
+
+Same names, argument order and error behaviour (RuntimeError on non-GPU / non-contiguous input, like the
+`CHECK_INPUT` macros of the reference extensions); outputs are allocated here as torch tensors on the input's device.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from .. import _lib
+
+
+def _dev(t):
+    return torch.cuda.device(t.device)
+
+
+def unproject_depth(depth: torch.Tensor, fx: float, fy: float, cx: float, cy: float) -> torch.Tensor:
+    """(H,W) f32 -> (H,W,3) f32.  reference `ext/imgproc/imgproc.cu:26-44`.  NaN depth -> NaN point (all three)."""
+    _lib.require_cuda(depth)
+    H, W = depth.shape
+    pc = torch.empty((H, W, 3), dtype=torch.float32, device=depth.device)
+    with _dev(depth):
+        _lib.check(_lib.load().dif_unproject(_lib.ptr(depth), _lib.ptr(pc), H, W, fx, fy, cx, cy, _lib.stream_ptr()), "dif_unproject")
+    return pc
+
+
+def compute_normal_weight(pc_map: torch.Tensor) -> torch.Tensor:
+    """(H,W,3) -> (H,W,4) normal + weight, w=-1 invalid.  reference `ext/imgproc/imgproc.cu:143-160`."""
+    _lib.require_cuda(pc_map)
+    H, W, _ = pc_map.shape
+    out = torch.empty((H, W, 4), dtype=torch.float32, device=pc_map.device)
+    with _dev(pc_map):
+        _lib.check(_lib.load().dif_compute_normal_weight(_lib.ptr(pc_map), _lib.ptr(out), H, W, _lib.stream_ptr()), "dif_compute_normal_weight")
+    return out
+
+
+def groupby_sum(values: torch.Tensor, indices: torch.Tensor, C) -> List[torch.Tensor]:
+    """[sum (C,L) f32, count (C,) i32].  reference `ext/indexing/indexing.cu:89-109` (counts here are per sample; the
+    reference's kernel counts L per sample, a bug its only caller never observes)."""
+    _lib.require_cuda(values, indices)
+    C = int(C)
+    N, L = values.shape
+    s = torch.zeros((C, L), dtype=torch.float32, device=values.device)
+    c = torch.zeros((C,), dtype=torch.int32, device=values.device)
+    with _dev(values):
+        _lib.check(_lib.load().dif_groupby_sum(_lib.ptr(values), _lib.ptr(indices), N, L, _lib.ptr(s), _lib.ptr(c), C, _lib.stream_ptr()), "dif_groupby_sum")
+    return [s, c]
+
+
+def pack_batch(indices: torch.Tensor, n_batch: int, n_point: int):
+    """reference `ext/indexing/indexing.cu:73-86`; only reachable through `pack_samples`, which nothing on the fusion
+    path calls."""
+    raise NotImplementedError("pack_batch is off the fusion path (dead in the reference product)")
+
+
+def marching_cubes_interp(indexer: torch.Tensor, valid_blocks: torch.Tensor, vec_batch_mapping: torch.Tensor,
+                          cube_sdf: torch.Tensor, cube_std: torch.Tensor, max_n_triangles: int, n_xyz, max_std: float):
+    """[triangles (T,3,3) f32, triangle_flatten_id (T,) i64, triangle_std (T,3) f32] in voxel units.
+    reference `ext/marching_cubes/mc.cpp:3-16`, `mc_interp_kernel.cu:322-382`.  Output order is canonical
+    (voxel, cell, table order) instead of atomic arrival order."""
+    _lib.require_cuda(indexer, valid_blocks, vec_batch_mapping, cube_sdf, cube_std)
+    dev = indexer.device
+    K = valid_blocks.size(0)
+    R = cube_sdf.size(1) if cube_sdf.dim() == 4 and cube_sdf.size(0) > 0 else 2
+    r3 = max(1, (R // 2) ** 3)
+    cap = int(min(max_n_triangles, max(1, K * r3 * 5)))
+    tri = torch.empty((cap, 3, 3), dtype=torch.float32, device=dev)
+    tid = torch.empty((cap,), dtype=torch.int64, device=dev)
+    tstd = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    cnt = torch.empty((max(K, 1),), dtype=torch.int32, device=dev)
+    off = torch.empty((max(K, 1),), dtype=torch.int32, device=dev)
+    tmp = torch.empty((4096,), dtype=torch.int32, device=dev)
+    counters = torch.zeros((_lib.C_COUNT,), dtype=torch.int32, device=dev)
+    with _dev(indexer):
+        _lib.check(_lib.load().dif_marching_cubes(_lib.ptr(indexer), int(n_xyz[0]), int(n_xyz[1]), int(n_xyz[2]), _lib.ptr(valid_blocks), K,
+                                                  _lib.ptr(vec_batch_mapping), vec_batch_mapping.size(0), _lib.ptr(cube_sdf), _lib.ptr(cube_std),
+                                                  R, float(max_std), cap, _lib.ptr(tri), _lib.ptr(tid), _lib.ptr(tstd), _lib.ptr(cnt),
+                                                  _lib.ptr(off), _lib.ptr(tmp), _lib.ptr(counters), _lib.stream_ptr()), "dif_marching_cubes")
+    T = int(counters[_lib.C_T].item())
+    if T >= max_n_triangles and T > cap:
+        import sys
+        print(f"Warning from marching cube: the max triangle number is too small {T} vs {max_n_triangles}", file=sys.stderr)
+    T = min(T, cap)
+    return [tri[:T], tid[:T], tstd[:T]]

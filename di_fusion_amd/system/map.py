@@ -1,0 +1,442 @@
+"""`DenseIndexedMap` — the map / integrate / extract surface of the reference's `pytorch/system/map.py:158-723`,
+backed by libdifusion.so (hand-written HIP for gfx950).  Same constructor, attributes, methods and return values;
+the tensors behind the properties live on the GPU and are owned here, the kernels receive raw pointers.
+
+Differences a caller can observe (all documented in DESIGN.md):
+  * no host round trip inside `integrate_keyframe` (the reference syncs 4 times, `map.py:382,441-444`);
+  * `n_occupied` is a device counter — reading the property synchronises;
+  * `latent_vecs`, `latent_vecs_pos`, `voxel_obs_count`, `voxel_optimized` are views of larger pre-allocated buffers,
+    sliced to the capacity the reference's doubling rule (`map.py:263-285`) would have reached;
+  * points outside the map bounds / NaN points are ignored instead of indexing out of range (`map.py:313`);
+  * triangles come out in a canonical order (voxel, cell, table) instead of atomic arrival order;
+  * `do_optimize=True`, the visualisers and `interpolate=False` raise NotImplementedError (out of scope / dead in the
+    reference: `system.ext.marching_cubes` does not exist there either, `map.py:693`).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import functools
+import logging
+import threading
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..network import utility as net_util
+
+
+class MeshExtractCache:
+    """reference `map.py:116-133`; `updated_vec_id` lives on the GPU as a dirty flag per slot."""
+
+    def __init__(self, device):
+        self.vertices = None
+        self.vertices_flatten_id = None
+        self.vertices_std = None
+        self.device = device
+
+    def clear_all(self):
+        self.vertices = None
+        self.vertices_flatten_id = None
+        self.vertices_std = None
+
+
+class Mesh:
+    """Minimal stand-in for `open3d.geometry.TriangleMesh` (Open3D is optional): what `_make_mesh_from_cache`
+    (`map.py:521-543`) would put into it."""
+
+    def __init__(self, vertices: np.ndarray, triangles: np.ndarray, vertex_std: np.ndarray):
+        self.vertices = vertices            # (3T, 3) float64
+        self.triangles = triangles          # (T, 3) int32
+        self.vertex_std = vertex_std        # (3T,) float
+
+
+def _next_pow2(n: int) -> int:
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+class DenseIndexedMap:
+    def __init__(self, model: net_util.Networks, args: argparse.Namespace, latent_dim: int, device: torch.device,
+                 enable_async: bool = False, optimization_device: torch.device = None, initial_capacity: int = 1 << 16):
+        """reference `map.py:159-234`.  `initial_capacity`: rows pre-allocated for latent vectors (grows by doubling)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("DenseIndexedMap runs on the GPU only (libdifusion has no CPU fallback)")
+        if latent_dim != _lib.LATENT_DIM:
+            raise NotImplementedError("libdifusion is specialised to latent_dim = 29 (ckpt/default/hyper.json)")
+        self.model = model
+        self.model.eval()
+        self.voxel_size = args.voxel_size
+        self.n_xyz = np.ceil((np.asarray(args.bound_max) - np.asarray(args.bound_min)) / args.voxel_size).astype(int).tolist()
+        logging.info(f"Map size Nx = {self.n_xyz[0]}, Ny = {self.n_xyz[1]}, Nz = {self.n_xyz[2]}")
+        self.args = args
+        self.bound_min = torch.tensor(args.bound_min, device=device).float()
+        self.bound_max = self.bound_min + self.voxel_size * torch.tensor(self.n_xyz, device=device)
+        self.latent_dim = latent_dim
+        self.device = device
+        self.extract_mesh_std_range = None
+        self.modifying_lock = threading.Lock()
+        self.meshing_thread = None
+        self.meshing_thread_id = -1
+        self.meshing_stream = torch.cuda.Stream(device=device)
+        self.mesh_cache = MeshExtractCache(self.device)
+
+        self._grid = int(np.prod(self.n_xyz))
+        if self._grid >= 2 ** 31:
+            raise RuntimeError("grid too large for 32-bit linear ids")
+        with torch.cuda.device(device):
+            self._indexer = torch.full((self._grid,), -1, device=device, dtype=torch.long)
+            self._frame_count = torch.zeros((self._grid,), device=device, dtype=torch.int32)
+            self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
+            self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
+        self._capacity = 0
+        self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
+        self._n_occ_ub = 0                  # host-side upper bound of n_occupied (exact after a counter read)
+        self._ws = None
+        self._ws_n = 0
+        self._xbuf = None
+        self._host_counters = (ctypes.c_int32 * _lib.C_COUNT)()
+        self.last_counters = {}
+
+    # ---- state ------------------------------------------------------------------------------------------------
+    def _alloc_state(self, capacity: int):
+        dev = self.device
+        with torch.cuda.device(dev):
+            lat = torch.zeros((capacity, self.latent_dim), dtype=torch.float32, device=dev)
+            pos = torch.full((capacity,), -1, dtype=torch.long, device=dev)
+            obs = torch.zeros((capacity,), dtype=torch.float32, device=dev)
+            dirty = torch.zeros((capacity,), dtype=torch.uint8, device=dev)
+            vbm = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
+            seg_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            seg_cnt = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            item_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            if self._capacity > 0:
+                c = self._capacity
+                lat[:c] = self._latent
+                pos[:c] = self._pos
+                obs[:c] = self._obs
+                dirty[:c] = self._dirty
+        self._latent, self._pos, self._obs, self._dirty = lat, pos, obs, dirty
+        self._vbm, self._seg_start, self._seg_cnt, self._item_start = vbm, seg_start, seg_cnt, item_start
+        self._capacity = capacity
+        m = _lib.DifMap()
+        m.nx, m.ny, m.nz = self.n_xyz
+        bm = [float(np.float32(v)) for v in self.args.bound_min]
+        m.bound_min = (ctypes.c_float * 3)(*bm)
+        m.voxel_size = float(self.voxel_size)
+        m.prune_min_vox_obs = int(self.args.prune_min_vox_obs)
+        m.ignore_count_th = float(self.args.ignore_count_th)
+        m.encoder_count_th = float(self.args.encoder_count_th)
+        m.capacity = capacity
+        m.indexer = _lib.ptr(self._indexer)
+        m.latent_vecs = _lib.ptr(lat)
+        m.latent_vecs_pos = _lib.ptr(pos)
+        m.voxel_obs_count = _lib.ptr(obs)
+        m.dirty = _lib.ptr(dirty)
+        m.counters = _lib.ptr(self._counters)
+        m.frame_count = _lib.ptr(self._frame_count)
+        m.grid_bits = _lib.ptr(self._grid_bits)
+        m.vbm = _lib.ptr(vbm)
+        m.seg_start = _lib.ptr(seg_start)
+        m.seg_cnt = _lib.ptr(seg_cnt)
+        m.item_start = _lib.ptr(item_start)
+        self._cmap = m
+
+    def _read_counters(self):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().dif_read_counters(ctypes.byref(self._cmap), self._host_counters, _lib.stream_ptr()), "dif_read_counters")
+        c = list(self._host_counters)
+        if c[_lib.C_OVERFLOW] != 0:
+            raise RuntimeError(f"libdifusion: device buffer overflow (code {c[_lib.C_OVERFLOW]}); the map state is incomplete")
+        self._n_occ_ub = c[_lib.C_N_OCCUPIED]
+        self.last_counters = dict(n_occupied=c[_lib.C_N_OCCUPIED], alloc_new=c[_lib.C_ALLOC_NEW], M=c[_lib.C_M], C=c[_lib.C_C],
+                                  items=c[_lib.C_ITEMS], K=c[_lib.C_K], B=c[_lib.C_B], VH=c[_lib.C_VH], T=c[_lib.C_T],
+                                  query_M=c[_lib.C_QUERY_M], n_kept=c[_lib.C_N_KEPT])
+        return self.last_counters
+
+    def _ensure_capacity(self, may_add: int):
+        if self._n_occ_ub + may_add > self._capacity:
+            self._read_counters()                                  # make the bound exact
+            if self._n_occ_ub + may_add > self._capacity:
+                self._alloc_state(_next_pow2(self._n_occ_ub + may_add))
+        self._n_occ_ub += may_add
+
+    def _ref_capacity(self) -> int:
+        """Buffer length the reference would have after the same allocations (doubling from 1, map.py:263-268)."""
+        return max(1, _next_pow2(self.n_occupied))
+
+    # properties of map.py:199-220
+    @property
+    def n_occupied(self) -> int:
+        return int(self._read_counters()["n_occupied"])
+
+    @property
+    def indexer(self) -> torch.Tensor:
+        return self._indexer
+
+    @property
+    def latent_vecs(self) -> torch.Tensor:
+        return self._latent[:self._ref_capacity()]
+
+    @property
+    def latent_vecs_pos(self) -> torch.Tensor:
+        return self._pos[:self._ref_capacity()]
+
+    @property
+    def voxel_obs_count(self) -> torch.Tensor:
+        return self._obs[:self._ref_capacity()]
+
+    @property
+    def voxel_optimized(self) -> torch.Tensor:
+        return torch.zeros((self._ref_capacity(),), dtype=torch.bool, device=self.device)
+
+    @property
+    def updated_vec_id(self) -> torch.Tensor:
+        """`mesh_cache.updated_vec_id` of the reference (sorted slot ids awaiting re-meshing, map.py:303-308)."""
+        n = self.n_occupied
+        return torch.nonzero(self._dirty[:n]).flatten()
+
+    @property
+    def cold_vars(self):
+        n = self.n_occupied
+        c = self._ref_capacity()
+        return {"n_occupied": n, "indexer": self._indexer, "latent_vecs": self._latent[:c], "latent_vecs_pos": self._pos[:c],
+                "voxel_obs_count": self._obs[:c], "voxel_optimized": torch.zeros((c,), dtype=torch.bool, device=self.device)}
+
+    def save(self, path):
+        """reference `map.py:239-243`: `torch.save` of the cold_vars dict (load-compatible with the reference)."""
+        path = Path(path)
+        with path.open("wb") as f:
+            torch.save({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in self.cold_vars.items()}, f)
+
+    def load(self, path):
+        """reference `map.py:245-249`; accepts maps saved by the reference or by `save`."""
+        path = Path(path)
+        with path.open("rb") as f:
+            cv = torch.load(f, map_location=self.device)
+        n = int(cv["n_occupied"])
+        if cv["indexer"].numel() != self._grid:
+            raise RuntimeError("saved map has a different grid")
+        if n > self._capacity:
+            self._alloc_state(_next_pow2(n))
+        self._indexer.copy_(cv["indexer"].view(-1))
+        self._latent.zero_(); self._pos.fill_(-1); self._obs.zero_(); self._dirty.zero_()
+        self._latent[:n] = cv["latent_vecs"][:n]
+        self._pos[:n] = cv["latent_vecs_pos"][:n]
+        self._obs[:n] = cv["voxel_obs_count"][:n]
+        self._counters.zero_()
+        self._counters[_lib.C_N_OCCUPIED] = n
+        self._n_occ_ub = n
+        self.mesh_cache.clear_all()
+
+    # ---- integrate --------------------------------------------------------------------------------------------
+    def integrate_keyframe(self, surface_xyz: torch.Tensor, surface_normal: torch.Tensor, do_optimize: bool = False,
+                           async_optimize: bool = False):
+        """reference `map.py:340-519`.  (N,3) xyz + (N,3) normals, float32 on the map's device.
+        :return: unq_mask (N,) bool — points whose voxel holds more than `prune_min_vox_obs` points (None if pruning is off)."""
+        assert surface_xyz.device == surface_normal.device == self.device, \
+            f"Device of map {self.device} and input observation {surface_xyz.device, surface_normal.device} must be the same."
+        if do_optimize:
+            raise NotImplementedError("latent optimisation (map.py:459-513) is outside the fusion hot path")
+        xyz = surface_xyz.contiguous().float()
+        nrm = surface_normal.contiguous().float()
+        N = xyz.size(0)
+        lib = _lib.load()
+        with self.modifying_lock, torch.cuda.device(self.device):
+            torch.cuda.current_stream().wait_stream(self.meshing_stream)
+            prune = int(self.args.prune_min_vox_obs)
+            self._ensure_capacity(7 * (N // (prune + 1)) if prune > 0 else 7 * N)
+            if self._ws is None or self._ws_n < N:
+                nb = int(lib.dif_integrate_workspace_bytes(N))
+                if nb < 0:
+                    raise RuntimeError("dif_integrate_workspace_bytes failed")
+                self._ws = torch.empty((nb,), dtype=torch.uint8, device=self.device)
+                self._ws_n = N
+            mask = torch.empty((N,), dtype=torch.uint8, device=self.device)
+            w = self.model.packed.weights_struct(self.device)
+            _lib.check(lib.dif_integrate(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), _lib.ptr(nrm), N, _lib.ptr(mask),
+                                         _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "dif_integrate")
+        return mask.view(torch.bool) if int(self.args.prune_min_vox_obs) > 0 else None
+
+    def allocate_block(self, idx: torch.Tensor):
+        """reference `map.py:310-319`.  Slots are handed out in ASCENDING linear-id order (the only order the reference's
+        own caller ever passes, `map.py:383-387`)."""
+        if idx.ndimension() == 2 and idx.size(1) == 3:
+            idx = idx[:, 2] + self.n_xyz[-1] * idx[:, 1] + (self.n_xyz[-1] * self.n_xyz[-2]) * idx[:, 0]
+        idx = idx.to(self.device).long().contiguous()
+        rec = torch.zeros((idx.size(0), 32), dtype=torch.int32, device=self.device)
+        rec[:, 0] = idx.to(torch.int32)          # grid < 2^31 (checked in __init__), high word stays 0
+        self.merge_records(rec)
+
+    # ---- get_sdf ----------------------------------------------------------------------------------------------
+    def get_sdf(self, xyz: torch.Tensor):
+        """reference `map.py:559-579`: (N,3) -> sdf (M,), std (M,), valid_mask (N,) bool.  Values only: the autograd
+        graph w.r.t. xyz that the tracker differentiates through (tracker.py:186-192) is SURVEY.md row 8f-1."""
+        xyz = xyz.detach().contiguous().float()
+        _lib.require_cuda(xyz)
+        N = xyz.size(0)
+        dev = self.device
+        with torch.cuda.device(dev):
+            mask = torch.empty((N,), dtype=torch.uint8, device=dev)
+            sel = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
+            sdf = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
+            std = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
+            scratch = torch.empty((N + 4096,), dtype=torch.int32, device=dev)
+            w = self.model.packed.weights_struct(dev)
+            _lib.check(_lib.load().dif_query_sdf(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), N, _lib.ptr(mask), _lib.ptr(sel),
+                                                 _lib.ptr(sdf), _lib.ptr(std), None, _lib.ptr(scratch), _lib.stream_ptr()), "dif_query_sdf")
+        M = self._read_counters()["query_M"]
+        return sdf[:M], std[:M], mask.view(torch.bool)
+
+    # ---- extract ----------------------------------------------------------------------------------------------
+    def _extract_buffers(self, resolution: int, max_n_triangles: int):
+        R = 2 * resolution
+        max_vox = _next_pow2(max(self._n_occ_ub, 1024))
+        key = (resolution, max_vox, int(max_n_triangles))
+        if self._xbuf is None or self._xbuf[0] != key:
+            dev = self.device
+            T = int(max_n_triangles)
+            t = dict(valid_blocks=torch.empty((max_vox,), dtype=torch.long, device=dev),
+                     occ_slot=torch.empty((max_vox,), dtype=torch.int32, device=dev),
+                     low_sdf=torch.empty((max_vox, resolution ** 3), dtype=torch.float32, device=dev),
+                     low_std=torch.empty((max_vox, resolution ** 3), dtype=torch.float32, device=dev),
+                     cube_sdf=torch.empty((max_vox, R, R, R), dtype=torch.float32, device=dev),
+                     cube_std=torch.empty((max_vox, R, R, R), dtype=torch.float32, device=dev),
+                     refine_list=torch.empty((max_vox * R ** 3,), dtype=torch.int32, device=dev),
+                     tri_count=torch.empty((max_vox,), dtype=torch.int32, device=dev),
+                     tri_offset=torch.empty((max_vox,), dtype=torch.int32, device=dev),
+                     block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev),
+                     triangles=torch.empty((T, 3, 3), dtype=torch.float32, device=dev),
+                     triangle_flatten_id=torch.empty((T,), dtype=torch.long, device=dev),
+                     triangle_std=torch.empty((T, 3), dtype=torch.float32, device=dev))
+            b = _lib.DifExtractBuffers()
+            b.max_voxels = max_vox
+            b.max_triangles = T
+            for k, v in t.items():
+                setattr(b, k, _lib.ptr(v))
+            self._xbuf = (key, t, b)
+        return self._xbuf[1], self._xbuf[2]
+
+    def extract_mesh_arrays(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,
+                            no_cache: bool = False, to_host: bool = True):
+        """The body of `do_meshing` (`map.py:624-714`): returns the updated mesh cache arrays
+        (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64, vertices_std (T,3) f32), or None if nothing changed."""
+        lib = _lib.load()
+        with self.modifying_lock, torch.cuda.device(self.device):
+            if no_cache:
+                self.mesh_cache.clear_all()
+            tens, buf = self._extract_buffers(voxel_resolution, max_n_triangles)
+            w = self.model.packed.weights_struct(self.device)
+            _lib.check(lib.dif_extract(ctypes.byref(self._cmap), ctypes.byref(w), ctypes.byref(buf), int(voxel_resolution), 1 if fast else 0,
+                                       float(max_std), 1 if no_cache else 0, 1, _lib.stream_ptr()), "dif_extract")
+            c = self._read_counters()
+            T = c["T"]
+            if T >= max_n_triangles:
+                logging.warning(f"Warning from marching cube: the max triangle number is too small {T} vs {max_n_triangles}")
+                T = int(max_n_triangles)
+            if not to_host:
+                return tens["triangles"][:T], tens["triangle_flatten_id"][:T], tens["triangle_std"][:T]
+            if c["K"] == 0:
+                return None
+            vertices = tens["triangles"][:T].cpu().numpy()
+            vertices_std = tens["triangle_std"][:T].cpu().numpy()
+            vertices_flatten_id = tens["triangle_flatten_id"][:T].cpu().numpy()
+        mc = self.mesh_cache                                     # map.py:703-714
+        if mc.vertices is None:
+            mc.vertices, mc.vertices_flatten_id, mc.vertices_std = vertices, vertices_flatten_id, vertices_std
+        else:
+            p = np.unique(vertices_flatten_id)
+            keep = ~np.isin(mc.vertices_flatten_id, p)
+            mc.vertices = np.concatenate([mc.vertices[keep], vertices], axis=0)
+            mc.vertices_flatten_id = np.concatenate([mc.vertices_flatten_id[keep], vertices_flatten_id], axis=0)
+            mc.vertices_std = np.concatenate([mc.vertices_std[keep], vertices_std], axis=0)
+        return mc.vertices, mc.vertices_flatten_id, mc.vertices_std
+
+    def _make_mesh_from_cache(self):
+        """reference `map.py:521-543` with Open3D optional."""
+        if self.mesh_cache.vertices is None:
+            vertices = np.zeros((0, 3), dtype=float)
+            std = np.zeros((0,), dtype=float)
+        else:
+            vertices = self.mesh_cache.vertices.reshape((-1, 3)).astype(float)
+            std = self.mesh_cache.vertices_std.reshape((-1,)).astype(float)
+        triangles = np.arange(vertices.shape[0]).reshape((-1, 3)).astype(np.int32)
+        try:
+            import open3d as o3d
+        except ImportError:
+            return Mesh(vertices, triangles, std)
+        final_mesh = o3d.geometry.TriangleMesh()
+        final_mesh.vertices = o3d.utility.Vector3dVector(vertices)
+        final_mesh.triangles = o3d.utility.Vector3iVector(triangles)
+        if vertices.shape[0] > 0:
+            import matplotlib.cm
+            if self.extract_mesh_std_range is not None:
+                lo, hi = self.extract_mesh_std_range
+                std = np.clip(std, lo, hi)
+            else:
+                lo, hi = std.min(), std.max()
+            final_mesh.vertex_colors = o3d.utility.Vector3dVector(matplotlib.cm.jet((std - lo) / (hi - lo))[:, :3])
+        return final_mesh
+
+    def extract_mesh(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,
+                     extract_async: bool = False, no_cache: bool = False, interpolate: bool = True):
+        """reference `map.py:581-723` (same return protocol, including the async one)."""
+        if not interpolate:
+            raise NotImplementedError("only the interpolating marching cubes exists (as in the reference, map.py:693)")
+        if self.meshing_thread is not None:
+            if not self.meshing_thread.is_alive():
+                self.meshing_thread = None
+                self.meshing_thread_id = -1
+                return self._make_mesh_from_cache()
+            elif not extract_async:
+                self.meshing_thread.join()
+                return self._make_mesh_from_cache()
+            else:
+                return None
+
+        def do_meshing():
+            with torch.cuda.device(self.device):
+                self.meshing_stream.wait_stream(torch.cuda.default_stream(self.device))
+                with torch.cuda.stream(self.meshing_stream):
+                    self.extract_mesh_arrays(voxel_resolution, max_n_triangles, fast, max_std, no_cache)
+
+        if extract_async:
+            self.meshing_thread = threading.Thread(target=do_meshing, daemon=True)
+            self.meshing_thread.start()
+            self.meshing_thread_id = self.meshing_thread.ident
+            return None
+        self.extract_mesh_arrays(voxel_resolution, max_n_triangles, fast, max_std, no_cache)
+        return self._make_mesh_from_cache()
+
+    # ---- multi-GPU (no reference counterpart) ---------------------------------------------
+    def export_records(self) -> torch.Tensor:
+        """(n_occupied, 32) int32 records: lin id (2 words) | w | w*z[29]."""
+        n = self.n_occupied
+        rec = torch.empty((max(n, 1), 32), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().dif_export_records(ctypes.byref(self._cmap), _lib.ptr(rec), max(n, 1), _lib.stream_ptr()), "dif_export_records")
+        return rec[:n]
+
+    def merge_records(self, rec: torch.Tensor):
+        """Accumulate records with DISTINCT lin ids (one rank's export) into this map."""
+        rec = rec.contiguous()
+        n = rec.size(0)
+        if n == 0:
+            return
+        with self.modifying_lock, torch.cuda.device(self.device):
+            self._ensure_capacity(n)
+            scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
+            _lib.check(_lib.load().dif_merge_records(ctypes.byref(self._cmap), _lib.ptr(rec), n, _lib.ptr(scratch), _lib.stream_ptr()), "dif_merge_records")
+
+    # ---- visualisers: out of scope (need Open3D) ---------------------------------------
+    def get_fast_preview_visuals(self):
+        raise NotImplementedError("Open3D visualisers are outside the fusion hot path")
+
+    def get_map_visuals(self, *a, **k):
+        raise NotImplementedError("Open3D visualisers are outside the fusion hot path")

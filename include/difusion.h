@@ -1,0 +1,171 @@
+/*
+ * difusion.h — C ABI of libdifusion.so, the MI355X (gfx950) implementation of DI-Fusion's per-frame fusion path.
+ *
+ * This is the drop-in boundary: the entry points below are what the reference's four pybind11 torch extensions
+ * (`/root/reference/pytorch/system/ext/__init__.py:15-44`) plus the torch-op sequences of
+ * `pytorch/system/map.py` (integrate_keyframe :340-519, extract_mesh :581-723, get_sdf :559-579) bind to.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *   - all buffers are caller-owned (the Python façade allocates them as torch tensors); no hidden allocation;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, nothing synchronises except dif_read_counters();
+ *   - return 0 on success, a negative DIF_E* code on a bad argument / launch failure (no exceptions, no exit);
+ *   - element counts that are only known on the device (#voxels allocated, #rows gathered, #triangles) stay on the
+ *     device in `dif_counters_t`; kernels read them there, the host reads them only at the end of extract.
+ *
+ * Linear voxel id:  lin = z + nz*y + nz*ny*x  of  ceil((p - bound_min)/voxel_size) - 1   (map.py:287-292,366-369).
+ */
+#ifndef DIFUSION_H
+#define DIFUSION_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIF_VERSION 100          /* 0.1.0 */
+#define DIF_LATENT_DIM 29        /* ckpt/default/hyper.json:34 */
+
+#define DIF_OK 0
+#define DIF_EINVAL (-1)
+#define DIF_ELAUNCH (-2)
+#define DIF_ENOSPACE (-3)
+
+/* Device-resident counters (one per map).  int32 each; indices into the `counters` array. */
+enum {
+    DIF_C_N_OCCUPIED = 0,   /* map.py:200  n_occupied                                                   */
+    DIF_C_OVERFLOW = 1,     /* set !=0 when an allocation exceeded `capacity` (checked by the façade)     */
+    DIF_C_ALLOC_NEW = 2,    /* voxels allocated by the last integrate                                     */
+    DIF_C_M = 3,            /* gathered (point, offset) rows of the last integrate  (map.py:434-435)      */
+    DIF_C_C = 4,            /* voxels updated by the encoder in the last integrate  (map.py:437)          */
+    DIF_C_ITEMS = 5,        /* encoder work items of the last integrate                                   */
+    DIF_C_K = 6,            /* dirty voxels handed to marching cubes ("valid_blocks", map.py:627)         */
+    DIF_C_B = 7,            /* confident voxels decoded ("occupied_vec_id", map.py:631)                   */
+    DIF_C_VH = 8,           /* refine rows of the fast two-level decode (map.py:667)                      */
+    DIF_C_T = 9,            /* triangles produced (may exceed max_n_triangles, mc_interp_kernel.cu:369)   */
+    DIF_C_QUERY_M = 10,     /* valid points of the last get_sdf query (map.py:569-572)                    */
+    DIF_C_N_KEPT = 11,      /* points surviving the >prune_min_vox_obs filter (map.py:375)                */
+    DIF_C_COUNT = 16
+};
+
+/* The map: geometry + persistent state (map.py:177-211) + per-map scratch that is all-zero / all -1 between calls. */
+typedef struct dif_map {
+    int32_t nx, ny, nz;             /* map.py:178 */
+    float bound_min[3];             /* map.py:182 */
+    float voxel_size;               /* map.py:177 */
+    int32_t prune_min_vox_obs;      /* configs/fusion-lr-kt.yaml:33 */
+    float ignore_count_th;          /* :34 */
+    float encoder_count_th;         /* :35 */
+    int64_t capacity;               /* rows of latent_vecs / latent_vecs_pos / voxel_obs_count / dirty / vbm / seg_* */
+    int64_t* indexer;               /* [nx*ny*nz] slot or -1                    map.py:201 */
+    float* latent_vecs;             /* [capacity][29]                           map.py:204 */
+    int64_t* latent_vecs_pos;       /* [capacity] lin id or -1                  map.py:206 */
+    float* voxel_obs_count;         /* [capacity]                               map.py:208 */
+    uint8_t* dirty;                 /* [capacity] 1 = member of mesh_cache.updated_vec_id (map.py:303-308) */
+    int32_t* counters;              /* [DIF_C_COUNT] */
+    /* scratch, restored to its idle value by every call that touches it */
+    int32_t* frame_count;           /* [nx*ny*nz] idle 0  : points of the current frame per voxel (map.py:374) */
+    uint32_t* grid_bits;            /* [ceil(nx*ny*nz/32)] idle 0 : candidate / occupied voxel bitmap          */
+    int32_t* vbm;                   /* [capacity] idle -1 : vec_id_batch_mapping (map.py:633-635)              */
+    int32_t* seg_start;             /* [capacity] first sorted row of the slot's segment                       */
+    int32_t* seg_cnt;               /* [capacity] idle 0  : rows gathered for the slot (pcounts, map.py:439)   */
+    int32_t* item_start;            /* [capacity] first encoder work item of the slot                          */
+} dif_map_t;
+
+/* Network weights packed for the MFMA kernels by di_fusion_amd/network/packing.py (layout documented there). */
+typedef struct dif_weights {
+    const float* enc_packed;        /* encoder: BN-folded conv weights, per-lane float4 order */
+    int64_t enc_packed_floats;
+    const float* dec_packed;        /* decoder: weight-norm-folded linear weights */
+    int64_t dec_packed_floats;
+} dif_weights_t;
+
+int dif_version(void);
+
+/* ---- a1/a2: depth -> points (ext/imgproc/imgproc.cu:5-44, utils/motion_util.py:322-327) -------------------- */
+/* pc[v][u] = ((u-cx)/fx*d, (v-cy)/fy*d, d); NaN depth -> (NaN,NaN,NaN).  depth (H,W) f32 -> pc (H,W,3) f32.     */
+int dif_unproject(const float* depth, float* pc, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
+                  void* stream);
+/* Fused: unproject, then world = R*p + t and n_world = R*n_cam (R row-major 3x3 [host], t[3] [host]).
+ * normal_cam may be NULL.  Outputs (H*W,3); invalid pixels are NaN rows (masked out by integrate).              */
+int dif_unproject_transform(const float* depth, const float* normal_cam, float* xyz_world, float* normal_world,
+                            int32_t H, int32_t W, float fx, float fy, float cx, float cy,
+                            const float* R, const float* t, void* stream);
+/* ext/imgproc/imgproc.cu:98-160: pc (H,W,3) -> normal_weight (H,W,4), w=-1 where invalid. */
+int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, int32_t W, void* stream);
+
+/* ---- a9: ext/indexing/indexing.cu:89-109 ------------------------------------------------------------------- */
+/* sum[idx[i]][:] += values[i][:], count[idx[i]] += 1 (per sample).  sum (C,L) / count (C) must be zeroed by the
+ * caller.  Deterministic is not promised here (float atomics, as the reference); the map path does not use it.  */
+int dif_groupby_sum(const float* values, const int64_t* indices, int64_t N, int32_t L, float* sum, int32_t* count,
+                    int64_t C, void* stream);
+
+/* ---- a3..a10: integrate_keyframe (map.py:340-519, do_optimize=False) --------------------------------------- */
+/* Bytes of scratch `ws` needed for N points (includes the radix-sort temporary). */
+int64_t dif_integrate_workspace_bytes(int64_t N);
+/* xyz, normal: (N,3) f32.  unq_mask: (N) u8 out (map.py:375; all-valid-points when prune_min_vox_obs<=0).
+ * Points with NaN coordinates or outside [bound_min, bound_max) are masked out (the reference indexes out of
+ * bounds there, map.py:313; documented divergence). */
+int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N,
+                  uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- a11..a16: extract_mesh (map.py:581-723) ---------------------------------------------------------------- */
+typedef struct dif_extract_buffers {
+    int64_t max_voxels;             /* rows available in the per-voxel buffers below                      */
+    int64_t* valid_blocks;          /* [max_voxels]  lin ids of dirty voxels, ascending slot order (map.py:627) */
+    int32_t* occ_slot;              /* [max_voxels]  slots of the B decoded voxels, ascending lin id      */
+    float* low_sdf;                 /* [max_voxels][l^3]   l = resolution                                 */
+    float* low_std;
+    float* cube_sdf;                /* [max_voxels][R^3]   R = 2*resolution, NEGATED sdf (map.py:687)     */
+    float* cube_std;
+    int32_t* refine_list;           /* [max_voxels*R^3]   b*R^3 + sb of samples to re-decode (map.py:667) */
+    int32_t* tri_count;             /* [max_voxels] triangles per dirty voxel                             */
+    int32_t* tri_offset;            /* [max_voxels] exclusive prefix of tri_count                         */
+    int32_t* block_tmp;             /* [4096] scan scratch                                                */
+    int64_t max_triangles;          /* map.py:581 max_n_triangles                                         */
+    float* triangles;               /* [max_triangles][3][3]                                              */
+    int64_t* triangle_flatten_id;   /* [max_triangles]                                                    */
+    float* triangle_std;            /* [max_triangles][3]                                                 */
+} dif_extract_buffers_t;
+
+/* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
+ * exact re-decode where |sdf|<0.05; map.py:655-682) else all R^3 samples decoded; max_std (mc_interp_kernel.cu:304),
+ * no_cache!=0 re-meshes every allocated voxel (map.py:614-616), scale_vertices!=0 writes v*voxel_size+bound_min
+ * (map.py:698) instead of voxel units.  Triangles come out in canonical order (dirty voxel, cell, table order). */
+int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution,
+                int32_t fast, float max_std, int32_t no_cache, int32_t scale_vertices, void* stream);
+
+/* Flat marching cubes = ext/marching_cubes mc.cpp:3-16.  indexer (nx,ny,nz) i64, valid_blocks (K) i64,
+ * vec_batch_mapping (V) i32, cube_sdf/std (B,R,R,R) f32.  counters[DIF_C_T] receives the triangle count.      */
+int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t nz, const int64_t* valid_blocks,
+                       int64_t K, const int32_t* vec_batch_mapping, int64_t V, const float* cube_sdf,
+                       const float* cube_std, int32_t R, float max_std, int64_t max_triangles, float* triangles,
+                       int64_t* triangle_flatten_id, float* triangle_std, int32_t* tri_count, int32_t* tri_offset,
+                       int32_t* block_tmp, int32_t* counters, void* stream);
+
+/* ---- a13/a17: decoder on explicit rows (network/utility.py:61-126, map.py:559-579) -------------------------- */
+/* rows (n,32) = [latent 29 | xyz 3] -> sdf (n), std (n). */
+int dif_decode_rows(const dif_weights_t* w, const float* rows, int64_t n, float* sdf, float* std_out, void* stream);
+/* encoder on explicit rows (network/di_encoder.py:26-30): rows (n,6) -> out (n,29).  Test / ext entry point.   */
+int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float* out, void* stream);
+/* get_sdf: xyz (N,3) -> mask (N) u8, and for the M valid points IN ORDER: sdf (M), std (M), grad (M,3) = d sdf / d xyz
+ * in world units (NULL to skip), sel (M) = index of the point.  M -> counters[DIF_C_QUERY_M].
+ * scratch: int32 [N + 4096]. */
+int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, uint8_t* mask,
+                  int32_t* sel, float* sdf, float* std_out, float* grad, int32_t* scratch, void* stream);
+
+/* ---- multi-GPU map merge (no reference counterpart) ----------------------------------- */
+/* Pack the occupied voxels as records (lin i64 | w f32 | w*z f32[29]) = 32 x 4-byte words each; n -> counters[N_OCCUPIED]. */
+int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, void* stream);
+/* Accumulate `n` records (any order, duplicates allowed) into the map: allocate unseen voxels in ascending lin order,
+ * then w += w_r, z = (z*w + wz_r)/(w + w_r).  scratch: int32 [n + 4096]. */
+int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t* scratch, void* stream);
+
+/* Copy the counters to the host; the only synchronising call (hipStreamSynchronize on `stream`). */
+int dif_read_counters(const dif_map_t* map, int32_t* host_out /* [DIF_C_COUNT], host */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFUSION_H */

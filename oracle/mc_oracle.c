@@ -16,6 +16,7 @@
  * Build: gcc -O2 -fPIC -shared -std=c99 -ffp-contract=off -o libmc_oracle.so mc_oracle.c -lm
  */
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "mc_tables_oracle.inc"

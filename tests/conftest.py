@@ -1,0 +1,45 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a machine without a GPU must fail loudly, not silently skip: the product has no CPU fallback.
+    pass
+
+
+@pytest.fixture(scope="session")
+def raw_weights():
+    import numpy as np
+    return {k: v for k, v in np.load(GOLDEN / "weights_default.npz").items()}
+
+
+@pytest.fixture(scope="session")
+def oracle_net(raw_weights):
+    from oracle import difusion_oracle as O
+    return O.OracleNetworks(raw_weights)
+
+
+@pytest.fixture(scope="session")
+def gpu_model(raw_weights):
+    from di_fusion_amd.network import utility as net_util
+    return net_util.networks_from_arrays(raw_weights)

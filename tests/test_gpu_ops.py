@@ -1,0 +1,145 @@
+"""GPU parity of the flat ops (through the C ABI) against the oracle and the golden vectors of the reference."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_library_loaded_and_version():
+    from di_fusion_amd import _lib
+    assert _lib.load().dif_version() == 100
+
+
+def test_cpu_tensor_is_rejected(gpu_model):
+    from di_fusion_amd.system import ext
+    with pytest.raises(RuntimeError):
+        ext.unproject_depth(torch.zeros((4, 4)), 1.0, 1.0, 0.0, 0.0)
+
+
+def test_unproject_bit_exact():
+    from di_fusion_amd.system import ext
+    from oracle import difusion_oracle as O
+    g = np.random.default_rng(0)
+    d = (g.random((480, 640), dtype=np.float32) * 4 + 0.5).astype(np.float32)
+    d[g.random((480, 640)) < 0.1] = np.nan
+    got = ext.unproject_depth(_t(d), 481.2, 480.0, 319.5, 239.5).cpu().numpy()
+    want = O.unproject_depth(d, 481.2, 480.0, 319.5, 239.5)
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_unproject_transform_bit_exact():
+    from di_fusion_amd import _lib, synthetic as syn
+    import ctypes
+    intr = syn.Intrinsic()
+    R, t = syn.orbit_pose(7)
+    depth, ncam = syn.render_frame(syn.default_room(), R, t, intr)
+    H, W = depth.shape
+    xyz = torch.empty((H * W, 3), device=DEV); nrm = torch.empty((H * W, 3), device=DEV)
+    Rf = (ctypes.c_float * 9)(*[float(np.float32(v)) for v in R.reshape(-1)])
+    tf = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in t])
+    d, n = depth.to(DEV), ncam.to(DEV)
+    _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(d), _lib.ptr(n), _lib.ptr(xyz), _lib.ptr(nrm), H, W, intr.fx, intr.fy, intr.cx,
+                                                   intr.cy, Rf, tf, _lib.stream_ptr()), "unproject_transform")
+    ok = ~torch.isnan(xyz[:, 0])
+    want_xyz, want_nrm = syn.frame_points(syn.default_room(), 7, intr)
+    assert torch.equal(xyz[ok].cpu(), want_xyz)
+    assert torch.equal(nrm[ok].cpu(), want_nrm)
+
+
+def test_compute_normal_weight():
+    from di_fusion_amd.system import ext
+    from di_fusion_amd import synthetic as syn
+    from oracle import difusion_oracle as O
+    intr = syn.Intrinsic().scaled(0.1)
+    R, t = syn.orbit_pose(0)
+    depth, _ = syn.render_frame(syn.default_room(), R, t, intr)
+    pc = O.unproject_depth(depth.numpy(), intr.fx, intr.fy, intr.cx, intr.cy)
+    pc[np.isnan(pc)] = 0.0
+    got = ext.compute_normal_weight(_t(pc)).cpu().numpy()
+    want = O.compute_normal_weight(pc)
+    valid = want[..., 3] > 0
+    assert np.array_equal(got[..., 3] > 0, valid)
+    assert np.abs(got[valid] - want[valid]).max() / np.abs(want[valid]).max() < 1e-4
+    assert (got[~valid][:, 3] == -1).all()
+
+
+def test_groupby_sum():
+    from di_fusion_amd.system import ext
+    from oracle import difusion_oracle as O
+    g = np.random.default_rng(1)
+    vals = g.standard_normal((5000, 29)).astype(np.float32)
+    idx = g.integers(0, 37, 5000).astype(np.int64)
+    s, c = ext.groupby_sum(_t(vals), _t(idx), 37)
+    ws, wc = O.groupby_sum(vals, idx, 37)
+    assert np.array_equal(c.cpu().numpy(), wc)
+    assert np.abs(s.cpu().numpy() - ws).max() < 1e-3      # float atomics: order differs
+
+
+def test_decoder_rows_vs_golden(gpu_model):
+    g = np.load(GOLDEN / "networks.npz")
+    sdf, std = gpu_model.decoder(_t(g["dec_x"]))
+    ds = np.abs(sdf.cpu().numpy() - g["dec_sdf"]).max()
+    dd = np.abs(std.cpu().numpy() - g["dec_std"]).max()
+    print(f"decoder vs reference: sdf {ds:.3e} std {dd:.3e}")
+    assert ds < 1e-5 and dd < 1e-5           # stated tolerance: 1e-5 abs
+
+
+def test_decoder_rows_ragged_sizes(gpu_model, oracle_net):
+    g = np.random.default_rng(3)
+    for n in (1, 31, 32, 33, 1000, 4097):
+        x = np.concatenate([g.standard_normal((n, 29)) * 0.3, g.random((n, 3)) * 2 - 1], 1).astype(np.float32)
+        sdf, std = gpu_model.decoder(_t(x))
+        ws, wd = oracle_net.decoder(x)
+        assert np.abs(sdf.cpu().numpy() - ws).max() < 1e-5, n
+        assert np.abs(std.cpu().numpy() - wd).max() < 1e-5, n
+
+
+def test_encoder_rows_vs_golden(gpu_model):
+    g = np.load(GOLDEN / "networks.npz")
+    out = gpu_model.encoder(_t(g["enc_x"])).cpu().numpy()
+    d = np.abs(out - g["enc_out"]).max()
+    print(f"encoder vs reference: {d:.3e}")
+    assert d < 2e-5
+
+
+def test_marching_cubes_flat_vs_oracle_on_golden_cubes():
+    """The reference's own MC argument tuple (recorded by the golden generator) through both implementations."""
+    from di_fusion_amd.system import ext
+    from oracle import difusion_oracle as O
+    g = np.load(GOLDEN / "seq_small.npz")
+    n_xyz = g["n_xyz"].tolist()
+    for f in range(int(g["n_frames"])):
+        indexer = -np.ones(int(np.prod(n_xyz)), dtype=np.int64)
+        indexer[g[f"f{f}_int_indexer_nz"]] = g[f"f{f}_int_indexer_val"]
+        vb, vbm = g[f"f{f}_mc_valid_blocks"], g[f"f{f}_mc_vec_batch_mapping"]
+        cs, cd = g[f"f{f}_mc_cube_sdf"], g[f"f{f}_mc_cube_std"]
+        for max_std in (0.15, 2000.0):
+            wt, wi, ws = O.marching_cubes_interp(indexer.reshape(n_xyz), vb, vbm, cs, cd, int(4e6), n_xyz, max_std)
+            tri, tid, tstd = ext.marching_cubes_interp(_t(indexer.reshape(n_xyz)), _t(vb), _t(vbm), _t(cs), _t(cd), int(4e6), n_xyz, max_std)
+            assert tri.shape[0] == wt.shape[0], (f, max_std, tri.shape, wt.shape)
+            assert np.array_equal(tid.cpu().numpy(), wi)
+            assert np.abs(tri.cpu().numpy() - wt).max() < 1e-5
+            assert np.abs(tstd.cpu().numpy() - ws).max() < 1e-5
+        assert wt.shape[0] > 0
+
+
+def test_marching_cubes_empty_and_truncation():
+    from di_fusion_amd.system import ext
+    g = np.load(GOLDEN / "seq_small.npz")
+    n_xyz = g["n_xyz"].tolist()
+    indexer = -np.ones(int(np.prod(n_xyz)), dtype=np.int64)
+    indexer[g["f0_int_indexer_nz"]] = g["f0_int_indexer_val"]
+    vb, vbm = g["f0_mc_valid_blocks"], g["f0_mc_vec_batch_mapping"]
+    cs, cd = g["f0_mc_cube_sdf"], g["f0_mc_cube_std"]
+    tri, tid, tstd = ext.marching_cubes_interp(_t(indexer.reshape(n_xyz)), _t(vb[:0]), _t(vbm), _t(cs), _t(cd), 100, n_xyz, 0.15)
+    assert tri.shape[0] == 0
+    tri, tid, tstd = ext.marching_cubes_interp(_t(indexer.reshape(n_xyz)), _t(vb), _t(vbm), _t(cs), _t(cd), 50, n_xyz, 2000.0)
+    assert tri.shape[0] == 50
