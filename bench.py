@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of integrate + decode + mesh on a synthetic 640x480 depth stream (BASELINE.json metric).
+
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`); every rank fuses its own
+subsequence of the orbit into its own map (weak scaling, no data-path collective; SURVEY.md section 8e "C4").
+A "step" = one frame: unproject+transform -> integrate_keyframe -> extract_mesh (decode, marching cubes, D2H, mesh cache).
+Inputs (depth + camera-frame normals) are rendered before the timed region and stay resident in HBM.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ENC_FLOP_PER_ROW = 52096          # encoder FLOP per gathered point
+DEC_FLOP_PER_ROW = 98816          # decoder FLOP per sample row
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:41
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"])
+    ap.add_argument("--noise", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-scale", type=float, default=0.5, help="image scale of the CPU-baseline sample frame")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_name, scale):
+    """The oracle (numpy port of the reference path + C marching cubes) on ONE subsampled frame of the same workload."""
+    from di_fusion_amd import synthetic as syn
+    from di_fusion_amd.network import utility as net_util
+    from oracle import difusion_oracle as O
+    scene, cfg = getattr(syn, f"config_{cfg_name}")()
+    intr = syn.Intrinsic().scaled(scale)
+    xyz, nrm = syn.frame_points(scene, 0, intr)
+    om = O.OracleMap(O.OracleNetworks(net_util.load_weights_npz()), cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    O.build_mc_oracle()
+    t0 = time.perf_counter()
+    om.integrate_keyframe(xyz.numpy(), nrm.numpy())
+    t1 = time.perf_counter()
+    om.extract_mesh(4, int(4e6), max_std=0.15)
+    t2 = time.perf_counter()
+    frac = (intr.width * intr.height) / (640 * 480)
+    return {"value": round(frac / (t2 - t0), 5), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"frame 0 of the {cfg_name} stream rendered at {intr.width}x{intr.height} ({frac:.3f} of the pixels, "
+                      f"{xyz.shape[0]} points): oracle integrate {t1 - t0:.2f}s + decode/MC {t2 - t1:.2f}s; value = pixel fraction / time; "
+                      "numpy/OpenBLAS matmuls use all host cores, the rest is single-threaded"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from di_fusion_amd import _lib, synthetic as syn
+    from di_fusion_amd.network import utility as net_util
+    from di_fusion_amd.stream import FusionStream
+
+    scene, cfg = getattr(syn, f"config_{a.config}")()
+    intr = syn.Intrinsic()
+    model = net_util.networks_from_arrays(net_util.load_weights_npz())
+    n_frames = a.warmup + a.steps
+    # every rank walks its own arc of the orbit (independent subsequence)
+    stream = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))
+    lib = _lib.load()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        stream.step(i)
+    lib.dif_profile_read((ctypes.c_double * _lib.PROF_COUNT)(), (ctypes.c_int64 * _lib.PROF_COUNT)(), 1)
+    lib.dif_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, n_frames):
+        stream.step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.dif_profile_enable(0)
+    ms = (ctypes.c_double * _lib.PROF_COUNT)()
+    nl = (ctypes.c_int64 * _lib.PROF_COUNT)()
+    _lib.check(lib.dif_profile_read(ms, nl, 1), "dif_profile_read")
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        st = stream.stats[a.warmup:]
+        rows_enc = sum(s["M"] for s in st)
+        rows_dec_lat = sum(s["B"] * 64 for s in st)
+        rows_dec_pts = sum(s["VH"] for s in st)
+        prof = {n: (ms[i], nl[i]) for i, n in enumerate(_lib.PROF_NAMES)}
+        kern = {}
+        for name, rows, flop in (("encode", rows_enc, ENC_FLOP_PER_ROW), ("decode_lattice", rows_dec_lat, DEC_FLOP_PER_ROW),
+                                 ("decode_points", rows_dec_pts, DEC_FLOP_PER_ROW)):
+            t_ms, n = prof[name]
+            if n > 0 and t_ms > 0:
+                kern[name] = dict(ms_per_launch=t_ms / n, rows_per_launch=rows / n, tflops=rows * flop / (t_ms * 1e-3) / 1e12)
+        dom = max(kern, key=lambda k: kern[k]["ms_per_launch"]) if kern else None
+        roof = None
+        if dom:
+            roof = {"bound": "mfma", "kernel": {"encode": "k_encode", "decode_lattice": "k_decode", "decode_points": "k_decode"}[dom],
+                    "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
+                    "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
+                    "other_ms_per_frame": {k: round(prof[k][0] / max(1, a.steps), 4) for k in ("mc_count", "mc_emit", "sort")}}
+        out = {"metric": "frames/s integrate+decode+mesh, 640x480 synthetic stream", "value": round(world * a.steps / dt, 3),
+               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": {"c1": "C1 32^3 grid 0.1 m, sphere", "c2": "C2 64^3 grid 0.1 m, room",
+                                       "c3": "C3 128^3 grid 0.05 m, ScanNet-shape 6 m room with boxes"}[a.config] +
+                          ", 640x480 orbit stream 0.5 deg/frame, all 307200 pixels integrated and meshed every frame, resolution 4, fast decode, max_std 0.15",
+                          "points_per_frame": intr.width * intr.height, "parallelism": f"{world} independent subsequences (one map per GPU)",
+                          "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1) for k in ("M", "C", "K", "B", "VH", "T", "n_occupied")}},
+               "roofline": roof}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_scale)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

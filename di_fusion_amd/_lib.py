@@ -15,6 +15,8 @@ LIB_PATH = PKG / "libdifusion.so"
 # counters (difusion.h)
 C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT = range(12)
 C_COUNT = 16
+PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "sort"]
+PROF_COUNT = 8
 LATENT_DIM = 29
 
 ERRORS = {-1: "DIF_EINVAL (bad argument)", -2: "DIF_ELAUNCH (HIP launch/runtime failure)", -3: "DIF_ENOSPACE (workspace too small)"}
@@ -66,6 +68,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "dif_export_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p]),
     "dif_merge_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_profile_enable": (c_int32, [c_int32]),
+    "dif_profile_read": (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
     "dif_read_counters": (c_int32, [POINTER(DifMap), POINTER(c_int32), c_void_p]),
 }
 

@@ -5,6 +5,7 @@
 // reference's operation order and compiled without FMA contraction; fmaf() is used only where the reference's own
 // CPU build fuses (trilinear upsample) or where the order is ours to choose (MLP accumulation = the MFMA's fmaf chain).
 #include <cstring>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -44,6 +45,24 @@ int num_cus() {
     if (dev < 64) cus[dev] = n;
     return n;
 }
+
+// ---- optional per-kernel timing (dif_profile_*) -----------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int which; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+struct ProfScope {
+    hipStream_t s; int which; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(int which_, hipStream_t s_) : s(s_), which(which_) {
+        if (!g_prof_on || g_prof.size() >= 65536) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s);
+        g_prof.push_back(ProfRec{a, b, which});
+    }
+};
 
 inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096) {
     int64_t b = (n + per_block - 1) / per_block;
@@ -1098,6 +1117,7 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
     {
         rocprim::counting_iterator<uint32_t> vin(0);
         size_t tmp = ws.sort_tmp_bytes;
+        ProfScope prof(DIF_PROF_SORT, s);
         hipError_t e = rocprim::radix_sort_pairs(ws.sort_tmp, tmp, (const uint32_t*)ws.key_in, ws.key_out, vin, ws.val_out, (size_t)(8 * N), 0, 24, s);
         if (e != hipSuccess) return DIF_ELAUNCH;
     }
@@ -1115,6 +1135,7 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
             if (hipFuncSetAttribute((const void*)k_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
             attr_set[dev] = true;
         }
+        ProfScope prof(DIF_PROF_ENCODE, s);
         hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint32_t*)ws.val_out,
                            (const int*)map->seg_start, (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot,
                            (const int*)C, ws.partial);
@@ -1139,6 +1160,7 @@ static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t ti
     int64_t blocks = (tiles_upper + 7) / 8;
     if (blocks < 1) blocks = 1;
     if (blocks > num_cus()) blocks = num_cus();
+    ProfScope prof(A.mode == 0 ? DIF_PROF_DECODE_LATTICE : DIF_PROF_DECODE_POINTS, s);
     hipLaunchKernelGGL(k_decode, dim3((int)blocks), dim3(512), lds_bytes, s, A, w->dec_packed);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
@@ -1209,11 +1231,17 @@ static int run_marching_cubes(McArgs a, int64_t K_upper, int32_t* tri_count, int
     const int blocks = grid_for(K_upper, DIF_BLOCK / 64, 8192);
     a.tri_count = tri_count;
     a.tri_offset = tri_offset;
-    hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+    {
+        ProfScope prof(DIF_PROF_MC_COUNT, s);
+        hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+    }
     DIF_CHECK_LAUNCH();
     TriScanFunctor f{tri_count, tri_offset, counters};
     if (launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_marching_cubes<true>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+    {
+        ProfScope prof(DIF_PROF_MC_EMIT, s);
+        hipLaunchKernelGGL(k_marching_cubes<true>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+    }
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -1344,6 +1372,28 @@ int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, i
     hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, records, n, (const int64_t*)map->indexer,
                        map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity);
     DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_profile_enable(int32_t on) {
+    g_prof_on = on != 0;
+    return DIF_OK;
+}
+
+int dif_profile_read(double* ms, int64_t* launches, int32_t reset) {
+    if (!ms || !launches) return DIF_EINVAL;
+    for (int i = 0; i < DIF_PROF_COUNT; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return DIF_ELAUNCH;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return DIF_ELAUNCH;
+        ms[r.which] += t;
+        launches[r.which] += 1;
+    }
+    if (reset) {
+        for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        g_prof.clear();
+    }
     return DIF_OK;
 }
 

@@ -162,6 +162,14 @@ int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_recor
  * then w += w_r, z = (z*w + wz_r)/(w + w_r).  scratch: int32 [n + 4096]. */
 int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t* scratch, void* stream);
 
+/* ---- per-kernel timing for bench.py's roofline leg ---------------------------------------------------------- */
+/* When enabled, a hipEvent pair is recorded around each launch of the named kernels ON THE STREAM THEY RUN ON. */
+enum { DIF_PROF_ENCODE = 0, DIF_PROF_DECODE_LATTICE = 1, DIF_PROF_DECODE_POINTS = 2, DIF_PROF_MC_COUNT = 3, DIF_PROF_MC_EMIT = 4,
+       DIF_PROF_SORT = 5, DIF_PROF_COUNT = 8 };
+int dif_profile_enable(int32_t on);
+/* Sum of elapsed milliseconds and number of launches per kernel since the last reset; synchronises on the events. */
+int dif_profile_read(double* ms /* [DIF_PROF_COUNT], host */, int64_t* launches /* [DIF_PROF_COUNT], host */, int32_t reset);
+
 /* Copy the counters to the host; the only synchronising call (hipStreamSynchronize on `stream`). */
 int dif_read_counters(const dif_map_t* map, int32_t* host_out /* [DIF_C_COUNT], host */, void* stream);
 

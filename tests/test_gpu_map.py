@@ -113,26 +113,37 @@ def test_sequence_vs_golden_and_oracle(name, gpu_model, oracle_net):
     assert np.abs(std.cpu().numpy() - g["probe_std"]).max() < SDF_TOL
 
 
-def test_mesh_cache_replace_by_voxel(gpu_model):
-    """map.py:703-714: triangles of re-meshed voxels are replaced, the rest of the cache is kept."""
+def test_mesh_cache_replace_by_voxel(gpu_model, oracle_net):
+    """map.py:703-714: triangles of voxels that produced new triangles are replaced, the rest of the cache is kept
+    (including the reference's quirk that a re-meshed voxel which now yields NO triangle keeps its stale ones)."""
+    from oracle import difusion_oracle as O
     scene, cfg, intr = CASES["seq_small"]
     g = np.load(GOLDEN / "seq_small.npz")
     m = make_map(gpu_model, cfg)
-    total = None
+    om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    cache = None
     for f in range(3):
         xyz, nrm = frame_inputs(g, "seq_small", f)
         m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+        om.integrate_keyframe(xyz, nrm)
         v, vid, vs = m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+        ov, oid, ostd = om.extract_mesh(4, int(4e6), max_std=0.15)
+        if cache is None:
+            cache = [ov, oid, ostd]
+        else:                                                     # the reference's host-side rule, restated
+            keep = ~np.isin(cache[1], np.unique(oid))
+            cache = [np.concatenate([cache[0][keep], ov]), np.concatenate([cache[1][keep], oid]), np.concatenate([cache[2][keep], ostd])]
         assert v.shape[0] == vid.shape[0] == vs.shape[0]
-    # a full re-extraction from scratch must give the same set of triangles as the incremental cache
-    inc = (v.copy(), vid.copy())
-    v2, vid2, _ = m.extract_mesh_arrays(4, int(4e6), max_std=0.15, no_cache=True)
-    a, b = sort_tris(inc[0], inc[1]), sort_tris(v2, vid2)
-    assert inc[0].shape == v2.shape
-    assert np.array_equal(inc[1][a], vid2[b])
-    assert np.abs(inc[0][a] - v2[b]).max() < 1e-6
+        # the oracle's fast-decode may flip a threshold sample, so compare as sets with a small slack
+        assert abs(v.shape[0] - cache[0].shape[0]) <= 8, (f, v.shape, cache[0].shape)
+        if v.shape[0] == cache[0].shape[0]:
+            a, b = sort_tris(v, vid), sort_tris(cache[0], cache[1])
+            assert np.array_equal(vid[a], cache[1][b])
+            close = np.abs(v[a] - cache[0][b]).reshape(len(a), -1).max(axis=1) < VERT_TOL * cfg.voxel_size
+            assert close.mean() > 0.99, close.mean()
+    assert len(np.unique(vid)) > 10
     mesh = m.extract_mesh(4, int(4e6), max_std=0.15)
-    assert mesh is not None
+    assert mesh is not None and mesh.triangles.shape[0] == v.shape[0]
 
 
 def test_edge_cases(gpu_model):
@@ -161,7 +172,10 @@ def test_capacity_growth_and_save_load(gpu_model, tmp_path):
     for f in range(2):
         xyz, nrm = frame_inputs(g, "seq_room16", f)
         m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
-    check_state(m, g, 1)
+        check_state(m, g, f)
+        if f == 0:
+            m.extract_mesh_arrays(4, int(4e6), max_std=0.15)      # the golden sequence meshes (and clears the dirty set) every frame
+            m._alloc_state(2048)                                    # grow mid-sequence: state must survive the re-allocation
     m.save(tmp_path / "map.pt")
     m2 = make_map(gpu_model, cfg)
     m2.load(tmp_path / "map.pt")
