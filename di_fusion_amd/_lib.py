@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libdifusion.so"
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT = range(12)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT = range(14)
 C_COUNT = 16
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "sort"]
 PROF_COUNT = 8
@@ -42,8 +42,9 @@ class DifExtractBuffers(Structure):
     _fields_ = [("max_voxels", c_int64), ("valid_blocks", c_void_p), ("occ_slot", c_void_p),
                 ("low_sdf", c_void_p), ("low_std", c_void_p), ("cube_sdf", c_void_p), ("cube_std", c_void_p),
                 ("refine_list", c_void_p), ("tri_count", c_void_p), ("tri_offset", c_void_p), ("block_tmp", c_void_p),
-                ("max_triangles", c_int64), ("triangles", c_void_p), ("triangle_flatten_id", c_void_p),
-                ("triangle_std", c_void_p)]
+                ("max_triangles", c_int64), ("cache_capacity", c_int64),
+                ("cache_src_tri", c_void_p), ("cache_src_id", c_void_p), ("cache_src_std", c_void_p),
+                ("cache_dst_tri", c_void_p), ("cache_dst_id", c_void_p), ("cache_dst_std", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)

@@ -715,6 +715,8 @@ struct McArgs {
     int64_t max_triangles;
     float* triangles; int64_t* tri_id; float* tri_std;
     int32_t* tri_count; const int32_t* tri_offset;
+    const int* base_ptr;            // device: first output triangle index (mesh-cache append), or NULL
+    int64_t new_limit;              // triangles this call may emit (max_n_triangles)
     int scale; float vs, bx, by, bz;
 };
 
@@ -857,11 +859,12 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
             const int incl = wave_incl_scan(ntri);
             const int chunk_total = __shfl(incl, 63);
             if (EMIT && ntri > 0) {
-                int64_t t = (int64_t)a.tri_offset[k] + voxel_total + (incl - ntri);
+                int64_t tl = (int64_t)a.tri_offset[k] + voxel_total + (incl - ntri);      // index among this call's triangles
+                int64_t t = tl + (a.base_ptr ? (int64_t)(*a.base_ptr) : 0);
                 for (int i = 0; c_mc_tri_table[cube_type][i] != -1; i += 3) {
                     V4 v0 = vl[c_mc_tri_table[cube_type][i]], v1 = vl[c_mc_tri_table[cube_type][i + 1]], v2 = vl[c_mc_tri_table[cube_type][i + 2]];
                     if (v0.w > a.max_std || v1.w > a.max_std || v2.w > a.max_std) continue;
-                    if (t < a.max_triangles) {
+                    if (tl < a.new_limit && t < a.max_triangles) {
                         V4 vv[3] = {v0, v1, v2};
 #pragma unroll
                         for (int vi = 0; vi < 3; ++vi) {
@@ -874,7 +877,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
                         }
                         a.tri_id[t] = vb;
                     }
-                    ++t;
+                    ++t; ++tl;
                 }
             }
             voxel_total += chunk_total;
@@ -882,6 +885,39 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
         if (!EMIT && lane == 0) a.tri_count[k] = voxel_total;
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// ---- a16 : device-resident mesh cache (map.py:703-714) ---------------------------------------------------------------
+// flag (in the frame_count scratch grid) the voxels that produced at least one new triangle
+__global__ void __launch_bounds__(DIF_BLOCK) k_cache_flag(const int64_t* __restrict__ valid_blocks, const int32_t* __restrict__ tri_count,
+                                                        int* __restrict__ flags, const int* __restrict__ counters, int value) {
+    const int K = counters[DIF_C_K];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
+        if (tri_count[k] > 0) flags[valid_blocks[k]] = value;
+}
+
+struct CacheCompactFunctor {    // ordered compaction: keep cached triangles whose voxel got no new triangle
+    const float* src_tri; const int64_t* src_id; const float* src_std;
+    float* dst_tri; int64_t* dst_id; float* dst_std;
+    const int* flags;
+    int* counters;
+    __device__ int count(int t) const { return flags[src_id[t]] ? 0 : 1; }
+    __device__ void emit(int t, int offset) const {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst_tri[(int64_t)offset * 9 + i] = src_tri[(int64_t)t * 9 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dst_std[(int64_t)offset * 3 + i] = src_std[(int64_t)t * 3 + i];
+        dst_id[offset] = src_id[t];
+    }
+    __device__ void finish(int total) const { counters[DIF_C_CACHE_KEPT] = total; }
+};
+
+__global__ void k_cache_finish(int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
+    int64_t n_new = counters[DIF_C_T];
+    if (n_new > new_limit) n_new = new_limit;
+    int64_t tot = (int64_t)counters[DIF_C_CACHE_KEPT] + n_new;
+    if (tot > capacity) { tot = capacity; counters[DIF_C_OVERFLOW] = 5; }
+    counters[DIF_C_CACHE_T] = (int)tot;
 }
 
 struct TriScanFunctor {
@@ -1223,12 +1259,19 @@ int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float*
 }
 
 // ---- marching cubes --------------------------------------------------------------------------------------------
-static int run_marching_cubes(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
+static int mc_setup(const McArgs& a, size_t& lds_bytes, int& blocks, int64_t K_upper) {
     if (upload_tables() != DIF_OK) return DIF_ELAUNCH;
     const int r = a.R / 2, nc = (r + 1) * (r + 1) * (r + 1);
-    const size_t lds_bytes = (size_t)(DIF_BLOCK / 64) * (2 * nc + 32) * sizeof(float);
+    lds_bytes = (size_t)(DIF_BLOCK / 64) * (2 * nc + 32) * sizeof(float);
     if (lds_bytes > 64 * 1024) return DIF_EINVAL;
-    const int blocks = grid_for(K_upper, DIF_BLOCK / 64, 8192);
+    blocks = grid_for(K_upper, DIF_BLOCK / 64, 8192);
+    return DIF_OK;
+}
+
+static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
+    size_t lds_bytes; int blocks;
+    int rc = mc_setup(a, lds_bytes, blocks, K_upper);
+    if (rc != DIF_OK) return rc;
     a.tri_count = tri_count;
     a.tri_offset = tri_offset;
     {
@@ -1237,13 +1280,27 @@ static int run_marching_cubes(McArgs a, int64_t K_upper, int32_t* tri_count, int
     }
     DIF_CHECK_LAUNCH();
     TriScanFunctor f{tri_count, tri_offset, counters};
-    if (launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    return launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s);
+}
+
+static int mc_emit(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, hipStream_t s) {
+    size_t lds_bytes; int blocks;
+    int rc = mc_setup(a, lds_bytes, blocks, K_upper);
+    if (rc != DIF_OK) return rc;
+    a.tri_count = tri_count;
+    a.tri_offset = tri_offset;
     {
         ProfScope prof(DIF_PROF_MC_EMIT, s);
         hipLaunchKernelGGL(k_marching_cubes<true>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
     }
     DIF_CHECK_LAUNCH();
     return DIF_OK;
+}
+
+static int run_marching_cubes(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
+    int rc = mc_count_and_scan(a, K_upper, tri_count, tri_offset, block_tmp, counters, s);
+    if (rc != DIF_OK) return rc;
+    return mc_emit(a, K_upper, tri_count, tri_offset, s);
 }
 
 int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t nz, const int64_t* valid_blocks, int64_t K,
@@ -1258,7 +1315,8 @@ int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t n
     McArgs a = {};
     a.indexer = indexer; a.nx = nx; a.ny = ny; a.nz = nz; a.valid_blocks = valid_blocks; a.K_ptr = nullptr; a.K_static = K;
     a.vbm = vec_batch_mapping; a.V = V; a.cube_sdf = cube_sdf; a.cube_std = cube_std; a.R = R; a.max_std = max_std;
-    a.max_triangles = max_triangles; a.triangles = triangles; a.tri_id = triangle_flatten_id; a.tri_std = triangle_std; a.scale = 0;
+    a.max_triangles = max_triangles; a.new_limit = max_triangles; a.base_ptr = nullptr;
+    a.triangles = triangles; a.tri_id = triangle_flatten_id; a.tri_std = triangle_std; a.scale = 0;
     return run_marching_cubes(a, K, tri_count, tri_offset, block_tmp, counters, s);
 }
 
@@ -1266,6 +1324,7 @@ int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t n
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                 float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
+    if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_dst_tri || !buf->cache_src_tri) return DIF_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     Geo g = geo_of(map);
@@ -1321,10 +1380,28 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     McArgs a = {};
     a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
     a.vbm = map->vbm; a.V = map->capacity; a.cube_sdf = buf->cube_sdf; a.cube_std = buf->cube_std; a.R = R; a.max_std = max_std;
-    a.max_triangles = buf->max_triangles; a.triangles = buf->triangles; a.tri_id = buf->triangle_flatten_id; a.tri_std = buf->triangle_std;
+    a.max_triangles = buf->cache_capacity; a.new_limit = buf->max_triangles; a.base_ptr = C + DIF_C_CACHE_KEPT;
+    a.triangles = buf->cache_dst_tri; a.tri_id = buf->cache_dst_id; a.tri_std = buf->cache_dst_std;
     a.scale = scale_vertices ? 1 : 0; a.vs = map->voxel_size; a.bx = map->bound_min[0]; a.by = map->bound_min[1]; a.bz = map->bound_min[2];
-    rc = run_marching_cubes(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s);
+    if (no_cache && hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;       // map.py:614-616
+    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s);
     if (rc != DIF_OK) return rc;
+    // mesh cache: keep the triangles of voxels that got no new triangle, then append the new ones (map.py:703-714)
+    const int flag_blocks = grid_for(buf->max_voxels, DIF_BLOCK, 1024);
+    hipLaunchKernelGGL(k_cache_flag, dim3(flag_blocks), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks, (const int32_t*)buf->tri_count,
+                       map->frame_count, (const int*)C, 1);
+    DIF_CHECK_LAUNCH();
+    {
+        CacheCompactFunctor f{buf->cache_src_tri, buf->cache_src_id, buf->cache_src_std, buf->cache_dst_tri, buf->cache_dst_id, buf->cache_dst_std,
+                              map->frame_count, C};
+        if (launch_scan(f, C + DIF_C_CACHE_T, 0, buf->cache_capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    }
+    rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
+    if (rc != DIF_OK) return rc;
+    hipLaunchKernelGGL(k_cache_flag, dim3(flag_blocks), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks, (const int32_t*)buf->tri_count,
+                       map->frame_count, (const int*)C, 0);
+    hipLaunchKernelGGL(k_cache_finish, dim3(1), dim3(1), 0, s, C, buf->max_triangles, buf->cache_capacity);
+    DIF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_reset_vbm, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm, (const int*)C);
     DIF_CHECK_LAUNCH();
     return DIF_OK;

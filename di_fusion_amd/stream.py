@@ -37,9 +37,12 @@ class FusionStream:
         self.xyz = torch.empty((H * W, 3), dtype=torch.float32, device=device)
         self.nrm = torch.empty((H * W, 3), dtype=torch.float32, device=device)
         self.stats = []
+        self._pin = None
 
-    def step(self, i: int, to_host: bool = True):
-        """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16)."""
+    def step(self, i: int, d2h: str = "new"):
+        """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
+        d2h: "none" leaves the mesh in HBM; "new" copies this frame's new triangles to pinned host memory (async);
+        "full" copies the whole merged cache to the host like the reference's numpy cache."""
         intr = self.intr
         R, t = self.poses[i]
         with torch.cuda.device(self.device):
@@ -47,6 +50,17 @@ class FusionStream:
                                                            intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
                        "dif_unproject_transform")
         self.map.integrate_keyframe(self.xyz, self.nrm)
-        out = self.map.extract_mesh_arrays(self.resolution, self.max_n_triangles, max_std=self.max_std, to_host=to_host)
+        out = self.map.extract_mesh_arrays(self.resolution, self.max_n_triangles, max_std=self.max_std, to_host=(d2h == "full"))
+        if d2h == "new" and out is not None:
+            tri, tid, tstd = self.map.mesh_cache_tensors(new_only=True)
+            n = tri.size(0)
+            if self._pin is None or self._pin[0].size(0) < n:
+                cap = max(1 << 18, 2 * n)
+                self._pin = (torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
+                             torch.empty((cap, 3), dtype=torch.float32).pin_memory())
+            self._pin[0][:n].copy_(tri, non_blocking=True)
+            self._pin[1][:n].copy_(tid, non_blocking=True)
+            self._pin[2][:n].copy_(tstd, non_blocking=True)
+            out = (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
         self.stats.append(dict(self.map.last_counters))
         return out

@@ -30,18 +30,42 @@ from ..network import utility as net_util
 
 
 class MeshExtractCache:
-    """reference `map.py:116-133`; `updated_vec_id` lives on the GPU as a dirty flag per slot."""
+    """reference `map.py:116-133`.  The three arrays live in HBM (two ping-pong buffer sets maintained by `dif_extract`,
+    same content and ORDER as the reference's host arrays); the attributes copy them to the host on demand.
+    `updated_vec_id` is a dirty flag per slot on the GPU (`DenseIndexedMap.updated_vec_id`)."""
 
-    def __init__(self, device):
-        self.vertices = None
-        self.vertices_flatten_id = None
-        self.vertices_std = None
+    def __init__(self, device, owner=None):
         self.device = device
+        self._owner = owner
+        self._host = None
+
+    def _fetch(self):
+        if self._host is None:
+            t = self._owner.mesh_cache_tensors()
+            self._host = None if t is None else tuple(x.cpu().numpy() for x in t)
+        return self._host
+
+    @property
+    def vertices(self):
+        h = self._fetch()
+        return None if h is None else h[0]
+
+    @property
+    def vertices_flatten_id(self):
+        h = self._fetch()
+        return None if h is None else h[1]
+
+    @property
+    def vertices_std(self):
+        h = self._fetch()
+        return None if h is None else h[2]
+
+    def invalidate_host_copy(self):
+        self._host = None
 
     def clear_all(self):
-        self.vertices = None
-        self.vertices_flatten_id = None
-        self.vertices_std = None
+        self._host = None
+        self._owner._cache_clear()
 
 
 class Mesh:
@@ -85,7 +109,10 @@ class DenseIndexedMap:
         self.meshing_thread = None
         self.meshing_thread_id = -1
         self.meshing_stream = torch.cuda.Stream(device=device)
-        self.mesh_cache = MeshExtractCache(self.device)
+        self.mesh_cache = MeshExtractCache(self.device, self)
+        self._cache = None                  # [set0, set1] of (tri, id, std) device buffers
+        self._cache_cur = 0
+        self._cache_any = False             # an extract has produced a cache
 
         self._grid = int(np.prod(self.n_xyz))
         if self._grid >= 2 ** 31:
@@ -157,7 +184,8 @@ class DenseIndexedMap:
         self._n_occ_ub = c[_lib.C_N_OCCUPIED]
         self.last_counters = dict(n_occupied=c[_lib.C_N_OCCUPIED], alloc_new=c[_lib.C_ALLOC_NEW], M=c[_lib.C_M], C=c[_lib.C_C],
                                   items=c[_lib.C_ITEMS], K=c[_lib.C_K], B=c[_lib.C_B], VH=c[_lib.C_VH], T=c[_lib.C_T],
-                                  query_M=c[_lib.C_QUERY_M], n_kept=c[_lib.C_N_KEPT])
+                                  query_M=c[_lib.C_QUERY_M], n_kept=c[_lib.C_N_KEPT], cache_T=c[_lib.C_CACHE_T],
+                                  cache_kept=c[_lib.C_CACHE_KEPT])
         return self.last_counters
 
     def _ensure_capacity(self, may_add: int):
@@ -295,13 +323,39 @@ class DenseIndexedMap:
         return sdf[:M], std[:M], mask.view(torch.bool)
 
     # ---- extract ----------------------------------------------------------------------------------------------
+    def _ensure_cache(self, capacity: int):
+        dev = self.device
+        if self._cache is not None and self._cache[0][0].size(0) >= capacity:
+            return
+        new = [(torch.empty((capacity, 3, 3), dtype=torch.float32, device=dev), torch.empty((capacity,), dtype=torch.long, device=dev),
+                torch.empty((capacity, 3), dtype=torch.float32, device=dev)) for _ in range(2)]
+        if self._cache is not None:
+            old = self._cache[self._cache_cur]
+            n = old[0].size(0)
+            for a, b in zip(new[self._cache_cur], old):
+                a[:n] = b
+        self._cache = new
+
+    def _cache_clear(self):
+        self._counters[_lib.C_CACHE_T] = 0
+        self._cache_any = False
+
+    def mesh_cache_tensors(self, new_only: bool = False):
+        """Device views of the mesh cache: (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64, vertices_std (T,3));
+        `new_only` restricts to the triangles produced by the last extract.  None before the first extract."""
+        if not self._cache_any:
+            return None
+        c = self.last_counters
+        lo, hi = (c["cache_kept"] if new_only else 0), c["cache_T"]
+        tri, tid, tstd = self._cache[self._cache_cur]
+        return tri[lo:hi], tid[lo:hi], tstd[lo:hi]
+
     def _extract_buffers(self, resolution: int, max_n_triangles: int):
         R = 2 * resolution
         max_vox = _next_pow2(max(self._n_occ_ub, 1024))
-        key = (resolution, max_vox, int(max_n_triangles))
+        key = (resolution, max_vox)
         if self._xbuf is None or self._xbuf[0] != key:
             dev = self.device
-            T = int(max_n_triangles)
             t = dict(valid_blocks=torch.empty((max_vox,), dtype=torch.long, device=dev),
                      occ_slot=torch.empty((max_vox,), dtype=torch.int32, device=dev),
                      low_sdf=torch.empty((max_vox, resolution ** 3), dtype=torch.float32, device=dev),
@@ -311,51 +365,44 @@ class DenseIndexedMap:
                      refine_list=torch.empty((max_vox * R ** 3,), dtype=torch.int32, device=dev),
                      tri_count=torch.empty((max_vox,), dtype=torch.int32, device=dev),
                      tri_offset=torch.empty((max_vox,), dtype=torch.int32, device=dev),
-                     block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev),
-                     triangles=torch.empty((T, 3, 3), dtype=torch.float32, device=dev),
-                     triangle_flatten_id=torch.empty((T,), dtype=torch.long, device=dev),
-                     triangle_std=torch.empty((T, 3), dtype=torch.float32, device=dev))
-            b = _lib.DifExtractBuffers()
-            b.max_voxels = max_vox
-            b.max_triangles = T
-            for k, v in t.items():
-                setattr(b, k, _lib.ptr(v))
-            self._xbuf = (key, t, b)
-        return self._xbuf[1], self._xbuf[2]
+                     block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev))
+            self._xbuf = (key, t)
+        t = self._xbuf[1]
+        self._ensure_cache(max(int(max_n_triangles), 1 << 16))
+        b = _lib.DifExtractBuffers()
+        b.max_voxels = max_vox
+        b.max_triangles = int(max_n_triangles)
+        for k, v in t.items():
+            setattr(b, k, _lib.ptr(v))
+        src, dst = self._cache[self._cache_cur], self._cache[1 - self._cache_cur]
+        b.cache_capacity = src[0].size(0)
+        b.cache_src_tri, b.cache_src_id, b.cache_src_std = _lib.ptr(src[0]), _lib.ptr(src[1]), _lib.ptr(src[2])
+        b.cache_dst_tri, b.cache_dst_id, b.cache_dst_std = _lib.ptr(dst[0]), _lib.ptr(dst[1]), _lib.ptr(dst[2])
+        return t, b
 
     def extract_mesh_arrays(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,
                             no_cache: bool = False, to_host: bool = True):
-        """The body of `do_meshing` (`map.py:624-714`): returns the updated mesh cache arrays
-        (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64, vertices_std (T,3) f32), or None if nothing changed."""
+        """The body of `do_meshing` (`map.py:624-714`): decode the dirty neighbourhood, run marching cubes, merge into the mesh
+        cache.  Returns the mesh cache arrays (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64,
+        vertices_std (T,3) f32) as numpy (`to_host`) or as device views; None while the cache is empty and nothing was dirty."""
         lib = _lib.load()
         with self.modifying_lock, torch.cuda.device(self.device):
-            if no_cache:
-                self.mesh_cache.clear_all()
             tens, buf = self._extract_buffers(voxel_resolution, max_n_triangles)
             w = self.model.packed.weights_struct(self.device)
             _lib.check(lib.dif_extract(ctypes.byref(self._cmap), ctypes.byref(w), ctypes.byref(buf), int(voxel_resolution), 1 if fast else 0,
                                        float(max_std), 1 if no_cache else 0, 1, _lib.stream_ptr()), "dif_extract")
+            self._cache_cur = 1 - self._cache_cur
+            self.mesh_cache.invalidate_host_copy()
             c = self._read_counters()
-            T = c["T"]
-            if T >= max_n_triangles:
-                logging.warning(f"Warning from marching cube: the max triangle number is too small {T} vs {max_n_triangles}")
-                T = int(max_n_triangles)
-            if not to_host:
-                return tens["triangles"][:T], tens["triangle_flatten_id"][:T], tens["triangle_std"][:T]
-            if c["K"] == 0:
+            if c["T"] >= max_n_triangles:
+                logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {max_n_triangles}")
+            if c["K"] > 0:
+                self._cache_any = True
+            if not self._cache_any:
                 return None
-            vertices = tens["triangles"][:T].cpu().numpy()
-            vertices_std = tens["triangle_std"][:T].cpu().numpy()
-            vertices_flatten_id = tens["triangle_flatten_id"][:T].cpu().numpy()
-        mc = self.mesh_cache                                     # map.py:703-714
-        if mc.vertices is None:
-            mc.vertices, mc.vertices_flatten_id, mc.vertices_std = vertices, vertices_flatten_id, vertices_std
-        else:
-            p = np.unique(vertices_flatten_id)
-            keep = ~np.isin(mc.vertices_flatten_id, p)
-            mc.vertices = np.concatenate([mc.vertices[keep], vertices], axis=0)
-            mc.vertices_flatten_id = np.concatenate([mc.vertices_flatten_id[keep], vertices_flatten_id], axis=0)
-            mc.vertices_std = np.concatenate([mc.vertices_std[keep], vertices_std], axis=0)
+            if not to_host:
+                return self.mesh_cache_tensors()
+        mc = self.mesh_cache
         return mc.vertices, mc.vertices_flatten_id, mc.vertices_std
 
     def _make_mesh_from_cache(self):

@@ -46,6 +46,8 @@ enum {
     DIF_C_T = 9,            /* triangles produced (may exceed max_n_triangles, mc_interp_kernel.cu:369)   */
     DIF_C_QUERY_M = 10,     /* valid points of the last get_sdf query (map.py:569-572)                    */
     DIF_C_N_KEPT = 11,      /* points surviving the >prune_min_vox_obs filter (map.py:375)                */
+    DIF_C_CACHE_T = 12,     /* triangles in the device-resident mesh cache (map.py:116-133, 703-714)      */
+    DIF_C_CACHE_KEPT = 13,  /* cached triangles kept by the last extract = offset of the new ones         */
     DIF_C_COUNT = 16
 };
 
@@ -123,10 +125,19 @@ typedef struct dif_extract_buffers {
     int32_t* tri_count;             /* [max_voxels] triangles per dirty voxel                             */
     int32_t* tri_offset;            /* [max_voxels] exclusive prefix of tri_count                         */
     int32_t* block_tmp;             /* [4096] scan scratch                                                */
-    int64_t max_triangles;          /* map.py:581 max_n_triangles                                         */
-    float* triangles;               /* [max_triangles][3][3]                                              */
-    int64_t* triangle_flatten_id;   /* [max_triangles]                                                    */
-    float* triangle_std;            /* [max_triangles][3]                                                 */
+    int64_t max_triangles;          /* map.py:581 max_n_triangles (per call)                              */
+    /* Device-resident mesh cache (the reference keeps it in host numpy arrays, map.py:703-714): two ping-pong sets of
+     * (vertices, voxel id, std); `cache_src` holds DIF_C_CACHE_T triangles on entry.  Each extract writes into `cache_dst`
+     * first the cached triangles whose voxel produced no new triangle (same order), then the new triangles in canonical
+     * order -- exactly the arrays `mesh_cache.vertices / vertices_flatten_id / vertices_std` of the reference.
+     * The new triangles of this call are cache_dst[DIF_C_CACHE_KEPT : DIF_C_CACHE_T]. */
+    int64_t cache_capacity;         /* triangles per cache buffer                                         */
+    const float* cache_src_tri;     /* [cache_capacity][3][3]                                             */
+    const int64_t* cache_src_id;    /* [cache_capacity]                                                   */
+    const float* cache_src_std;     /* [cache_capacity][3]                                                */
+    float* cache_dst_tri;
+    int64_t* cache_dst_id;
+    float* cache_dst_std;
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,

@@ -100,11 +100,13 @@ def test_sequence_vs_golden_and_oracle(name, gpu_model, oracle_net):
         # marching cubes on the GPU's own cubes through the C oracle: isolates the MC kernel
         wt, wi, ws = O.marching_cubes_interp(oa["indexer"], oa["valid_blocks"], oa["vec_batch_mapping"], cs, cd, int(4e6), om.n_xyz, 0.15)
         assert new_T == wt.shape[0]
-        gt = tens["triangles"][:new_T].cpu().numpy()
+        ntri, nid, nstd = m.mesh_cache_tensors(new_only=True)
+        assert ntri.size(0) == new_T
+        gt = ntri.cpu().numpy()
         want = (wt * np.float32(cfg.voxel_size)).astype(np.float32) + om.bound_min
-        assert np.array_equal(tens["triangle_flatten_id"][:new_T].cpu().numpy(), wi)
+        assert np.array_equal(nid.cpu().numpy(), wi)
         assert np.abs(gt - want).max() < 1e-5
-        assert np.abs(tens["triangle_std"][:new_T].cpu().numpy() - ws).max() < 1e-5
+        assert np.abs(nstd.cpu().numpy() - ws).max() < 1e-5
         assert new_T > 0
     # ---- get_sdf ---------------------------------------------------------------------------------------------
     sdf, std, qmask = m.get_sdf(torch.from_numpy(g["probe_xyz"]).to(DEV))
