@@ -71,7 +71,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-// Exclusive scan across a 256-thread block.  `smem` must hold >= 8 ints.  Returns the exclusive prefix; total in `total`.
+// Exclusive scan across a block of up to 1024 threads.  `smem` must hold >= blockDim.x/64 ints.  Returns the exclusive prefix; total in `total`.
 __device__ __forceinline__ int block_excl_scan(int v, int* smem, int& total) {
     int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int inc = wave_incl_scan(v);
@@ -150,6 +150,26 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_scan_pass2(F f, const int* n_ptr,
     if (blockIdx.x == 0 && threadIdx.x == 0) f.finish(total);
 }
 
+// Single-workgroup variant (one launch instead of two) for small n: thread t owns the contiguous range
+// [t*per, (t+1)*per), so offsets still follow index order.
+template <class F>
+__global__ void __launch_bounds__(1024) k_scan_single(F f, const int* n_ptr, int n_static) {
+    __shared__ int smem[16];
+    const int n = n_ptr ? *n_ptr : n_static;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += f.count(i);
+    int total;
+    int offset = block_excl_scan(c, smem, total);
+    for (int i = lo; i < hi; ++i) {
+        int ci = f.count(i);
+        if (ci > 0) f.emit(i, offset);
+        offset += ci;
+    }
+    if (threadIdx.x == 0) f.finish(total);
+}
+
 inline int scan_blocks(int64_t n_upper) {
     int64_t b = (n_upper + 4 * DIF_BLOCK - 1) / (4 * DIF_BLOCK);
     if (b < 1) b = 1;
@@ -159,6 +179,10 @@ inline int scan_blocks(int64_t n_upper) {
 
 template <class F>
 inline int launch_scan(F f, const int* n_ptr, int n_static, int64_t n_upper, int* block_tmp, hipStream_t s) {
+    if (n_upper <= (1 << 17)) {
+        hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(1024), 0, s, f, n_ptr, n_static);
+        return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+    }
     int nb = scan_blocks(n_upper);
     hipLaunchKernelGGL(k_scan_pass1<F>, dim3(nb), dim3(DIF_BLOCK), 0, s, f, n_ptr, n_static, block_tmp);
     hipLaunchKernelGGL(k_scan_pass2<F>, dim3(nb), dim3(DIF_BLOCK), 0, s, f, n_ptr, n_static, (const int*)block_tmp);

@@ -18,7 +18,7 @@ using namespace dif;
 namespace {
 
 constexpr int L = DIF_LATENT_DIM;     // 29
-constexpr int ITEM_ROWS = 256;        // gathered rows per encoder work item (8 MFMA tiles of 32 points)
+constexpr int ITEM_ROWS = 32;         // gathered rows per encoder work item = one MFMA tile of 32 points (finest load balance)
 
 __device__ __constant__ int c_mc_edge_table[256];
 __device__ __constant__ signed char c_mc_tri_table[256][16];
@@ -203,8 +203,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, 
     bool keep = false;
     if (lin >= 0) keep = (prune_min > 0) ? (frame_count[lin] > prune_min) : true;
     if (i < N) unq_mask[i] = keep ? 1 : 0;
-    unsigned long long kept = __ballot(keep);
-    if (lane == 0 && kept) atomicAdd(counters + DIF_C_N_KEPT, __popcll(kept));
     int prev = __shfl_up(lin, 1);
     bool head = (lane == 0) || (prev != lin);
     if (head && keep && indexer[lin] == -1) {
@@ -668,38 +666,54 @@ __device__ __forceinline__ float tri_sample(const float* __restrict__ low, int l
     return fmaf(v0, wx0, v1 * wx1);
 }
 
+// One thread per (voxel, x, y) row of R samples along z; selected samples are appended to the refine list with ONE atomic per
+// workgroup (a per-wave atomic on a single counter costs ~12 ns each and serialises: 15k waves = 200 us).
 __global__ void __launch_bounds__(DIF_BLOCK) k_upsample_mark(const float* __restrict__ low_sdf, const float* __restrict__ low_std, int l, int R,
                                                            float* __restrict__ cube_sdf, float* __restrict__ cube_std,
                                                            int32_t* __restrict__ refine_list, int* __restrict__ counters) {
+    __shared__ int smem[8];
+    __shared__ int s_base;
     const int B = counters[DIF_C_B];
-    const int R3 = R * R * R, l3 = l * l * l;
-    const int64_t n = (int64_t)B * R3;
+    const int R2 = R * R, R3 = R2 * R, l3 = l * l * l;
+    const int64_t n_rows = (int64_t)B * R2;
     const float scale = (float)(l - 1) / (float)(R - 1);
-    const int lane = lane_id();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n_pad = (n + 63) / 64 * 64;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pad; e += stride) {
-        bool refine = false;
-        if (e < n) {
-            int b = (int)(e / R3), j = (int)(e - (int64_t)b * R3);
-            int jx = j / (R * R), jy = (j / R) % R, jz = j % R;
-            int x0, x1, y0, y1, z0, z1; float wx0, wx1, wy0, wy1, wz0, wz1;
+    const int64_t n_pad = (n_rows + DIF_BLOCK - 1) / DIF_BLOCK * DIF_BLOCK;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_pad; row += stride) {
+        unsigned sel = 0;
+        int64_t e0 = 0;
+        if (row < n_rows) {
+            const int b = (int)(row / R2), jxy = (int)(row - (int64_t)b * R2);
+            const int jx = jxy / R, jy = jxy % R;
+            int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
             tri_axis(jx, l, scale, x0, x1, wx0, wx1);
             tri_axis(jy, l, scale, y0, y1, wy0, wy1);
-            tri_axis(jz, l, scale, z0, z1, wz0, wz1);
-            float s = tri_sample(low_sdf + (int64_t)b * l3, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-            float d = tri_sample(low_std + (int64_t)b * l3, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-            cube_sdf[e] = -s;
-            cube_std[e] = d;
-            refine = fabsf(s) < 0.05f;                       // map.py:667
+            const float* ls = low_sdf + (int64_t)b * l3;
+            const float* ld = low_std + (int64_t)b * l3;
+            e0 = (int64_t)b * R3 + (int64_t)jxy * R;
+            for (int jz = 0; jz < R; ++jz) {
+                int z0, z1; float wz0, wz1;
+                tri_axis(jz, l, scale, z0, z1, wz0, wz1);
+                float sv = tri_sample(ls, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                float dv = tri_sample(ld, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                cube_sdf[e0 + jz] = -sv;
+                cube_std[e0 + jz] = dv;
+                if (fabsf(sv) < 0.05f) sel |= 1u << jz;               // map.py:667
+            }
         }
-        unsigned long long m = __ballot(refine);
-        if (m) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(counters + DIF_C_VH, __popcll(m));
-            base = __shfl(base, 0);
-            if (refine) refine_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)e;
+        int total;
+        int ex = block_excl_scan(__popc(sel), smem, total);
+        if (total > 0) {
+            if (threadIdx.x == 0) s_base = atomicAdd(counters + DIF_C_VH, total);
+            __syncthreads();
+            int o = s_base + ex;
+            while (sel) {
+                int jz = __ffs((int)sel) - 1;
+                sel &= sel - 1;
+                refine_list[o++] = (int32_t)(e0 + jz);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -1357,7 +1371,7 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
         rc = launch_decode(A, w, buf->max_voxels * ((l * l * l + 31) / 32), s);
         if (rc != DIF_OK) return rc;
         // upsample + threshold (map.py:655-667)
-        hipLaunchKernelGGL(k_upsample_mark, dim3(grid_for(buf->max_voxels * (int64_t)R3, DIF_BLOCK, 8192)), dim3(DIF_BLOCK), 0, s,
+        hipLaunchKernelGGL(k_upsample_mark, dim3(grid_for(buf->max_voxels * (int64_t)(R * R), DIF_BLOCK, 4096)), dim3(DIF_BLOCK), 0, s,
                            (const float*)buf->low_sdf, (const float*)buf->low_std, l, R, buf->cube_sdf, buf->cube_std, buf->refine_list, C);
         DIF_CHECK_LAUNCH();
         // exact re-decode of the near-surface samples (map.py:668-679)

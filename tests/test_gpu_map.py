@@ -177,7 +177,7 @@ def test_capacity_growth_and_save_load(gpu_model, tmp_path):
         check_state(m, g, f)
         if f == 0:
             m.extract_mesh_arrays(4, int(4e6), max_std=0.15)      # the golden sequence meshes (and clears the dirty set) every frame
-            m._alloc_state(2048)                                    # grow mid-sequence: state must survive the re-allocation
+            m._alloc_state(m._capacity * 2)                         # grow mid-sequence: state must survive the re-allocation
     m.save(tmp_path / "map.pt")
     m2 = make_map(gpu_model, cfg)
     m2.load(tmp_path / "map.pt")

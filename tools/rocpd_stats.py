@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / % — the `--stats` table.
+Usage: python tools/rocpd_stats.py gpurun_out/prof/bench_results.db [--last N] > profiles/rNN_kernel_stats.md"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([\w:]+)(<.*)?", name)
+    base = m.group(1) if m else name
+    if "k_scan_pass" in name:
+        f = re.search(r"<(?:.*::)?(\w+Functor)", name)
+        base = base + "<" + (f.group(1) if f else "?") + ">"
+    elif "k_marching_cubes" in name:
+        base += "<emit>" if "true" in name else "<count>"
+    elif base.startswith("rocprim"):
+        base = "rocprim::" + (re.search(r"(\w+kernel\w*|\w+_kernel)", name).group(1) if re.search(r"(\w+kernel\w*|\w+_kernel)", name) else base)
+    return base[:70]
+
+
+def main():
+    db = sys.argv[1]
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    agg = {}
+    for n, s, e in rows:
+        k = short(n)
+        a = agg.setdefault(k, [0, 0])
+        a[0] += 1
+        a[1] += e - s
+    tot = sum(v[1] for v in agg.values())
+    span = rows[-1][2] - rows[0][1]
+    print(f"kernel dispatches: {len(rows)}   sum of kernel time: {tot / 1e6:.3f} ms   first-start to last-end: {span / 1e6:.3f} ms\n")
+    print("| kernel | calls | total ms | avg us | % of kernel time |")
+    print("|---|---:|---:|---:|---:|")
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"| `{k}` | {n} | {t / 1e6:.3f} | {t / n / 1e3:.2f} | {100 * t / tot:.1f} |")
+
+
+if __name__ == "__main__":
+    main()
