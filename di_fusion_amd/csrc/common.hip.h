@@ -179,7 +179,7 @@ inline int scan_blocks(int64_t n_upper) {
 
 template <class F>
 inline int launch_scan(F f, const int* n_ptr, int n_static, int64_t n_upper, int* block_tmp, hipStream_t s) {
-    if (n_upper <= (1 << 17)) {
+    if (n_upper <= 4096) {   // beyond a few elements per thread the serial single-workgroup scan is slower than two launches
         hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(1024), 0, s, f, n_ptr, n_static);
         return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
     }
