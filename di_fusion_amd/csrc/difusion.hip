@@ -7,7 +7,6 @@
 #include <cstring>
 #include <vector>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "common.hip.h"
 #include "mlp.hip.h"
@@ -171,9 +170,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_groupby_sum(const float* __restri
 // K1: per-point voxel id + per-voxel point count of this frame.  Adjacent pixels mostly fall in the same voxel, so
 // equal-id runs inside a wave are aggregated with a ballot before touching memory (1 atomic per run, not per point).
 __global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* __restrict__ xyz, int64_t N, int* __restrict__ pt_lin,
-                                                         int* __restrict__ frame_count) {
+                                                         int* __restrict__ frame_count, int* __restrict__ counters) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // grid covers N rounded up to a wave
     int lane = lane_id();
+    if (i < 4) counters[DIF_C_ALLOC_NEW + i] = 0;                   // ALLOC_NEW, M, C, ITEMS of this call
     int lin = -2;                                                    // -2: beyond N, -1: invalid point
     if (i < N) {
         float xn, yn, zn; int ix, iy, iz;
@@ -256,21 +256,43 @@ struct AllocFunctor {
 // K4: (i) commit n_occupied += newly allocated (all pass-2 blocks of K3 have read the old value by now),
 // (ii) restore frame_count to zero, (iii) focus mask + 8-offset gather keys (map.py:389-433).
 // Key of pair (offset o, point i), stored at o*N + i (the reference's concatenation order): slot of the neighbour voxel
-// if that voxel is in the encode set {obs_count < encoder_count_th}, else DIF_INVALID_KEY.
+// if that voxel is in the encode set {obs_count < encoder_count_th}, else DIF_INVALID_KEY.  Rows per slot are counted here
+// (seg_cnt = the reference's `pcounts`, map.py:437-439) with one atomic per distinct slot per wave.
 __device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
+
+// Wave-aggregated "fetch-add 1" on counter[key] for every lane whose key is valid; returns the lane's unique offset
+// (base + rank among the lanes of the wave that share the key).  One atomic per distinct key per wave.
+__device__ __forceinline__ int wave_grouped_fetch_add(int* __restrict__ counter, uint32_t key, bool valid) {
+    const int lane = lane_id();
+    int result = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+        const unsigned long long same = __ballot(valid && key == k0);
+        if (valid && key == k0) {
+            int base = 0;
+            if (lane == leader) base = atomicAdd(counter + k0, __popcll(same));
+            base = __shfl(base, leader);
+            result = base + __popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    return result;
+}
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
-                                                          uint32_t* __restrict__ pair_key, int* __restrict__ counters, int64_t capacity) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                          uint32_t* __restrict__ pair_key, int* __restrict__ seg_cnt,
+                                                          int* __restrict__ counters, int64_t capacity) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole waves
     if (i == 0) {
         int n = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (n > capacity) { n = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
         counters[DIF_C_N_OCCUPIED] = n;
     }
-    if (i >= N) return;
-    int lin = pt_lin[i];
+    const int lin = (i < N) ? pt_lin[i] : -1;
     uint32_t key[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) key[o] = DIF_INVALID_KEY;
@@ -301,66 +323,59 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
         }
     }
 #pragma unroll
-    for (int o = 0; o < 8; ++o) pair_key[(int64_t)o * N + i] = key[o];
-}
-
-// K6: segment boundaries of the sorted keys -> seg_start / seg_cnt per slot; M = #valid rows.
-__global__ void __launch_bounds__(DIF_BLOCK) k_segments(const uint32_t* __restrict__ keys, int64_t n, int* __restrict__ seg_start,
-                                                      int* __restrict__ seg_cnt, int* __restrict__ counters) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t k = keys[j];
-        if (k == DIF_INVALID_KEY) {
-            if (j == 0) counters[DIF_C_M] = 0;
-            continue;
-        }
-        uint32_t kp = (j > 0) ? keys[j - 1] : 0xFFFFFFFFu;
-        uint32_t kn = (j + 1 < n) ? keys[j + 1] : DIF_INVALID_KEY;
-        if (kp != k) seg_start[k] = (int)j;
-        if (kn != k) {
-            // the start of this segment is needed for the count: find it through the start written by another thread
-            // is racy, so count = end - start is formed in k_items (which runs after this kernel); store the end here.
-            seg_cnt[k] = (int)(j + 1);                       // temporarily the segment END
-            if (kn == DIF_INVALID_KEY) counters[DIF_C_M] = (int)(j + 1);
-        }
+    for (int o = 0; o < 8; ++o) {
+        if (i < N) pair_key[(int64_t)o * N + i] = key[o];
+        (void)wave_grouped_fetch_add(seg_cnt, key[o], key[o] != DIF_INVALID_KEY);
     }
 }
 
-// K7: per-slot encoder work items (ceil(cnt / ITEM_ROWS)), exclusive scan over slots, item -> slot table.
+// K5: per-slot encoder work items (ceil(cnt / ITEM_ROWS)), exclusive scan over slots, item -> slot table.  A slot's rows
+// live in the row table at [item_start*ITEM_ROWS, ...) (padded to whole items), so one scan yields both.
 struct ItemFunctor {
-    const int* seg_start;
-    int* seg_cnt;            // in: segment end (or 0); out (emit): row count
+    const int* seg_cnt;
     int* item_start;
     int* item_slot;
     int* counters;
     int64_t max_items;
-    __device__ int count(int s) const {
-        int e = seg_cnt[s];
-        if (e <= 0) return 0;
-        int c = e - seg_start[s];
-        return (c + ITEM_ROWS - 1) / ITEM_ROWS;
-    }
+    __device__ int count(int s) const { return (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS; }
     __device__ void emit(int s, int offset) const {
-        int c = seg_cnt[s] - seg_start[s];
-        int n = (c + ITEM_ROWS - 1) / ITEM_ROWS;
-        if ((int64_t)offset + n > max_items) { seg_cnt[s] = 0; counters[DIF_C_OVERFLOW] = 4; return; }
-        seg_cnt[s] = c;
+        int n = (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS;
         item_start[s] = offset;
+        if ((int64_t)offset + n > max_items) { counters[DIF_C_OVERFLOW] = 4; return; }
         for (int k = 0; k < n; ++k) item_slot[offset + k] = s;
     }
     __device__ void finish(int total) const { counters[DIF_C_ITEMS] = (total > max_items) ? (int)max_items : total; }
 };
 
+// K6: place every valid (offset, point) pair into its slot's rows.  Order inside a slot is arrival order — harmless, because
+// the per-voxel sum is accumulated in exact fixed point (order-independent, see k_encode).
+__global__ void __launch_bounds__(DIF_BLOCK) k_scatter_rows(const uint32_t* __restrict__ pair_key, int64_t n_pairs, const int* __restrict__ item_start,
+                                                          int* __restrict__ seg_cursor, uint32_t* __restrict__ row_val, int64_t max_rows) {
+    const int64_t n_pad = (n_pairs + 63) / 64 * 64;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_pad; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t key = (j < n_pairs) ? pair_key[j] : DIF_INVALID_KEY;
+        const bool valid = key != DIF_INVALID_KEY;
+        const int r = wave_grouped_fetch_add(seg_cursor, key, valid);
+        if (valid) {
+            const int64_t pos = (int64_t)item_start[key] * ITEM_ROWS + r;
+            if (pos < max_rows) row_val[pos] = (uint32_t)j;
+        }
+    }
+}
+
 // =================================================================================================================
 // a7..a9 : gather + encoder (MFMA) + per-voxel sums
 // =================================================================================================================
 // Persistent: one 512-thread workgroup per CU keeps the 107 KB of packed encoder weights in LDS; each wave pulls work
-// items (slot, up to 256 sorted rows), runs 32-point tiles through the MFMA chain and accumulates the 29 output
-// features over the item's rows in registers; one fixed-order cross-lane reduction per item => deterministic partials.
+// items (slot, 32 rows), runs the tile through the MFMA chain and reduces the 29 output features over the rows.
+// The reduction is done in 2^-30 FIXED POINT (int64): integer addition is associative, so the per-voxel sum does not
+// depend on row order, tile grouping or the order partials are added in => bit-reproducible, and more accurate than an
+// fp32 running sum (the reference sums with float atomics in arbitrary order, indexing.cu:59-71).
+#define DIF_FIX_SCALE 1073741824.0f          /* 2^30: |enc| < 2^12 and < 2^21 rows per voxel keep the sum inside int64 */
 __global__ void __launch_bounds__(512, 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
-         const uint32_t* __restrict__ sorted_val, const int* __restrict__ seg_start, const int* __restrict__ seg_cnt,
-         const int* __restrict__ item_start, const int* __restrict__ item_slot, const int* __restrict__ counters,
-         float* __restrict__ partial /* [items][32] */) {
+         const uint32_t* __restrict__ row_val, const int* __restrict__ seg_cnt, const int* __restrict__ item_start,
+         const int* __restrict__ item_slot, const int* __restrict__ counters, long long* __restrict__ partial /* [items][32] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights(lds, wblob, ENC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
@@ -370,73 +385,59 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
     for (int item = wave; item < n_items; item += nwaves) {
         const int slot = item_slot[item];
         const int chunk = item - item_start[slot];
-        const int row0 = seg_start[slot] + chunk * ITEM_ROWS;
-        const int row_end = min(seg_start[slot] + seg_cnt[slot], row0 + ITEM_ROWS);
-        f16v sum;
+        const bool live = chunk * ITEM_ROWS + col < seg_cnt[slot];
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (live) {
+            uint32_t v = row_val[(int64_t)item * ITEM_ROWS + col];
+            int o = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum[r] = 0.0f;
-        for (int r0 = row0; r0 < row_end; r0 += 32) {
-            const int row = r0 + col;
-            const bool live = row < row_end;
-            float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-            if (live) {
-                uint32_t v = sorted_val[row];
-                int o = 0;
-#pragma unroll
-                for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
-                int64_t i = (int64_t)v - (int64_t)o * N;
-                float xn = normalize1(xyz[i * 3 + 0], g.bx, g.vs);
-                float yn = normalize1(xyz[i * 3 + 1], g.by, g.vs);
-                float zn = normalize1(xyz[i * 3 + 2], g.bz, g.vs);
-                float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
-                float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
-                float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
-                float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
-                float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
-                float nxv = normal[i * 3 + 0], nyv = normal[i * 3 + 1], nzv = normal[i * 3 + 2];
-                x0 = half ? ry : rx;
-                x1 = half ? nxv : rz;
-                x2 = half ? nzv : nyv;
-            }
-            f16v out = encoder_tile(lds, x0, x1, x2, lane);
-            const float m = live ? 1.0f : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum[r] += out[r] * m;
+            for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
+            int64_t i = (int64_t)v - (int64_t)o * N;
+            float xn = normalize1(xyz[i * 3 + 0], g.bx, g.vs);
+            float yn = normalize1(xyz[i * 3 + 1], g.by, g.vs);
+            float zn = normalize1(xyz[i * 3 + 2], g.bz, g.vs);
+            float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
+            float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
+            float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
+            float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
+            float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
+            float nxv = normal[i * 3 + 0], nyv = normal[i * 3 + 1], nzv = normal[i * 3 + 2];
+            x0 = half ? ry : rx;
+            x1 = half ? nxv : rz;
+            x2 = half ? nzv : nyv;
         }
-        // sum over the 32 points (lanes) of each half; fixed butterfly => deterministic
+        f16v out = encoder_tile(lds, x0, x1, x2, lane);
+        long long* p = partial + (int64_t)item * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v = sum[r];
+            long long v = live ? __float2ll_rn(out[r] * DIF_FIX_SCALE) : 0ll;
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8);
             v += __shfl_xor(v, 16);
-            sum[r] = v;
-        }
-        if (col == 0) {
-            float* p = partial + (int64_t)item * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[(r & 3) + 8 * (r >> 2) + 4 * half] = sum[r];
+            if (col == 0) p[(r & 3) + 8 * (r >> 2) + 4 * half] = v;
         }
     }
 }
 
-// a10: fusion update (map.py:448-452).  One 32-lane group per slot; partials summed in item order.
-__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const float* __restrict__ partial, const int* __restrict__ item_start, int* __restrict__ seg_cnt,
-                                                  float* __restrict__ latent, float* __restrict__ obs, uint8_t* __restrict__ dirty,
-                                                  int* __restrict__ counters) {
+// a10: fusion update (map.py:448-452).  One 32-lane group per slot.
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ partial, const int* __restrict__ item_start, int* __restrict__ seg_cnt,
+                                                  int* __restrict__ seg_cursor, float* __restrict__ latent, float* __restrict__ obs,
+                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters) {
+    __shared__ int smem[8];
     const int n_occ = counters[DIF_C_N_OCCUPIED];
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
     const int f = threadIdx.x & 31;
-    int updated = 0;
+    int updated = 0, rows = 0;
     for (int s = grp; s < n_occ; s += ngrp) {
         int cnt = seg_cnt[s];
         if (cnt <= 0) continue;
         int it0 = item_start[s], nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
         if (f < L) {
-            float S = 0.0f;
-            for (int k = 0; k < nit; ++k) S += partial[(int64_t)(it0 + k) * 32 + f];
+            long long Si = 0;
+            for (int k = 0; k < nit; ++k) Si += partial[(int64_t)(it0 + k) * 32 + f];
+            float S = (float)Si * (1.0f / DIF_FIX_SCALE);    // one rounding: exact integer sum -> nearest float
             float w_old = obs[s];
             float z_old = latent[(int64_t)s * L + f];
             S = S + z_old * w_old;                           // map.py:449
@@ -448,10 +449,14 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const float* __restrict__ pa
             obs[s] = obs[s] + (float)cnt;
             dirty[s] = 1;                                    // map.py:452
             seg_cnt[s] = 0;
+            seg_cursor[s] = 0;
             ++updated;
+            rows += cnt;
         }
     }
-    if (f == 31 && updated) atomicAdd(counters + DIF_C_C, updated);
+    int tu = block_sum(updated, smem);
+    int tr = block_sum(rows, smem);
+    if (threadIdx.x == 0 && tu) { atomicAdd(counters + DIF_C_C, tu); atomicAdd(counters + DIF_C_M, tr); }
 }
 
 // =================================================================================================================
@@ -1081,14 +1086,11 @@ int dif_groupby_sum(const float* values, const int64_t* indices, int64_t N, int3
 // workspace carve (all offsets 256-byte aligned)
 struct IntegrateWs {
     int* pt_lin;            // [N]
-    uint32_t* key_in;       // [8N]
-    uint32_t* key_out;      // [8N]
-    uint32_t* val_out;      // [8N]
-    int* item_slot;         // [8N/ITEM_ROWS + N... ] bounded by M/ITEM_ROWS + C <= 8N/256 + 8N (loose) -> use 8N/16 + 4096... see below
-    float* partial;         // [max_items][32]
+    uint32_t* pair_key;     // [8N]
+    uint32_t* row_val;      // [max_items * ITEM_ROWS]
+    int* item_slot;         // [max_items]
+    long long* partial;     // [max_items][32]
     int* block_tmp;         // [4096]
-    void* sort_tmp;
-    size_t sort_tmp_bytes;
     int64_t max_items;
     int64_t total_bytes;
 };
@@ -1105,23 +1107,14 @@ static int64_t max_items_for(int64_t N) {
 static int carve_integrate(int64_t N, void* base, IntegrateWs& ws) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    size_t sort_bytes = 0;
-    {
-        uint32_t* kn = nullptr;
-        rocprim::counting_iterator<uint32_t> vin(0);
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, kn, kn, vin, kn, (size_t)(8 * N), 0, 24, (hipStream_t)0);
-        if (e != hipSuccess) return DIF_ELAUNCH;
-    }
     ws.max_items = max_items_for(N);
-    size_t o_lin = take((size_t)N * 4), o_kin = take((size_t)8 * N * 4), o_kout = take((size_t)8 * N * 4), o_vout = take((size_t)8 * N * 4);
-    size_t o_islot = take((size_t)ws.max_items * 4), o_part = take((size_t)ws.max_items * 32 * 4), o_tmp = take(4096 * 4);
-    size_t o_sort = take(sort_bytes + 256);
+    size_t o_lin = take((size_t)N * 4), o_key = take((size_t)8 * N * 4), o_row = take((size_t)ws.max_items * ITEM_ROWS * 4);
+    size_t o_islot = take((size_t)ws.max_items * 4), o_part = take((size_t)ws.max_items * 32 * 8), o_tmp = take(4096 * 4);
     ws.total_bytes = (int64_t)off;
-    ws.sort_tmp_bytes = sort_bytes;
     if (base) {
         char* b = (char*)base;
-        ws.pt_lin = (int*)(b + o_lin); ws.key_in = (uint32_t*)(b + o_kin); ws.key_out = (uint32_t*)(b + o_kout); ws.val_out = (uint32_t*)(b + o_vout);
-        ws.item_slot = (int*)(b + o_islot); ws.partial = (float*)(b + o_part); ws.block_tmp = (int*)(b + o_tmp); ws.sort_tmp = (void*)(b + o_sort);
+        ws.pt_lin = (int*)(b + o_lin); ws.pair_key = (uint32_t*)(b + o_key); ws.row_val = (uint32_t*)(b + o_row);
+        ws.item_slot = (int*)(b + o_islot); ws.partial = (long long*)(b + o_part); ws.block_tmp = (int*)(b + o_tmp);
     }
     return DIF_OK;
 }
@@ -1147,11 +1140,10 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
     if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
     Geo g = geo_of(map);
     int* C = map->counters;
-    if (hipMemsetAsync(C + DIF_C_ALLOC_NEW, 0, sizeof(int) * 4, s) != hipSuccess) return DIF_ELAUNCH;          // ALLOC_NEW, M, C, ITEMS
-    if (hipMemsetAsync(C + DIF_C_N_KEPT, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
     const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK);
 
-    hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count);
+    // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
+    hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C);
     hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
                        (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, map->grid_bits, C);
     DIF_CHECK_LAUNCH();
@@ -1162,21 +1154,18 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
     }
     hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
                        (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
-                       ws.key_in, C, map->capacity);
+                       ws.pair_key, map->seg_cnt, C, map->capacity);
     DIF_CHECK_LAUNCH();
     {
-        rocprim::counting_iterator<uint32_t> vin(0);
-        size_t tmp = ws.sort_tmp_bytes;
-        ProfScope prof(DIF_PROF_SORT, s);
-        hipError_t e = rocprim::radix_sort_pairs(ws.sort_tmp, tmp, (const uint32_t*)ws.key_in, ws.key_out, vin, ws.val_out, (size_t)(8 * N), 0, 24, s);
-        if (e != hipSuccess) return DIF_ELAUNCH;
-    }
-    hipLaunchKernelGGL(k_segments, dim3(grid_for(8 * N)), dim3(DIF_BLOCK), 0, s, (const uint32_t*)ws.key_out, 8 * N, map->seg_start, map->seg_cnt, C);
-    DIF_CHECK_LAUNCH();
-    {
-        ItemFunctor f{map->seg_start, map->seg_cnt, map->item_start, ws.item_slot, C, ws.max_items};
+        ItemFunctor f{map->seg_cnt, map->item_start, ws.item_slot, C, ws.max_items};
         if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     }
+    {
+        ProfScope prof(DIF_PROF_SORT, s);
+        hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(8 * N, DIF_BLOCK, 8192)), dim3(DIF_BLOCK), 0, s, (const uint32_t*)ws.pair_key, 8 * N,
+                           (const int*)map->item_start, map->seg_start /* row cursors, idle 0 */, ws.row_val, ws.max_items * ITEM_ROWS);
+    }
+    DIF_CHECK_LAUNCH();
     {
         const size_t lds_bytes = (size_t)ENC_FLOATS * 4;
         static bool attr_set[64] = {};
@@ -1186,13 +1175,12 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
             attr_set[dev] = true;
         }
         ProfScope prof(DIF_PROF_ENCODE, s);
-        hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint32_t*)ws.val_out,
-                           (const int*)map->seg_start, (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot,
-                           (const int*)C, ws.partial);
+        hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint32_t*)ws.row_val,
+                           (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot, (const int*)C, ws.partial);
         DIF_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, (const float*)ws.partial,
-                       (const int*)map->item_start, map->seg_cnt, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.partial,
+                       (const int*)map->item_start, map->seg_cnt, map->seg_start, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

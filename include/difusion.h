@@ -70,7 +70,7 @@ typedef struct dif_map {
     int32_t* frame_count;           /* [nx*ny*nz] idle 0  : points of the current frame per voxel (map.py:374) */
     uint32_t* grid_bits;            /* [ceil(nx*ny*nz/32)] idle 0 : candidate / occupied voxel bitmap          */
     int32_t* vbm;                   /* [capacity] idle -1 : vec_id_batch_mapping (map.py:633-635)              */
-    int32_t* seg_start;             /* [capacity] first sorted row of the slot's segment                       */
+    int32_t* seg_start;             /* [capacity] idle 0  : row cursor of the slot while rows are placed             */
     int32_t* seg_cnt;               /* [capacity] idle 0  : rows gathered for the slot (pcounts, map.py:439)   */
     int32_t* item_start;            /* [capacity] first encoder work item of the slot                          */
 } dif_map_t;
@@ -104,7 +104,7 @@ int dif_groupby_sum(const float* values, const int64_t* indices, int64_t N, int3
                     int64_t C, void* stream);
 
 /* ---- a3..a10: integrate_keyframe (map.py:340-519, do_optimize=False) --------------------------------------- */
-/* Bytes of scratch `ws` needed for N points (includes the radix-sort temporary). */
+/* Bytes of scratch `ws` needed for N points. */
 int64_t dif_integrate_workspace_bytes(int64_t N);
 /* xyz, normal: (N,3) f32.  unq_mask: (N) u8 out (map.py:375; all-valid-points when prune_min_vox_obs<=0).
  * Points with NaN coordinates or outside [bound_min, bound_max) are masked out (the reference indexes out of

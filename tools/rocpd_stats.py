@@ -25,6 +25,13 @@ def main():
     db = sys.argv[1]
     c = sqlite3.connect(db)
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    if "--after-nth" in sys.argv:           # e.g. --after-nth k_unproject_transform 5 : drop everything before the 6th frame
+        i = sys.argv.index("--after-nth")
+        marker, nth = sys.argv[i + 1], int(sys.argv[i + 2])
+        starts = [s for n, s, e in rows if marker in n]
+        t0 = starts[nth]
+        rows = [r for r in rows if r[1] >= t0]
+        print(f"(restricted to dispatches at/after dispatch #{nth} of `{marker}`: the timed region, {len(starts) - nth} frames)\n")
     agg = {}
     for n, s, e in rows:
         k = short(n)
