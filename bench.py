@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"])
     ap.add_argument("--noise", type=int, default=0)
     ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
+    ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.5, help="image scale of the CPU-baseline sample frame")
     return ap.parse_args()
@@ -91,14 +92,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run(i):
+        return stream.step_pipelined(i, a.d2h) if a.pipeline else stream.step(i, a.d2h)
+
     for i in range(a.warmup):
-        stream.step(i, a.d2h)
+        run(i)
+    stream.flush(a.d2h)
     lib.dif_profile_read((ctypes.c_double * _lib.PROF_COUNT)(), (ctypes.c_int64 * _lib.PROF_COUNT)(), 1)
     lib.dif_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
     for i in range(a.warmup, n_frames):
-        stream.step(i, a.d2h)
+        run(i)
+    stream.flush(a.d2h)
     barrier()
     dt = time.perf_counter() - t0
     lib.dif_profile_enable(0)
@@ -137,7 +143,7 @@ def main():
                "config": {"workload": {"c1": "C1 32^3 grid 0.1 m, sphere", "c2": "C2 64^3 grid 0.1 m, room",
                                        "c3": "C3 128^3 grid 0.05 m, ScanNet-shape 6 m room with boxes"}[a.config] +
                           ", 640x480 orbit stream 0.5 deg/frame, all 307200 pixels integrated and meshed every frame, resolution 4, fast decode, max_std 0.15",
-                          "points_per_frame": intr.width * intr.height, "parallelism": f"{world} independent subsequences (one map per GPU)", "d2h_per_frame": a.d2h,
+                          "points_per_frame": intr.width * intr.height, "parallelism": f"{world} independent subsequences (one map per GPU)", "d2h_per_frame": a.d2h, "host_pipeline_depth": 2 if a.pipeline else 1,
                           "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1) for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")}},
                "roofline": roof}
         if not a.no_cpu_baseline and world == 1:

@@ -462,31 +462,24 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
 // =================================================================================================================
 // a11 : extract — dirty list, confident neighbourhood, batch ids  (map.py:627-637)
 // =================================================================================================================
-struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> valid_blocks (lin ids), clears flags
-    uint8_t* dirty;
-    const int64_t* pos;
+struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> valid_blocks (lin ids), clears flags;
+    uint8_t* dirty;         // each dirty voxel also marks the confident voxels among itself and its 6 allocated neighbours
+    const int64_t* pos;     // in the grid bitmap (map.py:628-631)
     int64_t* valid_blocks;
     int* counters;
     int no_cache;
     int64_t max_voxels;
+    Geo g;
+    float ignore_th;
+    const int64_t* indexer;
+    const float* obs;
+    uint32_t* bits;
     __device__ int count(int s) const { return (no_cache || dirty[s]) ? 1 : 0; }
     __device__ void emit(int s, int offset) const {
         dirty[s] = 0;
-        if (offset < max_voxels) valid_blocks[offset] = pos[s];
-    }
-    __device__ void finish(int total) const {
-        if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 2; }
-        counters[DIF_C_K] = total;
-    }
-};
-
-// mark the confident voxels among each dirty voxel and its 6 allocated neighbours (map.py:628-631)
-__global__ void __launch_bounds__(DIF_BLOCK) k_mark_occupied(Geo g, float ignore_th, const int64_t* __restrict__ valid_blocks,
-                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
-                                                           uint32_t* __restrict__ bits, const int* __restrict__ counters) {
-    const int K = counters[DIF_C_K];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        int lin = (int)valid_blocks[k];
+        if (offset >= max_voxels) return;
+        const int lin = (int)pos[s];
+        valid_blocks[offset] = lin;
         int ix, iy, iz;
         unlinearize(g, lin, ix, iy, iz);
         int cand[7];
@@ -506,7 +499,11 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_mark_occupied(Geo g, float ignore
             if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
         }
     }
-}
+    __device__ void finish(int total) const {
+        if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 2; }
+        counters[DIF_C_K] = total;
+    }
+};
 
 struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm[slot] = b; clears the bitmap
     uint32_t* bits;
@@ -536,11 +533,6 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
         counters[DIF_C_VH] = 0;
     }
 };
-
-__global__ void __launch_bounds__(DIF_BLOCK) k_reset_vbm(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm, const int* __restrict__ counters) {
-    const int B = counters[DIF_C_B];
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) vbm[occ_slot[b]] = -1;
-}
 
 // =================================================================================================================
 // a12..a14 : decoder over the per-voxel sample lattice, fast two-level refinement  (map.py:640-687)
@@ -907,14 +899,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 }
 
 // ---- a16 : device-resident mesh cache (map.py:703-714) ---------------------------------------------------------------
-// flag (in the frame_count scratch grid) the voxels that produced at least one new triangle
-__global__ void __launch_bounds__(DIF_BLOCK) k_cache_flag(const int64_t* __restrict__ valid_blocks, const int32_t* __restrict__ tri_count,
-                                                        int* __restrict__ flags, const int* __restrict__ counters, int value) {
-    const int K = counters[DIF_C_K];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
-        if (tri_count[k] > 0) flags[valid_blocks[k]] = value;
-}
-
 struct CacheCompactFunctor {    // ordered compaction: keep cached triangles whose voxel got no new triangle
     const float* src_tri; const int64_t* src_id; const float* src_std;
     float* dst_tri; int64_t* dst_id; float* dst_std;
@@ -931,20 +915,36 @@ struct CacheCompactFunctor {    // ordered compaction: keep cached triangles who
     __device__ void finish(int total) const { counters[DIF_C_CACHE_KEPT] = total; }
 };
 
-__global__ void k_cache_finish(int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
-    int64_t n_new = counters[DIF_C_T];
-    if (n_new > new_limit) n_new = new_limit;
-    int64_t tot = (int64_t)counters[DIF_C_CACHE_KEPT] + n_new;
-    if (tot > capacity) { tot = capacity; counters[DIF_C_OVERFLOW] = 5; }
-    counters[DIF_C_CACHE_T] = (int)tot;
+// end of extract: clear the voxel flags and the batch map, publish the cache size
+__global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int64_t* __restrict__ valid_blocks, const int32_t* __restrict__ tri_count,
+                                                            int* __restrict__ flags, const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
+                                                            int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
+    const int K = counters[DIF_C_K], B = counters[DIF_C_B];
+    const int n = K > B ? K : B;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (i < K && tri_count[i] > 0) flags[valid_blocks[i]] = 0;
+        if (i < B) vbm[occ_slot[i]] = -1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t n_new = counters[DIF_C_T];
+        if (n_new > new_limit) n_new = new_limit;
+        int64_t tot = (int64_t)counters[DIF_C_CACHE_KEPT] + n_new;
+        if (tot > capacity) { tot = capacity; counters[DIF_C_OVERFLOW] = 5; }
+        counters[DIF_C_CACHE_T] = (int)tot;
+    }
 }
 
 struct TriScanFunctor {
     const int32_t* tri_count;
     int32_t* tri_offset;
     int* counters;
+    const int64_t* valid_blocks;    // with `flags`: mark the voxels that produced >= 1 new triangle (mesh-cache replace rule)
+    int* flags;
     __device__ int count(int k) const { return tri_count[k]; }
-    __device__ void emit(int k, int offset) const { tri_offset[k] = offset; }
+    __device__ void emit(int k, int offset) const {       // only called when tri_count[k] > 0
+        tri_offset[k] = offset;
+        if (flags) flags[valid_blocks[k]] = 1;
+    }
     __device__ void finish(int total) const { counters[DIF_C_T] = total; }
 };
 
@@ -1270,7 +1270,8 @@ static int mc_setup(const McArgs& a, size_t& lds_bytes, int& blocks, int64_t K_u
     return DIF_OK;
 }
 
-static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
+static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s,
+                             int* cache_flags = nullptr) {
     size_t lds_bytes; int blocks;
     int rc = mc_setup(a, lds_bytes, blocks, K_upper);
     if (rc != DIF_OK) return rc;
@@ -1281,7 +1282,7 @@ static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int3
         hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
     }
     DIF_CHECK_LAUNCH();
-    TriScanFunctor f{tri_count, tri_offset, counters};
+    TriScanFunctor f{tri_count, tri_offset, counters, a.valid_blocks, cache_flags};
     return launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s);
 }
 
@@ -1337,12 +1338,10 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     const double sample_a = -(double)(r / 2) * (1.0 / r), sample_b = 1.0 + (double)((r - 1) / 2) * (1.0 / r);   // map.py:640-641
 
     {   // dirty slots -> valid_blocks
-        DirtyFunctor f{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels};
+        DirtyFunctor f{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels, g, map->ignore_count_th,
+                       map->indexer, map->voxel_obs_count, map->grid_bits};
         if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     }
-    hipLaunchKernelGGL(k_mark_occupied, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th,
-                       (const int64_t*)buf->valid_blocks, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, map->grid_bits, (const int*)C);
-    DIF_CHECK_LAUNCH();
     {
         OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
         int nwords = (int)((grid + 31) / 32);
@@ -1386,13 +1385,9 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     a.triangles = buf->cache_dst_tri; a.tri_id = buf->cache_dst_id; a.tri_std = buf->cache_dst_std;
     a.scale = scale_vertices ? 1 : 0; a.vs = map->voxel_size; a.bx = map->bound_min[0]; a.by = map->bound_min[1]; a.bz = map->bound_min[2];
     if (no_cache && hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;       // map.py:614-616
-    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s);
+    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s, map->frame_count);
     if (rc != DIF_OK) return rc;
     // mesh cache: keep the triangles of voxels that got no new triangle, then append the new ones (map.py:703-714)
-    const int flag_blocks = grid_for(buf->max_voxels, DIF_BLOCK, 1024);
-    hipLaunchKernelGGL(k_cache_flag, dim3(flag_blocks), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks, (const int32_t*)buf->tri_count,
-                       map->frame_count, (const int*)C, 1);
-    DIF_CHECK_LAUNCH();
     {
         CacheCompactFunctor f{buf->cache_src_tri, buf->cache_src_id, buf->cache_src_std, buf->cache_dst_tri, buf->cache_dst_id, buf->cache_dst_std,
                               map->frame_count, C};
@@ -1400,11 +1395,8 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     }
     rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
     if (rc != DIF_OK) return rc;
-    hipLaunchKernelGGL(k_cache_flag, dim3(flag_blocks), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks, (const int32_t*)buf->tri_count,
-                       map->frame_count, (const int*)C, 0);
-    hipLaunchKernelGGL(k_cache_finish, dim3(1), dim3(1), 0, s, C, buf->max_triangles, buf->cache_capacity);
-    DIF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_reset_vbm, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm, (const int*)C);
+    hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks,
+                       (const int32_t*)buf->tri_count, map->frame_count, (const int32_t*)buf->occ_slot, map->vbm, C, buf->max_triangles, buf->cache_capacity);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

@@ -38,6 +38,9 @@ class FusionStream:
         self.nrm = torch.empty((H * W, 3), dtype=torch.float32, device=device)
         self.stats = []
         self._pin = None
+        self._pending = None
+        self._copy_stream = torch.cuda.Stream(device=device)
+        self._copy_done = None
 
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
@@ -63,4 +66,63 @@ class FusionStream:
             self._pin[2][:n].copy_(tstd, non_blocking=True)
             out = (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
         self.stats.append(dict(self.map.last_counters))
+        return out
+
+    # ---- pipelined variant: no host wait inside the frame -----------------------------------------------------------------
+    def _enqueue_frame(self, i: int):
+        intr = self.intr
+        R, t = self.poses[i]
+        with torch.cuda.device(self.device):
+            if self._copy_done is not None:                      # the buffer this frame's extract overwrites is still being copied out
+                torch.cuda.current_stream().wait_event(self._copy_done)
+                self._copy_done = None
+            _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(self.depth[i]), _lib.ptr(self.ncam[i]), _lib.ptr(self.xyz), _lib.ptr(self.nrm),
+                                                           intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
+                       "dif_unproject_transform")
+        self.map.integrate_keyframe(self.xyz, self.nrm)
+        return self.map.extract_mesh_enqueue(self.resolution, self.max_n_triangles, max_std=self.max_std)
+
+    def _finish_frame(self, handle, d2h: str):
+        tri, tid, tstd = self.map.extract_mesh_finish(handle)
+        out = (tri, tid, tstd)
+        if d2h == "new":
+            n = tri.size(0)
+            if self._pin is None or self._pin[0].size(0) < n:
+                cap = max(1 << 18, 2 * n)
+                self._pin = (torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
+                             torch.empty((cap, 3), dtype=torch.float32).pin_memory())
+            with torch.cuda.device(self.device):
+                # copy on a side stream so it overlaps the next frame's kernels; that frame only READS this buffer
+                self._copy_stream.wait_event(handle["event"])
+                with torch.cuda.stream(self._copy_stream):
+                    self._pin[0][:n].copy_(tri, non_blocking=True)
+                    self._pin[1][:n].copy_(tid, non_blocking=True)
+                    self._pin[2][:n].copy_(tstd, non_blocking=True)
+                    self._copy_done = torch.cuda.Event()
+                    self._copy_done.record()
+            out = (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
+        elif d2h == "full":
+            mc = self.map.mesh_cache
+            out = (mc.vertices, mc.vertices_flatten_id, mc.vertices_std)
+        self.stats.append(dict(self.map.last_counters))
+        return out
+
+    def step_pipelined(self, i: int, d2h: str = "new"):
+        """Same work per frame as `step`, software-pipelined by one frame: frame i is enqueued, then frame i-1 (already finished or
+        finishing on the GPU) is completed on the host — counter read-back, D2H of its new triangles on a side stream.  The mesh
+        handed back is the previous frame's; call `flush()` after the last frame."""
+        h = self._enqueue_frame(i)
+        out = None
+        if self._pending is not None:
+            out = self._finish_frame(self._pending, d2h)
+        self._pending = h
+        return out
+
+    def flush(self, d2h: str = "new"):
+        out = None
+        if self._pending is not None:
+            out = self._finish_frame(self._pending, d2h)
+            self._pending = None
+        with torch.cuda.device(self.device):
+            self._copy_stream.synchronize()
         return out

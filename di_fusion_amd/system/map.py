@@ -129,6 +129,9 @@ class DenseIndexedMap:
         self._ws_n = 0
         self._xbuf = None
         self._host_counters = (ctypes.c_int32 * _lib.C_COUNT)()
+        self._pinned_counters = None
+        self._pending_seq = 0
+        self._add_total = 0                 # running sum of the per-call allocation bounds (see _ensure_capacity)
         self.last_counters = {}
 
     # ---- state ------------------------------------------------------------------------------------------------
@@ -175,18 +178,20 @@ class DenseIndexedMap:
         m.item_start = _lib.ptr(item_start)
         self._cmap = m
 
+    def _publish_counters(self, c, add_total_at_read):
+        if c[_lib.C_OVERFLOW] != 0:
+            raise RuntimeError(f"libdifusion: device buffer overflow (code {c[_lib.C_OVERFLOW]}); the map state is incomplete")
+        # exact n_occupied at the time the counters were read + whatever later calls may have allocated since
+        self._n_occ_ub = c[_lib.C_N_OCCUPIED] + (self._add_total - add_total_at_read)
+        self.last_counters = dict(n_occupied=c[_lib.C_N_OCCUPIED], alloc_new=c[_lib.C_ALLOC_NEW], M=c[_lib.C_M], C=c[_lib.C_C],
+                                  items=c[_lib.C_ITEMS], K=c[_lib.C_K], B=c[_lib.C_B], VH=c[_lib.C_VH], T=c[_lib.C_T],
+                                  query_M=c[_lib.C_QUERY_M], cache_T=c[_lib.C_CACHE_T], cache_kept=c[_lib.C_CACHE_KEPT])
+        return self.last_counters
+
     def _read_counters(self):
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().dif_read_counters(ctypes.byref(self._cmap), self._host_counters, _lib.stream_ptr()), "dif_read_counters")
-        c = list(self._host_counters)
-        if c[_lib.C_OVERFLOW] != 0:
-            raise RuntimeError(f"libdifusion: device buffer overflow (code {c[_lib.C_OVERFLOW]}); the map state is incomplete")
-        self._n_occ_ub = c[_lib.C_N_OCCUPIED]
-        self.last_counters = dict(n_occupied=c[_lib.C_N_OCCUPIED], alloc_new=c[_lib.C_ALLOC_NEW], M=c[_lib.C_M], C=c[_lib.C_C],
-                                  items=c[_lib.C_ITEMS], K=c[_lib.C_K], B=c[_lib.C_B], VH=c[_lib.C_VH], T=c[_lib.C_T],
-                                  query_M=c[_lib.C_QUERY_M], n_kept=c[_lib.C_N_KEPT], cache_T=c[_lib.C_CACHE_T],
-                                  cache_kept=c[_lib.C_CACHE_KEPT])
-        return self.last_counters
+        return self._publish_counters(list(self._host_counters), self._add_total)
 
     def _ensure_capacity(self, may_add: int):
         if self._n_occ_ub + may_add > self._capacity:
@@ -194,6 +199,7 @@ class DenseIndexedMap:
             if self._n_occ_ub + may_add > self._capacity:
                 self._alloc_state(_next_pow2(self._n_occ_ub + may_add))
         self._n_occ_ub += may_add
+        self._add_total += may_add
 
     def _ref_capacity(self) -> int:
         """Buffer length the reference would have after the same allocations (doubling from 1, map.py:263-268)."""
@@ -380,11 +386,11 @@ class DenseIndexedMap:
         b.cache_dst_tri, b.cache_dst_id, b.cache_dst_std = _lib.ptr(dst[0]), _lib.ptr(dst[1]), _lib.ptr(dst[2])
         return t, b
 
-    def extract_mesh_arrays(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,
-                            no_cache: bool = False, to_host: bool = True):
-        """The body of `do_meshing` (`map.py:624-714`): decode the dirty neighbourhood, run marching cubes, merge into the mesh
-        cache.  Returns the mesh cache arrays (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64,
-        vertices_std (T,3) f32) as numpy (`to_host`) or as device views; None while the cache is empty and nothing was dirty."""
+    def extract_mesh_enqueue(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,
+                             no_cache: bool = False):
+        """Enqueue the body of `do_meshing` (`map.py:624-714`) without waiting for it: decode the dirty neighbourhood, marching
+        cubes, mesh-cache merge, then an async copy of the device counters into pinned host memory.  Returns a handle for
+        `extract_mesh_finish`.  Lets a streaming caller keep the GPU queue full (the next frame is enqueued while this one runs)."""
         lib = _lib.load()
         with self.modifying_lock, torch.cuda.device(self.device):
             tens, buf = self._extract_buffers(voxel_resolution, max_n_triangles)
@@ -393,15 +399,38 @@ class DenseIndexedMap:
                                        float(max_std), 1 if no_cache else 0, 1, _lib.stream_ptr()), "dif_extract")
             self._cache_cur = 1 - self._cache_cur
             self.mesh_cache.invalidate_host_copy()
-            c = self._read_counters()
-            if c["T"] >= max_n_triangles:
-                logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {max_n_triangles}")
-            if c["K"] > 0:
-                self._cache_any = True
-            if not self._cache_any:
-                return None
-            if not to_host:
-                return self.mesh_cache_tensors()
+            if self._pinned_counters is None:
+                self._pinned_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(4)]
+            pc = self._pinned_counters[self._pending_seq % 4]
+            self._pending_seq += 1
+            pc.copy_(self._counters, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return dict(event=ev, counters=pc, cache_index=self._cache_cur, add_total=self._add_total, max_n_triangles=max_n_triangles)
+
+    def extract_mesh_finish(self, handle):
+        """Wait for an enqueued extract and publish its counters (`last_counters`).  Returns the device views of the triangles that
+        extract produced (vertices (T,3,3), voxel ids (T,), std (T,3)) — valid until the next-but-one extract overwrites the buffer."""
+        handle["event"].synchronize()
+        c = self._publish_counters([int(v) for v in handle["counters"].tolist()], handle["add_total"])
+        if c["T"] >= handle["max_n_triangles"]:
+            logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {handle['max_n_triangles']}")
+        if c["K"] > 0:
+            self._cache_any = True
+        tri, tid, tstd = self._cache[handle["cache_index"]]
+        lo, hi = c["cache_kept"], c["cache_T"]
+        return tri[lo:hi], tid[lo:hi], tstd[lo:hi]
+
+    def extract_mesh_arrays(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,
+                            no_cache: bool = False, to_host: bool = True):
+        """Synchronous `do_meshing` (`map.py:624-714`).  Returns the mesh cache arrays (vertices (T,3,3) f32 world units,
+        vertices_flatten_id (T,) i64, vertices_std (T,3) f32) as numpy (`to_host`) or as device views; None while the cache is
+        empty and nothing was dirty."""
+        self.extract_mesh_finish(self.extract_mesh_enqueue(voxel_resolution, max_n_triangles, fast, max_std, no_cache))
+        if not self._cache_any:
+            return None
+        if not to_host:
+            return self.mesh_cache_tensors()
         mc = self.mesh_cache
         return mc.vertices, mc.vertices_flatten_id, mc.vertices_std
 
