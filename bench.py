@@ -71,9 +71,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("DIF_FORCE_DIST") == "1"      # DIF_FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from di_fusion_amd import _lib, synthetic as syn
     from di_fusion_amd.network import utility as net_util
     from di_fusion_amd.stream import FusionStream
@@ -88,7 +91,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +114,7 @@ def main():
     ms = (ctypes.c_double * _lib.PROF_COUNT)()
     nl = (ctypes.c_int64 * _lib.PROF_COUNT)()
     _lib.check(lib.dif_profile_read(ms, nl, 1), "dif_profile_read")
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -149,7 +152,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_scale)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
