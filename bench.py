@@ -133,10 +133,16 @@ def main():
                 kern[name] = dict(ms_per_launch=t_ms / n, rows_per_launch=rows / n, tflops=rows * flop / (t_ms * 1e-3) / 1e12)
         dom = max(kern, key=lambda k: kern[k]["ms_per_launch"]) if kern else None
         roof = None
+        pmc = {}
+        try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs; see profiles/README.md)
+            pmc = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_hbm.json"))[-1].read_text())["kernels"]
+        except Exception:
+            pass
         if dom:
             roof = {"bound": "mfma", "kernel": {"encode": "k_encode", "decode_lattice": "k_decode", "decode_points": "k_decode"}[dom],
                     "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": pmc.get({"encode": "k_encode"}.get(dom, "k_decode"), {}).get("hbm_bytes_per_launch"),
                     "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
                     "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
                     "other_ms_per_frame": {k: round(prof[k][0] / max(1, a.steps), 4) for k in ("mc_count", "mc_emit", "sort")}}
