@@ -35,7 +35,8 @@ class DifMap(Structure):
 
 class DifWeights(Structure):
     _fields_ = [("enc_packed", c_void_p), ("enc_packed_floats", c_int64),
-                ("dec_packed", c_void_p), ("dec_packed_floats", c_int64)]
+                ("dec_packed", c_void_p), ("dec_packed_floats", c_int64),
+                ("dec_bwd_packed", c_void_p), ("dec_bwd_packed_floats", c_int64)]
 
 
 class DifExtractBuffers(Structure):

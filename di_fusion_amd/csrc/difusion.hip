@@ -559,11 +559,18 @@ struct DecodeArgs {
     float* out_sdf;
     float* out_std;
     float sign;                     // -1 to store the negated sdf (map.py:687)
+    float* out_grad;                // GRAD kernels: (n,3) d sdf / d xyz (world units), mode 3 (or d sdf / d x0[29..31] for mode 2)
+    const float* wbwd;              // GRAD kernels: transposed-layer blob
+    float grad_scale;               // 1 / voxel_size (mode 3), 1 (mode 2)
 };
 
-__global__ void __launch_bounds__(512, 2) k_decode(DecodeArgs A, const float* __restrict__ wblob) {
+// GRAD: 256 threads = one wave per SIMD with the full 512-register budget (forward + reverse chain keep ~300 values live)
+template <bool GRAD>
+__global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(DecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights(lds, wblob, DEC_LDS_FLOATS);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
+    const __amdgpu_buffer_rsrc_t wbwd = make_rsrc(GRAD ? A.wbwd : wblob, GRAD ? DECB_FLOATS : DEC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
@@ -632,7 +639,17 @@ __global__ void __launch_bounds__(512, 2) k_decode(DecodeArgs A, const float* __
             xin[t] = v;
         }
         float sdf, sd;
-        decoder_tile(lds, wblob, xin, lane, sdf, sd);
+        if (GRAD) {
+            float gx, gy, gz;
+            decoder_tile_grad(lds, wfwd, wbwd, xin, lane, sdf, sd, gx, gy, gz);
+            if (live && half == 1) {
+                A.out_grad[out_idx * 3 + 0] = gx * A.grad_scale;      // d rel / d xyz = 1 / voxel_size (map.py:565,575)
+                A.out_grad[out_idx * 3 + 1] = gy * A.grad_scale;
+                A.out_grad[out_idx * 3 + 2] = gz * A.grad_scale;
+            }
+        } else {
+            decoder_tile(lds, wfwd, xin, lane, sdf, sd);
+        }
         if (live) {
             if (half == 0) A.out_sdf[out_idx] = A.sign * sdf;
             else A.out_std[out_idx] = sd;
@@ -1188,18 +1205,30 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
 // ---- decoder launches ------------------------------------------------------------------------------------------
 static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t tiles_upper, hipStream_t s) {
     if (!w || !w->dec_packed || w->dec_packed_floats != DEC_FLOATS) return DIF_EINVAL;
+    const bool grad = A.out_grad != nullptr;
+    if (grad && (!w->dec_bwd_packed || w->dec_bwd_packed_floats != DECB_FLOATS)) return DIF_EINVAL;
     const size_t lds_bytes = (size_t)DEC_LDS_FLOATS * 4;
     static bool attr_set[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
         attr_set[dev] = true;
     }
     int64_t blocks = (tiles_upper + 7) / 8;
     if (blocks < 1) blocks = 1;
     if (blocks > num_cus()) blocks = num_cus();
     ProfScope prof(A.mode == 0 ? DIF_PROF_DECODE_LATTICE : DIF_PROF_DECODE_POINTS, s);
-    hipLaunchKernelGGL(k_decode, dim3((int)blocks), dim3(512), lds_bytes, s, A, w->dec_packed);
+    if (grad) {
+        DecodeArgs B = A;
+        B.wbwd = w->dec_bwd_packed;
+        blocks = (tiles_upper + 3) / 4;
+        if (blocks < 1) blocks = 1;
+        if (blocks > num_cus()) blocks = num_cus();
+        hipLaunchKernelGGL(k_decode<true>, dim3((int)blocks), dim3(256), lds_bytes, s, B, w->dec_packed);
+    } else {
+        hipLaunchKernelGGL(k_decode<false>, dim3((int)blocks), dim3(512), lds_bytes, s, A, w->dec_packed);
+    }
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -1405,7 +1434,6 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
 int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, uint8_t* mask, int32_t* sel, float* sdf,
                   float* std_out, float* grad, int32_t* scratch, void* stream_) {
     if (!map || !w || N < 0 || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
-    if (grad) return DIF_EINVAL;                              // analytic d sdf/d xyz: SURVEY.md section 8f-1, not built yet
     hipStream_t s = (hipStream_t)stream_;
     if (N == 0) return hipMemsetAsync(map->counters + DIF_C_QUERY_M, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
     if (!xyz || !mask || !sel || !sdf || !std_out || !scratch) return DIF_EINVAL;
@@ -1415,6 +1443,7 @@ int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz
     DecodeArgs A = {};
     A.mode = 3; A.n_ptr = map->counters + DIF_C_QUERY_M; A.latent = map->latent_vecs; A.list = sel; A.xyz = xyz; A.indexer = map->indexer;
     A.geo = g; A.out_sdf = sdf; A.out_std = std_out; A.sign = 1.0f; A.lat.res = 1;
+    A.out_grad = grad; A.grad_scale = 1.0f / map->voxel_size;
     return launch_decode(A, w, (N + 31) / 32, s);
 }
 

@@ -42,16 +42,38 @@ __device__ __forceinline__ f16v relu16(f16v v) {
 // The A stream is software-pipelined by hand: the float4 for k-group t+1 is requested before the 4 MFMAs of k-group t
 // (256 cycles of matrix-pipe time cover the LDS / L2 latency); sched_barrier pins that order — left alone, the
 // scheduler hoists every ds_read of the fully unrolled chain to the top and spills hundreds of VGPRs.
-template <int NB>
-__device__ __forceinline__ f16v block_mm(const f4v* __restrict__ A, const f16v (&hin)[NB], f16v acc, int lane) {
-    f4v a = A[lane];
+// Where the A stream comes from: LDS (ds_read_b128) or a buffer resource over the packed blob in global memory
+// (buffer_load_dwordx4 with SGPR base + scalar offset: no per-load 64-bit VGPR address, nothing for LICM to hoist and spill).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+struct LdsA {
+    const f4v* p;
+    __device__ __forceinline__ f4v load(int t, int lane) const { return p[t * 64 + lane]; }
+};
+
+struct BufA {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int base;                           // byte offset of k-group 0 (wave-uniform)
+    __device__ __forceinline__ f4v load(int t, int lane) const {
+        u4v v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, base + t * 1024, 0);
+        return __builtin_bit_cast(f4v, v);
+    }
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int n_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, n_floats * 4, 0x00020000);
+}
+
+template <int NB, class ASRC>
+__device__ __forceinline__ f16v block_mm_src(const ASRC& A, const f16v (&hin)[NB], f16v acc, int lane) {
+    f4v a = A.load(0, lane);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int t = kb * 4 + g;
             f4v an = a;
-            if (t + 1 < NB * 4) an = A[(t + 1) * 64 + lane];
+            if (t + 1 < NB * 4) an = A.load(t + 1, lane);
             acc = mfma32(a.x, hin[kb][4 * g + 0], acc);
             acc = mfma32(a.y, hin[kb][4 * g + 1], acc);
             acc = mfma32(a.z, hin[kb][4 * g + 2], acc);
@@ -61,6 +83,11 @@ __device__ __forceinline__ f16v block_mm(const f4v* __restrict__ A, const f16v (
         }
     }
     return acc;
+}
+
+template <int NB>
+__device__ __forceinline__ f16v block_mm(const f4v* __restrict__ A, const f16v (&hin)[NB], f16v acc, int lane) {
+    return block_mm_src<NB>(LdsA{A}, hin, acc, lane);
 }
 
 // ---- encoder -------------------------------------------------------------------------------------------------
@@ -127,7 +154,7 @@ __device__ __forceinline__ f16v encoder_tile(const float* __restrict__ W /* LDS 
 
 // One 32-point tile through the decoder.  xin[t] = x0[k = 2t + half] of point (lane&31), x0 = [latent 29 | xyz 3].
 // Returns (sdf, std) for point (lane & 31), identical in both halves.
-__device__ __forceinline__ void decoder_tile(const float* __restrict__ W /* LDS */, const float* __restrict__ Wg /* global blob */,
+__device__ __forceinline__ void decoder_tile(const float* __restrict__ W /* LDS */, __amdgpu_buffer_rsrc_t Wg /* global blob */,
                                              const f16v& xin, int lane, float& sdf, float& stdv) {
     const int half = lane >> 5;
     f16v hx[1];
@@ -154,16 +181,15 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W /* LDS 
         h2x[mb] = relu16(acc);
     }
     h2x[3] = xin;
-    // L3's A operand comes from global memory and is loop-invariant per lane: without this barrier LICM hoists all 64
-    // float4 loads out of the persistent tile loop and spills them (256 VGPRs) instead of streaming them through L1/L2.
-    // (The base pointer is also made opaque per tile: otherwise the 64 per-load 64-bit addresses get hoisted and spilled.)
-    const float* Wg3 = Wg + DEC_A3;
-    asm volatile("" : "+s"(Wg3) : : "memory");
+    // L3's A operand comes from global memory and is loop-invariant per lane: the offset is made opaque per tile, otherwise
+    // LICM hoists all 64 loads out of the persistent tile loop and spills them (256 VGPRs) instead of streaming through L1/L2.
+    int off3 = DEC_A3 * 4;
+    asm volatile("" : "+s"(off3) : : "memory");
     float ps = 0.0f, pu = 0.0f;        // per-lane partial dot products of the two 128->1 heads
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         f16v acc = load_bias16(W + DEC_B3 + mb * 32, half);
-        acc = block_mm<4>(reinterpret_cast<const f4v*>(Wg3) + (mb * 16) * 64, h2x, acc, lane);
+        acc = block_mm_src<4>(BufA{Wg, off3 + mb * 16 * 1024}, h2x, acc, lane);
         acc = relu16(acc);
         f16v ws = load_bias16(W + DEC_HW + mb * 32, half);
         f16v wu = load_bias16(W + DEC_HU + mb * 32, half);
@@ -180,6 +206,118 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W /* LDS 
     sdf = tanhf(ps);                                                       // di_decoder.py:84
     float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));                       // F.softplus (beta=1, threshold=20)
     stdv = 0.05f + 0.5f * sp;                                              // di_decoder.py:68
+}
+
+// ---- decoder with input gradient (get_sdf for the tracker: d sdf / d xyz, reference tracker.py:186-192) -------------------
+// Backward blob (global memory, packing.py:pack_decoder_backward): transposed layers, k order = D-fragment order of the
+// forward layer's OUTPUT blocks, so the masked upstream gradient fragments are again ready-made B operands.
+#define DECB_T3 0                     // W3^T  MB=4 (rows: h2 0..95 | x0 96..127)  KG=16   16384
+#define DECB_T2 16384                 // W2^T  MB=4 (h1)   KG=12                           12288
+#define DECB_T1 28672                 // W1^T  MB=4 (h0)   KG=16                           16384
+#define DECB_T0 45056                 // W0^T  MB=1 (x0)   KG=16                            4096
+#define DECB_FLOATS 49152
+
+__device__ __forceinline__ f16v relu16_mask(f16v v, unsigned& mask) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        m |= (v[i] > 0.0f) ? (1u << i) : 0u;
+        v[i] = fmaxf(v[i], 0.0f);
+    }
+    mask = m;
+    return v;
+}
+
+__device__ __forceinline__ f16v apply_mask16(f16v v, unsigned mask) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ((mask >> i) & 1u) ? v[i] : 0.0f;
+    return v;
+}
+
+__device__ __forceinline__ f16v zero16() {
+    f16v z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return z;
+}
+
+// Forward as decoder_tile (recording the ReLU masks, 16 bits per out-block), then the reverse chain
+//   g3 = w4 (.) mask3 ; [g2 | gx_skip] = W3^T g3 ; g1 = W2^T (g2 (.) mask2) ; g0 = W1^T (g1 (.) mask1) ; gx = W0^T (g0 (.) mask0)
+// d sdf / d x0[29..31] = (1 - sdf^2) * (gx + gx_skip)[29..31]   (tanh').  Features 29,30,31 of a natural-order block sit in
+// registers 13,14,15 of the lanes 32..63.  Returns them in (gx, gy, gz) on those lanes (garbage on lanes 0..31).
+__device__ __forceinline__ void decoder_tile_grad(const float* __restrict__ W /* LDS */, __amdgpu_buffer_rsrc_t Wg /* fwd blob */,
+                                                  __amdgpu_buffer_rsrc_t Wb /* bwd blob */, const f16v& xin, int lane,
+                                                  float& sdf, float& stdv, float& gx, float& gy, float& gz) {
+    const int half = lane >> 5;
+    unsigned m0[4], m1[4], m2[3], m3[4];
+    f16v hx[1];
+    hx[0] = xin;
+    f16v h0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = load_bias16(W + DEC_B0 + mb * 32, half);
+        acc = block_mm<1>(reinterpret_cast<const f4v*>(W + DEC_A0) + (mb * 4) * 64, hx, acc, lane);
+        h0[mb] = relu16_mask(acc, m0[mb]);
+    }
+    f16v h1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = load_bias16(W + DEC_B1 + mb * 32, half);
+        acc = block_mm<4>(reinterpret_cast<const f4v*>(W + DEC_A1) + (mb * 16) * 64, h0, acc, lane);
+        h1[mb] = relu16_mask(acc, m1[mb]);
+    }
+    f16v h2x[4];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        f16v acc = load_bias16(W + DEC_B2 + mb * 32, half);
+        acc = block_mm<4>(reinterpret_cast<const f4v*>(W + DEC_A2) + (mb * 16) * 64, h1, acc, lane);
+        h2x[mb] = relu16_mask(acc, m2[mb]);
+    }
+    h2x[3] = xin;
+    int off3 = DEC_A3 * 4, offb = 0;
+    asm volatile("" : "+s"(off3), "+s"(offb) : : "memory");
+    float ps = 0.0f, pu = 0.0f;
+    f16v g3[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = load_bias16(W + DEC_B3 + mb * 32, half);
+        acc = block_mm_src<4>(BufA{Wg, off3 + mb * 16 * 1024}, h2x, acc, lane);
+        acc = relu16_mask(acc, m3[mb]);
+        f16v ws = load_bias16(W + DEC_HW + mb * 32, half);
+        f16v wu = load_bias16(W + DEC_HU + mb * 32, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ps = fmaf(acc[r], ws[r], ps);
+            pu = fmaf(acc[r], wu[r], pu);
+        }
+        g3[mb] = apply_mask16(ws, m3[mb]);                 // d sdf_pre / d (pre-activation of lin3)
+    }
+    ps += __shfl_xor(ps, 32);
+    pu += __shfl_xor(pu, 32);
+    ps += W[DEC_HB + 0];
+    pu += W[DEC_HB + 1];
+    sdf = tanhf(ps);
+    float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));
+    stdv = 0.05f + 0.5f * sp;
+    // ---- reverse chain ----
+    f16v g2[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+        g2[mb] = apply_mask16(block_mm_src<4>(BufA{Wb, offb + DECB_T3 * 4 + mb * 16 * 1024}, g3, zero16(), lane), m2[mb]);
+    f16v gskip = block_mm_src<4>(BufA{Wb, offb + DECB_T3 * 4 + 3 * 16 * 1024}, g3, zero16(), lane);
+    f16v g1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+        g1[mb] = apply_mask16(block_mm_src<3>(BufA{Wb, offb + DECB_T2 * 4 + mb * 12 * 1024}, g2, zero16(), lane), m1[mb]);
+    f16v g0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+        g0[mb] = apply_mask16(block_mm_src<4>(BufA{Wb, offb + DECB_T1 * 4 + mb * 16 * 1024}, g1, zero16(), lane), m0[mb]);
+    f16v gxv = block_mm_src<4>(BufA{Wb, offb + DECB_T0 * 4}, g0, gskip, lane);
+    const float dt = 1.0f - sdf * sdf;
+    gx = dt * gxv[13];
+    gy = dt * gxv[14];
+    gz = dt * gxv[15];
 }
 
 // cooperative global -> LDS copy of `n_floats` (multiple of 4) by the whole block

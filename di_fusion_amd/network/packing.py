@@ -22,6 +22,7 @@ import numpy as np
 ENC_FLOATS = 27264
 DEC_LDS_FLOATS = 33508
 DEC_FLOATS = 49892
+DECB_FLOATS = 49152
 
 
 def _frag_feature(r: int, half: int) -> int:
@@ -120,4 +121,18 @@ def pack_decoder(w: Dict[str, np.ndarray]) -> np.ndarray:
     assert lds.shape[0] == DEC_LDS_FLOATS, lds.shape
     blob = np.concatenate([lds, pack_A(Ws[3], 4, 16, kmap_l3).reshape(-1)]).astype(np.float32)
     assert blob.shape[0] == DEC_FLOATS, blob.shape
+    return blob
+
+
+def pack_decoder_backward(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """Transposed decoder layers for the input-gradient chain of `decoder_tile_grad` (mlp.hip.h).  Each W^T is packed like a
+    forward layer: rows (MFMA M) = the layer's INPUT features, k = its OUTPUT features in D-fragment order (the masked upstream
+    gradient blocks are the B operands)."""
+    Ws, bs, Wu, bu = fold_decoder(w)
+    parts = [pack_A(np.ascontiguousarray(Ws[3].T), 4, 16, kmap_dfrag),      # (128 in: h2 96 | x0 32) x (128 out)
+             pack_A(np.ascontiguousarray(Ws[2].T), 4, 12, kmap_dfrag),      # (128 in) x (96 out)
+             pack_A(np.ascontiguousarray(Ws[1].T), 4, 16, kmap_dfrag),      # (128) x (128)
+             pack_A(np.ascontiguousarray(Ws[0].T), 1, 16, kmap_dfrag)]      # (32 in: latent 29 | xyz 3) x (128 out)
+    blob = np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
+    assert blob.shape[0] == DECB_FLOATS, blob.shape
     return blob

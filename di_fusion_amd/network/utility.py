@@ -28,6 +28,7 @@ class _PackedNet:
         self.raw = raw
         self._enc_blob = packing.pack_encoder(raw)
         self._dec_blob = packing.pack_decoder(raw)
+        self._decb_blob = packing.pack_decoder_backward(raw)
         self._dev = {}
 
     def weights_struct(self, device: torch.device):
@@ -36,8 +37,9 @@ class _PackedNet:
         if key not in self._dev:
             enc = torch.from_numpy(self._enc_blob).to(device)
             dec = torch.from_numpy(self._dec_blob).to(device)
-            w = _lib.DifWeights(_lib.ptr(enc), enc.numel(), _lib.ptr(dec), dec.numel())
-            self._dev[key] = (w, enc, dec)
+            decb = torch.from_numpy(self._decb_blob).to(device)
+            w = _lib.DifWeights(_lib.ptr(enc), enc.numel(), _lib.ptr(dec), dec.numel(), _lib.ptr(decb), decb.numel())
+            self._dev[key] = (w, enc, dec, decb)
         return self._dev[key][0]
 
 

@@ -78,6 +78,25 @@ class Mesh:
         self.vertex_std = vertex_std        # (3T,) float
 
 
+class _GetSdfFn(torch.autograd.Function):
+    """sdf(xyz) with the kernel-computed Jacobian d sdf_m / d xyz_{sel[m]} (each output depends on one input point only)."""
+
+    @staticmethod
+    def forward(ctx, xyz, owner):
+        sdf, std, mask, sel, grad = owner._query(xyz, True)
+        ctx.save_for_backward(sel, grad)
+        ctx.n = xyz.size(0)
+        ctx.mark_non_differentiable(std, mask)
+        return sdf, std, mask
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_std, g_mask):
+        sel, grad = ctx.saved_tensors
+        out = torch.zeros((ctx.n, 3), dtype=torch.float32, device=grad.device)
+        out[sel.long()] = grad * g_sdf.unsqueeze(1)
+        return out, None
+
+
 def _next_pow2(n: int) -> int:
     p = 1
     while p < n:
@@ -309,9 +328,7 @@ class DenseIndexedMap:
         self.merge_records(rec)
 
     # ---- get_sdf ----------------------------------------------------------------------------------------------
-    def get_sdf(self, xyz: torch.Tensor):
-        """reference `map.py:559-579`: (N,3) -> sdf (M,), std (M,), valid_mask (N,) bool.  Values only: the autograd
-        graph w.r.t. xyz that the tracker differentiates through (tracker.py:186-192) is SURVEY.md row 8f-1."""
+    def _query(self, xyz: torch.Tensor, want_grad: bool):
         xyz = xyz.detach().contiguous().float()
         _lib.require_cuda(xyz)
         N = xyz.size(0)
@@ -321,12 +338,24 @@ class DenseIndexedMap:
             sel = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
             sdf = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
             std = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
+            grad = torch.empty((max(N, 1), 3), dtype=torch.float32, device=dev) if want_grad else None
             scratch = torch.empty((N + 4096,), dtype=torch.int32, device=dev)
             w = self.model.packed.weights_struct(dev)
             _lib.check(_lib.load().dif_query_sdf(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), N, _lib.ptr(mask), _lib.ptr(sel),
-                                                 _lib.ptr(sdf), _lib.ptr(std), None, _lib.ptr(scratch), _lib.stream_ptr()), "dif_query_sdf")
+                                                 _lib.ptr(sdf), _lib.ptr(std), _lib.ptr(grad), _lib.ptr(scratch), _lib.stream_ptr()), "dif_query_sdf")
         M = self._read_counters()["query_M"]
-        return sdf[:M], std[:M], mask.view(torch.bool)
+        return sdf[:M], std[:M], mask.view(torch.bool), sel[:M], (grad[:M] if want_grad else None)
+
+    def get_sdf(self, xyz: torch.Tensor):
+        """reference `map.py:559-579`: (N,3) -> sdf (M,), std (M,), valid_mask (N,) bool.
+        If `xyz.requires_grad`, `sdf` carries an autograd edge back to `xyz` (analytic d sdf / d xyz from the decoder's reverse
+        MFMA chain), which is what `SDFTracker.compute_sdf_Hg` differentiates (reference `tracker.py:186-192`: the loss is
+        sdf / std.detach(), so `std` is returned without a graph)."""
+        if torch.is_grad_enabled() and xyz.requires_grad:
+            sdf, std, mask = _GetSdfFn.apply(xyz, self)
+            return sdf, std, mask
+        sdf, std, mask, _, _ = self._query(xyz, False)
+        return sdf, std, mask
 
     # ---- extract ----------------------------------------------------------------------------------------------
     def _ensure_cache(self, capacity: int):

@@ -81,6 +81,8 @@ typedef struct dif_weights {
     int64_t enc_packed_floats;
     const float* dec_packed;        /* decoder: weight-norm-folded linear weights */
     int64_t dec_packed_floats;
+    const float* dec_bwd_packed;    /* decoder, transposed layers for d sdf / d xyz (may be NULL if gradients are never asked) */
+    int64_t dec_bwd_packed_floats;
 } dif_weights_t;
 
 int dif_version(void);
@@ -161,7 +163,7 @@ int dif_decode_rows(const dif_weights_t* w, const float* rows, int64_t n, float*
 /* encoder on explicit rows (network/di_encoder.py:26-30): rows (n,6) -> out (n,29).  Test / ext entry point.   */
 int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float* out, void* stream);
 /* get_sdf: xyz (N,3) -> mask (N) u8, and for the M valid points IN ORDER: sdf (M), std (M), grad (M,3) = d sdf / d xyz
- * in world units (NULL to skip), sel (M) = index of the point.  M -> counters[DIF_C_QUERY_M].
+ * in world units (NULL to skip; reference tracker.py:186-192 obtains it by autograd), sel (M) = index of the point.  M -> counters[DIF_C_QUERY_M].
  * scratch: int32 [N + 4096]. */
 int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, uint8_t* mask,
                   int32_t* sel, float* sdf, float* std_out, float* grad, int32_t* scratch, void* stream);

@@ -227,3 +227,59 @@ def test_c1_full_frame_vs_golden(gpu_model):
     sdf, std, qmask = m.get_sdf(torch.from_numpy(g["probe_xyz"]).to(DEV))
     assert np.array_equal(qmask.cpu().numpy(), g["probe_mask"])
     assert np.abs(sdf.cpu().numpy() - g["probe_sdf"]).max() < SDF_TOL
+
+
+def test_get_sdf_gradient_matches_autograd_and_finite_differences(gpu_model, raw_weights):
+    """a17 / SURVEY 8f-1: d sdf / d xyz from the reverse MFMA chain vs (i) torch autograd through a plain fp32 torch
+    re-statement of the decoder on the same latents, (ii) central finite differences of the kernel's own sdf."""
+    from di_fusion_amd.network import packing
+    scene, cfg, intr = CASES["seq_small"]
+    g = np.load(GOLDEN / "seq_small.npz")
+    m = make_map(gpu_model, cfg)
+    for f in range(2):
+        xyz, nrm = frame_inputs(g, "seq_small", f)
+        m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+    q = torch.from_numpy(g["probe_xyz"]).to(DEV).requires_grad_(True)
+    sdf, std, mask = m.get_sdf(q)
+    loss = sdf / std.detach()                                    # the tracker's residual (tracker.py:186)
+    (gq,) = torch.autograd.grad(loss, [q], grad_outputs=torch.ones_like(loss))
+    assert gq.shape == q.shape and mask.sum().item() == sdf.numel() > 100
+    assert torch.all(gq[~mask] == 0)
+    # (i) torch reference on CPU
+    Ws, bs, Wu, bu = packing.fold_decoder(raw_weights)
+    Ws = [torch.from_numpy(w) for w in Ws]; bs = [torch.from_numpy(b) for b in bs]
+    qc = q.detach().cpu().double().requires_grad_(True)
+    bmin = torch.tensor(cfg.bound_min, dtype=torch.float64)
+    xn = (qc - bmin) / cfg.voxel_size
+    gid = torch.ceil(xn.detach()) - 1
+    lin = (gid[:, 2] + m.n_xyz[2] * gid[:, 1] + m.n_xyz[2] * m.n_xyz[1] * gid[:, 0]).long()
+    slot = m.indexer.cpu()[lin]
+    mk = mask.cpu()
+    lat = m.latent_vecs.cpu()[slot[mk]].double()
+    rel = xn[mk] - gid[mk] - 0.5
+    x0 = torch.cat([lat, rel], 1)
+    h = x0
+    for l in range(4):
+        if l == 3:
+            h = torch.cat([h, x0], 1)
+        h = torch.relu(h @ Ws[l].double().T + bs[l].double())
+    ref_sdf = torch.tanh(h @ Ws[4].double().T + bs[4].double())[:, 0]
+    ref_loss = ref_sdf / std.detach().cpu().double()
+    (gref,) = torch.autograd.grad(ref_loss, [qc], grad_outputs=torch.ones_like(ref_loss))
+    assert np.abs(sdf.detach().cpu().numpy() - ref_sdf.detach().numpy()).max() < SDF_TOL
+    d = (gq.cpu().double() - gref).abs().max().item()
+    scale = gref.abs().max().item()
+    print(f"  get_sdf grad: max |diff| {d:.3e} (max |grad| {scale:.3e})")
+    assert d < 1e-4 * max(scale, 1.0)
+    # (ii) finite differences along x on the kernel itself (skip points close to a ReLU kink / voxel face)
+    eps = 1e-3
+    qp = q.detach().clone(); qp[:, 0] += eps
+    qm = q.detach().clone(); qm[:, 0] -= eps
+    sp, _, mp = m.get_sdf(qp)
+    sm, _, mm = m.get_sdf(qm)
+    both = (mask & mp & mm)
+    idx = torch.cumsum(mask.long(), 0) - 1
+    fd = (sp[(torch.cumsum(mp.long(), 0) - 1)[both]] - sm[(torch.cumsum(mm.long(), 0) - 1)[both]]) / (2 * eps)
+    an = (gq[:, 0] * std.detach()[idx.clamp(min=0)])[both]        # undo the 1/std factor
+    rel_err = ((fd - an).abs() / (an.abs() + 0.05)).median().item()
+    assert rel_err < 0.05, rel_err
