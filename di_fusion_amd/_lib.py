@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libdifusion.so"
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT = range(14)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N = range(15)
 C_COUNT = 16
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "sort"]
 PROF_COUNT = 8
@@ -30,7 +30,8 @@ class DifMap(Structure):
                 ("indexer", c_void_p), ("latent_vecs", c_void_p), ("latent_vecs_pos", c_void_p),
                 ("voxel_obs_count", c_void_p), ("dirty", c_void_p), ("counters", c_void_p),
                 ("frame_count", c_void_p), ("grid_bits", c_void_p), ("vbm", c_void_p),
-                ("seg_start", c_void_p), ("seg_cnt", c_void_p), ("item_start", c_void_p)]
+                ("seg_start", c_void_p), ("seg_cnt", c_void_p), ("item_start", c_void_p),
+                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32)]
 
 
 class DifWeights(Structure):
@@ -68,8 +69,8 @@ SIGNATURES = {
     "dif_encode_rows": (c_int32, [POINTER(DifWeights), c_void_p, c_int64, c_void_p, c_void_p]),
     "dif_query_sdf": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dif_export_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p]),
-    "dif_merge_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_export_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "dif_merge_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "dif_profile_enable": (c_int32, [c_int32]),
     "dif_profile_read": (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
     "dif_read_counters": (c_int32, [POINTER(DifMap), POINTER(c_int32), c_void_p]),

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_groupby_sum(const float* __restri
 // K1: per-point voxel id + per-voxel point count of this frame.  Adjacent pixels mostly fall in the same voxel, so
 // equal-id runs inside a wave are aggregated with a ballot before touching memory (1 atomic per run, not per point).
 __global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* __restrict__ xyz, int64_t N, int* __restrict__ pt_lin,
-                                                         int* __restrict__ frame_count, int* __restrict__ counters) {
+                                                         int* __restrict__ frame_count, int* __restrict__ counters, int px_lo, int px_hi) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // grid covers N rounded up to a wave
     int lane = lane_id();
     if (i < 4) counters[DIF_C_ALLOC_NEW + i] = 0;                   // ALLOC_NEW, M, C, ITEMS of this call
@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* _
     if (i < N) {
         float xn, yn, zn; int ix, iy, iz;
         bool ok = voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        ok = ok && ix >= px_lo && ix < px_hi;                         // spatial tiling: own slab + halo only
         lin = ok ? linearize(g, ix, iy, iz) : -1;
         pt_lin[i] = lin;
     }
@@ -474,7 +475,14 @@ struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> v
     const int64_t* indexer;
     const float* obs;
     uint32_t* bits;
-    __device__ int count(int s) const { return (no_cache || dirty[s]) ? 1 : 0; }
+    int64_t own_lin_lo, own_lin_hi;     // only owned voxels are meshed (spatial tiling); the whole grid by default
+    __device__ int count(int s) const {
+        if (!(no_cache || dirty[s])) return 0;
+        const int64_t p = pos[s];
+        if (p >= own_lin_lo && p < own_lin_hi) return 1;
+        dirty[s] = 0;                   // halo voxel: its owner meshes it
+        return 0;
+    }
     __device__ void emit(int s, int offset) const {
         dirty[s] = 0;
         if (offset >= max_voxels) return;
@@ -994,23 +1002,31 @@ struct QueryFunctor {
 // =================================================================================================================
 // multi-GPU merge helpers
 // =================================================================================================================
-__global__ void __launch_bounds__(DIF_BLOCK) k_export_records(const int64_t* __restrict__ pos, const float* __restrict__ obs,
-                                                            const float* __restrict__ latent, const int* __restrict__ counters,
-                                                            int32_t* __restrict__ rec, int64_t max_records) {
-    int n = counters[DIF_C_N_OCCUPIED];
-    if (n > max_records) n = (int)max_records;
-    const int64_t total = (int64_t)n * 32;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        int64_t s = e >> 5;
-        int f = (int)(e & 31);
-        int32_t out;
-        if (f == 0) out = (int32_t)(pos[s] & 0xFFFFFFFFll);
-        else if (f == 1) out = (int32_t)(pos[s] >> 32);
-        else if (f == 2) out = __float_as_int(obs[s]);
-        else out = __float_as_int(latent[s * L + (f - 3)] * obs[s]);
-        rec[e] = out;
+struct ExportFunctor {       // ordered compaction over slots: allocated voxels with x index in [x_lo, x_hi)
+    const int64_t* pos; const float* obs; const float* latent;
+    int32_t* rec; int64_t max_records;
+    int64_t lin_lo, lin_hi;
+    int raw;
+    int* counters;
+    __device__ int count(int s) const { int64_t p = pos[s]; return (p >= lin_lo && p < lin_hi) ? 1 : 0; }
+    __device__ void emit(int s, int offset) const {
+        if (offset >= max_records) return;
+        int32_t* r = rec + (int64_t)offset * 32;
+        const int64_t p = pos[s];
+        const float w = obs[s];
+        r[0] = (int32_t)(p & 0xFFFFFFFFll);
+        r[1] = (int32_t)(p >> 32);
+        r[2] = __float_as_int(w);
+        for (int f = 0; f < L; ++f) {
+            float z = latent[(int64_t)s * L + f];
+            r[3 + f] = __float_as_int(raw ? z : z * w);
+        }
     }
-}
+    __device__ void finish(int total) const {
+        if (total > max_records) { total = (int)max_records; counters[DIF_C_OVERFLOW] = 6; }
+        counters[DIF_C_EXPORT_N] = total;
+    }
+};
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
                                                         uint32_t* __restrict__ bits, int64_t grid) {
@@ -1024,7 +1040,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restr
 // records of one call carry distinct lin ids => plain read-modify-write, deterministic
 __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
                                                          float* __restrict__ latent, float* __restrict__ obs, uint8_t* __restrict__ dirty,
-                                                         int* __restrict__ counters, int64_t grid, int64_t capacity) {
+                                                         int* __restrict__ counters, int64_t grid, int64_t capacity, int assign) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int no = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (no > capacity) { no = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
@@ -1041,16 +1057,17 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __rest
         if (s < 0) continue;
         float w_r = __int_as_float(rec[i * 32 + 2]);
         float w_old = obs[s];
-        float w_new = w_old + w_r;
+        float w_new = assign ? w_r : w_old + w_r;
         if (f < L) {
-            float wz = __int_as_float(rec[i * 32 + 3 + f]);
+            float pay = __int_as_float(rec[i * 32 + 3 + f]);
             float z = latent[s * L + f];
-            if (w_new > 0.0f) latent[s * L + f] = (z * w_old + wz) / w_new;
+            if (assign) latent[s * L + f] = pay;
+            else if (w_new > 0.0f) latent[s * L + f] = (z * w_old + pay) / w_new;
         }
         __builtin_amdgcn_wave_barrier();
         if (f == 31) {
             obs[s] = w_new;
-            if (w_r > 0.0f) dirty[s] = 1;
+            if (!assign && w_r > 0.0f) dirty[s] = 1;
         }
     }
 }
@@ -1160,7 +1177,9 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
     const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK);
 
     // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
-    hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C);
+    const int own_lo = map->own_x_hi > map->own_x_lo ? map->own_x_lo : 0, own_hi = map->own_x_hi > map->own_x_lo ? map->own_x_hi : map->nx;
+    hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C, own_lo - map->halo,
+                       own_hi + map->halo);
     hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
                        (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, map->grid_bits, C);
     DIF_CHECK_LAUNCH();
@@ -1367,8 +1386,10 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     const double sample_a = -(double)(r / 2) * (1.0 / r), sample_b = 1.0 + (double)((r - 1) / 2) * (1.0 / r);   // map.py:640-641
 
     {   // dirty slots -> valid_blocks
+        const int64_t plane = (int64_t)map->ny * map->nz;
+        const bool tiled = map->own_x_hi > map->own_x_lo;
         DirtyFunctor f{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels, g, map->ignore_count_th,
-                       map->indexer, map->voxel_obs_count, map->grid_bits};
+                       map->indexer, map->voxel_obs_count, map->grid_bits, tiled ? map->own_x_lo * plane : 0, tiled ? map->own_x_hi * plane : grid};
         if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     }
     {
@@ -1448,16 +1469,18 @@ int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz
 }
 
 // ---- multi-GPU merge -------------------------------------------------------------------------------------------
-int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, void* stream) {
-    if (!map || !records || max_records <= 0) return DIF_EINVAL;
-    hipLaunchKernelGGL(k_export_records, dim3(grid_for(max_records * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, (hipStream_t)stream,
-                       (const int64_t*)map->latent_vecs_pos, (const float*)map->voxel_obs_count, (const float*)map->latent_vecs,
-                       (const int*)map->counters, records, max_records);
-    DIF_CHECK_LAUNCH();
-    return DIF_OK;
+int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t raw, int32_t* scratch,
+                       void* stream) {
+    if (!map || !records || !scratch || max_records <= 0) return DIF_EINVAL;
+    if (x_lo < 0) x_lo = 0;
+    if (x_hi > map->nx) x_hi = map->nx;
+    const int64_t plane = (int64_t)map->ny * map->nz;
+    ExportFunctor f{map->latent_vecs_pos, map->voxel_obs_count, map->latent_vecs, records, max_records, x_lo * plane, (x_hi > x_lo ? x_hi : x_lo) * plane,
+                    raw ? 1 : 0, map->counters};
+    return launch_scan(f, map->counters + DIF_C_N_OCCUPIED, 0, map->capacity, scratch, (hipStream_t)stream);
 }
 
-int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t* scratch, void* stream_) {
+int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t assign, int32_t* scratch, void* stream_) {
     if (!map || n < 0) return DIF_EINVAL;
     if (n == 0) return DIF_OK;
     if (!records || !scratch) return DIF_EINVAL;
@@ -1470,7 +1493,7 @@ int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, i
     int nwords = (int)((grid + 31) / 32);
     if (launch_scan(f, nullptr, nwords, nwords, scratch, s) != DIF_OK) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, records, n, (const int64_t*)map->indexer,
-                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity);
+                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

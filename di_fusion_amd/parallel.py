@@ -44,3 +44,38 @@ def build_global_map(local_map, make_map, group=None):
     for c in chunks:
         g.merge_records(c)
     return g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# C5: one stream, the grid cut into x-slabs, one slab per GPU, halo exchange on the slab boundaries
+# ------------------------------------------------------------------------------------------------------------------
+# x is the slowest-varying axis of the linear voxel id (reference `map.py:292`), so a slab is a contiguous id range.
+# Every rank sees the whole frame (640x480 points are 3.7 MB: replicating them is cheaper than routing them) and keeps the
+# points whose own voxel lies within HALO voxels of its slab.  Why HALO = 3 makes every OWNED voxel bit-identical to the
+# single-map result, provided the boundary layers are refreshed from their owners after every integrate:
+#   * an owned voxel v is updated by points whose own voxel u is within 1 of v (the 8-offset gather, map.py:421-429);
+#   * such a point is kept only if u holds > prune_min_vox_obs points of the frame (map.py:375)  -> all points of u: dist 1;
+#   * and only if u or a 6-neighbour w of u is in the encode set (map.py:392-397): w is within 2 of the slab, and "in the encode
+#     set" means allocated (possibly by THIS frame: some new voxel u' within 1 of w, i.e. within 3 of the slab, with all its
+#     points and its exact pre-frame indexer entry) and voxel_obs_count[w] < encoder_count_th before this frame's fusion;
+#   * sums are order-independent (fixed point), so the same contributions give the same bits.
+# Halo voxels are updated locally from incomplete data and are overwritten by the owner's exact (w, z) right after.
+HALO = 3
+
+
+def slab_range(nx: int, rank: int, world: int):
+    return (rank * nx) // world, ((rank + 1) * nx) // world
+
+
+def exchange_halo(m, rank: int, world: int, group=None):
+    """Refresh the halo layers of `m` (a DenseIndexedMap with `set_ownership`) from the neighbouring slabs' owners.
+    Two small variable-length all-gathers of raw (w, z) records; ring neighbours are directly xGMI-linked."""
+    lo, hi = m._ownership[0], m._ownership[1]
+    left = m.export_records(lo, lo + HALO, raw=True)            # what rank-1 needs
+    right = m.export_records(hi - HALO, hi, raw=True)           # what rank+1 needs
+    gl = all_gather_records(left, group)
+    gr = all_gather_records(right, group)
+    if rank > 0:
+        m.merge_records(gr[rank - 1], assign=True)
+    if rank < world - 1:
+        m.merge_records(gl[rank + 1], assign=True)

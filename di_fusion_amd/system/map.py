@@ -195,6 +195,7 @@ class DenseIndexedMap:
         m.seg_start = _lib.ptr(seg_start)
         m.seg_cnt = _lib.ptr(seg_cnt)
         m.item_start = _lib.ptr(item_start)
+        m.own_x_lo, m.own_x_hi, m.halo = getattr(self, "_ownership", (0, self.n_xyz[0], 0))
         self._cmap = m
 
     def _publish_counters(self, c, add_total_at_read):
@@ -520,16 +521,32 @@ class DenseIndexedMap:
         return self._make_mesh_from_cache()
 
     # ---- multi-GPU (no reference counterpart) ---------------------------------------------
-    def export_records(self) -> torch.Tensor:
-        """(n_occupied, 32) int32 records: lin id (2 words) | w | w*z[29]."""
-        n = self.n_occupied
-        rec = torch.empty((max(n, 1), 32), dtype=torch.int32, device=self.device)
+    def set_ownership(self, x_lo: int, x_hi: int, halo: int = 3):
+        """Spatial tiling (SURVEY.md section 8e "C5"): this map owns the voxels with x index in [x_lo, x_hi).  Integrate ignores points
+        whose own voxel is farther than `halo` voxels from the slab, and only owned voxels are meshed.  With the boundary layers
+        refreshed after every integrate (`parallel.exchange_halo`), halo = 3 makes every owned voxel bit-identical to the
+        single-map result (see the derivation in parallel.py)."""
+        self._ownership = (int(x_lo), int(x_hi), int(halo))
+        self._cmap.own_x_lo, self._cmap.own_x_hi, self._cmap.halo = self._ownership
+
+    def export_records(self, x_lo: int = None, x_hi: int = None, raw: bool = False) -> torch.Tensor:
+        """(n, 32) int32 records of the allocated voxels with x index in [x_lo, x_hi) (default: all), slot order:
+        lin id (2 words) | w | w*z[29]  (raw=False, for additive merging)  or  z[29] itself (raw=True, exact copies)."""
+        x_lo = 0 if x_lo is None else max(0, int(x_lo))
+        x_hi = self.n_xyz[0] if x_hi is None else min(self.n_xyz[0], int(x_hi))
+        cap = max(self._n_occ_ub, 1)
+        rec = torch.empty((cap, 32), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().dif_export_records(ctypes.byref(self._cmap), _lib.ptr(rec), max(n, 1), _lib.stream_ptr()), "dif_export_records")
+            scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
+            _lib.check(_lib.load().dif_export_records(ctypes.byref(self._cmap), _lib.ptr(rec), cap, x_lo, x_hi, 1 if raw else 0,
+                                                      _lib.ptr(scratch), _lib.stream_ptr()), "dif_export_records")
+        self._read_counters()
+        n = int(self._host_counters[_lib.C_EXPORT_N])
         return rec[:n]
 
-    def merge_records(self, rec: torch.Tensor):
-        """Accumulate records with DISTINCT lin ids (one rank's export) into this map."""
+    def merge_records(self, rec: torch.Tensor, assign: bool = False):
+        """Fold records with DISTINCT lin ids into this map: accumulate (one rank's `export_records()`), or `assign`
+        (overwrite w and z with `export_records(raw=True)` payloads: halo refresh)."""
         rec = rec.contiguous()
         n = rec.size(0)
         if n == 0:
@@ -537,7 +554,8 @@ class DenseIndexedMap:
         with self.modifying_lock, torch.cuda.device(self.device):
             self._ensure_capacity(n)
             scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
-            _lib.check(_lib.load().dif_merge_records(ctypes.byref(self._cmap), _lib.ptr(rec), n, _lib.ptr(scratch), _lib.stream_ptr()), "dif_merge_records")
+            _lib.check(_lib.load().dif_merge_records(ctypes.byref(self._cmap), _lib.ptr(rec), n, 1 if assign else 0, _lib.ptr(scratch),
+                                                     _lib.stream_ptr()), "dif_merge_records")
 
     # ---- visualisers: out of scope (need Open3D) ---------------------------------------
     def get_fast_preview_visuals(self):

@@ -48,6 +48,7 @@ enum {
     DIF_C_N_KEPT = 11,      /* points surviving the >prune_min_vox_obs filter (map.py:375)                */
     DIF_C_CACHE_T = 12,     /* triangles in the device-resident mesh cache (map.py:116-133, 703-714)      */
     DIF_C_CACHE_KEPT = 13,  /* cached triangles kept by the last extract = offset of the new ones         */
+    DIF_C_EXPORT_N = 14,    /* records written by the last dif_export_records                             */
     DIF_C_COUNT = 16
 };
 
@@ -73,6 +74,10 @@ typedef struct dif_map {
     int32_t* seg_start;             /* [capacity] idle 0  : row cursor of the slot while rows are placed             */
     int32_t* seg_cnt;               /* [capacity] idle 0  : rows gathered for the slot (pcounts, map.py:439)   */
     int32_t* item_start;            /* [capacity] first encoder work item of the slot                          */
+    /* Spatial tiling (SURVEY.md section 8e "C5"): this map OWNS the voxels with x index in [own_x_lo, own_x_hi); points whose own
+     * voxel lies outside [own_x_lo - halo, own_x_hi + halo) are ignored by integrate, and only owned voxels are meshed.
+     * 0, nx, 0 = the whole grid (single-map behaviour). */
+    int32_t own_x_lo, own_x_hi, halo;
 } dif_map_t;
 
 /* Network weights packed for the MFMA kernels by di_fusion_amd/network/packing.py (layout documented there). */
@@ -169,11 +174,16 @@ int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz
                   int32_t* sel, float* sdf, float* std_out, float* grad, int32_t* scratch, void* stream);
 
 /* ---- multi-GPU map merge (no reference counterpart) ----------------------------------- */
-/* Pack the occupied voxels as records (lin i64 | w f32 | w*z f32[29]) = 32 x 4-byte words each; n -> counters[N_OCCUPIED]. */
-int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, void* stream);
-/* Accumulate `n` records (any order, duplicates allowed) into the map: allocate unseen voxels in ascending lin order,
- * then w += w_r, z = (z*w + wz_r)/(w + w_r).  scratch: int32 [n + 4096]. */
-int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t* scratch, void* stream);
+/* Pack the allocated voxels whose x index lies in [x_lo, x_hi) as 32-word records, in slot order:
+ *   lin (2 words) | w f32 | payload f32[29],  payload = w*z (raw == 0: additive merge) or z itself (raw != 0: exact copy).
+ * The number written goes to counters[DIF_C_EXPORT_N].  scratch: int32 [4096]. */
+int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t raw,
+                       int32_t* scratch, void* stream);
+/* Fold `n` records WITH DISTINCT lin ids into the map; unseen voxels are allocated in ascending lin order first.
+ *   assign == 0 (records exported with raw == 0):  w += w_r ; z = (z*w + wz_r) / (w + w_r) ; dirty if w_r > 0   (map merge, C4)
+ *   assign != 0 (records exported with raw != 0):  w = w_r ; z = z_r                                             (halo copy, C5)
+ * scratch: int32 [4096]. */
+int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t assign, int32_t* scratch, void* stream);
 
 /* ---- per-kernel timing for bench.py's roofline leg ---------------------------------------------------------- */
 /* When enabled, a hipEvent pair is recorded around each launch of the named kernels ON THE STREAM THEY RUN ON. */

@@ -45,3 +45,70 @@ def test_export_merge_records_vs_oracle(gpu_model, oracle_net):
     # the merged map meshes
     v, vid, vs = g.extract_mesh_arrays(4, int(4e6), max_std=0.15)
     assert v.shape[0] > 0
+
+
+def test_spatial_tiling_matches_single_map_bit_for_bit(gpu_model):
+    """C5: two x-slabs with halo exchange (emulated in one process, same kernels and record path as the RCCL version) reproduce
+    the single-map state of every owned voxel BIT FOR BIT, and the union of the slab meshes equals the single-map mesh."""
+    from di_fusion_amd import parallel
+    from di_fusion_amd.system.map import DenseIndexedMap
+    cfg = syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4)          # 16^3
+    intr = syn.Intrinsic().scaled(0.25)
+    scene = syn.default_room()
+    full = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=2048)
+    nx = full.n_xyz[0]
+    world = 2
+    slabs = []
+    for r in range(world):
+        m = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=2048)
+        m.set_ownership(*parallel.slab_range(nx, r, world), halo=parallel.HALO)
+        slabs.append(m)
+    plane = full.n_xyz[1] * full.n_xyz[2]
+    for f in range(4):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=15.0)
+        xyz, nrm = xyz.to(DEV), nrm.to(DEV)
+        full.integrate_keyframe(xyz, nrm)
+        for m in slabs:
+            m.integrate_keyframe(xyz, nrm)
+        # halo exchange (what parallel.exchange_halo does over RCCL)
+        lefts = [m.export_records(m._ownership[0], m._ownership[0] + parallel.HALO, raw=True).clone() for m in slabs]
+        rights = [m.export_records(m._ownership[1] - parallel.HALO, m._ownership[1], raw=True).clone() for m in slabs]
+        for r, m in enumerate(slabs):
+            if r > 0:
+                m.merge_records(rights[r - 1], assign=True)
+            if r < world - 1:
+                m.merge_records(lefts[r + 1], assign=True)
+        # ---- state of owned voxels ----
+        nF = full.n_occupied
+        posF = full.latent_vecs_pos[:nF].cpu().numpy()
+        wF = full.voxel_obs_count[:nF].cpu().numpy()
+        zF = full.latent_vecs[:nF].cpu().numpy()
+        covered = 0
+        for r, m in enumerate(slabs):
+            lo, hi = m._ownership[0] * plane, m._ownership[1] * plane
+            own = (posF >= lo) & (posF < hi)
+            idx = m.indexer.cpu().numpy()[posF[own]]
+            assert (idx >= 0).all(), f"frame {f} rank {r}: owned voxel not allocated"
+            assert np.array_equal(m._obs.cpu().numpy()[idx], wF[own])
+            assert np.array_equal(m._latent.cpu().numpy()[idx], zF[own]), f"frame {f} rank {r}: latent bits differ"
+            # and nothing extra is allocated inside the owned slab
+            nS = m.n_occupied
+            posS = m.latent_vecs_pos[:nS].cpu().numpy()
+            assert ((posS >= lo) & (posS < hi)).sum() == own.sum()
+            covered += own.sum()
+        assert covered == nF
+        # ---- meshes ----
+        vF, idF, _ = full.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+        newF = full.mesh_cache_tensors(new_only=True)
+        tris, ids = [], []
+        for m in slabs:
+            m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+            t, i, _ = m.mesh_cache_tensors(new_only=True)
+            tris.append(t.cpu().numpy()); ids.append(i.cpu().numpy())
+        tS, iS = np.concatenate(tris), np.concatenate(ids)
+        tF, iF = newF[0].cpu().numpy(), newF[1].cpu().numpy()
+        assert tS.shape == tF.shape, (f, tS.shape, tF.shape)
+        kS = np.lexsort(tuple(tS.reshape(len(tS), -1).T[::-1]) + (iS,))
+        kF = np.lexsort(tuple(tF.reshape(len(tF), -1).T[::-1]) + (iF,))
+        assert np.array_equal(iS[kS], iF[kF])
+        assert np.array_equal(tS[kS], tF[kF])                  # bit-identical vertices

@@ -87,3 +87,68 @@ def test_merge_equals_weighted_mean():
         if wa + wb > 0:
             want = (a.latent_vecs[sa] * wa + b.latent_vecs[sb] * wb) / (wa + wb)
             assert np.abs(g.latent_vecs[sg] - want).max() < 1e-5
+
+
+class _FakeSlabMap:
+    """Stands in for DenseIndexedMap in the exchange plumbing test: records are kept as a dict lin -> (w, z)."""
+
+    def __init__(self, nx, ny, nz, lo, hi):
+        self.n_xyz = [nx, ny, nz]
+        self._ownership = (lo, hi, 3)
+        self.store = {}
+
+    def export_records(self, x_lo, x_hi, raw=False):
+        plane = self.n_xyz[1] * self.n_xyz[2]
+        rows = []
+        for lin in sorted(self.store):
+            if x_lo * plane <= lin < x_hi * plane:
+                w, z = self.store[lin]
+                r = np.zeros(32, dtype=np.int32)
+                r[0] = lin; r[2] = np.float32(w).view(np.int32); r[3:32] = z.astype(np.float32).view(np.int32)
+                rows.append(r)
+        return torch.from_numpy(np.stack(rows) if rows else np.zeros((0, 32), dtype=np.int32))
+
+    def merge_records(self, rec, assign=False):
+        assert assign
+        for r in rec.numpy():
+            self.store[int(r[0])] = (float(r[2:3].view(np.float32)[0]), r[3:32].view(np.float32).copy())
+
+
+def _halo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from di_fusion_amd import parallel
+    nx = ny = nz = 8
+    lo, hi = parallel.slab_range(nx, rank, world)
+    m = _FakeSlabMap(nx, ny, nz, lo, hi)
+    rng = np.random.default_rng(rank)
+    for x in range(lo, hi):                       # every owned voxel of column (y=1,z=2) holds rank-specific data
+        m.store[x * ny * nz + 1 * nz + 2] = (100.0 * rank + x, rng.standard_normal(29).astype(np.float32))
+    parallel.exchange_halo(m, rank, world)
+    q.put((rank, {k: (v[0], v[1].copy()) for k, v in m.store.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ny = nz = 8
+    col = lambda x: x * ny * nz + 1 * nz + 2
+    # rank 0 owns x 0..3 and must now also hold rank 1's x = 4,5,6 (its left boundary, 3 layers), bit-exact; and vice versa
+    for x in (4, 5, 6):
+        assert col(x) in res[0] and res[0][col(x)][0] == res[1][col(x)][0]
+        assert np.array_equal(res[0][col(x)][1], res[1][col(x)][1])
+    assert col(7) not in res[0]
+    for x in (1, 2, 3):
+        assert col(x) in res[1] and np.array_equal(res[1][col(x)][1], res[0][col(x)][1])
+    assert col(0) not in res[1]
