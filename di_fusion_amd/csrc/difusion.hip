@@ -463,6 +463,46 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
 // =================================================================================================================
 // a11 : extract — dirty list, confident neighbourhood, batch ids  (map.py:627-637)
 // =================================================================================================================
+// set the bitmap bits of the confident voxels among `lin` and its 6 allocated neighbours (map.py:628-631)
+__device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float ignore_th, const int64_t* __restrict__ indexer,
+                                                    const float* __restrict__ obs, uint32_t* __restrict__ bits) {
+    int ix, iy, iz;
+    unlinearize(g, lin, ix, iy, iz);
+    int cand[7];
+    cand[0] = lin;
+    cand[1] = linearize(g, clampi(ix - 1, 0, g.nx - 1), iy, iz);
+    cand[2] = linearize(g, clampi(ix + 1, 0, g.nx - 1), iy, iz);
+    cand[3] = linearize(g, ix, clampi(iy - 1, 0, g.ny - 1), iz);
+    cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
+    cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
+    cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        int v = cand[c];
+        int64_t slot = indexer[v];
+        if (slot < 0 || !(obs[slot] > ignore_th)) continue;
+        uint32_t b = 1u << (v & 31);
+        if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
+    }
+}
+
+// Spatial tiling: dirty HALO voxels (flag copied from their owner by the halo refresh) are not meshed here, but they pull their
+// confident neighbourhood into the decoded batch exactly as they do in the single-map run (the blend of a corner depends on
+// which neighbours are in the batch, mc_interp_kernel.cu:17-24).
+__global__ void __launch_bounds__(DIF_BLOCK) k_mark_halo_dirty(Geo g, float ignore_th, uint8_t* __restrict__ dirty, const int64_t* __restrict__ pos,
+                                                             const int64_t* __restrict__ indexer, const float* __restrict__ obs,
+                                                             uint32_t* __restrict__ bits, const int* __restrict__ counters, int64_t own_lo,
+                                                             int64_t own_hi) {
+    const int n = counters[DIF_C_N_OCCUPIED];
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        if (!dirty[s]) continue;
+        const int64_t p = pos[s];
+        if (p >= own_lo && p < own_hi) continue;
+        dirty[s] = 0;
+        mark_confident_nbhd(g, (int)p, ignore_th, indexer, obs, bits);
+    }
+}
+
 struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> valid_blocks (lin ids), clears flags;
     uint8_t* dirty;         // each dirty voxel also marks the confident voxels among itself and its 6 allocated neighbours
     const int64_t* pos;     // in the grid bitmap (map.py:628-631)
@@ -479,33 +519,14 @@ struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> v
     __device__ int count(int s) const {
         if (!(no_cache || dirty[s])) return 0;
         const int64_t p = pos[s];
-        if (p >= own_lin_lo && p < own_lin_hi) return 1;
-        dirty[s] = 0;                   // halo voxel: its owner meshes it
-        return 0;
+        return (p >= own_lin_lo && p < own_lin_hi) ? 1 : 0;      // halo voxels are meshed by their owner
     }
     __device__ void emit(int s, int offset) const {
         dirty[s] = 0;
         if (offset >= max_voxels) return;
         const int lin = (int)pos[s];
         valid_blocks[offset] = lin;
-        int ix, iy, iz;
-        unlinearize(g, lin, ix, iy, iz);
-        int cand[7];
-        cand[0] = lin;
-        cand[1] = linearize(g, clampi(ix - 1, 0, g.nx - 1), iy, iz);
-        cand[2] = linearize(g, clampi(ix + 1, 0, g.nx - 1), iy, iz);
-        cand[3] = linearize(g, ix, clampi(iy - 1, 0, g.ny - 1), iz);
-        cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
-        cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
-        cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
-#pragma unroll
-        for (int c = 0; c < 7; ++c) {
-            int v = cand[c];
-            int64_t slot = indexer[v];
-            if (slot < 0 || !(obs[slot] > ignore_th)) continue;
-            uint32_t b = 1u << (v & 31);
-            if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
-        }
+        mark_confident_nbhd(g, lin, ignore_th, indexer, obs, bits);
     }
     __device__ void finish(int total) const {
         if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 2; }
@@ -1003,7 +1024,7 @@ struct QueryFunctor {
 // multi-GPU merge helpers
 // =================================================================================================================
 struct ExportFunctor {       // ordered compaction over slots: allocated voxels with x index in [x_lo, x_hi)
-    const int64_t* pos; const float* obs; const float* latent;
+    const int64_t* pos; const float* obs; const float* latent; const uint8_t* dirty;
     int32_t* rec; int64_t max_records;
     int64_t lin_lo, lin_hi;
     int raw;
@@ -1014,8 +1035,8 @@ struct ExportFunctor {       // ordered compaction over slots: allocated voxels 
         int32_t* r = rec + (int64_t)offset * 32;
         const int64_t p = pos[s];
         const float w = obs[s];
-        r[0] = (int32_t)(p & 0xFFFFFFFFll);
-        r[1] = (int32_t)(p >> 32);
+        r[0] = (int32_t)p;                       // grid < 2^31 (checked by every entry point)
+        r[1] = dirty[s] ? 1 : 0;                 // flags: bit 0 = awaiting re-meshing
         r[2] = __float_as_int(w);
         for (int f = 0; f < L; ++f) {
             float z = latent[(int64_t)s * L + f];
@@ -1031,7 +1052,7 @@ struct ExportFunctor {       // ordered compaction over slots: allocated voxels 
 __global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
                                                         uint32_t* __restrict__ bits, int64_t grid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t lin = ((int64_t)(uint32_t)rec[i * 32]) | ((int64_t)rec[i * 32 + 1] << 32);
+        int64_t lin = rec[i * 32];
         if (lin < 0 || lin >= grid) continue;
         if (indexer[lin] == -1) atomicOr(bits + (lin >> 5), 1u << (lin & 31));
     }
@@ -1051,7 +1072,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __rest
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t i = e >> 5;
         int f = (int)(e & 31);
-        int64_t lin = ((int64_t)(uint32_t)rec[i * 32]) | ((int64_t)rec[i * 32 + 1] << 32);
+        int64_t lin = rec[i * 32];
         if (lin < 0 || lin >= grid) continue;
         int64_t s = indexer[lin];
         if (s < 0) continue;
@@ -1067,7 +1088,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __rest
         __builtin_amdgcn_wave_barrier();
         if (f == 31) {
             obs[s] = w_new;
-            if (!assign && w_r > 0.0f) dirty[s] = 1;
+            if (assign) dirty[s] = (uint8_t)(rec[i * 32 + 1] & 1);
+            else if (w_r > 0.0f) dirty[s] = 1;
         }
     }
 }
@@ -1388,8 +1410,15 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     {   // dirty slots -> valid_blocks
         const int64_t plane = (int64_t)map->ny * map->nz;
         const bool tiled = map->own_x_hi > map->own_x_lo;
+        const int64_t own_lo = tiled ? map->own_x_lo * plane : 0, own_hi = tiled ? map->own_x_hi * plane : grid;
+        if (tiled) {
+            hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th, map->dirty,
+                               (const int64_t*)map->latent_vecs_pos, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, map->grid_bits,
+                               (const int*)C, own_lo, own_hi);
+            DIF_CHECK_LAUNCH();
+        }
         DirtyFunctor f{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels, g, map->ignore_count_th,
-                       map->indexer, map->voxel_obs_count, map->grid_bits, tiled ? map->own_x_lo * plane : 0, tiled ? map->own_x_hi * plane : grid};
+                       map->indexer, map->voxel_obs_count, map->grid_bits, own_lo, own_hi};
         if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     }
     {
@@ -1475,7 +1504,7 @@ int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_recor
     if (x_lo < 0) x_lo = 0;
     if (x_hi > map->nx) x_hi = map->nx;
     const int64_t plane = (int64_t)map->ny * map->nz;
-    ExportFunctor f{map->latent_vecs_pos, map->voxel_obs_count, map->latent_vecs, records, max_records, x_lo * plane, (x_hi > x_lo ? x_hi : x_lo) * plane,
+    ExportFunctor f{map->latent_vecs_pos, map->voxel_obs_count, map->latent_vecs, map->dirty, records, max_records, x_lo * plane, (x_hi > x_lo ? x_hi : x_lo) * plane,
                     raw ? 1 : 0, map->counters};
     return launch_scan(f, map->counters + DIF_C_N_OCCUPIED, 0, map->capacity, scratch, (hipStream_t)stream);
 }

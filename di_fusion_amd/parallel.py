@@ -15,7 +15,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
-RECORD_WORDS = 32          # int32 words per voxel record: lin (2) | w (1) | w*z (29)
+RECORD_WORDS = 32          # int32 words per voxel record: lin | flags | w | payload (29)
 
 
 def all_gather_records(rec: torch.Tensor, group=None) -> List[torch.Tensor]:
@@ -59,7 +59,9 @@ def build_global_map(local_map, make_map, group=None):
 #     set" means allocated (possibly by THIS frame: some new voxel u' within 1 of w, i.e. within 3 of the slab, with all its
 #     points and its exact pre-frame indexer entry) and voxel_obs_count[w] < encoder_count_th before this frame's fusion;
 #   * sums are order-independent (fixed point), so the same contributions give the same bits.
-# Halo voxels are updated locally from incomplete data and are overwritten by the owner's exact (w, z) right after.
+# Halo voxels are updated locally from incomplete data and are overwritten by the owner's exact (w, z, dirty flag) right after;
+# the dirty flag matters because a dirty neighbour pulls ITS neighbourhood into the decoded batch, and marching cubes blends a
+# corner over whichever neighbours are in the batch (mc_interp_kernel.cu:17-24).
 HALO = 3
 
 

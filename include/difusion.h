@@ -175,13 +175,13 @@ int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz
 
 /* ---- multi-GPU map merge (no reference counterpart) ----------------------------------- */
 /* Pack the allocated voxels whose x index lies in [x_lo, x_hi) as 32-word records, in slot order:
- *   lin (2 words) | w f32 | payload f32[29],  payload = w*z (raw == 0: additive merge) or z itself (raw != 0: exact copy).
+ *   lin int32 | flags int32 (bit 0 = dirty) | w f32 | payload f32[29],  payload = w*z (raw == 0: additive merge) or z itself (raw != 0: exact copy).
  * The number written goes to counters[DIF_C_EXPORT_N].  scratch: int32 [4096]. */
 int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t raw,
                        int32_t* scratch, void* stream);
 /* Fold `n` records WITH DISTINCT lin ids into the map; unseen voxels are allocated in ascending lin order first.
  *   assign == 0 (records exported with raw == 0):  w += w_r ; z = (z*w + wz_r) / (w + w_r) ; dirty if w_r > 0   (map merge, C4)
- *   assign != 0 (records exported with raw != 0):  w = w_r ; z = z_r                                             (halo copy, C5)
+ *   assign != 0 (records exported with raw != 0):  w = w_r ; z = z_r ; dirty = flags & 1                         (halo copy, C5)
  * scratch: int32 [4096]. */
 int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t assign, int32_t* scratch, void* stream);
 
