@@ -283,3 +283,34 @@ def test_get_sdf_gradient_matches_autograd_and_finite_differences(gpu_model, raw
     an = (gq[:, 0] * std.detach()[idx.clamp(min=0)])[both]        # undo the 1/std factor
     rel_err = ((fd - an).abs() / (an.abs() + 0.05)).median().item()
     assert rel_err < 0.05, rel_err
+
+
+@pytest.mark.parametrize("resolution,fast", [(4, False), (2, True), (8, True), (3, True)])
+def test_other_resolutions_and_exact_decode(resolution, fast, gpu_model, oracle_net):
+    """extract_mesh(voxel_resolution, fast) away from the shipped default (4, True): same pipeline, checked against the oracle."""
+    from oracle import difusion_oracle as O
+    scene, cfg, intr = CASES["seq_small"]
+    g = np.load(GOLDEN / "seq_small.npz")
+    m = make_map(gpu_model, cfg)
+    om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    xyz, nrm = frame_inputs(g, "seq_small", 0)
+    m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+    om.integrate_keyframe(xyz, nrm)
+    m.extract_mesh_arrays(resolution, int(4e6), fast=fast, max_std=0.15)
+    oa = om.extract_prepare(resolution, fast=fast)
+    B = m.last_counters["B"]
+    tens = m._xbuf[1]
+    cs = tens["cube_sdf"][:B].cpu().numpy(); cd = tens["cube_std"][:B].cpu().numpy()
+    assert cs.shape == oa["cube_sdf"].shape
+    flip = np.zeros(cs.shape, dtype=bool).reshape(B, -1)
+    if len(oa["near_threshold"]):
+        flip[oa["near_threshold"][:, 0], oa["near_threshold"][:, 1]] = True
+    flip = flip.reshape(cs.shape)
+    assert np.abs(cs - oa["cube_sdf"])[~flip].max() < SDF_TOL
+    assert np.abs(cd - oa["cube_std"])[~flip].max() < SDF_TOL
+    wt, wi, ws = O.marching_cubes_interp(oa["indexer"], oa["valid_blocks"], oa["vec_batch_mapping"], cs, cd, int(4e6), om.n_xyz, 0.15)
+    ntri, nid, nstd = m.mesh_cache_tensors(new_only=True)
+    assert ntri.size(0) == wt.shape[0] > 0
+    want = (wt * np.float32(cfg.voxel_size)).astype(np.float32) + om.bound_min
+    assert np.array_equal(nid.cpu().numpy(), wi)
+    assert np.abs(ntri.cpu().numpy() - want).max() < 1e-5
