@@ -125,6 +125,8 @@ def main():
         rows_dec_lat = sum(s["B"] * 64 for s in st)
         rows_dec_pts = sum(s["VH"] for s in st)
         prof = {n: (ms[i], nl[i]) for i, n in enumerate(_lib.PROF_NAMES)}
+        if prof["decode_points"][1] == 0:          # fused per-voxel decode: one launch covers lattice + refine rows
+            rows_dec_lat, rows_dec_pts = rows_dec_lat + rows_dec_pts, 0
         kern = {}
         for name, rows, flop in (("encode", rows_enc, ENC_FLOP_PER_ROW), ("decode_lattice", rows_dec_lat, DEC_FLOP_PER_ROW),
                                  ("decode_points", rows_dec_pts, DEC_FLOP_PER_ROW)):

@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libdifusion.so"
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N = range(15)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK = range(16)
 C_COUNT = 16
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "sort"]
 PROF_COUNT = 8

@@ -49,6 +49,7 @@ enum {
     DIF_C_CACHE_T = 12,     /* triangles in the device-resident mesh cache (map.py:116-133, 703-714)      */
     DIF_C_CACHE_KEPT = 13,  /* cached triangles kept by the last extract = offset of the new ones         */
     DIF_C_EXPORT_N = 14,    /* records written by the last dif_export_records                             */
+    DIF_C_WORK = 15,        /* dynamic work-queue head of the fused per-voxel decode                      */
     DIF_C_COUNT = 16
 };
 
