@@ -29,8 +29,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:41
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"])
     ap.add_argument("--noise", type=int, default=0)
     ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
@@ -125,8 +125,6 @@ def main():
         rows_dec_lat = sum(s["B"] * 64 for s in st)
         rows_dec_pts = sum(s["VH"] for s in st)
         prof = {n: (ms[i], nl[i]) for i, n in enumerate(_lib.PROF_NAMES)}
-        if prof["decode_points"][1] == 0:          # fused per-voxel decode: one launch covers lattice + refine rows
-            rows_dec_lat, rows_dec_pts = rows_dec_lat + rows_dec_pts, 0
         kern = {}
         for name, rows, flop in (("encode", rows_enc, ENC_FLOP_PER_ROW), ("decode_lattice", rows_dec_lat, DEC_FLOP_PER_ROW),
                                  ("decode_points", rows_dec_pts, DEC_FLOP_PER_ROW)):

@@ -761,22 +761,25 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_upsample_mark(const float* __rest
     }
 }
 
-// Fused per-voxel decode for the fast two-level scheme (resolution <= 4): one wave owns one voxel — low lattice through the MLP
-// (values stay in LDS), ATen-exact trilinear x2 upsample straight out of LDS, wave-level selection of the |sdf| < 0.05 samples
-// (ballot-free prefix sum of popcounts), exact re-decode of exactly those, cube written once.  Replaces k_decode + k_upsample_mark
-// + k_decode and the global refine list: one launch, one weight staging, one tail.
+// Fused low-lattice decode + upsample for the fast two-level scheme (resolution <= 4, i.e. R^2 <= 64 rows = one per lane):
+// one wave owns one voxel — the l^3 low samples go through the MLP and stay in LDS, the ATen-exact trilinear x2 upsample reads
+// them from there, the cube is written once, and the |sdf| < 0.05 samples are appended to the global refine list with ONE
+// atomic per voxel (wave prefix sum of popcounts).  Work per voxel is uniform (ceil(l^3/32) tiles), so the launch is balanced;
+// the exact re-decode of the selected samples stays a separate, globally balanced launch (per-voxel counts range 0..R^3).
 struct VoxelDecodeArgs {
     const int32_t* occ_slot;
     const float* latent;
-    Lattice low, high;
+    Lattice low;
+    int R;
     float* cube_sdf;
     float* cube_std;
+    int32_t* refine_list;
     int* counters;
 };
 
 #define VD_MAX_L3 64
-#define VD_MAX_R3 512
-#define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3 + VD_MAX_R3 / 2)      /* low sdf + low std + u16 sample list */
+#define VD_MAX_R2 64
+#define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3)      /* low sdf + low std */
 
 __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -785,18 +788,11 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
     const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
     float* w_low_sdf = lds + ((DEC_LDS_FLOATS + 3) & ~3) + wid * VD_WAVE_LDS_FLOATS;
     float* w_low_std = w_low_sdf + VD_MAX_L3;
-    unsigned short* w_list = reinterpret_cast<unsigned short*>(w_low_std + VD_MAX_L3);
-    const int l = A.low.res, R = A.high.res, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
+    const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
     const float scale = (float)(l - 1) / (float)(R - 1);
     const int B = A.counters[DIF_C_B];
-    int refined = 0;
-    // dynamic voxel queue: per-voxel work varies from 2 to 2 + R3/32 tiles
-    int b = 0;
-    if (lane == 0) b = atomicAdd(A.counters + DIF_C_WORK, 1);
-    b = __shfl(b, 0);
-    while (b < B) {
-        int b_next = 0;
-        if (lane == 0) b_next = atomicAdd(A.counters + DIF_C_WORK, 1);       // in flight while this voxel is processed
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + wid), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int b = wave; b < B; b += nwaves) {
         const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
         f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
 #pragma unroll
@@ -820,62 +816,40 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        // ---- trilinear x2 + threshold (map.py:655-667) ----
-        int n_sel = 0;
-        float* cs = A.cube_sdf + (int64_t)b * R3;
-        float* cd = A.cube_std + (int64_t)b * R3;
-        for (int row0 = 0; row0 < R2; row0 += 64) {
-            const int row = row0 + lane;
-            unsigned sel = 0;
-            if (row < R2) {
-                const int jx = row / R, jy = row % R;
-                int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
-                tri_axis(jx, l, scale, x0, x1, wx0, wx1);
-                tri_axis(jy, l, scale, y0, y1, wy0, wy1);
-                for (int jz = 0; jz < R; ++jz) {
-                    int z0, z1; float wz0, wz1;
-                    tri_axis(jz, l, scale, z0, z1, wz0, wz1);
-                    float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                    if (fabsf(sv) < 0.05f) {
-                        sel |= 1u << jz;                    // re-decoded below, written there
-                    } else {
-                        float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                        cs[row * R + jz] = -sv;
-                        cd[row * R + jz] = dv;
-                    }
-                }
+        // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z ----
+        const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
+        unsigned sel = 0;
+        if (lane < R2) {
+            const int jx = lane / R, jy = lane % R;
+            int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
+            tri_axis(jx, l, scale, x0, x1, wx0, wx1);
+            tri_axis(jy, l, scale, y0, y1, wy0, wy1);
+            for (int jz = 0; jz < R; ++jz) {
+                int z0, z1; float wz0, wz1;
+                tri_axis(jz, l, scale, z0, z1, wz0, wz1);
+                float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                A.cube_sdf[e0 + jz] = -sv;
+                A.cube_std[e0 + jz] = dv;
+                if (fabsf(sv) < 0.05f) sel |= 1u << jz;
             }
-            const int c = __popc(sel);
-            const int incl = wave_incl_scan(c);
-            int o = n_sel + incl - c;
+        }
+        const int c = __popc(sel);
+        const int incl = wave_incl_scan(c);
+        const int total = __shfl(incl, 63);
+        if (total > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(A.counters + DIF_C_VH, total);
+            base = __shfl(base, 0);
+            int o = base + incl - c;
             while (sel) {
                 const int jz = __ffs((int)sel) - 1;
                 sel &= sel - 1;
-                w_list[o++] = (unsigned short)(row * R + jz);
-            }
-            n_sel += __shfl(incl, 63);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        // ---- exact re-decode of the near-surface samples (map.py:668-679) ----
-        for (int t0 = 0; t0 < n_sel; t0 += 32) {
-            const bool live = t0 + col < n_sel;
-            const int e = live ? (int)w_list[t0 + col] : 0;
-            const float px = A.high.coord(e / R2), py = A.high.coord((e / R) % R), pz = A.high.coord(e % R);
-            f16v xin = xlat;
-            if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }
-            float sdf, sd;
-            decoder_tile(lds, wfwd, xin, lane, sdf, sd);
-            if (live) {
-                if (half == 0) cs[e] = -sdf;
-                else cd[e] = sd;
+                A.refine_list[o++] = (int32_t)(e0 + jz);
             }
         }
-        refined += n_sel;
         __builtin_amdgcn_wave_barrier();
-        b = __shfl(b_next, 0);
     }
-    if (lane == 0 && refined) atomicAdd(A.counters + DIF_C_VH, refined);
 }
 
 // =================================================================================================================
@@ -1545,13 +1519,13 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
         if (launch_scan(f, nullptr, nwords, nwords, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     }
     int rc;
-    if (fast && l * l * l <= VD_MAX_L3 && R3 <= VD_MAX_R3) {
-        // fused per-voxel path: low lattice -> upsample -> refine inside one wave
+    if (fast && l * l * l <= VD_MAX_L3 && R * R <= VD_MAX_R2) {
+        // fused per-voxel low lattice + upsample + threshold, then the balanced exact re-decode (map.py:644-679)
         if (!w->dec_packed || w->dec_packed_floats != DEC_FLOATS) return DIF_EINVAL;
         VoxelDecodeArgs V = {};
         V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std; V.counters = C;
+        V.refine_list = buf->refine_list; V.R = R;
         V.low.res = l; V.low.a = (float)sample_a; V.low.vsize = (l > 1) ? (float)((sample_b - sample_a) / (l - 1)) : 0.0f;
-        V.high.res = R; V.high.a = (float)sample_a; V.high.vsize = (float)((sample_b - sample_a) / (R - 1));
         const size_t lds_bytes = ((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 8 * VD_WAVE_LDS_FLOATS) * 4;
         static bool attr_set[64] = {};
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1561,9 +1535,17 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
         }
         int64_t blocks = (buf->max_voxels + 7) / 8;
         if (blocks > num_cus()) blocks = num_cus();
-        ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
-        hipLaunchKernelGGL(k_decode_voxels, dim3((int)blocks), dim3(512), lds_bytes, s, V, w->dec_packed);
+        {
+            ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
+            hipLaunchKernelGGL(k_decode_voxels, dim3((int)blocks), dim3(512), lds_bytes, s, V, w->dec_packed);
+        }
         DIF_CHECK_LAUNCH();
+        DecodeArgs Rf = {};
+        Rf.mode = 1; Rf.n_ptr = C + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
+        Rf.lat.res = R; Rf.lat.a = (float)sample_a; Rf.lat.vsize = (float)((sample_b - sample_a) / (R - 1));
+        Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
+        rc = launch_decode(Rf, w, buf->max_voxels * (int64_t)(R3 / 32), s);
+        if (rc != DIF_OK) return rc;
     } else if (fast) {
         // low lattice decode (map.py:644-653)
         DecodeArgs A = {};
