@@ -55,6 +55,8 @@ SIGNATURES = {
     "dif_unproject": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
     "dif_unproject_transform": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
                                           c_float, c_float, POINTER(c_float), POINTER(c_float), c_void_p]),
+    "dif_unproject_transform_dev": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
+                                              c_float, c_float, c_void_p, c_void_p]),
     "dif_compute_normal_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "dif_groupby_sum": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "dif_integrate_workspace_bytes": (c_int64, [c_int64]),

@@ -96,7 +96,13 @@ struct Pose { float r[9]; float t[3]; };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* __restrict__ depth, const float* __restrict__ ncam,
                                                                  float* __restrict__ xyz, float* __restrict__ nrm, int H, int W,
-                                                                 float fx, float fy, float cx, float cy, Pose P) {
+                                                                 float fx, float fy, float cx, float cy, Pose P, const float* __restrict__ pose_dev) {
+    if (pose_dev) {                                   // pose read from device memory: lets a captured hipGraph be replayed per frame
+#pragma unroll
+        for (int i = 0; i < 9; ++i) P.r[i] = pose_dev[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) P.t[i] = pose_dev[9 + i];
+    }
     int64_t n = (int64_t)H * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
@@ -1210,7 +1216,18 @@ int dif_unproject_transform(const float* depth, const float* normal_cam, float* 
     for (int i = 0; i < 9; ++i) P.r[i] = R[i];
     for (int i = 0; i < 3; ++i) P.t[i] = t[i];
     hipLaunchKernelGGL(k_unproject_transform, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth, normal_cam,
-                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P);
+                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P, (const float*)nullptr);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_unproject_transform_dev(const float* depth, const float* normal_cam, float* xyz_world, float* normal_world, int32_t H, int32_t W,
+                                float fx, float fy, float cx, float cy, const float* pose_dev, void* stream) {
+    if (!depth || !xyz_world || !pose_dev || H <= 0 || W <= 0) return DIF_EINVAL;
+    if ((normal_cam == nullptr) != (normal_world == nullptr)) return DIF_EINVAL;
+    Pose P = {};
+    hipLaunchKernelGGL(k_unproject_transform, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth, normal_cam,
+                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P, pose_dev);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

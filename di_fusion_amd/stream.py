@@ -41,6 +41,9 @@ class FusionStream:
         self._pending = None
         self._copy_stream = torch.cuda.Stream(device=device)
         self._copy_done = None
+        self._graphs = None
+        self._graph_sig = None
+        self._g_in = None
 
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
@@ -125,4 +128,91 @@ class FusionStream:
             self._pending = None
         with torch.cuda.device(self.device):
             self._copy_stream.synchronize()
+        return out
+
+    # ---- hipGraph variant: the ~22 launches of a frame are captured once and replayed --------------------------------------
+    # Everything a frame launches has host-independent shapes (device counters carry the sizes), so a frame is a static graph:
+    # stage depth / normals / pose into fixed buffers, replay, read the counters one frame later.  Two graphs, one per parity of
+    # the mesh-cache ping-pong.  Re-captured only when a buffer is re-allocated (capacity growth).
+    def _graph_signature(self):
+        m = self.map
+        return (m._capacity, m._ws.data_ptr() if m._ws is not None else 0, m._xbuf[0] if m._xbuf else None,
+                m._cache[0][0].data_ptr() if m._cache else 0)
+
+    def _capture_graphs(self):
+        m, intr, dev = self.map, self.intr, self.device
+        lib = _lib.load()
+        H, W = intr.height, intr.width
+        N = H * W
+        with torch.cuda.device(dev):
+            if self._g_in is None:
+                self._g_in = (torch.empty((H, W), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.float32, device=dev),
+                              torch.empty((12,), dtype=torch.float32, device=dev), torch.empty((N,), dtype=torch.uint8, device=dev))
+                self._g_pose_host = [torch.empty((12,), dtype=torch.float32).pin_memory() for _ in range(4)]
+                self._g_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(2)]
+            depth, ncam, pose, mask = self._g_in
+            w = m.model.packed.weights_struct(dev)
+            tens, _ = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+            graphs = []
+            torch.cuda.synchronize()
+            for parity in (0, 1):
+                saved = m._cache_cur
+                m._cache_cur = parity
+                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+                m._cache_cur = saved
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    sp = _lib.stream_ptr()
+                    _lib.check(lib.dif_unproject_transform_dev(_lib.ptr(depth), _lib.ptr(ncam), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
+                                                               intr.fx, intr.fy, intr.cx, intr.cy, _lib.ptr(pose), sp), "dif_unproject_transform_dev")
+                    _lib.check(lib.dif_integrate(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), N, _lib.ptr(mask),
+                                                 _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate")
+                    _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
+                                               0, 1, sp), "dif_extract")
+                    self._g_counters[parity].copy_(m._counters, non_blocking=True)
+                graphs.append((g, buf))
+            self._graphs = graphs
+            self._graph_sig = self._graph_signature()
+
+    def step_graph(self, i: int, d2h: str = "new"):
+        """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: two staging copies, a 48-byte
+        pose upload and one graph launch)."""
+        m = self.map
+        N = self.intr.height * self.intr.width
+        prune = int(m.args.prune_min_vox_obs)
+        may_add = 7 * (N // (prune + 1)) if prune > 0 else 7 * N
+        with torch.cuda.device(self.device):
+            if m._ws is None or m._xbuf is None or m._cache is None:
+                raise RuntimeError("run at least one eager step before step_graph (buffers are sized there)")
+            if m._n_occ_ub + may_add > m._capacity:
+                if self._pending is not None:                    # make the bound exact before deciding to grow
+                    out_prev = self._finish_frame(self._pending, d2h)
+                    self._pending = None
+            m._ensure_capacity(may_add)
+            if self._graphs is None or self._graph_sig != self._graph_signature():
+                torch.cuda.synchronize()
+                self._capture_graphs()
+            if self._copy_done is not None:
+                torch.cuda.current_stream().wait_event(self._copy_done)
+                self._copy_done = None
+            depth, ncam, pose, mask = self._g_in
+            R, t = self.poses[i]
+            ph = self._g_pose_host[i % 4]
+            ph[:9] = torch.tensor(list(R)); ph[9:] = torch.tensor(list(t))
+            pose.copy_(ph, non_blocking=True)
+            depth.copy_(self.depth[i], non_blocking=True)
+            ncam.copy_(self.ncam[i], non_blocking=True)
+            parity = m._cache_cur
+            g, _ = self._graphs[parity]
+            g.replay()
+            m._cache_cur = 1 - parity
+            m.mesh_cache.invalidate_host_copy()
+            ev = torch.cuda.Event()
+            ev.record()
+            h = dict(event=ev, counters=self._g_counters[parity], cache_index=m._cache_cur, add_total=m._add_total,
+                     max_n_triangles=self.max_n_triangles)
+        out = None
+        if self._pending is not None:
+            out = self._finish_frame(self._pending, d2h)
+        self._pending = h
         return out

@@ -386,9 +386,12 @@ class DenseIndexedMap:
         tri, tid, tstd = self._cache[self._cache_cur]
         return tri[lo:hi], tid[lo:hi], tstd[lo:hi]
 
-    def _extract_buffers(self, resolution: int, max_n_triangles: int):
+    def _extract_buffers(self, resolution: int, max_n_triangles: int, max_vox: int = None):
         R = 2 * resolution
-        max_vox = _next_pow2(max(self._n_occ_ub, 1024))
+        if max_vox is None:
+            max_vox = _next_pow2(max(self._n_occ_ub, 1024))
+            if self._xbuf is not None and self._xbuf[0][0] == resolution and self._xbuf[0][1] >= max_vox:
+                max_vox = self._xbuf[0][1]                      # never shrink: keeps pointers stable
         key = (resolution, max_vox)
         if self._xbuf is None or self._xbuf[0] != key:
             dev = self.device

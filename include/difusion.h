@@ -102,6 +102,11 @@ int dif_unproject(const float* depth, float* pc, int32_t H, int32_t W, float fx,
 int dif_unproject_transform(const float* depth, const float* normal_cam, float* xyz_world, float* normal_world,
                             int32_t H, int32_t W, float fx, float fy, float cx, float cy,
                             const float* R, const float* t, void* stream);
+/* Same with the pose in DEVICE memory (12 floats: R row-major, then t), so the call can sit in a captured hipGraph that is
+ * replayed every frame with a new pose copied into `pose_dev`. */
+int dif_unproject_transform_dev(const float* depth, const float* normal_cam, float* xyz_world, float* normal_world,
+                                int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* pose_dev,
+                                void* stream);
 /* ext/imgproc/imgproc.cu:98-160: pc (H,W,3) -> normal_weight (H,W,4), w=-1 where invalid. */
 int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, int32_t W, void* stream);
 
