@@ -386,7 +386,8 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights(lds, wblob, ENC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
-    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     const int n_items = counters[DIF_C_ITEMS];
     for (int item = wave; item < n_items; item += nwaves) {
@@ -608,7 +609,8 @@ __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(Decod
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
     const __amdgpu_buffer_rsrc_t wbwd = make_rsrc(GRAD ? A.wbwd : wblob, GRAD ? DECB_FLOATS : DEC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
-    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     const int res3 = A.lat.res * A.lat.res * A.lat.res;
     const int tiles_per_voxel = (res3 + 31) / 32;
@@ -797,7 +799,7 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
     const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
     const float scale = (float)(l - 1) / (float)(R - 1);
     const int B = A.counters[DIF_C_B];
-    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + wid), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int wave = (int)(wid * gridDim.x + blockIdx.x), nwaves = (int)(gridDim.x * (blockDim.x >> 6));   // spread over CUs first
     for (int b = wave; b < B; b += nwaves) {
         const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
         f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
@@ -1397,7 +1399,8 @@ __global__ void __launch_bounds__(512, 2) k_encode_rows(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights(lds, wblob, ENC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
-    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     const int64_t n_tiles = (n + 31) / 32;
     for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
