@@ -288,6 +288,19 @@ __device__ __forceinline__ int wave_grouped_fetch_add(int* __restrict__ counter,
     return result;
 }
 
+// Same grouping, fire-and-forget: nobody waits for the atomic's return value.
+__device__ __forceinline__ void wave_grouped_add(int* __restrict__ counter, uint32_t key, bool valid) {
+    const int lane = lane_id();
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+        const unsigned long long same = __ballot(valid && key == k0);
+        if (lane == leader) atomicAdd(counter + k0, __popcll(same));
+        todo &= ~same;
+    }
+}
+
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
@@ -332,7 +345,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         if (i < N) pair_key[(int64_t)o * N + i] = key[o];
-        (void)wave_grouped_fetch_add(seg_cnt, key[o], key[o] != DIF_INVALID_KEY);
+        wave_grouped_add(seg_cnt, key[o], key[o] != DIF_INVALID_KEY);
     }
 }
 
@@ -1521,7 +1534,7 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
 
     {   // dirty slots -> valid_blocks
         const int64_t plane = (int64_t)map->ny * map->nz;
-        const bool tiled = map->own_x_hi > map->own_x_lo;
+        const bool tiled = map->own_x_hi > map->own_x_lo && (map->own_x_lo > 0 || map->own_x_hi < map->nx);
         const int64_t own_lo = tiled ? map->own_x_lo * plane : 0, own_hi = tiled ? map->own_x_hi * plane : grid;
         if (tiled) {
             hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th, map->dirty,
