@@ -154,6 +154,124 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_normal_weight(const float* __rest
     }
 }
 
+// ---- 8f-2: image-space preprocessing next to the path -------------------------------------------------------------------
+// filter_depth (ext/imgproc/imgproc.cu:48-94): 5x5 bilateral filter whose range sigma follows the depth-noise model;
+// border pixels (2 px) are left untouched, depth < 1e-6 -> 0.
+__global__ void __launch_bounds__(DIF_BLOCK) k_filter_depth(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
+    const float sig_l2 = 1.2232f * 1.2232f;                  // MEAN_SIGMA_L^2
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        if (v < 2 || v >= H - 2 || u < 2 || u >= W - 2) continue;
+        float z = in[i];
+        if (z < 1e-6) { out[i] = 0.0f; continue; }
+        float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
+        float w_sum = 0.0f, acc = 0.0f;
+        for (int di = -2; di <= 2; ++di)
+            for (int dj = -2; dj <= 2; ++dj) {
+                float nz = in[i + (int64_t)di * W + dj];
+                if (nz < 1e-6) continue;
+                float dz = (nz - z) * (nz - z);
+                float wgt = expf(-0.5f * ((float)(abs(di) + abs(dj)) * sig_l2 + dz * sigma_z * sigma_z));
+                w_sum += wgt;
+                acc += wgt * nz;
+            }
+        out[i] = acc / w_sum;
+    }
+}
+
+// point_box_filter (system/tracker.py:13-23): mean point / mean normal per voxel_size box, boxes in ascending linear id
+// (x fastest).  Bounds -> box bitmap -> ordered ranks -> order-independent fixed-point sums -> means.
+struct BoxGrid { float minb[3]; int n[3]; };
+
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_bounds(const float* __restrict__ pts, int64_t N, unsigned* __restrict__ mm /* [6]: min xyz, max xyz (ordered uint) */) {
+    unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { unsigned o = f2ord(pts[i * 3 + a]); lo[a] = min(lo[a], o); hi[a] = max(hi[a], o); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int d = 32; d >= 1; d >>= 1) { lo[a] = min(lo[a], (unsigned)__shfl_xor((int)lo[a], d)); hi[a] = max(hi[a], (unsigned)__shfl_xor((int)hi[a], d)); }
+        if (lane_id() == 0) { atomicMin(mm + a, lo[a]); atomicMax(mm + 3 + a, hi[a]); }
+    }
+}
+
+__device__ __forceinline__ BoxGrid pbf_grid(const unsigned* __restrict__ mm, float vs) {
+    BoxGrid G;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float mn = ord2f(mm[a]) - vs * 0.5f, mx = ord2f(mm[3 + a]) + vs * 0.5f;     // tracker.py:15-16
+        G.minb[a] = mn;
+        G.n[a] = (int)floorf((mx - mn) / vs) + 16;                                    // tracker.py:18
+    }
+    return G;
+}
+
+__device__ __forceinline__ int64_t pbf_cell(const BoxGrid& G, const float* p, float vs) {
+    int64_t cx = (int64_t)floorf((p[0] - G.minb[0]) / vs), cy = (int64_t)floorf((p[1] - G.minb[1]) / vs), cz = (int64_t)floorf((p[2] - G.minb[2]) / vs);
+    return cx + cy * G.n[0] + cz * (int64_t)G.n[0] * G.n[1];                          // tracker.py:17,19
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_mark(const float* __restrict__ pts, int64_t N, float vs, const unsigned* __restrict__ mm,
+                                                      uint32_t* __restrict__ bits, int64_t max_cells, int* __restrict__ status) {
+    const BoxGrid G = pbf_grid(mm, vs);
+    if ((int64_t)G.n[0] * G.n[1] * G.n[2] > max_cells) { if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 1; return; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = pbf_cell(G, pts + i * 3, vs);
+        uint32_t b = 1u << (c & 31);
+        if (!(bits[c >> 5] & b)) atomicOr(bits + (c >> 5), b);
+    }
+}
+
+struct BoxRankFunctor {      // exclusive prefix of popcounts per bitmap word = rank of the word's first box
+    const uint32_t* bits;
+    int* word_rank;
+    int* out_count;
+    __device__ int count(int w) const { return __popc(bits[w]); }
+    __device__ void emit(int w, int offset) const { word_rank[w] = offset; }
+    __device__ void finish(int total) const { out_count[0] = total; }
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_accumulate(const float* __restrict__ pts, const float* __restrict__ nrm, int64_t N, float vs,
+                                                            const unsigned* __restrict__ mm, const uint32_t* __restrict__ bits,
+                                                            const int* __restrict__ word_rank, long long* __restrict__ sums /* [boxes][8] */,
+                                                            const int* __restrict__ status) {
+    if (status[0]) return;
+    const BoxGrid G = pbf_grid(mm, vs);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = pbf_cell(G, pts + i * 3, vs);
+        int r = word_rank[c >> 5] + __popc(bits[c >> 5] & ((1u << (c & 31)) - 1u));
+        long long* s = sums + (int64_t)r * 8;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicAdd((unsigned long long*)(s + a), (unsigned long long)__float2ll_rn(pts[i * 3 + a] * 16777216.0f));       // 2^-24 fixed point
+            atomicAdd((unsigned long long*)(s + 3 + a), (unsigned long long)__float2ll_rn(nrm[i * 3 + a] * 16777216.0f));
+        }
+        atomicAdd((unsigned long long*)(s + 6), 1ull);
+    }
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_finish(const long long* __restrict__ sums, const int* __restrict__ n_boxes, float* __restrict__ out_pts,
+                                                        float* __restrict__ out_nrm, uint32_t* __restrict__ bits, const float* __restrict__ pts, int64_t N,
+                                                        float vs, const unsigned* __restrict__ mm, const int* __restrict__ status) {
+    const int nb = n_boxes[0];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)nb * 3; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e / 3; int a = (int)(e - r * 3);
+        const float cnt = (float)sums[r * 8 + 6];
+        out_pts[e] = (float)((double)sums[r * 8 + a] * (1.0 / 16777216.0)) / cnt;
+        out_nrm[e] = (float)((double)sums[r * 8 + 3 + a] * (1.0 / 16777216.0)) / cnt;
+    }
+    if (status[0]) return;
+    const BoxGrid G = pbf_grid(mm, vs);                      // restore the bitmap to all-zero for the next call
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = pbf_cell(G, pts + i * 3, vs);
+        bits[c >> 5] = 0u;
+    }
+}
+
 // =================================================================================================================
 // a9 : flat groupby_sum (ext/indexing/indexing.cu:59-109) — API parity entry; the map path uses the sorted reduction
 // =================================================================================================================
@@ -1250,6 +1368,41 @@ int dif_unproject_transform_dev(const float* depth, const float* normal_cam, flo
 int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, int32_t W, void* stream) {
     if (!pc || !normal_weight || H <= 0 || W <= 0) return DIF_EINVAL;
     hipLaunchKernelGGL(k_normal_weight, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, pc, normal_weight, H, W);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_filter_depth(const float* depth_in, float* depth_out, int32_t H, int32_t W, void* stream) {
+    if (!depth_in || !depth_out || H <= 0 || W <= 0) return DIF_EINVAL;
+    hipLaunchKernelGGL(k_filter_depth, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth_in, depth_out, H, W);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_point_box_filter(const float* points, const float* normals, int64_t N, float voxel_size, float* out_points, float* out_normals,
+                         int32_t* out_count, uint32_t* bits, int64_t max_cells, int32_t* word_rank, int64_t* sums, int32_t* scratch, void* stream) {
+    if (N < 0 || !(voxel_size > 0.0f) || max_cells <= 0 || max_cells >= ((int64_t)1 << 36)) return DIF_EINVAL;
+    if (!out_count || !scratch) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) return hipMemsetAsync(out_count, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+    if (!points || !normals || !out_points || !out_normals || !bits || !word_rank || !sums || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    // scratch: [0..4095] scan block totals, [4096..4101] ordered-uint bounds, [4102] status
+    unsigned* mm = (unsigned*)(scratch + 4096);
+    int* status = scratch + 4102;
+    static const unsigned init_mm[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
+    if (hipMemcpyAsync(mm, init_mm, sizeof(init_mm), hipMemcpyHostToDevice, s) != hipSuccess) return DIF_ELAUNCH;
+    if (hipMemsetAsync(sums, 0, (size_t)N * 8 * sizeof(int64_t), s) != hipSuccess) return DIF_ELAUNCH;      // <= N boxes
+    hipLaunchKernelGGL(k_pbf_bounds, dim3(grid_for(N, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, points, N, mm);
+    hipLaunchKernelGGL(k_pbf_mark, dim3(grid_for(N)), dim3(DIF_BLOCK), 0, s, points, N, voxel_size, (const unsigned*)mm, bits, max_cells, status);
+    DIF_CHECK_LAUNCH();
+    BoxRankFunctor f{bits, word_rank, out_count};
+    const int64_t nwords = (max_cells + 31) / 32;
+    if (nwords >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    if (launch_scan(f, nullptr, (int)nwords, nwords, scratch, s) != DIF_OK) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_pbf_accumulate, dim3(grid_for(N)), dim3(DIF_BLOCK), 0, s, points, normals, N, voxel_size, (const unsigned*)mm,
+                       (const uint32_t*)bits, (const int*)word_rank, (long long*)sums, (const int*)status);
+    hipLaunchKernelGGL(k_pbf_finish, dim3(grid_for(N)), dim3(DIF_BLOCK), 0, s, (const long long*)sums, (const int*)out_count, out_points, out_normals,
+                       bits, points, N, voxel_size, (const unsigned*)mm, (const int*)status);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

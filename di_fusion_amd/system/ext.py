@@ -84,3 +84,42 @@ def marching_cubes_interp(indexer: torch.Tensor, valid_blocks: torch.Tensor, vec
         print(f"Warning from marching cube: the max triangle number is too small {T} vs {max_n_triangles}", file=sys.stderr)
     T = min(T, cap)
     return [tri[:T], tid[:T], tstd[:T]]
+
+
+def filter_depth(depth_in: torch.Tensor, depth_out: torch.Tensor) -> None:
+    """In-place-style bilateral depth filter, reference `ext/imgproc/imgproc.cu:81-94` (writes `depth_out`, border untouched)."""
+    _lib.require_cuda(depth_in, depth_out)
+    H, W = depth_in.shape
+    with _dev(depth_in):
+        _lib.check(_lib.load().dif_filter_depth(_lib.ptr(depth_in), _lib.ptr(depth_out), H, W, _lib.stream_ptr()), "dif_filter_depth")
+
+
+_PBF_SCRATCH = {}
+
+
+def point_box_filter(points: torch.Tensor, normals: torch.Tensor, voxel_size: float, max_cells: int = 1 << 27):
+    """Voxel-mean down-sampling, reference `system/tracker.py:13-23` (the step right before `integrate_keyframe`):
+    (N,3) points + normals -> (n_boxes,3) means, boxes ordered by ascending linear box id.  `max_cells` bounds the box grid
+    (bounding box of the cloud / voxel_size + 16 per axis); 2^27 cells = 16 MB of bitmap."""
+    _lib.require_cuda(points, normals)
+    N = points.size(0)
+    dev = points.device
+    key = (str(dev), int(max_cells))
+    with _dev(points):
+        if key not in _PBF_SCRATCH:
+            nw = (max_cells + 31) // 32
+            _PBF_SCRATCH[key] = (torch.zeros((nw,), dtype=torch.int32, device=dev), torch.empty((nw,), dtype=torch.int32, device=dev))
+        bits, word_rank = _PBF_SCRATCH[key]
+        out_p = torch.empty((max(N, 1), 3), dtype=torch.float32, device=dev)
+        out_n = torch.empty((max(N, 1), 3), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        sums = torch.empty((max(N, 1) * 8,), dtype=torch.int64, device=dev)
+        scratch = torch.zeros((4200,), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().dif_point_box_filter(_lib.ptr(points), _lib.ptr(normals), N, float(voxel_size), _lib.ptr(out_p), _lib.ptr(out_n),
+                                                    _lib.ptr(cnt), _lib.ptr(bits), int(max_cells), _lib.ptr(word_rank), _lib.ptr(sums),
+                                                    _lib.ptr(scratch), _lib.stream_ptr()), "dif_point_box_filter")
+        st = scratch[4102].item()
+    if st != 0:
+        raise RuntimeError("point_box_filter: the cloud's box grid exceeds max_cells")
+    n = int(cnt.item())
+    return out_p[:n], out_n[:n]

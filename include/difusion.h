@@ -110,6 +110,18 @@ int dif_unproject_transform_dev(const float* depth, const float* normal_cam, flo
 /* ext/imgproc/imgproc.cu:98-160: pc (H,W,3) -> normal_weight (H,W,4), w=-1 where invalid. */
 int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, int32_t W, void* stream);
 
+/* ---- 8f-2: image-space preprocessing on either side of the path ----------------------------------------------------- */
+/* ext/imgproc/imgproc.cu:48-94: 5x5 bilateral depth filter (range sigma from the depth-noise model); the 2-pixel border of
+ * depth_out is left untouched, depth < 1e-6 -> 0. */
+int dif_filter_depth(const float* depth_in, float* depth_out, int32_t H, int32_t W, void* stream);
+/* system/tracker.py:13-23 point_box_filter: mean point and mean normal per voxel_size box; boxes come out in ascending
+ * linear box id (x fastest), out_count[0] (device) = number of boxes.  out_points/out_normals: (N,3) capacity.
+ * bits: uint32[(max_cells+31)/32] all-zero on entry and on exit; word_rank: int32[(max_cells+31)/32]; sums: int64[N*8];
+ * scratch: int32[4200].  If the box grid of the cloud exceeds max_cells, scratch[4102] is set and nothing is produced. */
+int dif_point_box_filter(const float* points, const float* normals, int64_t N, float voxel_size, float* out_points,
+                         float* out_normals, int32_t* out_count, uint32_t* bits, int64_t max_cells, int32_t* word_rank,
+                         int64_t* sums, int32_t* scratch, void* stream);
+
 /* ---- a9: ext/indexing/indexing.cu:89-109 ------------------------------------------------------------------- */
 /* sum[idx[i]][:] += values[i][:], count[idx[i]] += 1 (per sample).  sum (C,L) / count (C) must be zeroed by the
  * caller.  Deterministic is not promised here (float atomics, as the reference); the map path does not use it.  */

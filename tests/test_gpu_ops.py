@@ -143,3 +143,36 @@ def test_marching_cubes_empty_and_truncation():
     assert tri.shape[0] == 0
     tri, tid, tstd = ext.marching_cubes_interp(_t(indexer.reshape(n_xyz)), _t(vb), _t(vbm), _t(cs), _t(cd), 50, n_xyz, 2000.0)
     assert tri.shape[0] == 50
+
+
+def test_filter_depth_vs_oracle():
+    from di_fusion_amd.system import ext
+    from di_fusion_amd import synthetic as syn
+    from oracle import difusion_oracle as O
+    intr = syn.Intrinsic().scaled(0.1)
+    R, t = syn.orbit_pose(0)
+    depth, _ = syn.render_frame(syn.default_room(), R, t, intr, noise_seed=3)
+    d = torch.nan_to_num(depth, nan=0.0).numpy()
+    out = torch.full(d.shape, -7.0, device=DEV)
+    ext.filter_depth(_t(d), out)
+    want = O.filter_depth(d)
+    got = out.cpu().numpy()
+    assert (got[:2] == -7).all() and (got[-2:] == -7).all() and (got[:, :2] == -7).all() and (got[:, -2:] == -7).all()   # border untouched
+    assert np.abs(got[2:-2, 2:-2] - want[2:-2, 2:-2]).max() < 1e-5
+
+
+def test_point_box_filter_vs_oracle():
+    from di_fusion_amd.system import ext
+    from di_fusion_amd import synthetic as syn
+    from oracle import difusion_oracle as O
+    xyz, nrm = syn.frame_points(syn.default_room(), 3, syn.Intrinsic().scaled(0.5))
+    fp, fn = ext.point_box_filter(xyz.to(DEV), nrm.to(DEV), 0.02)
+    wp, wn = O.point_box_filter(xyz.numpy(), nrm.numpy(), 0.02)
+    assert fp.shape == wp.shape and fp.shape[0] < xyz.shape[0]
+    assert np.abs(fp.cpu().numpy() - wp).max() < 2e-6
+    assert np.abs(fn.cpu().numpy() - wn).max() < 2e-6
+    # scratch bitmap restored: a second call gives the same answer
+    fp2, _ = ext.point_box_filter(xyz.to(DEV), nrm.to(DEV), 0.02)
+    assert torch.equal(fp, fp2)
+    with pytest.raises(RuntimeError):
+        ext.point_box_filter(xyz.to(DEV), nrm.to(DEV), 0.02, max_cells=1 << 12)
