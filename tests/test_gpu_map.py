@@ -314,3 +314,55 @@ def test_other_resolutions_and_exact_decode(resolution, fast, gpu_model, oracle_
     want = (wt * np.float32(cfg.voxel_size)).astype(np.float32) + om.bound_min
     assert np.array_equal(nid.cpu().numpy(), wi)
     assert np.abs(ntri.cpu().numpy() - want).max() < 1e-5
+
+
+def test_sdf_gauss_newton_pose_refinement(gpu_model):
+    """The caller of the path: `SDFTracker.compute_sdf_Hg` (reference tracker.py:174-218) restated on top of `map.get_sdf` —
+    residual sdf/std.detach(), Jacobian from autograd through the map, 6-DoF Gauss-Newton.  A perturbed camera pose must be
+    pulled back towards the truth: this is what 'drops into the existing tracking loop' means for row a17."""
+    scene = syn.default_room()                                   # boxes + walls constrain all 6 DoF (a sphere would not)
+    cfg = syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.2)
+    intr = syn.Intrinsic().scaled(0.5)
+    m = make_map(gpu_model, cfg)
+    for f in range(3):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=4.0)
+        m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV))
+    # observation: frame 1 in CAMERA coordinates
+    R, t = syn.orbit_pose(1, deg_per_frame=4.0)
+    depth, _ = syn.render_frame(scene, R, t, intr)
+    pc = syn.unproject_reference_order(depth, intr).reshape(-1, 3)
+    pc = pc[~torch.isnan(pc[:, 0])][::11].to(DEV).double()
+    Rt = torch.tensor(R, device=DEV); tt = torch.tensor(t, device=DEV)
+
+    def hat(w):
+        z = torch.zeros((), dtype=torch.float64, device=DEV)
+        return torch.stack([torch.stack([z, -w[2], w[1]]), torch.stack([w[2], z, -w[0]]), torch.stack([-w[1], w[0], z])])
+
+    def residual_and_jac(Rc, tc):
+        xyz = (pc @ Rc.T + tc).float().requires_grad_(True)
+        sdf, std, mask = m.get_sdf(xyz)
+        r = sdf / std.detach()
+        (g,) = torch.autograd.grad(r, [xyz], grad_outputs=torch.ones_like(r))
+        g = g[mask].double()                                      # d r / d xyz_world   (M,3)
+        p = xyz.detach()[mask].double()
+        J = torch.cat([g, torch.cross(p, g, dim=1)], dim=1)       # left perturbation: [translation | rotation]
+        return r.detach().double(), J
+
+    # perturb: 1.5 degrees about y, 2 cm translation
+    a = np.deg2rad(1.5)
+    dR = torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], device=DEV)
+    Rc, tc = dR @ Rt, tt + torch.tensor([0.02, -0.01, 0.015], device=DEV)
+    e0 = (residual_and_jac(Rc, tc)[0] ** 2).mean().item()
+    err0 = (torch.linalg.norm(tc - tt).item(), np.rad2deg(np.arccos(np.clip((torch.trace(Rc @ Rt.T).item() - 1) / 2, -1, 1))))
+    for it in range(8):
+        r, J = residual_and_jac(Rc, tc)
+        H = J.T @ J + 1e-6 * torch.eye(6, dtype=torch.float64, device=DEV)
+        xi = -torch.linalg.solve(H, J.T @ r)
+        W = hat(xi[3:])
+        dRot = torch.linalg.matrix_exp(W)
+        Rc, tc = dRot @ Rc, dRot @ tc + xi[:3]
+    e1 = (residual_and_jac(Rc, tc)[0] ** 2).mean().item()
+    err1 = (torch.linalg.norm(tc - tt).item(), np.rad2deg(np.arccos(np.clip((torch.trace(Rc @ Rt.T).item() - 1) / 2, -1, 1))))
+    print(f"  GN on map.get_sdf: residual {e0:.4f} -> {e1:.4f}; pose error {err0[0]*100:.2f} cm / {err0[1]:.2f} deg -> {err1[0]*100:.2f} cm / {err1[1]:.2f} deg")
+    assert e1 < 0.5 * e0
+    assert err1[0] < 0.5 * err0[0] and err1[1] < 0.5 * err0[1]
