@@ -13,8 +13,8 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libdifusion.so"
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK = range(16)
-C_COUNT = 16
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE = range(18)
+C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "sort"]
 PROF_COUNT = 8
 LATENT_DIM = 29
@@ -31,6 +31,7 @@ class DifMap(Structure):
                 ("voxel_obs_count", c_void_p), ("dirty", c_void_p), ("counters", c_void_p),
                 ("frame_count", c_void_p), ("grid_bits", c_void_p), ("vbm", c_void_p),
                 ("seg_start", c_void_p), ("seg_cnt", c_void_p), ("item_start", c_void_p),
+                ("tri_start", c_void_p), ("tri_n", c_void_p),
                 ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32)]
 
 
@@ -45,8 +46,7 @@ class DifExtractBuffers(Structure):
                 ("low_sdf", c_void_p), ("low_std", c_void_p), ("cube_sdf", c_void_p), ("cube_std", c_void_p),
                 ("refine_list", c_void_p), ("tri_count", c_void_p), ("tri_offset", c_void_p), ("block_tmp", c_void_p),
                 ("max_triangles", c_int64), ("cache_capacity", c_int64),
-                ("cache_src_tri", c_void_p), ("cache_src_id", c_void_p), ("cache_src_std", c_void_p),
-                ("cache_dst_tri", c_void_p), ("cache_dst_id", c_void_p), ("cache_dst_std", c_void_p)]
+                ("cache_tri", c_void_p), ("cache_id", c_void_p), ("cache_std", c_void_p), ("cache_alive", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)
@@ -67,6 +67,8 @@ SIGNATURES = {
                                 c_int64, c_void_p]),
     "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
                               c_int32, c_int32, c_void_p]),
+    "dif_mesh_cache_compact": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_mesh_cache_reindex": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_int64, c_void_p]),
     "dif_marching_cubes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                      c_void_p, c_int32, c_float, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1001,7 +1001,7 @@ struct McArgs {
     const float* cube_sdf; const float* cube_std; int R;
     float max_std;
     int64_t max_triangles;
-    float* triangles; int64_t* tri_id; float* tri_std;
+    float* triangles; int64_t* tri_id; float* tri_std; uint8_t* tri_alive;
     int32_t* tri_count; const int32_t* tri_offset;
     const int* base_ptr;            // device: first output triangle index (mesh-cache append), or NULL
     int64_t new_limit;              // triangles this call may emit (max_n_triangles)
@@ -1164,6 +1164,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
                             a.tri_std[t * 3 + vi] = vv[vi].w;
                         }
                         a.tri_id[t] = vb;
+                        if (a.tri_alive) a.tri_alive[t] = 1;
                     }
                     ++t; ++tl;
                 }
@@ -1175,38 +1176,82 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     }
 }
 
-// ---- a16 : device-resident mesh cache (map.py:703-714) ---------------------------------------------------------------
-struct CacheCompactFunctor {    // ordered compaction: keep cached triangles whose voxel got no new triangle
-    const float* src_tri; const int64_t* src_id; const float* src_std;
+// ---- a16 : device-resident mesh cache as an append-only log (map.py:703-714) -----------------------------------------
+// A voxel that produced >= 1 new triangle replaces its previous batch (the reference drops cached triangles whose voxel id
+// occurs among the new ones, map.py:708-709): mark the old batch dead, point the voxel at its new batch.
+__global__ void __launch_bounds__(DIF_BLOCK) k_log_replace(const int64_t* __restrict__ valid_blocks, const int32_t* __restrict__ tri_count,
+                                                         const int32_t* __restrict__ tri_offset, const int64_t* __restrict__ indexer,
+                                                         int32_t* __restrict__ tri_start, int32_t* __restrict__ tri_n, uint8_t* __restrict__ alive,
+                                                         int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
+    __shared__ int smem[8];
+    const int K = counters[DIF_C_K];
+    const int64_t log_n = counters[DIF_C_CACHE_T];
+    int dead = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int c = tri_count[k];
+        if (c <= 0) continue;
+        const int64_t slot = indexer[valid_blocks[k]];
+        const int old_n = tri_n[slot], old_s = tri_start[slot];
+        for (int j = 0; j < old_n; ++j) alive[old_s + j] = 0;
+        dead += old_n;
+        int64_t off = tri_offset[k];
+        int64_t n_new = c;
+        if (off + n_new > new_limit) n_new = new_limit > off ? new_limit - off : 0;          // truncated by max_n_triangles
+        if (log_n + off + n_new > capacity) n_new = capacity > log_n + off ? capacity - (log_n + off) : 0;
+        tri_start[slot] = (int)(log_n + off);
+        tri_n[slot] = (int)n_new;
+    }
+    dead = block_sum(dead, smem);
+    if (threadIdx.x == 0 && dead) atomicAdd(counters + DIF_C_CACHE_DEAD, dead);
+}
+
+struct CacheLiveFunctor {       // ordered compaction of the live log entries
+    const float* src_tri; const int64_t* src_id; const float* src_std; const uint8_t* alive;
     float* dst_tri; int64_t* dst_id; float* dst_std;
-    const int* flags;
+    int64_t out_capacity;
     int* counters;
-    __device__ int count(int t) const { return flags[src_id[t]] ? 0 : 1; }
+    __device__ int count(int t) const { return alive[t] ? 1 : 0; }
     __device__ void emit(int t, int offset) const {
+        if (offset >= out_capacity) return;
 #pragma unroll
         for (int i = 0; i < 9; ++i) dst_tri[(int64_t)offset * 9 + i] = src_tri[(int64_t)t * 9 + i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) dst_std[(int64_t)offset * 3 + i] = src_std[(int64_t)t * 3 + i];
         dst_id[offset] = src_id[t];
     }
-    __device__ void finish(int total) const { counters[DIF_C_CACHE_KEPT] = total; }
+    __device__ void finish(int total) const { counters[DIF_C_CACHE_LIVE] = total > out_capacity ? (int)out_capacity : total; }
 };
 
-// end of extract: clear the voxel flags and the batch map, publish the cache size
-__global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int64_t* __restrict__ valid_blocks, const int32_t* __restrict__ tri_count,
-                                                            int* __restrict__ flags, const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
-                                                            int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
-    const int K = counters[DIF_C_K], B = counters[DIF_C_B];
-    const int n = K > B ? K : B;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (i < K && tri_count[i] > 0) flags[valid_blocks[i]] = 0;
-        if (i < B) vbm[occ_slot[i]] = -1;
+__global__ void __launch_bounds__(DIF_BLOCK) k_cache_reindex(const int64_t* __restrict__ id, int64_t n, const int64_t* __restrict__ indexer,
+                                                           int32_t* __restrict__ tri_start, int32_t* __restrict__ tri_n, uint8_t* __restrict__ alive,
+                                                           int* __restrict__ counters) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        alive[t] = 1;
+        const int64_t v = id[t];
+        const int64_t slot = indexer[v];
+        if (slot < 0) continue;
+        if (t == 0 || id[t - 1] != v) tri_start[slot] = (int)t;            // a live voxel owns exactly one contiguous batch
+        atomicAdd(tri_n + slot, 1);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters[DIF_C_CACHE_T] = (int)n;
+        counters[DIF_C_CACHE_KEPT] = (int)n;
+        counters[DIF_C_CACHE_DEAD] = 0;
+    }
+}
+
+// end of extract: clear the batch map, publish the log length
+__global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
+                                                            int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
+    const int B = counters[DIF_C_B];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int64_t n_new = counters[DIF_C_T];
         if (n_new > new_limit) n_new = new_limit;
-        int64_t tot = (int64_t)counters[DIF_C_CACHE_KEPT] + n_new;
+        const int64_t old_n = counters[DIF_C_CACHE_T];
+        int64_t tot = old_n + n_new;
         if (tot > capacity) { tot = capacity; counters[DIF_C_OVERFLOW] = 5; }
+        counters[DIF_C_CACHE_KEPT] = (int)old_n;
         counters[DIF_C_CACHE_T] = (int)tot;
     }
 }
@@ -1215,13 +1260,8 @@ struct TriScanFunctor {
     const int32_t* tri_count;
     int32_t* tri_offset;
     int* counters;
-    const int64_t* valid_blocks;    // with `flags`: mark the voxels that produced >= 1 new triangle (mesh-cache replace rule)
-    int* flags;
     __device__ int count(int k) const { return tri_count[k]; }
-    __device__ void emit(int k, int offset) const {       // only called when tri_count[k] > 0
-        tri_offset[k] = offset;
-        if (flags) flags[valid_blocks[k]] = 1;
-    }
+    __device__ void emit(int k, int offset) const { tri_offset[k] = offset; }
     __device__ void finish(int total) const { counters[DIF_C_T] = total; }
 };
 
@@ -1618,8 +1658,7 @@ static int mc_setup(const McArgs& a, size_t& lds_bytes, int& blocks, int64_t K_u
     return DIF_OK;
 }
 
-static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s,
-                             int* cache_flags = nullptr) {
+static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
     size_t lds_bytes; int blocks;
     int rc = mc_setup(a, lds_bytes, blocks, K_upper);
     if (rc != DIF_OK) return rc;
@@ -1630,7 +1669,7 @@ static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int3
         hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
     }
     DIF_CHECK_LAUNCH();
-    TriScanFunctor f{tri_count, tri_offset, counters, a.valid_blocks, cache_flags};
+    TriScanFunctor f{tri_count, tri_offset, counters};
     return launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s);
 }
 
@@ -1667,7 +1706,7 @@ int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t n
     a.indexer = indexer; a.nx = nx; a.ny = ny; a.nz = nz; a.valid_blocks = valid_blocks; a.K_ptr = nullptr; a.K_static = K;
     a.vbm = vec_batch_mapping; a.V = V; a.cube_sdf = cube_sdf; a.cube_std = cube_std; a.R = R; a.max_std = max_std;
     a.max_triangles = max_triangles; a.new_limit = max_triangles; a.base_ptr = nullptr;
-    a.triangles = triangles; a.tri_id = triangle_flatten_id; a.tri_std = triangle_std; a.scale = 0;
+    a.triangles = triangles; a.tri_id = triangle_flatten_id; a.tri_std = triangle_std; a.tri_alive = nullptr; a.scale = 0;
     return run_marching_cubes(a, K, tri_count, tri_offset, block_tmp, counters, s);
 }
 
@@ -1675,7 +1714,9 @@ int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t n
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                 float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
-    if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_dst_tri || !buf->cache_src_tri) return DIF_EINVAL;
+    if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_tri || !buf->cache_id || !buf->cache_std || !buf->cache_alive)
+        return DIF_EINVAL;
+    if (!map->tri_start || !map->tri_n) return DIF_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     Geo g = geo_of(map);
@@ -1765,22 +1806,41 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     McArgs a = {};
     a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
     a.vbm = map->vbm; a.V = map->capacity; a.cube_sdf = buf->cube_sdf; a.cube_std = buf->cube_std; a.R = R; a.max_std = max_std;
-    a.max_triangles = buf->cache_capacity; a.new_limit = buf->max_triangles; a.base_ptr = C + DIF_C_CACHE_KEPT;
-    a.triangles = buf->cache_dst_tri; a.tri_id = buf->cache_dst_id; a.tri_std = buf->cache_dst_std;
+    a.max_triangles = buf->cache_capacity; a.new_limit = buf->max_triangles; a.base_ptr = C + DIF_C_CACHE_T;     // append at the log's end
+    a.triangles = buf->cache_tri; a.tri_id = buf->cache_id; a.tri_std = buf->cache_std; a.tri_alive = buf->cache_alive;
     a.scale = scale_vertices ? 1 : 0; a.vs = map->voxel_size; a.bx = map->bound_min[0]; a.by = map->bound_min[1]; a.bz = map->bound_min[2];
-    if (no_cache && hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;       // map.py:614-616
-    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s, map->frame_count);
-    if (rc != DIF_OK) return rc;
-    // mesh cache: keep the triangles of voxels that got no new triangle, then append the new ones (map.py:703-714)
-    {
-        CacheCompactFunctor f{buf->cache_src_tri, buf->cache_src_id, buf->cache_src_std, buf->cache_dst_tri, buf->cache_dst_id, buf->cache_dst_std,
-                              map->frame_count, C};
-        if (launch_scan(f, C + DIF_C_CACHE_T, 0, buf->cache_capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    if (no_cache) {                                                                                               // map.py:614-616
+        if (hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
+        if (hipMemsetAsync(C + DIF_C_CACHE_DEAD, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
+        if (hipMemsetAsync(map->tri_n, 0, sizeof(int32_t) * (size_t)map->capacity, s) != hipSuccess) return DIF_ELAUNCH;
     }
+    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s);
+    if (rc != DIF_OK) return rc;
+    hipLaunchKernelGGL(k_log_replace, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks,
+                       (const int32_t*)buf->tri_count, (const int32_t*)buf->tri_offset, (const int64_t*)map->indexer, map->tri_start, map->tri_n,
+                       buf->cache_alive, C, buf->max_triangles, buf->cache_capacity);
+    DIF_CHECK_LAUNCH();
     rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
     if (rc != DIF_OK) return rc;
-    hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks,
-                       (const int32_t*)buf->tri_count, map->frame_count, (const int32_t*)buf->occ_slot, map->vbm, C, buf->max_triangles, buf->cache_capacity);
+    hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
+                       C, buf->max_triangles, buf->cache_capacity);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,
+                           int64_t out_capacity, int32_t* scratch, void* stream) {
+    if (!map || !buf || !out_tri || !out_id || !out_std || !scratch || out_capacity <= 0) return DIF_EINVAL;
+    CacheLiveFunctor f{buf->cache_tri, buf->cache_id, buf->cache_std, buf->cache_alive, out_tri, out_id, out_std, out_capacity, map->counters};
+    return launch_scan(f, map->counters + DIF_C_CACHE_T, 0, buf->cache_capacity, scratch, (hipStream_t)stream);
+}
+
+int dif_mesh_cache_reindex(const dif_map_t* map, const dif_extract_buffers_t* buf, int64_t n, void* stream) {
+    if (!map || !buf || n < 0 || n > buf->cache_capacity) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(map->tri_n, 0, sizeof(int32_t) * (size_t)map->capacity, s) != hipSuccess) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_cache_reindex, dim3(grid_for(n > 0 ? n : 1)), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->cache_id, n, (const int64_t*)map->indexer,
+                       map->tri_start, map->tri_n, buf->cache_alive, map->counters);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

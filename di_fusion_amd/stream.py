@@ -132,12 +132,12 @@ class FusionStream:
 
     # ---- hipGraph variant: the ~22 launches of a frame are captured once and replayed --------------------------------------
     # Everything a frame launches has host-independent shapes (device counters carry the sizes), so a frame is a static graph:
-    # stage depth / normals / pose into fixed buffers, replay, read the counters one frame later.  Two graphs, one per parity of
-    # the mesh-cache ping-pong.  Re-captured only when a buffer is re-allocated (capacity growth).
+    # stage depth / normals / pose into fixed buffers, replay, read the counters one frame later.  Re-captured only when a buffer is
+    # re-allocated (capacity growth, mesh-cache garbage collection).
     def _graph_signature(self):
         m = self.map
         return (m._capacity, m._ws.data_ptr() if m._ws is not None else 0, m._xbuf[0] if m._xbuf else None,
-                m._cache[0][0].data_ptr() if m._cache else 0)
+                m._cache[0].data_ptr() if m._cache else 0)
 
     def _capture_graphs(self):
         m, intr, dev = self.map, self.intr, self.device
@@ -149,28 +149,24 @@ class FusionStream:
                 self._g_in = (torch.empty((H, W), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.float32, device=dev),
                               torch.empty((12,), dtype=torch.float32, device=dev), torch.empty((N,), dtype=torch.uint8, device=dev))
                 self._g_pose_host = [torch.empty((12,), dtype=torch.float32).pin_memory() for _ in range(4)]
-                self._g_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(2)]
+                self._g_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(4)]
+                self._g_seq = 0
             depth, ncam, pose, mask = self._g_in
             w = m.model.packed.weights_struct(dev)
             tens, _ = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
             graphs = []
             torch.cuda.synchronize()
-            for parity in (0, 1):
-                saved = m._cache_cur
-                m._cache_cur = parity
-                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
-                m._cache_cur = saved
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    sp = _lib.stream_ptr()
-                    _lib.check(lib.dif_unproject_transform_dev(_lib.ptr(depth), _lib.ptr(ncam), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
-                                                               intr.fx, intr.fy, intr.cx, intr.cy, _lib.ptr(pose), sp), "dif_unproject_transform_dev")
-                    _lib.check(lib.dif_integrate(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), N, _lib.ptr(mask),
-                                                 _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate")
-                    _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
-                                               0, 1, sp), "dif_extract")
-                    self._g_counters[parity].copy_(m._counters, non_blocking=True)
-                graphs.append((g, buf))
+            _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sp = _lib.stream_ptr()
+                _lib.check(lib.dif_unproject_transform_dev(_lib.ptr(depth), _lib.ptr(ncam), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
+                                                           intr.fx, intr.fy, intr.cx, intr.cy, _lib.ptr(pose), sp), "dif_unproject_transform_dev")
+                _lib.check(lib.dif_integrate(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), N, _lib.ptr(mask),
+                                             _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate")
+                _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
+                                           0, 1, sp), "dif_extract")
+            graphs.append((g, buf))
             self._graphs = graphs
             self._graph_sig = self._graph_signature()
 
@@ -189,6 +185,8 @@ class FusionStream:
                     out_prev = self._finish_frame(self._pending, d2h)
                     self._pending = None
             m._ensure_capacity(may_add)
+            if m._gc_wanted:
+                m._cache_gc()
             if self._graphs is None or self._graph_sig != self._graph_signature():
                 torch.cuda.synchronize()
                 self._capture_graphs()
@@ -202,15 +200,15 @@ class FusionStream:
             pose.copy_(ph, non_blocking=True)
             depth.copy_(self.depth[i], non_blocking=True)
             ncam.copy_(self.ncam[i], non_blocking=True)
-            parity = m._cache_cur
-            g, _ = self._graphs[parity]
+            g, _ = self._graphs[0]
             g.replay()
-            m._cache_cur = 1 - parity
             m.mesh_cache.invalidate_host_copy()
+            pc = self._g_counters[self._g_seq % 4]                 # counters read back outside the graph: alternating pinned buffers
+            self._g_seq += 1
+            pc.copy_(m._counters, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            h = dict(event=ev, counters=self._g_counters[parity], cache_index=m._cache_cur, add_total=m._add_total,
-                     max_n_triangles=self.max_n_triangles)
+            h = dict(event=ev, counters=pc, epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles)
         out = None
         if self._pending is not None:
             out = self._finish_frame(self._pending, d2h)

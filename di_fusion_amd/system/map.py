@@ -129,9 +129,13 @@ class DenseIndexedMap:
         self.meshing_thread_id = -1
         self.meshing_stream = torch.cuda.Stream(device=device)
         self.mesh_cache = MeshExtractCache(self.device, self)
-        self._cache = None                  # [set0, set1] of (tri, id, std) device buffers
-        self._cache_cur = 0
+        self._cache = None                  # mesh-cache log: (tri, id, std, alive) device buffers
+        self._cache_out = None              # compaction target (and the next log after a garbage collection)
+        self._cache_cur = 0                 # kept for API compatibility of handles; the log is a single buffer
         self._cache_any = False             # an extract has produced a cache
+        self._gc_epoch = 0
+        self._gc_log_len = 0
+        self._gc_wanted = False
 
         self._grid = int(np.prod(self.n_xyz))
         if self._grid >= 2 ** 31:
@@ -165,13 +169,18 @@ class DenseIndexedMap:
             seg_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             seg_cnt = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             item_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            tri_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            tri_n = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             if self._capacity > 0:
                 c = self._capacity
                 lat[:c] = self._latent
                 pos[:c] = self._pos
                 obs[:c] = self._obs
                 dirty[:c] = self._dirty
+                tri_start[:c] = self._tri_start
+                tri_n[:c] = self._tri_n
         self._latent, self._pos, self._obs, self._dirty = lat, pos, obs, dirty
+        self._tri_start, self._tri_n = tri_start, tri_n
         self._vbm, self._seg_start, self._seg_cnt, self._item_start = vbm, seg_start, seg_cnt, item_start
         self._capacity = capacity
         m = _lib.DifMap()
@@ -195,6 +204,8 @@ class DenseIndexedMap:
         m.seg_start = _lib.ptr(seg_start)
         m.seg_cnt = _lib.ptr(seg_cnt)
         m.item_start = _lib.ptr(item_start)
+        m.tri_start = _lib.ptr(tri_start)
+        m.tri_n = _lib.ptr(tri_n)
         m.own_x_lo, m.own_x_hi, m.halo = getattr(self, "_ownership", (0, self.n_xyz[0], 0))
         self._cmap = m
 
@@ -205,7 +216,8 @@ class DenseIndexedMap:
         self._n_occ_ub = c[_lib.C_N_OCCUPIED] + (self._add_total - add_total_at_read)
         self.last_counters = dict(n_occupied=c[_lib.C_N_OCCUPIED], alloc_new=c[_lib.C_ALLOC_NEW], M=c[_lib.C_M], C=c[_lib.C_C],
                                   items=c[_lib.C_ITEMS], K=c[_lib.C_K], B=c[_lib.C_B], VH=c[_lib.C_VH], T=c[_lib.C_T],
-                                  query_M=c[_lib.C_QUERY_M], cache_T=c[_lib.C_CACHE_T], cache_kept=c[_lib.C_CACHE_KEPT])
+                                  query_M=c[_lib.C_QUERY_M], cache_T=c[_lib.C_CACHE_T], cache_kept=c[_lib.C_CACHE_KEPT],
+                                  cache_dead=c[_lib.C_CACHE_DEAD], cache_live=c[_lib.C_CACHE_LIVE])
         return self.last_counters
 
     def _read_counters(self):
@@ -359,32 +371,74 @@ class DenseIndexedMap:
         return sdf, std, mask
 
     # ---- extract ----------------------------------------------------------------------------------------------
-    def _ensure_cache(self, capacity: int):
+    def _new_cache_set(self, capacity: int):
         dev = self.device
-        if self._cache is not None and self._cache[0][0].size(0) >= capacity:
+        return (torch.empty((capacity, 3, 3), dtype=torch.float32, device=dev), torch.empty((capacity,), dtype=torch.long, device=dev),
+                torch.empty((capacity, 3), dtype=torch.float32, device=dev), torch.zeros((capacity,), dtype=torch.uint8, device=dev))
+
+    def _ensure_cache(self, capacity: int):
+        if self._cache is not None and self._cache[0].size(0) >= capacity:
             return
-        new = [(torch.empty((capacity, 3, 3), dtype=torch.float32, device=dev), torch.empty((capacity,), dtype=torch.long, device=dev),
-                torch.empty((capacity, 3), dtype=torch.float32, device=dev)) for _ in range(2)]
+        new = self._new_cache_set(capacity)
         if self._cache is not None:
-            old = self._cache[self._cache_cur]
-            n = old[0].size(0)
-            for a, b in zip(new[self._cache_cur], old):
+            n = self._cache[0].size(0)
+            for a, b in zip(new, self._cache):
                 a[:n] = b
         self._cache = new
+        self._cache_out = None
 
     def _cache_clear(self):
         self._counters[_lib.C_CACHE_T] = 0
+        self._counters[_lib.C_CACHE_KEPT] = 0
+        self._counters[_lib.C_CACHE_DEAD] = 0
+        self._tri_n.zero_()
         self._cache_any = False
 
+    def _cache_struct(self):
+        b = _lib.DifExtractBuffers()
+        b.cache_capacity = self._cache[0].size(0)
+        b.cache_tri, b.cache_id, b.cache_std, b.cache_alive = (_lib.ptr(t) for t in self._cache)
+        return b
+
+    def _cache_compact(self):
+        """Live log entries, in log order, into `_cache_out` (device).  Returns the number of live triangles."""
+        cap = self._cache[0].size(0)
+        if self._cache_out is None:
+            self._cache_out = self._new_cache_set(cap)
+        with torch.cuda.device(self.device):
+            scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
+            b = self._cache_struct()
+            o = self._cache_out
+            _lib.check(_lib.load().dif_mesh_cache_compact(ctypes.byref(self._cmap), ctypes.byref(b), _lib.ptr(o[0]), _lib.ptr(o[1]), _lib.ptr(o[2]), cap,
+                                                          _lib.ptr(scratch), _lib.stream_ptr()), "dif_mesh_cache_compact")
+        return self._read_counters()["cache_live"]
+
+    def _cache_gc(self):
+        """Drop the dead entries: the compacted copy becomes the log (same content and order as before for the live part)."""
+        n = self._cache_compact()
+        self._cache, self._cache_out = self._cache_out, self._cache
+        with torch.cuda.device(self.device):
+            b = self._cache_struct()
+            _lib.check(_lib.load().dif_mesh_cache_reindex(ctypes.byref(self._cmap), ctypes.byref(b), n, _lib.stream_ptr()), "dif_mesh_cache_reindex")
+        self._gc_epoch += 1
+        self._gc_log_len = n
+        self._gc_wanted = False
+        self._read_counters()
+
     def mesh_cache_tensors(self, new_only: bool = False):
-        """Device views of the mesh cache: (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64, vertices_std (T,3));
-        `new_only` restricts to the triangles produced by the last extract.  None before the first extract."""
+        """Device views of the mesh cache: (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64, vertices_std (T,3)) — the
+        reference's `mesh_cache` arrays, same order; `new_only` restricts to the triangles produced by the last extract.
+        None before the first extract."""
         if not self._cache_any:
             return None
-        c = self.last_counters
-        lo, hi = (c["cache_kept"] if new_only else 0), c["cache_T"]
-        tri, tid, tstd = self._cache[self._cache_cur]
-        return tri[lo:hi], tid[lo:hi], tstd[lo:hi]
+        if new_only:
+            c = self.last_counters
+            lo, hi = c["cache_kept"], c["cache_T"]
+            tri, tid, tstd, _ = self._cache
+            return tri[lo:hi], tid[lo:hi], tstd[lo:hi]
+        n = self._cache_compact()
+        o = self._cache_out
+        return o[0][:n], o[1][:n], o[2][:n]
 
     def _extract_buffers(self, resolution: int, max_n_triangles: int, max_vox: int = None):
         R = 2 * resolution
@@ -407,16 +461,14 @@ class DenseIndexedMap:
                      block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev))
             self._xbuf = (key, t)
         t = self._xbuf[1]
-        self._ensure_cache(max(int(max_n_triangles), 1 << 16))
-        b = _lib.DifExtractBuffers()
+        # the log must always have room for two calls' worth of output beyond what the host last saw (counters lag one frame
+        # in the pipelined driver); it is garbage-collected in extract_mesh_finish before it gets there
+        self._ensure_cache(max(3 * int(max_n_triangles), 1 << 16))
+        b = self._cache_struct()
         b.max_voxels = max_vox
         b.max_triangles = int(max_n_triangles)
         for k, v in t.items():
             setattr(b, k, _lib.ptr(v))
-        src, dst = self._cache[self._cache_cur], self._cache[1 - self._cache_cur]
-        b.cache_capacity = src[0].size(0)
-        b.cache_src_tri, b.cache_src_id, b.cache_src_std = _lib.ptr(src[0]), _lib.ptr(src[1]), _lib.ptr(src[2])
-        b.cache_dst_tri, b.cache_dst_id, b.cache_dst_std = _lib.ptr(dst[0]), _lib.ptr(dst[1]), _lib.ptr(dst[2])
         return t, b
 
     def extract_mesh_enqueue(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,
@@ -425,12 +477,13 @@ class DenseIndexedMap:
         cubes, mesh-cache merge, then an async copy of the device counters into pinned host memory.  Returns a handle for
         `extract_mesh_finish`.  Lets a streaming caller keep the GPU queue full (the next frame is enqueued while this one runs)."""
         lib = _lib.load()
+        if self._gc_wanted and self._cache is not None:
+            self._cache_gc()                                      # safe point: at most one (the latest) extract is still pending
         with self.modifying_lock, torch.cuda.device(self.device):
             tens, buf = self._extract_buffers(voxel_resolution, max_n_triangles)
             w = self.model.packed.weights_struct(self.device)
             _lib.check(lib.dif_extract(ctypes.byref(self._cmap), ctypes.byref(w), ctypes.byref(buf), int(voxel_resolution), 1 if fast else 0,
                                        float(max_std), 1 if no_cache else 0, 1, _lib.stream_ptr()), "dif_extract")
-            self._cache_cur = 1 - self._cache_cur
             self.mesh_cache.invalidate_host_copy()
             if self._pinned_counters is None:
                 self._pinned_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(4)]
@@ -439,7 +492,7 @@ class DenseIndexedMap:
             pc.copy_(self._counters, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            return dict(event=ev, counters=pc, cache_index=self._cache_cur, add_total=self._add_total, max_n_triangles=max_n_triangles)
+            return dict(event=ev, counters=pc, epoch=self._gc_epoch, add_total=self._add_total, max_n_triangles=max_n_triangles)
 
     def extract_mesh_finish(self, handle):
         """Wait for an enqueued extract and publish its counters (`last_counters`).  Returns the device views of the triangles that
@@ -450,8 +503,16 @@ class DenseIndexedMap:
             logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {handle['max_n_triangles']}")
         if c["K"] > 0:
             self._cache_any = True
-        tri, tid, tstd = self._cache[handle["cache_index"]]
+        cap = self._cache[0].size(0)
+        if c["cache_dead"] > max(1 << 20, c["cache_T"] // 2) or c["cache_T"] + 2 * handle["max_n_triangles"] > cap:
+            self._gc_wanted = True                                # performed at the next enqueue (a safe point)
+        tri, tid, tstd, _ = self._cache
         lo, hi = c["cache_kept"], c["cache_T"]
+        if handle.get("epoch", self._gc_epoch) != self._gc_epoch:
+            # the log was compacted after this extract was enqueued: its triangles (all alive, the newest) are now the log's tail
+            n_new = hi - lo
+            lo, hi = self._gc_log_len - n_new, self._gc_log_len
+            c["cache_kept"], c["cache_T"] = lo, hi
         return tri[lo:hi], tid[lo:hi], tstd[lo:hi]
 
     def extract_mesh_arrays(self, voxel_resolution: int, max_n_triangles: int, fast: bool = True, max_std: float = 2000.0,

@@ -46,11 +46,13 @@ enum {
     DIF_C_T = 9,            /* triangles produced (may exceed max_n_triangles, mc_interp_kernel.cu:369)   */
     DIF_C_QUERY_M = 10,     /* valid points of the last get_sdf query (map.py:569-572)                    */
     DIF_C_N_KEPT = 11,      /* points surviving the >prune_min_vox_obs filter (map.py:375)                */
-    DIF_C_CACHE_T = 12,     /* triangles in the device-resident mesh cache (map.py:116-133, 703-714)      */
-    DIF_C_CACHE_KEPT = 13,  /* cached triangles kept by the last extract = offset of the new ones         */
+    DIF_C_CACHE_T = 12,     /* entries in the device-resident mesh-cache LOG (live + dead; map.py:116-133, 703-714) */
+    DIF_C_CACHE_KEPT = 13,  /* log length before the last extract = offset of that extract's new triangles */
     DIF_C_EXPORT_N = 14,    /* records written by the last dif_export_records                             */
-    DIF_C_WORK = 15,        /* dynamic work-queue head of the fused per-voxel decode                      */
-    DIF_C_COUNT = 16
+    DIF_C_WORK = 15,        /* scratch                                                                    */
+    DIF_C_CACHE_DEAD = 16,  /* dead entries in the mesh-cache log (replaced triangles awaiting compaction)  */
+    DIF_C_CACHE_LIVE = 17,  /* triangles written by the last dif_mesh_cache_compact                        */
+    DIF_C_COUNT = 32
 };
 
 /* The map: geometry + persistent state (map.py:177-211) + per-map scratch that is all-zero / all -1 between calls. */
@@ -75,6 +77,8 @@ typedef struct dif_map {
     int32_t* seg_start;             /* [capacity] idle 0  : row cursor of the slot while rows are placed             */
     int32_t* seg_cnt;               /* [capacity] idle 0  : rows gathered for the slot (pcounts, map.py:439)   */
     int32_t* item_start;            /* [capacity] first encoder work item of the slot                          */
+    int32_t* tri_start;             /* [capacity] mesh-cache log position of the slot's live triangle batch     */
+    int32_t* tri_n;                 /* [capacity] idle 0 when the voxel has no cached triangles                 */
     /* Spatial tiling (SURVEY.md section 8e "C5"): this map OWNS the voxels with x index in [own_x_lo, own_x_hi); points whose own
      * voxel lies outside [own_x_lo - halo, own_x_hi + halo) are ignored by integrate, and only owned voxels are meshed.
      * 0, nx, 0 = the whole grid (single-map behaviour). */
@@ -151,18 +155,17 @@ typedef struct dif_extract_buffers {
     int32_t* tri_offset;            /* [max_voxels] exclusive prefix of tri_count                         */
     int32_t* block_tmp;             /* [4096] scan scratch                                                */
     int64_t max_triangles;          /* map.py:581 max_n_triangles (per call)                              */
-    /* Device-resident mesh cache (the reference keeps it in host numpy arrays, map.py:703-714): two ping-pong sets of
-     * (vertices, voxel id, std); `cache_src` holds DIF_C_CACHE_T triangles on entry.  Each extract writes into `cache_dst`
-     * first the cached triangles whose voxel produced no new triangle (same order), then the new triangles in canonical
-     * order -- exactly the arrays `mesh_cache.vertices / vertices_flatten_id / vertices_std` of the reference.
-     * The new triangles of this call are cache_dst[DIF_C_CACHE_KEPT : DIF_C_CACHE_T]. */
-    int64_t cache_capacity;         /* triangles per cache buffer                                         */
-    const float* cache_src_tri;     /* [cache_capacity][3][3]                                             */
-    const int64_t* cache_src_id;    /* [cache_capacity]                                                   */
-    const float* cache_src_std;     /* [cache_capacity][3]                                                */
-    float* cache_dst_tri;
-    int64_t* cache_dst_id;
-    float* cache_dst_std;
+    /* Device-resident mesh cache (the reference keeps it in host numpy arrays and rebuilds them on every extract, map.py:703-714).
+     * Here it is an append-only LOG: an extract appends its new triangles (canonical order) and kills the previous batch of
+     * every voxel that produced >= 1 new triangle (`map->tri_start/tri_n` locate it) -- O(new + replaced) per extract instead
+     * of O(whole mesh).  The live entries, in log order, ARE the reference's `mesh_cache.vertices / vertices_flatten_id /
+     * vertices_std` arrays (kept old triangles in their order, then the new ones): `dif_mesh_cache_compact` materialises them.
+     * The new triangles of a call are log[DIF_C_CACHE_KEPT : DIF_C_CACHE_T]. */
+    int64_t cache_capacity;         /* log capacity in triangles                                          */
+    float* cache_tri;               /* [cache_capacity][3][3]                                             */
+    int64_t* cache_id;              /* [cache_capacity]                                                   */
+    float* cache_std;               /* [cache_capacity][3]                                                */
+    uint8_t* cache_alive;           /* [cache_capacity]                                                   */
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
@@ -171,6 +174,14 @@ typedef struct dif_extract_buffers {
  * (map.py:698) instead of voxel units.  Triangles come out in canonical order (dirty voxel, cell, table order). */
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution,
                 int32_t fast, float max_std, int32_t no_cache, int32_t scale_vertices, void* stream);
+
+/* Materialise the live cache entries in log order into (out_tri, out_id, out_std); count -> counters[DIF_C_CACHE_LIVE].
+ * scratch: int32 [4096]. */
+int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,
+                           int64_t out_capacity, int32_t* scratch, void* stream);
+/* After the caller has swapped a compacted copy in as the new log (n = its length): rebuild tri_start / tri_n, mark everything
+ * alive, set CACHE_T = CACHE_KEPT = n, CACHE_DEAD = 0. */
+int dif_mesh_cache_reindex(const dif_map_t* map, const dif_extract_buffers_t* buf, int64_t n, void* stream);
 
 /* Flat marching cubes = ext/marching_cubes mc.cpp:3-16.  indexer (nx,ny,nz) i64, valid_blocks (K) i64,
  * vec_batch_mapping (V) i32, cube_sdf/std (B,R,R,R) f32.  counters[DIF_C_T] receives the triangle count.      */

@@ -366,3 +366,33 @@ def test_sdf_gauss_newton_pose_refinement(gpu_model):
     print(f"  GN on map.get_sdf: residual {e0:.4f} -> {e1:.4f}; pose error {err0[0]*100:.2f} cm / {err0[1]:.2f} deg -> {err1[0]*100:.2f} cm / {err1[1]:.2f} deg")
     assert e1 < 0.5 * e0
     assert err1[0] < 0.5 * err0[0] and err1[1] < 0.5 * err0[1]
+
+
+def test_mesh_cache_log_garbage_collection(gpu_model):
+    """The cache is an append-only log; compaction (on host access) and garbage collection must not change its content/order."""
+    scene, cfg, intr = CASES["seq_small"]
+    g = np.load(GOLDEN / "seq_small.npz")
+    m = make_map(gpu_model, cfg)
+    for f in range(3):
+        xyz, nrm = frame_inputs(g, "seq_small", f)
+        m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+        v, vid, vs = m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+    assert m.last_counters["cache_dead"] > 0                      # frames 1, 2 replaced earlier batches
+    before = (v.copy(), vid.copy(), vs.copy())
+    m._cache_gc()
+    assert m.last_counters["cache_dead"] == 0 and m.last_counters["cache_T"] == before[0].shape[0]
+    mc = m.mesh_cache
+    mc.invalidate_host_copy()
+    assert np.array_equal(mc.vertices, before[0]) and np.array_equal(mc.vertices_flatten_id, before[1]) and np.array_equal(mc.vertices_std, before[2])
+    # a further frame after the GC still replaces the right batches: compare with a map that never collected
+    m2 = make_map(gpu_model, cfg)
+    for f in range(3):
+        xyz, nrm = frame_inputs(g, "seq_small", f)
+        m2.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+        m2.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+    xyz, nrm = frame_inputs(g, "seq_small", 0)
+    for mm in (m, m2):
+        mm.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+    a = m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+    b = m2.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
