@@ -53,6 +53,8 @@ struct ProfScope {
     hipStream_t s; int which; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(int which_, hipStream_t s_) : s(s_), which(which_) {
         if (!g_prof_on || g_prof.size() >= 65536) return;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;      // never put events into a captured graph
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         (void)hipEventRecord(a, s);
     }
