@@ -147,10 +147,11 @@ def main():
         except Exception:
             pass
         if dom:
-            roof = {"bound": "mfma", "kernel": {"encode": "k_encode", "decode_lattice": "k_decode", "decode_points": "k_decode"}[dom],
+            kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode<false>"}[dom]
+            roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": pmc.get({"encode": "k_encode"}.get(dom, "k_decode"), {}).get("hbm_bytes_per_launch"),
+                    "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
                     "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
                     "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
                     "event_timed_frames": len(sst),
