@@ -10,7 +10,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libdifusion.so"
 SOURCES = [CSRC / "difusion.hip"]
-HEADERS = [CSRC / "common.hip.h", CSRC / "mlp.hip.h", CSRC / "mc_tables.inc", PKG.parent / "include" / "difusion.h"]
+HEADERS = sorted(CSRC.glob("*.hip.h")) + [CSRC / "mc_tables.inc", PKG.parent / "include" / "difusion.h"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-result", "-DNDEBUG"]

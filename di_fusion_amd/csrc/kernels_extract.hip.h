@@ -1,0 +1,396 @@
+// extract_mesh front half: a11 dirty/occupied sets, a12-a14 decoder over sample lattices (MFMA), upsample + refine  (part of libdifusion; included by difusion.hip inside its anonymous namespace)
+#pragma once
+
+// =================================================================================================================
+// a11 : extract — dirty list, confident neighbourhood, batch ids  (map.py:627-637)
+// =================================================================================================================
+// set the bitmap bits of the confident voxels among `lin` and its 6 allocated neighbours (map.py:628-631)
+__device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float ignore_th, const int64_t* __restrict__ indexer,
+                                                    const float* __restrict__ obs, uint32_t* __restrict__ bits) {
+    int ix, iy, iz;
+    unlinearize(g, lin, ix, iy, iz);
+    int cand[7];
+    cand[0] = lin;
+    cand[1] = linearize(g, clampi(ix - 1, 0, g.nx - 1), iy, iz);
+    cand[2] = linearize(g, clampi(ix + 1, 0, g.nx - 1), iy, iz);
+    cand[3] = linearize(g, ix, clampi(iy - 1, 0, g.ny - 1), iz);
+    cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
+    cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
+    cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        int v = cand[c];
+        int64_t slot = indexer[v];
+        if (slot < 0 || !(obs[slot] > ignore_th)) continue;
+        uint32_t b = 1u << (v & 31);
+        if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
+    }
+}
+
+// Spatial tiling: dirty HALO voxels (flag copied from their owner by the halo refresh) are not meshed here, but they pull their
+// confident neighbourhood into the decoded batch exactly as they do in the single-map run (the blend of a corner depends on
+// which neighbours are in the batch, mc_interp_kernel.cu:17-24).
+__global__ void __launch_bounds__(DIF_BLOCK) k_mark_halo_dirty(Geo g, float ignore_th, uint8_t* __restrict__ dirty, const int64_t* __restrict__ pos,
+                                                             const int64_t* __restrict__ indexer, const float* __restrict__ obs,
+                                                             uint32_t* __restrict__ bits, const int* __restrict__ counters, int64_t own_lo,
+                                                             int64_t own_hi) {
+    const int n = counters[DIF_C_N_OCCUPIED];
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        if (!dirty[s]) continue;
+        const int64_t p = pos[s];
+        if (p >= own_lo && p < own_hi) continue;
+        dirty[s] = 0;
+        mark_confident_nbhd(g, (int)p, ignore_th, indexer, obs, bits);
+    }
+}
+
+struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> valid_blocks (lin ids), clears flags;
+    uint8_t* dirty;         // each dirty voxel also marks the confident voxels among itself and its 6 allocated neighbours
+    const int64_t* pos;     // in the grid bitmap (map.py:628-631)
+    int64_t* valid_blocks;
+    int* counters;
+    int no_cache;
+    int64_t max_voxels;
+    Geo g;
+    float ignore_th;
+    const int64_t* indexer;
+    const float* obs;
+    uint32_t* bits;
+    int64_t own_lin_lo, own_lin_hi;     // only owned voxels are meshed (spatial tiling); the whole grid by default
+    __device__ int count(int s) const {
+        if (!(no_cache || dirty[s])) return 0;
+        const int64_t p = pos[s];
+        return (p >= own_lin_lo && p < own_lin_hi) ? 1 : 0;      // halo voxels are meshed by their owner
+    }
+    __device__ void emit(int s, int offset) const {
+        dirty[s] = 0;
+        if (offset >= max_voxels) return;
+        const int lin = (int)pos[s];
+        valid_blocks[offset] = lin;
+        mark_confident_nbhd(g, lin, ignore_th, indexer, obs, bits);
+    }
+    __device__ void finish(int total) const {
+        if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 2; }
+        counters[DIF_C_K] = total;
+    }
+};
+
+struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm[slot] = b; clears the bitmap
+    uint32_t* bits;
+    const int64_t* indexer;
+    int32_t* occ_slot;
+    int32_t* vbm;
+    int* counters;
+    int64_t max_voxels;
+    __device__ int count(int w) const { return __popc(bits[w]); }
+    __device__ void emit(int w, int offset) const {
+        uint32_t word = bits[w];
+        bits[w] = 0u;
+        while (word) {
+            int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            int slot = (int)indexer[w * 32 + b];
+            if (offset < max_voxels) {
+                occ_slot[offset] = slot;
+                vbm[slot] = offset;
+            }
+            ++offset;
+        }
+    }
+    __device__ void finish(int total) const {
+        if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 3; }
+        counters[DIF_C_B] = total;
+        counters[DIF_C_VH] = 0;
+        counters[DIF_C_WORK] = 0;
+    }
+};
+
+// =================================================================================================================
+// a12..a14 : decoder over the per-voxel sample lattice, fast two-level refinement  (map.py:640-687)
+// =================================================================================================================
+struct Lattice {            // get_samples(res, a, b) - 0.5 (utility.py:129-149, map.py:645-646): fl(fl(i)*vsize) + a, then - 0.5
+    int res;
+    float vsize, a;
+    __device__ __forceinline__ float coord(int i) const { return ((float)i * vsize + a) - 0.5f; }
+};
+
+// decode mode: 0 = lattice (rows are (voxel b, sample s)), 1 = refine list, 2 = explicit rows, 3 = map point query
+struct DecodeArgs {
+    int mode;
+    const int* n_ptr;               // device row / voxel count (modes 0,1,3), or NULL
+    int64_t n_static;               // mode 2
+    Lattice lat;                    // modes 0,1
+    const int32_t* occ_slot;        // modes 0,1 : batch -> slot
+    const float* latent;            // modes 0,1,3
+    const int32_t* list;            // mode 1: b*R3+sb ; mode 3: point index
+    const float* rows;              // mode 2: (n,32)
+    const float* xyz;               // mode 3
+    const int64_t* indexer;         // mode 3
+    Geo geo;                        // mode 3
+    float* out_sdf;
+    float* out_std;
+    float sign;                     // -1 to store the negated sdf (map.py:687)
+    float* out_grad;                // GRAD kernels: (n,3) d sdf / d xyz (world units), mode 3 (or d sdf / d x0[29..31] for mode 2)
+    const float* wbwd;              // GRAD kernels: transposed-layer blob
+    float grad_scale;               // 1 / voxel_size (mode 3), 1 (mode 2)
+};
+
+// GRAD: 256 threads = one wave per SIMD with the full 512-register budget (forward + reverse chain keep ~300 values live)
+template <bool GRAD>
+__global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(DecodeArgs A, const float* __restrict__ wblob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, DEC_LDS_FLOATS);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
+    const __amdgpu_buffer_rsrc_t wbwd = make_rsrc(GRAD ? A.wbwd : wblob, GRAD ? DECB_FLOATS : DEC_FLOATS);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int res3 = A.lat.res * A.lat.res * A.lat.res;
+    const int tiles_per_voxel = (res3 + 31) / 32;
+    int64_t n_rows, n_tiles;
+    if (A.mode == 0) {
+        n_rows = (int64_t)(*A.n_ptr) * res3;
+        n_tiles = (int64_t)(*A.n_ptr) * tiles_per_voxel;
+    } else {
+        n_rows = A.n_ptr ? (int64_t)(*A.n_ptr) : A.n_static;
+        n_tiles = (n_rows + 31) / 32;
+    }
+    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+        bool live;
+        int64_t out_idx = 0;
+        const float* lat_row = nullptr;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        const float* row32 = nullptr;
+        if (A.mode == 0) {
+            int64_t b = tile / tiles_per_voxel;
+            int s = (int)(tile - b * tiles_per_voxel) * 32 + col;
+            live = s < res3;
+            if (live) {
+                int r = A.lat.res;
+                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
+                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+                out_idx = b * res3 + s;
+            }
+        } else if (A.mode == 1) {
+            int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) {
+                int e = A.list[row];
+                int b = e / res3, s = e - b * res3, r = A.lat.res;
+                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
+                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+                out_idx = e;
+            }
+        } else if (A.mode == 2) {
+            int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) { row32 = A.rows + row * 32; out_idx = row; }
+        } else {
+            int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) {
+                int64_t p = A.list[row];
+                float xn, yn, zn; int ix, iy, iz;
+                voxel_of(A.geo, A.xyz[p * 3 + 0], A.xyz[p * 3 + 1], A.xyz[p * 3 + 2], xn, yn, zn, ix, iy, iz);
+                px = (xn - (float)ix) - 0.5f; py = (yn - (float)iy) - 0.5f; pz = (zn - (float)iz) - 0.5f;      // map.py:575
+                lat_row = A.latent + A.indexer[linearize(A.geo, ix, iy, iz)] * L;
+                out_idx = row;
+            }
+        }
+        f16v xin;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int k = 2 * t + half;                     // natural k order of layer 0 (and of the skip input)
+            float v = 0.0f;
+            if (live) {
+                if (row32) v = row32[k];
+                else if (k < L) v = lat_row[k];
+                else v = (k == L) ? px : ((k == L + 1) ? py : pz);
+            }
+            xin[t] = v;
+        }
+        float sdf, sd;
+        if (GRAD) {
+            float gx, gy, gz;
+            decoder_tile_grad(lds, wfwd, wbwd, xin, lane, sdf, sd, gx, gy, gz);
+            if (live && half == 1) {
+                A.out_grad[out_idx * 3 + 0] = gx * A.grad_scale;      // d rel / d xyz = 1 / voxel_size (map.py:565,575)
+                A.out_grad[out_idx * 3 + 1] = gy * A.grad_scale;
+                A.out_grad[out_idx * 3 + 2] = gz * A.grad_scale;
+            }
+        } else {
+            decoder_tile(lds, wfwd, xin, lane, sdf, sd);
+        }
+        if (live) {
+            if (half == 0) A.out_sdf[out_idx] = A.sign * sdf;
+            else A.out_std[out_idx] = sd;
+        }
+    }
+}
+
+// Trilinear x2 upsample (align_corners) of the low lattice + selection of samples to re-decode (map.py:655-667).
+// ATen CPU semantics (see oracle.trilinear_upsample_align_corners): per axis src = scale*j, i0 = int(src),
+// lam1 = src - i0, lam0 = 1 - lam1, two-tap value = fma(t0, lam0, t1*lam1), w innermost then h then d.
+__device__ __forceinline__ void tri_axis(int j, int l, float scale, int& i0, int& i1, float& w0, float& w1) {
+    float src = scale * (float)j;
+    i0 = min((int)src, l - 1);
+    i1 = i0 + ((i0 < l - 1) ? 1 : 0);
+    w1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
+    w0 = 1.0f - w1;
+}
+
+__device__ __forceinline__ float tri_sample(const float* __restrict__ low, int l, int x0, int x1, int y0, int y1, int z0, int z1,
+                                            float wx0, float wx1, float wy0, float wy1, float wz0, float wz1) {
+    // layout [x][y][z], z innermost ("w"), x outermost ("d")
+    float v00 = fmaf(low[(x0 * l + y0) * l + z0], wz0, low[(x0 * l + y0) * l + z1] * wz1);
+    float v01 = fmaf(low[(x0 * l + y1) * l + z0], wz0, low[(x0 * l + y1) * l + z1] * wz1);
+    float v10 = fmaf(low[(x1 * l + y0) * l + z0], wz0, low[(x1 * l + y0) * l + z1] * wz1);
+    float v11 = fmaf(low[(x1 * l + y1) * l + z0], wz0, low[(x1 * l + y1) * l + z1] * wz1);
+    float v0 = fmaf(v00, wy0, v01 * wy1);
+    float v1 = fmaf(v10, wy0, v11 * wy1);
+    return fmaf(v0, wx0, v1 * wx1);
+}
+
+// One thread per (voxel, x, y) row of R samples along z; selected samples are appended to the refine list with ONE atomic per
+// workgroup (a per-wave atomic on a single counter costs ~12 ns each and serialises: 15k waves = 200 us).
+__global__ void __launch_bounds__(DIF_BLOCK) k_upsample_mark(const float* __restrict__ low_sdf, const float* __restrict__ low_std, int l, int R,
+                                                           float* __restrict__ cube_sdf, float* __restrict__ cube_std,
+                                                           int32_t* __restrict__ refine_list, int* __restrict__ counters) {
+    __shared__ int smem[8];
+    __shared__ int s_base;
+    const int B = counters[DIF_C_B];
+    const int R2 = R * R, R3 = R2 * R, l3 = l * l * l;
+    const int64_t n_rows = (int64_t)B * R2;
+    const float scale = (float)(l - 1) / (float)(R - 1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_pad = (n_rows + DIF_BLOCK - 1) / DIF_BLOCK * DIF_BLOCK;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_pad; row += stride) {
+        unsigned sel = 0;
+        int64_t e0 = 0;
+        if (row < n_rows) {
+            const int b = (int)(row / R2), jxy = (int)(row - (int64_t)b * R2);
+            const int jx = jxy / R, jy = jxy % R;
+            int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
+            tri_axis(jx, l, scale, x0, x1, wx0, wx1);
+            tri_axis(jy, l, scale, y0, y1, wy0, wy1);
+            const float* ls = low_sdf + (int64_t)b * l3;
+            const float* ld = low_std + (int64_t)b * l3;
+            e0 = (int64_t)b * R3 + (int64_t)jxy * R;
+            for (int jz = 0; jz < R; ++jz) {
+                int z0, z1; float wz0, wz1;
+                tri_axis(jz, l, scale, z0, z1, wz0, wz1);
+                float sv = tri_sample(ls, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                float dv = tri_sample(ld, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                cube_sdf[e0 + jz] = -sv;
+                cube_std[e0 + jz] = dv;
+                if (fabsf(sv) < 0.05f) sel |= 1u << jz;               // map.py:667
+            }
+        }
+        int total;
+        int ex = block_excl_scan(__popc(sel), smem, total);
+        if (total > 0) {
+            if (threadIdx.x == 0) s_base = atomicAdd(counters + DIF_C_VH, total);
+            __syncthreads();
+            int o = s_base + ex;
+            while (sel) {
+                int jz = __ffs((int)sel) - 1;
+                sel &= sel - 1;
+                refine_list[o++] = (int32_t)(e0 + jz);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Fused low-lattice decode + upsample for the fast two-level scheme (resolution <= 4, i.e. R^2 <= 64 rows = one per lane):
+// one wave owns one voxel — the l^3 low samples go through the MLP and stay in LDS, the ATen-exact trilinear x2 upsample reads
+// them from there, the cube is written once, and the |sdf| < 0.05 samples are appended to the global refine list with ONE
+// atomic per voxel (wave prefix sum of popcounts).  Work per voxel is uniform (ceil(l^3/32) tiles), so the launch is balanced;
+// the exact re-decode of the selected samples stays a separate, globally balanced launch (per-voxel counts range 0..R^3).
+struct VoxelDecodeArgs {
+    const int32_t* occ_slot;
+    const float* latent;
+    Lattice low;
+    int R;
+    float* cube_sdf;
+    float* cube_std;
+    int32_t* refine_list;
+    int* counters;
+};
+
+#define VD_MAX_L3 64
+#define VD_MAX_R2 64
+#define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3)      /* low sdf + low std */
+
+__global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, DEC_LDS_FLOATS);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
+    float* w_low_sdf = lds + ((DEC_LDS_FLOATS + 3) & ~3) + wid * VD_WAVE_LDS_FLOATS;
+    float* w_low_std = w_low_sdf + VD_MAX_L3;
+    const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
+    const float scale = (float)(l - 1) / (float)(R - 1);
+    const int B = A.counters[DIF_C_B];
+    const int wave = (int)(wid * gridDim.x + blockIdx.x), nwaves = (int)(gridDim.x * (blockDim.x >> 6));   // spread over CUs first
+    for (int b = wave; b < B; b += nwaves) {
+        const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+        f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int k = 2 * t + half;
+            xlat[t] = (k < L) ? lat_row[k] : 0.0f;
+        }
+        // ---- low lattice -> LDS (map.py:644-653) ----
+        for (int t0 = 0; t0 < l3; t0 += 32) {
+            const int s = t0 + col;
+            const bool live = s < l3;
+            const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
+            f16v xin = xlat;
+            if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }        // k = 29 (x), 30 (y), 31 (z)
+            float sdf, sd;
+            decoder_tile(lds, wfwd, xin, lane, sdf, sd);
+            if (live) {
+                if (half == 0) w_low_sdf[s] = sdf;
+                else w_low_std[s] = sd;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z ----
+        const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
+        unsigned sel = 0;
+        if (lane < R2) {
+            const int jx = lane / R, jy = lane % R;
+            int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
+            tri_axis(jx, l, scale, x0, x1, wx0, wx1);
+            tri_axis(jy, l, scale, y0, y1, wy0, wy1);
+            for (int jz = 0; jz < R; ++jz) {
+                int z0, z1; float wz0, wz1;
+                tri_axis(jz, l, scale, z0, z1, wz0, wz1);
+                float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                A.cube_sdf[e0 + jz] = -sv;
+                A.cube_std[e0 + jz] = dv;
+                if (fabsf(sv) < 0.05f) sel |= 1u << jz;
+            }
+        }
+        const int c = __popc(sel);
+        const int incl = wave_incl_scan(c);
+        const int total = __shfl(incl, 63);
+        if (total > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(A.counters + DIF_C_VH, total);
+            base = __shfl(base, 0);
+            int o = base + incl - c;
+            while (sel) {
+                const int jz = __ffs((int)sel) - 1;
+                sel &= sel - 1;
+                A.refine_list[o++] = (int32_t)(e0 + jz);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+

@@ -1,0 +1,313 @@
+// integrate_keyframe kernels: a3-a10 voxel ids, prune, allocate, gather, encoder (MFMA), fusion  (part of libdifusion; included by difusion.hip inside its anonymous namespace)
+#pragma once
+
+// =================================================================================================================
+// a3..a6 : voxel ids, prune, allocate   (map.py:366-387)
+// =================================================================================================================
+// K1: per-point voxel id + per-voxel point count of this frame.  Adjacent pixels mostly fall in the same voxel, so
+// equal-id runs inside a wave are aggregated with a ballot before touching memory (1 atomic per run, not per point).
+__global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* __restrict__ xyz, int64_t N, int* __restrict__ pt_lin,
+                                                         int* __restrict__ frame_count, int* __restrict__ counters, int px_lo, int px_hi) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // grid covers N rounded up to a wave
+    int lane = lane_id();
+    if (i < 4) counters[DIF_C_ALLOC_NEW + i] = 0;                   // ALLOC_NEW, M, C, ITEMS of this call
+    int lin = -2;                                                    // -2: beyond N, -1: invalid point
+    if (i < N) {
+        float xn, yn, zn; int ix, iy, iz;
+        bool ok = voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        ok = ok && ix >= px_lo && ix < px_hi;                         // spatial tiling: own slab + halo only
+        lin = ok ? linearize(g, ix, iy, iz) : -1;
+        pt_lin[i] = lin;
+    }
+    int prev = __shfl_up(lin, 1);
+    bool head = (lane == 0) || (prev != lin);
+    unsigned long long heads = __ballot(head);
+    if (head && lin >= 0) {
+        unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        int run = above ? __ffsll((long long)above) : (64 - lane);
+        atomicAdd(frame_count + lin, run);
+    }
+}
+
+// K2: prune mask + candidate voxels.  mask[i] = count(voxel of i) > prune_min_vox_obs (map.py:375).  A kept point whose
+// voxel has no slot marks that voxel and its 6 clamped neighbours (if empty) in the bitmap (map.py:383-386).
+__global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, const int* __restrict__ pt_lin, int64_t N,
+                                                        const int* __restrict__ frame_count, const int64_t* __restrict__ indexer,
+                                                        uint8_t* __restrict__ unq_mask, uint32_t* __restrict__ bits,
+                                                        int* __restrict__ counters) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = lane_id();
+    int lin = (i < N) ? pt_lin[i] : -2;
+    bool keep = false;
+    if (lin >= 0) keep = (prune_min > 0) ? (frame_count[lin] > prune_min) : true;
+    if (i < N) unq_mask[i] = keep ? 1 : 0;
+    int prev = __shfl_up(lin, 1);
+    bool head = (lane == 0) || (prev != lin);
+    if (head && keep && indexer[lin] == -1) {
+        int ix, iy, iz;
+        unlinearize(g, lin, ix, iy, iz);
+        int cand[7];
+        cand[0] = lin;
+        cand[1] = linearize(g, clampi(ix - 1, 0, g.nx - 1), iy, iz);
+        cand[2] = linearize(g, clampi(ix + 1, 0, g.nx - 1), iy, iz);
+        cand[3] = linearize(g, ix, clampi(iy - 1, 0, g.ny - 1), iz);
+        cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
+        cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
+        cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            int v = cand[c];
+            if (indexer[v] != -1) continue;
+            uint32_t b = 1u << (v & 31);
+            if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
+        }
+    }
+}
+
+// K3: ordered compaction of the candidate bitmap -> slots n_occupied, n_occupied+1, ... in ASCENDING lin order
+// (torch.unique order, map.py:385-387, 310-319).  Clears the bitmap as it goes.
+struct AllocFunctor {
+    uint32_t* bits;
+    int64_t* indexer;
+    int64_t* pos;
+    int* counters;
+    int64_t capacity;
+    __device__ int count(int w) const { return __popc(bits[w]); }
+    __device__ void emit(int w, int offset) const {
+        uint32_t word = bits[w];
+        bits[w] = 0u;
+        int base = counters[DIF_C_N_OCCUPIED] + offset;
+        while (word) {
+            int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            int lin = w * 32 + b;
+            if (base < capacity) {
+                indexer[lin] = base;
+                pos[base] = lin;
+            }
+            ++base;
+        }
+    }
+    __device__ void finish(int total) const { counters[DIF_C_ALLOC_NEW] = total; }
+};
+
+// K4: (i) commit n_occupied += newly allocated (all pass-2 blocks of K3 have read the old value by now),
+// (ii) restore frame_count to zero, (iii) focus mask + 8-offset gather keys (map.py:389-433).
+// Key of pair (offset o, point i), stored at o*N + i (the reference's concatenation order): slot of the neighbour voxel
+// if that voxel is in the encode set {obs_count < encoder_count_th}, else DIF_INVALID_KEY.  Rows per slot are counted here
+// (seg_cnt = the reference's `pcounts`, map.py:437-439) with one atomic per distinct slot per wave.
+__device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
+
+// Wave-aggregated "fetch-add 1" on counter[key] for every lane whose key is valid; returns the lane's unique offset
+// (base + rank among the lanes of the wave that share the key).  One atomic per distinct key per wave.
+__device__ __forceinline__ int wave_grouped_fetch_add(int* __restrict__ counter, uint32_t key, bool valid) {
+    const int lane = lane_id();
+    int result = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+        const unsigned long long same = __ballot(valid && key == k0);
+        if (valid && key == k0) {
+            int base = 0;
+            if (lane == leader) base = atomicAdd(counter + k0, __popcll(same));
+            base = __shfl(base, leader);
+            result = base + __popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    return result;
+}
+
+// Same grouping, fire-and-forget: nobody waits for the atomic's return value.
+__device__ __forceinline__ void wave_grouped_add(int* __restrict__ counter, uint32_t key, bool valid) {
+    const int lane = lane_id();
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+        const unsigned long long same = __ballot(valid && key == k0);
+        if (lane == leader) atomicAdd(counter + k0, __popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
+                                                          const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
+                                                          const int64_t* __restrict__ indexer, const float* __restrict__ obs,
+                                                          uint32_t* __restrict__ pair_key, int* __restrict__ seg_cnt,
+                                                          int* __restrict__ counters, int64_t capacity) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole waves
+    if (i == 0) {
+        int n = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
+        if (n > capacity) { n = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
+        counters[DIF_C_N_OCCUPIED] = n;
+    }
+    const int lin = (i < N) ? pt_lin[i] : -1;
+    uint32_t key[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) key[o] = DIF_INVALID_KEY;
+    if (lin >= 0) {
+        frame_count[lin] = 0;
+        if (unq_mask[i]) {
+            float xn, yn, zn; int ix, iy, iz;
+            voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+            // get_pruned_surface: own voxel in expand(encode set) <=> own voxel or an in-grid 6-neighbour is in the set
+            bool focus = in_encode_set(indexer[lin], obs, enc_th);
+            if (!focus && ix > 0) focus = in_encode_set(indexer[lin - g.ny * g.nz], obs, enc_th);
+            if (!focus && ix < g.nx - 1) focus = in_encode_set(indexer[lin + g.ny * g.nz], obs, enc_th);
+            if (!focus && iy > 0) focus = in_encode_set(indexer[lin - g.nz], obs, enc_th);
+            if (!focus && iy < g.ny - 1) focus = in_encode_set(indexer[lin + g.nz], obs, enc_th);
+            if (!focus && iz > 0) focus = in_encode_set(indexer[lin - 1], obs, enc_th);
+            if (!focus && iz < g.nz - 1) focus = in_encode_set(indexer[lin + 1], obs, enc_th);
+            if (focus) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;   // map.py:186-189
+                    int gx = clampi((int)(ceilf(xn + ox) - 1.0f), 0, g.nx - 1);                                   // map.py:422-424
+                    int gy = clampi((int)(ceilf(yn + oy) - 1.0f), 0, g.ny - 1);
+                    int gz = clampi((int)(ceilf(zn + oz) - 1.0f), 0, g.nz - 1);
+                    int64_t slot = indexer[linearize(g, gx, gy, gz)];
+                    if (in_encode_set(slot, obs, enc_th)) key[o] = (uint32_t)slot;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (i < N) pair_key[(int64_t)o * N + i] = key[o];
+        wave_grouped_add(seg_cnt, key[o], key[o] != DIF_INVALID_KEY);
+    }
+}
+
+// K5: per-slot encoder work items (ceil(cnt / ITEM_ROWS)), exclusive scan over slots, item -> slot table.  A slot's rows
+// live in the row table at [item_start*ITEM_ROWS, ...) (padded to whole items), so one scan yields both.
+struct ItemFunctor {
+    const int* seg_cnt;
+    int* item_start;
+    int* item_slot;
+    int* counters;
+    int64_t max_items;
+    __device__ int count(int s) const { return (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS; }
+    __device__ void emit(int s, int offset) const {
+        int n = (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS;
+        item_start[s] = offset;
+        if ((int64_t)offset + n > max_items) { counters[DIF_C_OVERFLOW] = 4; return; }
+        for (int k = 0; k < n; ++k) item_slot[offset + k] = s;
+    }
+    __device__ void finish(int total) const { counters[DIF_C_ITEMS] = (total > max_items) ? (int)max_items : total; }
+};
+
+// K6: place every valid (offset, point) pair into its slot's rows.  Order inside a slot is arrival order — harmless, because
+// the per-voxel sum is accumulated in exact fixed point (order-independent, see k_encode).
+__global__ void __launch_bounds__(DIF_BLOCK) k_scatter_rows(const uint32_t* __restrict__ pair_key, int64_t n_pairs, const int* __restrict__ item_start,
+                                                          int* __restrict__ seg_cursor, uint32_t* __restrict__ row_val, int64_t max_rows) {
+    const int64_t n_pad = (n_pairs + 63) / 64 * 64;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_pad; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t key = (j < n_pairs) ? pair_key[j] : DIF_INVALID_KEY;
+        const bool valid = key != DIF_INVALID_KEY;
+        const int r = wave_grouped_fetch_add(seg_cursor, key, valid);
+        if (valid) {
+            const int64_t pos = (int64_t)item_start[key] * ITEM_ROWS + r;
+            if (pos < max_rows) row_val[pos] = (uint32_t)j;
+        }
+    }
+}
+
+// =================================================================================================================
+// a7..a9 : gather + encoder (MFMA) + per-voxel sums
+// =================================================================================================================
+// Persistent: one 512-thread workgroup per CU keeps the 107 KB of packed encoder weights in LDS; each wave pulls work
+// items (slot, 32 rows), runs the tile through the MFMA chain and reduces the 29 output features over the rows.
+// The reduction is done in 2^-30 FIXED POINT (int64): integer addition is associative, so the per-voxel sum does not
+// depend on row order, tile grouping or the order partials are added in => bit-reproducible, and more accurate than an
+// fp32 running sum (the reference sums with float atomics in arbitrary order, indexing.cu:59-71).
+#define DIF_FIX_SCALE 1073741824.0f          /* 2^30: |enc| < 2^12 and < 2^21 rows per voxel keep the sum inside int64 */
+__global__ void __launch_bounds__(512, 2)
+k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
+         const uint32_t* __restrict__ row_val, const int* __restrict__ seg_cnt, const int* __restrict__ item_start,
+         const int* __restrict__ item_slot, const int* __restrict__ counters, long long* __restrict__ partial /* [items][32] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, ENC_FLOATS);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int n_items = counters[DIF_C_ITEMS];
+    for (int item = wave; item < n_items; item += nwaves) {
+        const int slot = item_slot[item];
+        const int chunk = item - item_start[slot];
+        const bool live = chunk * ITEM_ROWS + col < seg_cnt[slot];
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (live) {
+            uint32_t v = row_val[(int64_t)item * ITEM_ROWS + col];
+            int o = 0;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
+            int64_t i = (int64_t)v - (int64_t)o * N;
+            float xn = normalize1(xyz[i * 3 + 0], g.bx, g.vs);
+            float yn = normalize1(xyz[i * 3 + 1], g.by, g.vs);
+            float zn = normalize1(xyz[i * 3 + 2], g.bz, g.vs);
+            float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
+            float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
+            float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
+            float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
+            float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
+            float nxv = normal[i * 3 + 0], nyv = normal[i * 3 + 1], nzv = normal[i * 3 + 2];
+            x0 = half ? ry : rx;
+            x1 = half ? nxv : rz;
+            x2 = half ? nzv : nyv;
+        }
+        f16v out = encoder_tile(lds, x0, x1, x2, lane);
+        long long* p = partial + (int64_t)item * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            long long v = live ? __float2ll_rn(out[r] * DIF_FIX_SCALE) : 0ll;
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            if (col == 0) p[(r & 3) + 8 * (r >> 2) + 4 * half] = v;
+        }
+    }
+}
+
+// a10: fusion update (map.py:448-452).  One 32-lane group per slot.
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ partial, const int* __restrict__ item_start, int* __restrict__ seg_cnt,
+                                                  int* __restrict__ seg_cursor, float* __restrict__ latent, float* __restrict__ obs,
+                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters) {
+    __shared__ int smem[8];
+    const int n_occ = counters[DIF_C_N_OCCUPIED];
+    const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
+    const int f = threadIdx.x & 31;
+    int updated = 0, rows = 0;
+    for (int s = grp; s < n_occ; s += ngrp) {
+        int cnt = seg_cnt[s];
+        if (cnt <= 0) continue;
+        int it0 = item_start[s], nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
+        if (f < L) {
+            long long Si = 0;
+            for (int k = 0; k < nit; ++k) Si += partial[(int64_t)(it0 + k) * 32 + f];
+            float S = (float)Si * (1.0f / DIF_FIX_SCALE);    // one rounding: exact integer sum -> nearest float
+            float w_old = obs[s];
+            float z_old = latent[(int64_t)s * L + f];
+            S = S + z_old * w_old;                           // map.py:449
+            float w_new = w_old + (float)cnt;                // map.py:450
+            latent[(int64_t)s * L + f] = S / w_new;          // map.py:451
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (f == 31) {                                       // after every lane of the group has read obs[s]
+            obs[s] = obs[s] + (float)cnt;
+            dirty[s] = 1;                                    // map.py:452
+            seg_cnt[s] = 0;
+            seg_cursor[s] = 0;
+            ++updated;
+            rows += cnt;
+        }
+    }
+    int tu = block_sum(updated, smem);
+    int tr = block_sum(rows, smem);
+    if (threadIdx.x == 0 && tu) { atomicAdd(counters + DIF_C_C, tu); atomicAdd(counters + DIF_C_M, tr); }
+}
+

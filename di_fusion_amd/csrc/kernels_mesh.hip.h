@@ -1,0 +1,377 @@
+// a15 sparse marching cubes, a16 mesh-cache log, a17 point query, multi-GPU record export / merge  (part of libdifusion; included by difusion.hip inside its anonymous namespace)
+#pragma once
+
+// =================================================================================================================
+// a15 : sparse marching cubes with cross-voxel std-weighted blending (ext/marching_cubes/mc_interp_kernel.cu:7-320)
+// =================================================================================================================
+struct McArgs {
+    const int64_t* indexer; int nx, ny, nz;
+    const int64_t* valid_blocks; const int* K_ptr; int64_t K_static;
+    const int32_t* vbm; int64_t V;
+    const float* cube_sdf; const float* cube_std; int R;
+    float max_std;
+    int64_t max_triangles;
+    float* triangles; int64_t* tri_id; float* tri_std; uint8_t* tri_alive;
+    int32_t* tri_count; const int32_t* tri_offset;
+    const int* base_ptr;            // device: first output triangle index (mesh-cache append), or NULL
+    int64_t new_limit;              // triangles this call may emit (max_n_triangles)
+    int scale; float vs, bx, by, bz;
+};
+
+// batch index of voxel (bx,by,bz) or -1   (query_sdf_raw :13-24)
+__device__ __forceinline__ int mc_batch_of(const McArgs& a, int bx, int by, int bz) {
+    if ((unsigned)bx >= (unsigned)a.nx || (unsigned)by >= (unsigned)a.ny || (unsigned)bz >= (unsigned)a.nz) return -1;
+    int64_t vec = a.indexer[((int64_t)bx * a.ny + by) * a.nz + bz];
+    if (vec == -1 || vec >= a.V) return -1;
+    return a.vbm[vec];
+}
+
+// get_sdf (:34-185), STD_W_SDF branch: blend of the <=8 voxels whose cubes overlap corner `c` of voxel at nb[13].
+// nb: batch ids of the 3x3x3 neighbourhood (index (dx+1)*9 + (dy+1)*3 + (dz+1)).  Returns false => NaN (cell dropped).
+__device__ __forceinline__ bool mc_corner(const McArgs& a, const int* nb, int r, int cx, int cy, int cz, float& sdf, float& sd) {
+    const int R = a.R;
+    const int rbound = (r - 1) / 2, rstart = r / 2;
+    const float rmid = (float)r / 2.0f;
+    int c[3] = {cx, cy, cz};
+    int dm[3], dp[3], im[3], ip[3], zero[3];
+    float wm[3], wp[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (c[ax] <= rbound) {
+            dm[ax] = -1; im[ax] = c[ax] + rstart + r; dp[ax] = 0; ip[ax] = c[ax] + rstart;
+            wp[ax] = (float)c[ax] + rmid; wm[ax] = rmid - (float)c[ax];
+            zero[ax] = 1;
+        } else {
+            dm[ax] = 0; im[ax] = c[ax] + rstart; dp[ax] = 1; ip[ax] = c[ax] + rstart - r;
+            wp[ax] = (float)c[ax] - rmid; wm[ax] = rmid + (float)r - (float)c[ax];
+            zero[ax] = 0;
+        }
+        wm[ax] /= (float)r; wp[ax] /= (float)r;
+    }
+    const int zero_det = zero[0] * 4 + zero[1] * 2 + zero[2];
+    float ts = 0.0f, tw = 0.0f, tsd = 0.0f, twd = 0.0f;     // total_sdf.x, total_weight.x, total_sdf.y, total_weight.y
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sx = (k >> 2) & 1, sy = (k >> 1) & 1, sz = k & 1;
+        const int ddx = sx ? dp[0] : dm[0], ddy = sy ? dp[1] : dm[1], ddz = sz ? dp[2] : dm[2];
+        const int b = nb[(ddx + 1) * 9 + (ddy + 1) * 3 + (ddz + 1)];
+        float s = __builtin_nanf(""), d = 0.0f;
+        if (b >= 0) {
+            const int64_t off = (((int64_t)b * R + (sx ? ip[0] : im[0])) * R + (sy ? ip[1] : im[1])) * R + (sz ? ip[2] : im[2]);
+            s = a.cube_sdf[off];
+            d = a.cube_std[off];
+        }
+        const float w = (sx ? wp[0] : wm[0]) * (sy ? wp[1] : wm[1]) * (sz ? wp[2] : wm[2]);
+        if (s == s) {
+            ts += s * w * d; tw += w * d;
+            tsd += w * d;    twd += w;
+        } else if (zero_det == k) {
+            return false;
+        }
+    }
+    sdf = ts / tw;
+    sd = tsd / twd;
+    return sdf == sdf;
+}
+
+struct V4 { float x, y, z, w; };
+
+__device__ __forceinline__ V4 mc_interp(const float* p1, const float* p2, float s1, float s2, float v1, float v2) {   // sdf_interp :187-200
+    if (fabsf(0.0f - v1) < 1.0e-5f) return V4{p1[0], p1[1], p1[2], s1};
+    if (fabsf(0.0f - v2) < 1.0e-5f) return V4{p2[0], p2[1], p2[2], s2};
+    if (fabsf(v1 - v2) < 1.0e-5f) return V4{p1[0], p1[1], p1[2], s1};
+    float w2 = (0.0f - v1) / (v2 - v1);
+    float w1 = 1 - w2;
+    return V4{p1[0] * w1 + p2[0] * w2, p1[1] * w1 + p2[1] * w2, p1[2] * w1 + p2[2] * w2, s1 * w1 + s2 * w2};
+}
+
+// One wave per dirty voxel.  Phase 1: the (r+1)^3 blended corner values are computed ONCE into LDS (the reference
+// recomputes each corner for up to 8 cells).  Phase 2: lane = cell; EMIT=false counts the triangles that survive
+// max_std, EMIT=true writes them at tri_offset[k] + wave-prefix (canonical order: voxel, cell, table order).
+template <bool EMIT>
+__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int r = a.R / 2, r1 = r + 1, nc = r1 * r1 * r1, r3 = r * r * r;
+    const int lane = lane_id(), wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    float* c_sdf = lds + (size_t)wid * (2 * nc + 32);
+    float* c_std = c_sdf + nc;
+    int* nb = reinterpret_cast<int*>(c_std + nc);            // 27 (+pad)
+    const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
+    const float sbs = 1.0f / (float)r;
+    for (int64_t k = (int64_t)blockIdx.x * wpb + wid; k < K; k += (int64_t)gridDim.x * wpb) {
+        const int64_t vb = a.valid_blocks[k];
+        const int bx = (int)((vb / ((int64_t)a.ny * a.nz)) % a.nx), by = (int)((vb / a.nz) % a.ny), bz = (int)(vb % a.nz);
+        if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): nb[] visible to the whole wave
+        for (int c = lane; c < nc; c += 64) {
+            float s, d;
+            bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, s, d);
+            c_sdf[c] = ok ? s : __builtin_nanf("");
+            c_std[c] = ok ? d : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        int voxel_total = 0;
+        for (int s0 = 0; s0 < r3; s0 += 64) {
+            const int s = s0 + lane;
+            int ntri = 0;
+            V4 vl[12];
+            int cube_type = 0;
+            if (s < r3) {
+                const int rx = s / (r * r), ry = (s / r) % r, rz = s % r;
+                float val[8], sdv[8], pts[8][3];
+                bool dropped = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int dx = (q == 1 || q == 2 || q == 5 || q == 6), dy = (q == 2 || q == 3 || q == 6 || q == 7), dz = (q >= 4);
+                    const int ci = ((rx + dx) * r1 + (ry + dy)) * r1 + (rz + dz);
+                    val[q] = c_sdf[ci]; sdv[q] = c_std[ci];
+                    dropped |= !(val[q] == val[q]);
+                    pts[q][0] = (float)bx + (float)(rx + dx) * sbs;
+                    pts[q][1] = (float)by + (float)(ry + dy) * sbs;
+                    pts[q][2] = (float)bz + (float)(rz + dz) * sbs;
+                }
+                if (!dropped) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) cube_type |= (val[q] < 0.0f) ? (1 << q) : 0;
+                    const int edge_config = c_mc_edge_table[cube_type];
+                    if (edge_config) {
+                        const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+#pragma unroll
+                        for (int e = 0; e < 12; ++e)
+                            if (edge_config & (1 << e)) vl[e] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
+                        for (int i = 0; c_mc_tri_table[cube_type][i] != -1; i += 3) {
+                            float w0 = vl[c_mc_tri_table[cube_type][i]].w, w1 = vl[c_mc_tri_table[cube_type][i + 1]].w,
+                                  w2 = vl[c_mc_tri_table[cube_type][i + 2]].w;
+                            if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
+                            ++ntri;
+                        }
+                    } else {
+                        cube_type = 0;
+                    }
+                } else {
+                    cube_type = 0;
+                }
+            }
+            const int incl = wave_incl_scan(ntri);
+            const int chunk_total = __shfl(incl, 63);
+            if (EMIT && ntri > 0) {
+                int64_t tl = (int64_t)a.tri_offset[k] + voxel_total + (incl - ntri);      // index among this call's triangles
+                int64_t t = tl + (a.base_ptr ? (int64_t)(*a.base_ptr) : 0);
+                for (int i = 0; c_mc_tri_table[cube_type][i] != -1; i += 3) {
+                    V4 v0 = vl[c_mc_tri_table[cube_type][i]], v1 = vl[c_mc_tri_table[cube_type][i + 1]], v2 = vl[c_mc_tri_table[cube_type][i + 2]];
+                    if (v0.w > a.max_std || v1.w > a.max_std || v2.w > a.max_std) continue;
+                    if (tl < a.new_limit && t < a.max_triangles) {
+                        V4 vv[3] = {v0, v1, v2};
+#pragma unroll
+                        for (int vi = 0; vi < 3; ++vi) {
+                            float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
+                            if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }   // map.py:698
+                            a.triangles[(t * 3 + vi) * 3 + 0] = x;
+                            a.triangles[(t * 3 + vi) * 3 + 1] = y;
+                            a.triangles[(t * 3 + vi) * 3 + 2] = z;
+                            a.tri_std[t * 3 + vi] = vv[vi].w;
+                        }
+                        a.tri_id[t] = vb;
+                        if (a.tri_alive) a.tri_alive[t] = 1;
+                    }
+                    ++t; ++tl;
+                }
+            }
+            voxel_total += chunk_total;
+        }
+        if (!EMIT && lane == 0) a.tri_count[k] = voxel_total;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- a16 : device-resident mesh cache as an append-only log (map.py:703-714) -----------------------------------------
+// A voxel that produced >= 1 new triangle replaces its previous batch (the reference drops cached triangles whose voxel id
+// occurs among the new ones, map.py:708-709): mark the old batch dead, point the voxel at its new batch.
+__global__ void __launch_bounds__(DIF_BLOCK) k_log_replace(const int64_t* __restrict__ valid_blocks, const int32_t* __restrict__ tri_count,
+                                                         const int32_t* __restrict__ tri_offset, const int64_t* __restrict__ indexer,
+                                                         int32_t* __restrict__ tri_start, int32_t* __restrict__ tri_n, uint8_t* __restrict__ alive,
+                                                         int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
+    __shared__ int smem[8];
+    const int K = counters[DIF_C_K];
+    const int64_t log_n = counters[DIF_C_CACHE_T];
+    int dead = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int c = tri_count[k];
+        if (c <= 0) continue;
+        const int64_t slot = indexer[valid_blocks[k]];
+        const int old_n = tri_n[slot], old_s = tri_start[slot];
+        for (int j = 0; j < old_n; ++j) alive[old_s + j] = 0;
+        dead += old_n;
+        int64_t off = tri_offset[k];
+        int64_t n_new = c;
+        if (off + n_new > new_limit) n_new = new_limit > off ? new_limit - off : 0;          // truncated by max_n_triangles
+        if (log_n + off + n_new > capacity) n_new = capacity > log_n + off ? capacity - (log_n + off) : 0;
+        tri_start[slot] = (int)(log_n + off);
+        tri_n[slot] = (int)n_new;
+    }
+    dead = block_sum(dead, smem);
+    if (threadIdx.x == 0 && dead) atomicAdd(counters + DIF_C_CACHE_DEAD, dead);
+}
+
+struct CacheLiveFunctor {       // ordered compaction of the live log entries
+    const float* src_tri; const int64_t* src_id; const float* src_std; const uint8_t* alive;
+    float* dst_tri; int64_t* dst_id; float* dst_std;
+    int64_t out_capacity;
+    int* counters;
+    __device__ int count(int t) const { return alive[t] ? 1 : 0; }
+    __device__ void emit(int t, int offset) const {
+        if (offset >= out_capacity) return;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst_tri[(int64_t)offset * 9 + i] = src_tri[(int64_t)t * 9 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dst_std[(int64_t)offset * 3 + i] = src_std[(int64_t)t * 3 + i];
+        dst_id[offset] = src_id[t];
+    }
+    __device__ void finish(int total) const { counters[DIF_C_CACHE_LIVE] = total > out_capacity ? (int)out_capacity : total; }
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_cache_reindex(const int64_t* __restrict__ id, int64_t n, const int64_t* __restrict__ indexer,
+                                                           int32_t* __restrict__ tri_start, int32_t* __restrict__ tri_n, uint8_t* __restrict__ alive,
+                                                           int* __restrict__ counters) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        alive[t] = 1;
+        const int64_t v = id[t];
+        const int64_t slot = indexer[v];
+        if (slot < 0) continue;
+        if (t == 0 || id[t - 1] != v) tri_start[slot] = (int)t;            // a live voxel owns exactly one contiguous batch
+        atomicAdd(tri_n + slot, 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters[DIF_C_CACHE_T] = (int)n;
+        counters[DIF_C_CACHE_KEPT] = (int)n;
+        counters[DIF_C_CACHE_DEAD] = 0;
+    }
+}
+
+// end of extract: clear the batch map, publish the log length
+__global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
+                                                            int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
+    const int B = counters[DIF_C_B];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t n_new = counters[DIF_C_T];
+        if (n_new > new_limit) n_new = new_limit;
+        const int64_t old_n = counters[DIF_C_CACHE_T];
+        int64_t tot = old_n + n_new;
+        if (tot > capacity) { tot = capacity; counters[DIF_C_OVERFLOW] = 5; }
+        counters[DIF_C_CACHE_KEPT] = (int)old_n;
+        counters[DIF_C_CACHE_T] = (int)tot;
+    }
+}
+
+struct TriScanFunctor {
+    const int32_t* tri_count;
+    int32_t* tri_offset;
+    int* counters;
+    __device__ int count(int k) const { return tri_count[k]; }
+    __device__ void emit(int k, int offset) const { tri_offset[k] = offset; }
+    __device__ void finish(int total) const { counters[DIF_C_T] = total; }
+};
+
+// =================================================================================================================
+// a17 : get_sdf — validity mask + ordered compaction of valid points  (map.py:565-573)
+// =================================================================================================================
+struct QueryFunctor {
+    Geo g;
+    float ignore_th;
+    const float* xyz;
+    const int64_t* indexer;
+    const float* obs;
+    uint8_t* mask;
+    int32_t* sel;
+    int* counters;
+    __device__ int count(int i) const {
+        float xn, yn, zn; int ix, iy, iz;
+        bool ok = voxel_of(g, xyz[(int64_t)i * 3 + 0], xyz[(int64_t)i * 3 + 1], xyz[(int64_t)i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        if (ok) {
+            int64_t slot = indexer[linearize(g, ix, iy, iz)];
+            ok = slot >= 0 && obs[slot] > ignore_th;
+        }
+        mask[i] = ok ? 1 : 0;
+        return ok ? 1 : 0;
+    }
+    __device__ void emit(int i, int offset) const { sel[offset] = i; }
+    __device__ void finish(int total) const { counters[DIF_C_QUERY_M] = total; }
+};
+
+// =================================================================================================================
+// multi-GPU merge helpers
+// =================================================================================================================
+struct ExportFunctor {       // ordered compaction over slots: allocated voxels with x index in [x_lo, x_hi)
+    const int64_t* pos; const float* obs; const float* latent; const uint8_t* dirty;
+    int32_t* rec; int64_t max_records;
+    int64_t lin_lo, lin_hi;
+    int raw;
+    int* counters;
+    __device__ int count(int s) const { int64_t p = pos[s]; return (p >= lin_lo && p < lin_hi) ? 1 : 0; }
+    __device__ void emit(int s, int offset) const {
+        if (offset >= max_records) return;
+        int32_t* r = rec + (int64_t)offset * 32;
+        const int64_t p = pos[s];
+        const float w = obs[s];
+        r[0] = (int32_t)p;                       // grid < 2^31 (checked by every entry point)
+        r[1] = dirty[s] ? 1 : 0;                 // flags: bit 0 = awaiting re-meshing
+        r[2] = __float_as_int(w);
+        for (int f = 0; f < L; ++f) {
+            float z = latent[(int64_t)s * L + f];
+            r[3 + f] = __float_as_int(raw ? z : z * w);
+        }
+    }
+    __device__ void finish(int total) const {
+        if (total > max_records) { total = (int)max_records; counters[DIF_C_OVERFLOW] = 6; }
+        counters[DIF_C_EXPORT_N] = total;
+    }
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
+                                                        uint32_t* __restrict__ bits, int64_t grid) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lin = rec[i * 32];
+        if (lin < 0 || lin >= grid) continue;
+        if (indexer[lin] == -1) atomicOr(bits + (lin >> 5), 1u << (lin & 31));
+    }
+}
+
+// records of one call carry distinct lin ids => plain read-modify-write, deterministic
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
+                                                         float* __restrict__ latent, float* __restrict__ obs, uint8_t* __restrict__ dirty,
+                                                         int* __restrict__ counters, int64_t grid, int64_t capacity, int assign) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int no = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
+        if (no > capacity) { no = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
+        counters[DIF_C_N_OCCUPIED] = no;
+        counters[DIF_C_ALLOC_NEW] = 0;
+    }
+    const int64_t total = n * 32;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = e >> 5;
+        int f = (int)(e & 31);
+        int64_t lin = rec[i * 32];
+        if (lin < 0 || lin >= grid) continue;
+        int64_t s = indexer[lin];
+        if (s < 0) continue;
+        float w_r = __int_as_float(rec[i * 32 + 2]);
+        float w_old = obs[s];
+        float w_new = assign ? w_r : w_old + w_r;
+        if (f < L) {
+            float pay = __int_as_float(rec[i * 32 + 3 + f]);
+            float z = latent[s * L + f];
+            if (assign) latent[s * L + f] = pay;
+            else if (w_new > 0.0f) latent[s * L + f] = (z * w_old + pay) / w_new;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (f == 31) {
+            obs[s] = w_new;
+            if (assign) dirty[s] = (uint8_t)(rec[i * 32 + 1] & 1);
+            else if (w_r > 0.0f) dirty[s] = 1;
+        }
+    }
+}
+

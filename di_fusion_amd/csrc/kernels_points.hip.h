@@ -1,0 +1,221 @@
+// Image / point-cloud kernels on either side of the path: a1-a2 depth -> points, normals, 8f-2 preprocessing, flat groupby_sum  (part of libdifusion; included by difusion.hip inside its anonymous namespace)
+#pragma once
+
+// =================================================================================================================
+// a1 / a2 : depth -> points  (ext/imgproc/imgproc.cu:5-44; utils/motion_util.py:322-327)
+// =================================================================================================================
+// One thread per pixel, threadIdx.x walks u (columns) => coalesced 4 B reads / 12 B writes (the reference walks rows).
+__global__ void __launch_bounds__(DIF_BLOCK) k_unproject(const float* __restrict__ depth, float* __restrict__ pc, int H, int W,
+                                                       float fx, float fy, float cx, float cy) {
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        float d = depth[i];
+        float x, y, z;
+        if (d == d) {
+            x = ((float)u - cx) / fx * d;       // (u - cx) / fx * d, imgproc.cu:18
+            y = ((float)v - cy) / fy * d;
+            z = d;
+        } else {
+            x = y = z = __builtin_nanf("");
+        }
+        pc[i * 3 + 0] = x; pc[i * 3 + 1] = y; pc[i * 3 + 2] = z;
+    }
+}
+
+struct Pose { float r[9]; float t[3]; };
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* __restrict__ depth, const float* __restrict__ ncam,
+                                                                 float* __restrict__ xyz, float* __restrict__ nrm, int H, int W,
+                                                                 float fx, float fy, float cx, float cy, Pose P, const float* __restrict__ pose_dev) {
+    if (pose_dev) {                                   // pose read from device memory: lets a captured hipGraph be replayed per frame
+#pragma unroll
+        for (int i = 0; i < 9; ++i) P.r[i] = pose_dev[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) P.t[i] = pose_dev[9 + i];
+    }
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        float d = depth[i];
+        const float qnan = __builtin_nanf("");
+        float ox = qnan, oy = qnan, oz = qnan, nx = qnan, ny = qnan, nz = qnan;
+        if (d == d) {
+            float x = ((float)u - cx) / fx * d;
+            float y = ((float)v - cy) / fy * d;
+            float z = d;
+            // ((r0*x + r1*y) + r2*z) + t, every op rounded (synthetic.transform_points states the same order)
+            ox = ((P.r[0] * x + P.r[1] * y) + P.r[2] * z) + P.t[0];
+            oy = ((P.r[3] * x + P.r[4] * y) + P.r[5] * z) + P.t[1];
+            oz = ((P.r[6] * x + P.r[7] * y) + P.r[8] * z) + P.t[2];
+            if (ncam) {
+                float a = ncam[i * 3 + 0], b = ncam[i * 3 + 1], c = ncam[i * 3 + 2];
+                nx = (P.r[0] * a + P.r[1] * b) + P.r[2] * c;
+                ny = (P.r[3] * a + P.r[4] * b) + P.r[5] * c;
+                nz = (P.r[6] * a + P.r[7] * b) + P.r[8] * c;
+            }
+        }
+        xyz[i * 3 + 0] = ox; xyz[i * 3 + 1] = oy; xyz[i * 3 + 2] = oz;
+        if (nrm) { nrm[i * 3 + 0] = nx; nrm[i * 3 + 1] = ny; nrm[i * 3 + 2] = nz; }
+    }
+}
+
+// ext/imgproc/imgproc.cu:98-141
+__global__ void __launch_bounds__(DIF_BLOCK) k_normal_weight(const float* __restrict__ pc, float* __restrict__ out, int H, int W) {
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        float* o = out + i * 4;
+        if (v < 1 || v > H - 2 || u < 1 || u > W - 2) { o[3] = -1.0f; continue; }
+        const float* c = pc + i * 3;
+        if (c[2] <= 1e-6) { o[3] = -1.0f; continue; }
+        const float* xp = pc + (i + 1) * 3; const float* xm = pc + (i - 1) * 3;
+        const float* yp = pc + (i + W) * 3; const float* ym = pc + (i - W) * 3;
+        if (xp[2] < 1e-6 || xm[2] < 1e-6 || yp[2] < 1e-6 || ym[2] < 1e-6) { o[3] = -1.0f; continue; }
+        float dxx = xp[0] - xm[0], dxy = xp[1] - xm[1], dxz = xp[2] - xm[2];
+        float dyx = yp[0] - ym[0], dyy = yp[1] - ym[1], dyz = yp[2] - ym[2];
+        float nx = dyy * dxz - dyz * dxy, ny = dyz * dxx - dyx * dxz, nz = dyx * dxy - dyy * dxx;   // cross(diff_y, diff_x)
+        float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        if (len < 1e-6) { o[3] = -1.0f; continue; }
+        nx /= len; ny /= len; nz /= len;
+        float theta = acosf(nz);
+        float td = theta / (0.5f * 3.14159f - theta);
+        float wgt = (0.0012f + 0.0019f * (c[2] - 0.4f) * (c[2] - 0.4f) + 0.0001f / sqrtf(c[2]) * td * td);
+        o[0] = nx; o[1] = ny; o[2] = nz; o[3] = 1.0f / wgt;
+    }
+}
+
+// ---- 8f-2: image-space preprocessing next to the path -------------------------------------------------------------------
+// filter_depth (ext/imgproc/imgproc.cu:48-94): 5x5 bilateral filter whose range sigma follows the depth-noise model;
+// border pixels (2 px) are left untouched, depth < 1e-6 -> 0.
+__global__ void __launch_bounds__(DIF_BLOCK) k_filter_depth(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
+    const float sig_l2 = 1.2232f * 1.2232f;                  // MEAN_SIGMA_L^2
+    int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+        if (v < 2 || v >= H - 2 || u < 2 || u >= W - 2) continue;
+        float z = in[i];
+        if (z < 1e-6) { out[i] = 0.0f; continue; }
+        float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
+        float w_sum = 0.0f, acc = 0.0f;
+        for (int di = -2; di <= 2; ++di)
+            for (int dj = -2; dj <= 2; ++dj) {
+                float nz = in[i + (int64_t)di * W + dj];
+                if (nz < 1e-6) continue;
+                float dz = (nz - z) * (nz - z);
+                float wgt = expf(-0.5f * ((float)(abs(di) + abs(dj)) * sig_l2 + dz * sigma_z * sigma_z));
+                w_sum += wgt;
+                acc += wgt * nz;
+            }
+        out[i] = acc / w_sum;
+    }
+}
+
+// point_box_filter (system/tracker.py:13-23): mean point / mean normal per voxel_size box, boxes in ascending linear id
+// (x fastest).  Bounds -> box bitmap -> ordered ranks -> order-independent fixed-point sums -> means.
+struct BoxGrid { float minb[3]; int n[3]; };
+
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_bounds(const float* __restrict__ pts, int64_t N, unsigned* __restrict__ mm /* [6]: min xyz, max xyz (ordered uint) */) {
+    unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { unsigned o = f2ord(pts[i * 3 + a]); lo[a] = min(lo[a], o); hi[a] = max(hi[a], o); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int d = 32; d >= 1; d >>= 1) { lo[a] = min(lo[a], (unsigned)__shfl_xor((int)lo[a], d)); hi[a] = max(hi[a], (unsigned)__shfl_xor((int)hi[a], d)); }
+        if (lane_id() == 0) { atomicMin(mm + a, lo[a]); atomicMax(mm + 3 + a, hi[a]); }
+    }
+}
+
+__device__ __forceinline__ BoxGrid pbf_grid(const unsigned* __restrict__ mm, float vs) {
+    BoxGrid G;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float mn = ord2f(mm[a]) - vs * 0.5f, mx = ord2f(mm[3 + a]) + vs * 0.5f;     // tracker.py:15-16
+        G.minb[a] = mn;
+        G.n[a] = (int)floorf((mx - mn) / vs) + 16;                                    // tracker.py:18
+    }
+    return G;
+}
+
+__device__ __forceinline__ int64_t pbf_cell(const BoxGrid& G, const float* p, float vs) {
+    int64_t cx = (int64_t)floorf((p[0] - G.minb[0]) / vs), cy = (int64_t)floorf((p[1] - G.minb[1]) / vs), cz = (int64_t)floorf((p[2] - G.minb[2]) / vs);
+    return cx + cy * G.n[0] + cz * (int64_t)G.n[0] * G.n[1];                          // tracker.py:17,19
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_mark(const float* __restrict__ pts, int64_t N, float vs, const unsigned* __restrict__ mm,
+                                                      uint32_t* __restrict__ bits, int64_t max_cells, int* __restrict__ status) {
+    const BoxGrid G = pbf_grid(mm, vs);
+    if ((int64_t)G.n[0] * G.n[1] * G.n[2] > max_cells) { if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 1; return; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = pbf_cell(G, pts + i * 3, vs);
+        uint32_t b = 1u << (c & 31);
+        if (!(bits[c >> 5] & b)) atomicOr(bits + (c >> 5), b);
+    }
+}
+
+struct BoxRankFunctor {      // exclusive prefix of popcounts per bitmap word = rank of the word's first box
+    const uint32_t* bits;
+    int* word_rank;
+    int* out_count;
+    __device__ int count(int w) const { return __popc(bits[w]); }
+    __device__ void emit(int w, int offset) const { word_rank[w] = offset; }
+    __device__ void finish(int total) const { out_count[0] = total; }
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_accumulate(const float* __restrict__ pts, const float* __restrict__ nrm, int64_t N, float vs,
+                                                            const unsigned* __restrict__ mm, const uint32_t* __restrict__ bits,
+                                                            const int* __restrict__ word_rank, long long* __restrict__ sums /* [boxes][8] */,
+                                                            const int* __restrict__ status) {
+    if (status[0]) return;
+    const BoxGrid G = pbf_grid(mm, vs);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = pbf_cell(G, pts + i * 3, vs);
+        int r = word_rank[c >> 5] + __popc(bits[c >> 5] & ((1u << (c & 31)) - 1u));
+        long long* s = sums + (int64_t)r * 8;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicAdd((unsigned long long*)(s + a), (unsigned long long)__float2ll_rn(pts[i * 3 + a] * 16777216.0f));       // 2^-24 fixed point
+            atomicAdd((unsigned long long*)(s + 3 + a), (unsigned long long)__float2ll_rn(nrm[i * 3 + a] * 16777216.0f));
+        }
+        atomicAdd((unsigned long long*)(s + 6), 1ull);
+    }
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_pbf_finish(const long long* __restrict__ sums, const int* __restrict__ n_boxes, float* __restrict__ out_pts,
+                                                        float* __restrict__ out_nrm, uint32_t* __restrict__ bits, const float* __restrict__ pts, int64_t N,
+                                                        float vs, const unsigned* __restrict__ mm, const int* __restrict__ status) {
+    const int nb = n_boxes[0];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)nb * 3; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e / 3; int a = (int)(e - r * 3);
+        const float cnt = (float)sums[r * 8 + 6];
+        out_pts[e] = (float)((double)sums[r * 8 + a] * (1.0 / 16777216.0)) / cnt;
+        out_nrm[e] = (float)((double)sums[r * 8 + 3 + a] * (1.0 / 16777216.0)) / cnt;
+    }
+    if (status[0]) return;
+    const BoxGrid G = pbf_grid(mm, vs);                      // restore the bitmap to all-zero for the next call
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = pbf_cell(G, pts + i * 3, vs);
+        bits[c >> 5] = 0u;
+    }
+}
+
+// =================================================================================================================
+// a9 : flat groupby_sum (ext/indexing/indexing.cu:59-109) — API parity entry; the map path uses the sorted reduction
+// =================================================================================================================
+__global__ void __launch_bounds__(DIF_BLOCK) k_groupby_sum(const float* __restrict__ values, const int64_t* __restrict__ idx, int64_t N,
+                                                         int Lw, float* __restrict__ sum, int* __restrict__ cnt, int64_t C) {
+    int64_t total = N * Lw;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = e / Lw;
+        int l = (int)(e - i * Lw);
+        int64_t g = idx[i];
+        if (g < 0 || g >= C) continue;
+        atomicAdd(sum + g * Lw + l, values[e]);
+        if (l == 0) atomicAdd(cnt + g, 1);
+    }
+}
+
