@@ -364,8 +364,15 @@ int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float*
 static int mc_setup(const McArgs& a, size_t& lds_bytes, int& blocks, int64_t K_upper) {
     if (upload_tables() != DIF_OK) return DIF_ELAUNCH;
     const int r = a.R / 2, nc = (r + 1) * (r + 1) * (r + 1);
-    lds_bytes = (size_t)(DIF_BLOCK / 64) * (2 * nc + 32) * sizeof(float);
-    if (lds_bytes > 64 * 1024) return DIF_EINVAL;
+    lds_bytes = (size_t)(DIF_BLOCK / 64) * MC_WAVE_LDS_FLOATS(nc) * sizeof(float);
+    if (lds_bytes > 128 * 1024) return DIF_EINVAL;
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)k_marching_cubes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_marching_cubes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        attr_set[dev] = true;
+    }
     blocks = grid_for(K_upper, DIF_BLOCK / 64, 8192);
     return DIF_OK;
 }
