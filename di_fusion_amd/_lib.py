@@ -61,6 +61,11 @@ SIGNATURES = {
     "dif_filter_depth": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "dif_point_box_filter": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "dif_cloud_workspace_bytes": (c_int64, [c_int64]),
+    "dif_knn": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dif_remove_radius_outlier": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dif_estimate_normals": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, POINTER(c_float), c_void_p, c_void_p, c_int64,
+                                       c_void_p]),
     "dif_groupby_sum": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "dif_integrate_workspace_bytes": (c_int64, [c_int64]),
     "dif_integrate": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

@@ -76,6 +76,7 @@ inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096)
 #include "kernels_integrate.hip.h"
 #include "kernels_extract.hip.h"
 #include "kernels_mesh.hip.h"
+#include "kernels_cloud.hip.h"
 
 }  // namespace
 
@@ -167,6 +168,131 @@ int dif_groupby_sum(const float* values, const int64_t* indices, int64_t N, int3
     return DIF_OK;
 }
 
+// ---- 8f-3: point-cloud neighbourhood ops ------------------------------------------------------------------------
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C++" {
+struct CloudWs {
+    CloudGrid g;
+    int* block_tmp;
+    int64_t T;
+    size_t o_keys, o_cnt, o_end, o_sorted, keys_cnt_bytes, sorted_bytes;
+    int64_t total_bytes;
+};
+
+static int carve_cloud(int64_t n, void* base, CloudWs& ws) {
+    if (n < 1) n = 1;
+    if (n >= ((int64_t)1 << 28)) return DIF_EINVAL;
+    int64_t T = 4096;
+    int bits = 12;
+    while (T < 4 * n) { T <<= 1; ++bits; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    ws.T = T;
+    ws.o_keys = take((size_t)T * 8);
+    ws.o_cnt = take((size_t)T * 4);             // keys and cnt are adjacent: one memset region each
+    ws.o_end = take((size_t)T * 4);
+    ws.o_sorted = take((size_t)n * 16);
+    size_t o_slot = take((size_t)n * 4), o_tmp = take(4096 * 4);
+    ws.keys_cnt_bytes = (size_t)T * 8;
+    ws.sorted_bytes = (size_t)n * 16;
+    ws.total_bytes = (int64_t)off;
+    if (base) {
+        char* b = (char*)base;
+        ws.g.keys = (unsigned long long*)(b + ws.o_keys);
+        ws.g.cnt = (int*)(b + ws.o_cnt);
+        ws.g.end = (int*)(b + ws.o_end);
+        ws.g.sorted = (float4*)(b + ws.o_sorted);
+        ws.g.slot = (int*)(b + o_slot);
+        ws.block_tmp = (int*)(b + o_tmp);
+        ws.g.mask = (unsigned)(T - 1);
+        ws.g.shift = 64 - bits;
+    }
+    return DIF_OK;
+}
+
+// Builds the cell table for `pc` with `rings` rings covering `radius`.
+static int cloud_build(const float* pc, int64_t n, int stride, float radius, int rings, void* wsp, int64_t ws_bytes, hipStream_t s, CloudWs& ws) {
+    int rc = carve_cloud(n, wsp, ws);
+    if (rc != DIF_OK) return rc;
+    if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
+    ws.g.c = radius / (float)rings * 1.002f;    // ring `rings` then bounds every unvisited point beyond the radius (see k_cloud_query)
+    ws.g.inv_c = 1.0f / ws.g.c;
+    if (hipMemsetAsync(ws.g.keys, 0xFF, ws.keys_cnt_bytes, s) != hipSuccess) return DIF_ELAUNCH;
+    if (hipMemsetAsync(ws.g.cnt, 0, (size_t)ws.T * 4, s) != hipSuccess) return DIF_ELAUNCH;
+    if (hipMemsetAsync(ws.g.sorted, 0xFF, ws.sorted_bytes, s) != hipSuccess) return DIF_ELAUNCH;   // original index -1 = unused row
+    hipLaunchKernelGGL(k_cloud_insert, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, ws.g, pc, (int)n, stride);
+    DIF_CHECK_LAUNCH();
+    CloudStartFunctor f{ws.g.cnt, ws.g.end};
+    if (launch_scan(f, nullptr, (int)ws.T, ws.T, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_cloud_place, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, ws.g, pc, (int)n, stride);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+template <int MODE>
+static int cloud_query(const CloudWs& ws, const float* pc, int64_t n, int stride, int k, float radius, int rings, const CloudQueryOut& out, hipStream_t s) {
+    const dim3 grid((unsigned)((n + DIF_BLOCK - 1) / DIF_BLOCK)), block(DIF_BLOCK);
+    if (k <= 8) hipLaunchKernelGGL((k_cloud_query<8, MODE>), grid, block, 0, s, ws.g, pc, (int)n, stride, k, radius, rings, out);
+    else if (k <= 16) hipLaunchKernelGGL((k_cloud_query<16, MODE>), grid, block, 0, s, ws.g, pc, (int)n, stride, k, radius, rings, out);
+    else hipLaunchKernelGGL((k_cloud_query<32, MODE>), grid, block, 0, s, ws.g, pc, (int)n, stride, k, radius, rings, out);
+    hipLaunchKernelGGL(k_cloud_invalid<MODE>, dim3(grid_for(n)), block, 0, s, ws.g, (int)n, k, out);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+static bool cloud_args_ok(const float* pc, int64_t n, int stride, int k, float radius, const void* out, const void* ws) {
+    return n >= 0 && (stride == 3 || stride == 4) && k >= 1 && k <= 32 && radius > 0.0f && radius < 1e6f && (n == 0 || (pc && out && ws));
+}
+
+}  // extern "C++"
+
+int64_t dif_cloud_workspace_bytes(int64_t n) {
+    CloudWs ws;
+    if (carve_cloud(n, nullptr, ws) != DIF_OK) return -1;
+    return ws.total_bytes;
+}
+
+int dif_knn(const float* pc, int64_t n, int32_t stride, int32_t k, float radius, int32_t* out_idx, float* out_dist, void* wsp, int64_t ws_bytes,
+            void* stream) {
+    if (!cloud_args_ok(pc, n, stride, k, radius, out_idx, wsp) || (n > 0 && !out_dist)) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    CloudWs ws;
+    const int rings = 4;
+    int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
+    if (rc != DIF_OK) return rc;
+    CloudQueryOut out{};
+    out.idx = out_idx; out.dist = out_dist;
+    return cloud_query<CLOUD_KNN>(ws, pc, n, stride, k, radius, rings, out, (hipStream_t)stream);
+}
+
+int dif_remove_radius_outlier(const float* pc, int64_t n, int32_t stride, int32_t nb_points, float radius, uint8_t* out_mask, void* wsp,
+                              int64_t ws_bytes, void* stream) {
+    if (!cloud_args_ok(pc, n, stride, nb_points, radius, out_mask, wsp)) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    CloudWs ws;
+    const int rings = 2;        // only "are there nb_points inside the radius" is asked: coarse cells, at most 125 of them
+    int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
+    if (rc != DIF_OK) return rc;
+    CloudQueryOut out{};
+    out.mask = out_mask;
+    return cloud_query<CLOUD_OUTLIER>(ws, pc, n, stride, nb_points, radius, rings, out, (hipStream_t)stream);
+}
+
+int dif_estimate_normals(const float* pc, int64_t n, int32_t stride, int32_t max_nn, float radius, const float* cam_xyz, float* out_normals,
+                         void* wsp, int64_t ws_bytes, void* stream) {
+    if (!cloud_args_ok(pc, n, stride, max_nn, radius, out_normals, wsp) || !cam_xyz) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    CloudWs ws;
+    const int rings = 4;
+    int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
+    if (rc != DIF_OK) return rc;
+    CloudQueryOut out{};
+    out.normal = out_normals;
+    out.cam[0] = cam_xyz[0]; out.cam[1] = cam_xyz[1]; out.cam[2] = cam_xyz[2];
+    return cloud_query<CLOUD_NORMAL>(ws, pc, n, stride, max_nn, radius, rings, out, (hipStream_t)stream);
+}
+
 // ---- integrate ------------------------------------------------------------------------------------------------
 // workspace carve (all offsets 256-byte aligned)
 struct IntegrateWs {
@@ -180,7 +306,6 @@ struct IntegrateWs {
     int64_t total_bytes;
 };
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int64_t max_items_for(int64_t N) {
     // items = sum_s ceil(cnt_s / ITEM_ROWS) <= M/ITEM_ROWS + C with M <= 8N rows.  With pruning on, every kept point shares its

@@ -123,3 +123,65 @@ def point_box_filter(points: torch.Tensor, normals: torch.Tensor, voxel_size: fl
         raise RuntimeError("point_box_filter: the cloud's box grid exceeds max_cells")
     n = int(cnt.item())
     return out_p[:n], out_n[:n]
+
+
+# ---- ext/pcproc (tracker.py:105-113) -----------------------------------------------------------------
+_CLOUD_WS = {}
+
+
+def _cloud_workspace(dev, n: int) -> torch.Tensor:
+    need = int(_lib.load().dif_cloud_workspace_bytes(max(int(n), 1)))
+    if need < 0:
+        raise RuntimeError("point cloud too large for the neighbourhood index")
+    ws = _CLOUD_WS.get(str(dev))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((int(need * 1.25),), dtype=torch.uint8, device=dev)
+        _CLOUD_WS[str(dev)] = ws
+    return ws
+
+
+def _cloud_input(input_pc: torch.Tensor):
+    _lib.require_cuda(input_pc)
+    if input_pc.dim() != 2 or input_pc.size(1) not in (3, 4) or input_pc.dtype != torch.float32:
+        raise RuntimeError("input_pc must be a (N,3) or (N,4) float32 tensor")
+    return int(input_pc.size(0)), int(input_pc.size(1))
+
+
+def knn_search(input_pc: torch.Tensor, k: int, radius: float):
+    """Exact k nearest neighbours of every point inside its own cloud, bounded by `radius`: (idx (N,k) int32, dist2 (N,k) f32),
+    ascending by (dist2, idx), self included; entries at or beyond the radius are (-1, inf).  What the reference's
+    `KDTreeCuda3dIndex.knnSearch` (`ext/pcproc/cuda_kdtree.cu:1173`) feeds to its two kernels."""
+    n, stride = _cloud_input(input_pc)
+    idx = torch.empty((n, int(k)), dtype=torch.int32, device=input_pc.device)
+    dist = torch.empty((n, int(k)), dtype=torch.float32, device=input_pc.device)
+    with _dev(input_pc):
+        ws = _cloud_workspace(input_pc.device, n)
+        _lib.check(_lib.load().dif_knn(_lib.ptr(input_pc), n, stride, int(k), float(radius), _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(ws),
+                                       ws.numel(), _lib.stream_ptr()), "dif_knn")
+    return idx, dist
+
+
+def remove_radius_outlier(input_pc: torch.Tensor, nb_points: int, radius: float) -> torch.Tensor:
+    """(N,) bool: the point has at least `nb_points` points (itself included) closer than `radius`.
+    reference `ext/pcproc/pcproc.cu:160-186`."""
+    n, stride = _cloud_input(input_pc)
+    mask = torch.empty((n,), dtype=torch.bool, device=input_pc.device)
+    with _dev(input_pc):
+        ws = _cloud_workspace(input_pc.device, n)
+        _lib.check(_lib.load().dif_remove_radius_outlier(_lib.ptr(input_pc), n, stride, int(nb_points), float(radius), _lib.ptr(mask),
+                                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "dif_remove_radius_outlier")
+    return mask
+
+
+def estimate_normals(input_pc: torch.Tensor, max_nn: int, radius: float, cam_xyz) -> torch.Tensor:
+    """(N,3) PCA normals over the `max_nn` nearest neighbours inside `radius`, oriented towards `cam_xyz`; NaN rows where
+    fewer than 5 neighbours qualify.  reference `ext/pcproc/pcproc.cu:188-209`."""
+    import ctypes
+    n, stride = _cloud_input(input_pc)
+    out = torch.empty((n, 3), dtype=torch.float32, device=input_pc.device)
+    cam = (ctypes.c_float * 3)(float(cam_xyz[0]), float(cam_xyz[1]), float(cam_xyz[2]))
+    with _dev(input_pc):
+        ws = _cloud_workspace(input_pc.device, n)
+        _lib.check(_lib.load().dif_estimate_normals(_lib.ptr(input_pc), n, stride, int(max_nn), float(radius), cam, _lib.ptr(out), _lib.ptr(ws),
+                                                    ws.numel(), _lib.stream_ptr()), "dif_estimate_normals")
+    return out

@@ -126,6 +126,25 @@ int dif_point_box_filter(const float* points, const float* normals, int64_t N, f
                          float* out_normals, int32_t* out_count, uint32_t* bits, int64_t max_cells, int32_t* word_rank,
                          int64_t* sums, int32_t* scratch, void* stream);
 
+/* ---- 8f-3: point-cloud neighbourhood ops of the tracker's pre-processing (system/tracker.py:105-113) --------------------- */
+/* The reference builds a FLANN-derived CUDA kd-tree per call (ext/pcproc/cuda_kdtree.cu:644-960) and runs an exact kNN
+ * (nearestKernel, :1070; squared L2 of CudaL2::dist, :1152-1155; results ascending by distance).  Here the index is a hashed
+ * uniform grid living in the caller's workspace and the search is exact below `radius`: among the k nearest points of a
+ * query (itself included, order (d2, index)), every one with d2 < radius^2 is reported exactly; the others as idx -1,
+ * dist +inf.  pc is (n, stride) with stride 3 or 4 (the tracker passes xyz0 rows); 1 <= k <= 32.  Points with a non-finite
+ * coordinate have no neighbours and are nobody's neighbour. */
+int64_t dif_cloud_workspace_bytes(int64_t n);
+int dif_knn(const float* pc, int64_t n, int32_t stride, int32_t k, float radius, int32_t* out_idx, float* out_dist, void* workspace,
+            int64_t workspace_bytes, void* stream);
+/* ext/pcproc/pcproc.cu:98-105,160-186 remove_radius_outlier: out_mask[i] = (squared distance to the nb_points-th nearest
+ * point, self included) < radius^2. */
+int dif_remove_radius_outlier(const float* pc, int64_t n, int32_t stride, int32_t nb_points, float radius, uint8_t* out_mask,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+/* ext/pcproc/pcproc.cu:107-158,188-209 estimate_normals: PCA normal over neighbours 1..max_nn-1 of the sorted kNN list while
+ * inside `radius` (fewer than 5 -> NaN), eigenvector by pcproc.cu:21-96, oriented towards cam_xyz (host float[3]). */
+int dif_estimate_normals(const float* pc, int64_t n, int32_t stride, int32_t max_nn, float radius, const float* cam_xyz,
+                         float* out_normals, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- a9: ext/indexing/indexing.cu:89-109 ------------------------------------------------------------------- */
 /* sum[idx[i]][:] += values[i][:], count[idx[i]] += 1 (per sample).  sum (C,L) / count (C) must be zeroed by the
  * caller.  Deterministic is not promised here (float atomics, as the reference); the map path does not use it.  */
