@@ -217,8 +217,24 @@ def _extract(m):
     return m.extract_mesh(4, int(4e6), max_std=0.15, extract_async=False, interpolate=True)
 
 
+def save_reference_map(model):
+    """A map written by the reference's own `DenseIndexedMap.save` (map.py:239-243) after the three seq_small frames:
+    the wire format `di_fusion_amd`'s `load` must keep opening."""
+    intr_s = syn.Intrinsic().scaled(0.125)
+    cfg = syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.4)
+    m = ref_map.DenseIndexedMap(model, cfg.namespace(), 29, torch.device("cpu"))
+    for f in range(3):
+        xyz, nrm = syn.frame_points(syn.Scene(kind="sphere", radius=1.3), f, intr_s, deg_per_frame=20.0)
+        m.integrate_keyframe(xyz, nrm)
+    m.save(HERE / "ref_map_small.pt")
+    print("ref_map_small.pt:", (HERE / "ref_map_small.pt").stat().st_size, "bytes, keys", sorted(m.cold_vars.keys()))
+
+
 def main():
     model, hyper = load_reference_model()
+    if "--map-only" in sys.argv:
+        save_reference_map(model)
+        return
     export_weights(model)
     golden_networks(model)
 
@@ -237,6 +253,7 @@ def main():
     scene, cfg = syn.config_c1()
     run_sequence(model, "seq_c1", scene, cfg, syn.Intrinsic(), n_frames=1, deg_per_frame=0.5,
                  store_inputs=False, store_cubes=False)
+    save_reference_map(model)
 
 
 if __name__ == "__main__":

@@ -190,6 +190,38 @@ def test_capacity_growth_and_save_load(gpu_model, tmp_path):
     assert torch.equal(sdf1, sdf2)
 
 
+def test_loads_a_map_saved_by_the_reference(gpu_model, tmp_path):
+    """tests/golden/ref_map_small.pt was written by the reference's own `DenseIndexedMap.save` (map.py:239-243) after the three
+    seq_small frames; `load` must reproduce the golden state of frame 2, answer `get_sdf` like the reference, and a re-save
+    must open again with the same content (wire format of SURVEY.md 8f-4)."""
+    scene, cfg, intr = CASES["seq_small"]
+    g = np.load(GOLDEN / "seq_small.npz")
+    m = make_map(gpu_model, cfg)
+    m.load(GOLDEN / "ref_map_small.pt")
+    n = int(g["f2_int_n_occupied"])
+    assert m.n_occupied == n
+    idx = m.indexer.cpu().numpy().reshape(-1)
+    nz = np.nonzero(idx != -1)[0]
+    assert np.array_equal(nz, g["f2_int_indexer_nz"]) and np.array_equal(idx[nz], g["f2_int_indexer_val"])
+    assert np.array_equal(m.latent_vecs_pos[:n].cpu().numpy(), g["f2_int_latent_vecs_pos"])
+    assert np.array_equal(m.voxel_obs_count[:n].cpu().numpy(), g["f2_int_voxel_obs_count"])
+    assert np.array_equal(m.latent_vecs[:n].cpu().numpy(), g["f2_int_latent_vecs"])       # the reference's own floats, bit for bit
+    sdf, std, qmask = m.get_sdf(torch.from_numpy(g["probe_xyz"]).to(DEV))
+    assert np.array_equal(qmask.cpu().numpy(), g["probe_mask"])
+    assert np.abs(sdf.cpu().numpy() - g["probe_sdf"]).max() < SDF_TOL
+    # a loaded map has no dirty voxels of its own: a full (no_cache) extraction meshes everything it holds
+    verts, vid, vstd = m.extract_mesh_arrays(4, int(4e6), max_std=0.15, no_cache=True)
+    assert verts.shape[0] > 0
+    m.save(tmp_path / "again.pt")
+    cv = torch.load(tmp_path / "again.pt", map_location="cpu")
+    ref = torch.load(GOLDEN / "ref_map_small.pt", map_location="cpu")
+    assert int(cv["n_occupied"]) == int(ref["n_occupied"])
+    assert torch.equal(cv["indexer"].view(-1), ref["indexer"].view(-1))
+    for k in ("latent_vecs", "latent_vecs_pos", "voxel_obs_count"):
+        assert torch.equal(cv[k][:n], ref[k][:n]), k
+    assert set(ref.keys()) <= set(cv.keys())
+
+
 def test_determinism(gpu_model):
     """Same inputs twice -> bit-identical latents and triangles (the reference's float atomics cannot promise this)."""
     scene, cfg, intr = CASES["seq_small"]
