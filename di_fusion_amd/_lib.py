@@ -57,6 +57,7 @@ SIGNATURES = {
                                           c_float, c_float, POINTER(c_float), POINTER(c_float), c_void_p]),
     "dif_unproject_transform_dev": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
                                               c_float, c_float, c_void_p, c_void_p]),
+    "dif_unproject_transform_frame": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
     "dif_compute_normal_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "dif_filter_depth": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "dif_point_box_filter": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,

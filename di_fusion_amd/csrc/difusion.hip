@@ -102,7 +102,7 @@ int dif_unproject_transform(const float* depth, const float* normal_cam, float* 
     for (int i = 0; i < 9; ++i) P.r[i] = R[i];
     for (int i = 0; i < 3; ++i) P.t[i] = t[i];
     hipLaunchKernelGGL(k_unproject_transform, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth, normal_cam,
-                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P, (const float*)nullptr);
+                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P, (const float*)nullptr, (const dif_frame_t*)nullptr);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -113,7 +113,17 @@ int dif_unproject_transform_dev(const float* depth, const float* normal_cam, flo
     if ((normal_cam == nullptr) != (normal_world == nullptr)) return DIF_EINVAL;
     Pose P = {};
     hipLaunchKernelGGL(k_unproject_transform, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth, normal_cam,
-                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P, pose_dev);
+                       xyz_world, normal_world, H, W, fx, fy, cx, cy, P, pose_dev, (const dif_frame_t*)nullptr);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_unproject_transform_frame(const dif_frame_t* frame_dev, float* xyz_world, float* normal_world, int32_t H, int32_t W, float fx, float fy,
+                                  float cx, float cy, void* stream) {
+    if (!frame_dev || !xyz_world || !normal_world || H <= 0 || W <= 0) return DIF_EINVAL;
+    Pose P = {};
+    hipLaunchKernelGGL(k_unproject_transform, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, (const float*)nullptr,
+                       (const float*)nullptr, xyz_world, normal_world, H, W, fx, fy, cx, cy, P, (const float*)nullptr, frame_dev);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

@@ -27,7 +27,13 @@ struct Pose { float r[9]; float t[3]; };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* __restrict__ depth, const float* __restrict__ ncam,
                                                                  float* __restrict__ xyz, float* __restrict__ nrm, int H, int W,
-                                                                 float fx, float fy, float cx, float cy, Pose P, const float* __restrict__ pose_dev) {
+                                                                 float fx, float fy, float cx, float cy, Pose P, const float* __restrict__ pose_dev,
+                                                                 const dif_frame_t* __restrict__ frame) {
+    if (frame) {                                      // whole frame descriptor in device memory: a captured hipGraph replays on new inputs
+        depth = frame->depth;                         // after one 64-byte upload, without staging copies
+        ncam = frame->normal_cam;
+        pose_dev = frame->pose;
+    }
     if (pose_dev) {                                   // pose read from device memory: lets a captured hipGraph be replayed per frame
 #pragma unroll
         for (int i = 0; i < 9; ++i) P.r[i] = pose_dev[i];

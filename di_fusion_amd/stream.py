@@ -6,6 +6,7 @@ Depth frames are rendered up front and stay resident in HBM; the timed part star
 from __future__ import annotations
 
 import ctypes
+import struct
 from typing import List, Optional
 
 import numpy as np
@@ -146,12 +147,12 @@ class FusionStream:
         N = H * W
         with torch.cuda.device(dev):
             if self._g_in is None:
-                self._g_in = (torch.empty((H, W), dtype=torch.float32, device=dev), torch.empty((H, W, 3), dtype=torch.float32, device=dev),
-                              torch.empty((12,), dtype=torch.float32, device=dev), torch.empty((N,), dtype=torch.uint8, device=dev))
-                self._g_pose_host = [torch.empty((12,), dtype=torch.float32).pin_memory() for _ in range(4)]
+                # frame descriptor (dif_frame_t: two device pointers + pose, 64 bytes) and the prune mask
+                self._g_in = (torch.zeros((64,), dtype=torch.uint8, device=dev), torch.empty((N,), dtype=torch.uint8, device=dev))
+                self._g_frame_host = [torch.zeros((64,), dtype=torch.uint8).pin_memory() for _ in range(4)]
                 self._g_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(4)]
                 self._g_seq = 0
-            depth, ncam, pose, mask = self._g_in
+            frame, mask = self._g_in
             w = m.model.packed.weights_struct(dev)
             tens, _ = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
             graphs = []
@@ -160,8 +161,8 @@ class FusionStream:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 sp = _lib.stream_ptr()
-                _lib.check(lib.dif_unproject_transform_dev(_lib.ptr(depth), _lib.ptr(ncam), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
-                                                           intr.fx, intr.fy, intr.cx, intr.cy, _lib.ptr(pose), sp), "dif_unproject_transform_dev")
+                _lib.check(lib.dif_unproject_transform_frame(_lib.ptr(frame), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
+                                                             intr.fx, intr.fy, intr.cx, intr.cy, sp), "dif_unproject_transform_frame")
                 _lib.check(lib.dif_integrate(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), N, _lib.ptr(mask),
                                              _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate")
                 _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
@@ -171,18 +172,19 @@ class FusionStream:
             self._graph_sig = self._graph_signature()
 
     def step_graph(self, i: int, d2h: str = "new"):
-        """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: two staging copies, a 48-byte
-        pose upload and one graph launch)."""
+        """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: a 64-byte
+        frame descriptor upload (input pointers + pose) and one graph launch)."""
         m = self.map
         N = self.intr.height * self.intr.width
         prune = int(m.args.prune_min_vox_obs)
         may_add = 7 * (N // (prune + 1)) if prune > 0 else 7 * N
+        out = None
         with torch.cuda.device(self.device):
             if m._ws is None or m._xbuf is None or m._cache is None:
                 raise RuntimeError("run at least one eager step before step_graph (buffers are sized there)")
             if m._n_occ_ub + may_add > m._capacity:
                 if self._pending is not None:                    # make the bound exact before deciding to grow
-                    out_prev = self._finish_frame(self._pending, d2h)
+                    out = self._finish_frame(self._pending, d2h)
                     self._pending = None
             m._ensure_capacity(may_add)
             if m._gc_wanted:
@@ -193,13 +195,11 @@ class FusionStream:
             if self._copy_done is not None:
                 torch.cuda.current_stream().wait_event(self._copy_done)
                 self._copy_done = None
-            depth, ncam, pose, mask = self._g_in
+            frame, mask = self._g_in
             R, t = self.poses[i]
-            ph = self._g_pose_host[i % 4]
-            ph[:9] = torch.tensor(list(R)); ph[9:] = torch.tensor(list(t))
-            pose.copy_(ph, non_blocking=True)
-            depth.copy_(self.depth[i], non_blocking=True)
-            ncam.copy_(self.ncam[i], non_blocking=True)
+            fh = self._g_frame_host[self._g_seq % 4]
+            fh.numpy()[:] = np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8)
+            frame.copy_(fh, non_blocking=True)
             g, _ = self._graphs[0]
             g.replay()
             m.mesh_cache.invalidate_host_copy()
@@ -209,7 +209,6 @@ class FusionStream:
             ev = torch.cuda.Event()
             ev.record()
             h = dict(event=ev, counters=pc, epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles)
-        out = None
         if self._pending is not None:
             out = self._finish_frame(self._pending, d2h)
         self._pending = h

@@ -111,6 +111,15 @@ int dif_unproject_transform(const float* depth, const float* normal_cam, float* 
 int dif_unproject_transform_dev(const float* depth, const float* normal_cam, float* xyz_world, float* normal_world,
                                 int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* pose_dev,
                                 void* stream);
+/* Same, with the whole frame input behind one device-resident descriptor: a captured hipGraph of the per-frame chain is replayed
+ * on new inputs after a single 64-byte upload (no staging copies of depth / normals into fixed buffers). */
+typedef struct dif_frame {
+    const float* depth;        /* (H,W) f32, device */
+    const float* normal_cam;   /* (H,W,3) f32, device */
+    float pose[12];            /* R row-major (9) then t (3) */
+} dif_frame_t;
+int dif_unproject_transform_frame(const dif_frame_t* frame_dev, float* xyz_world, float* normal_world, int32_t H, int32_t W,
+                                  float fx, float fy, float cx, float cy, void* stream);
 /* ext/imgproc/imgproc.cu:98-160: pc (H,W,3) -> normal_weight (H,W,4), w=-1 where invalid. */
 int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, int32_t W, void* stream);
 
