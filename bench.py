@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--noise", type=int, default=0)
     ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
+    ap.add_argument("--overlap", type=int, default=0, help="1: the extract of frame i-1 runs beside the integrate of frame i (two streams, one gate "
+                    "event; bit-identical results); needs --graph 1")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the frame's launches from a captured hipGraph; every --sample-every-th frame runs "
                     "eagerly with HIP events around the MFMA kernels (the roofline sample)")
     ap.add_argument("--sample-every", type=int, default=8)
@@ -99,20 +101,29 @@ def main():
         torch.cuda.synchronize()
 
     def run(i):
+        if a.overlap and i >= 1:
+            return stream.step_overlap(i, a.d2h, graph=bool(a.graph and (i % a.sample_every) != 0))
         if a.graph and i >= 2 and (i % a.sample_every) != 0:
             return stream.step_graph(i, a.d2h)
         return stream.step_pipelined(i, a.d2h) if (a.pipeline or a.graph) else stream.step(i, a.d2h)
 
+    def drain():
+        if a.overlap:
+            stream.flush_overlap(a.d2h)         # includes the extract of the last integrated frame: nothing is left outside the clock
+        else:
+            stream.flush(a.d2h)
+
     for i in range(a.warmup):
         run(i)
-    stream.flush(a.d2h)
+    drain()
+    stats_base = len(stream.stats)
     lib.dif_profile_read((ctypes.c_double * _lib.PROF_COUNT)(), (ctypes.c_int64 * _lib.PROF_COUNT)(), 1)
     lib.dif_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
     for i in range(a.warmup, n_frames):
         run(i)
-    stream.flush(a.d2h)
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     lib.dif_profile_enable(0)
@@ -125,9 +136,11 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        st = stream.stats[a.warmup:]
+        st = stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
         timed_idx = [j for j in range(a.steps) if not (a.graph and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
+        if a.overlap:   # unit j = integrate of frame j beside the extract of frame j-1; the flush adds one extract-only entry
+            timed_idx = [j for j in timed_idx if j < len(st)]
         sst = [st[j] for j in timed_idx]
         rows_enc = sum(s["M"] for s in sst)
         rows_dec_lat = sum(s["B"] * 64 for s in sst)
@@ -163,7 +176,8 @@ def main():
                                        "c3": "C3 128^3 grid 0.05 m, ScanNet-shape 6 m room with boxes"}[a.config] +
                           ", 640x480 orbit stream 0.5 deg/frame, all 307200 pixels integrated and meshed every frame, resolution 4, fast decode, max_std 0.15",
                           "points_per_frame": intr.width * intr.height, "parallelism": f"{world} independent subsequences (one map per GPU)", "d2h_per_frame": a.d2h, "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1,
-                          "launch": (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager"),
+                          "launch": (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager") +
+                                    (", extract of frame i-1 overlapped with integrate of frame i on a second stream" if a.overlap else ""),
                           "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1) for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")}},
                "roofline": roof}
         if not a.no_cpu_baseline and world == 1:

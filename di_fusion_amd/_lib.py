@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libdifusion.so"
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE = range(18)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_N_FUSED = range(19)
 C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "sort"]
 PROF_COUNT = 8
@@ -32,7 +32,7 @@ class DifMap(Structure):
                 ("frame_count", c_void_p), ("grid_bits", c_void_p), ("vbm", c_void_p),
                 ("seg_start", c_void_p), ("seg_cnt", c_void_p), ("item_start", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
-                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32)]
+                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("grid_bits_extract", c_void_p)]
 
 
 class DifWeights(Structure):
@@ -73,6 +73,10 @@ SIGNATURES = {
                                 c_int64, c_void_p]),
     "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
                               c_int32, c_int32, c_void_p]),
+    "dif_extract_overlapped": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
+                                         c_int32, c_int32, c_void_p, c_void_p]),
+    "dif_integrate_gated": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_int64, c_void_p, c_void_p]),
     "dif_mesh_cache_compact": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "dif_mesh_cache_reindex": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_int64, c_void_p]),
     "dif_marching_cubes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p,

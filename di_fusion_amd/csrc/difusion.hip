@@ -346,8 +346,8 @@ int64_t dif_integrate_workspace_bytes(int64_t N) {
     return ws.total_bytes;
 }
 
-int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
-                  void* wsp, int64_t ws_bytes, void* stream_) {
+static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
+                          void* wsp, int64_t ws_bytes, hipEvent_t gate, void* stream_) {
     if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0) return DIF_EINVAL;
     if (N == 0) return DIF_OK;
     if (!xyz || !normal || !unq_mask || !wsp) return DIF_EINVAL;
@@ -401,10 +401,23 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
                            (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot, (const int*)C, ws.partial);
         DIF_CHECK_LAUNCH();
     }
+    // k_fuse is the only kernel of an integrate that writes what an extract reads (latents, observation counts, dirty flags)
+    if (gate && hipStreamWaitEvent(s, gate, 0) != hipSuccess) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.partial,
                        (const int*)map->item_start, map->seg_cnt, map->seg_start, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
+}
+
+int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
+                  void* wsp, int64_t ws_bytes, void* stream_) {
+    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, nullptr, stream_);
+}
+
+int dif_integrate_gated(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
+                        void* wsp, int64_t ws_bytes, void* gate_event, void* stream_) {
+    if (!gate_event) return DIF_EINVAL;
+    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, (hipEvent_t)gate_event, stream_);
 }
 
 // ---- decoder launches ------------------------------------------------------------------------------------------
@@ -565,9 +578,13 @@ int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t n
 }
 
 // ---- extract ---------------------------------------------------------------------------------------------------
-int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
-                float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
+static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
+                        float max_std, int32_t no_cache, int32_t scale_vertices, bool overlapped, hipEvent_t decode_done, void* stream_) {
     if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
+    if (overlapped && (!map->grid_bits_extract || !decode_done || no_cache)) return DIF_EINVAL;
+    // what an overlapped extract may look at while the next integrate runs: the slots of the last COMPLETED integrate, its own bitmap
+    const int* n_slots = map->counters + (overlapped ? DIF_C_N_FUSED : DIF_C_N_OCCUPIED);
+    uint32_t* const bits = overlapped ? map->grid_bits_extract : map->grid_bits;
     if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_tri || !buf->cache_id || !buf->cache_std || !buf->cache_alive)
         return DIF_EINVAL;
     if (!map->tri_start || !map->tri_n) return DIF_EINVAL;
@@ -586,16 +603,16 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
         const int64_t own_lo = tiled ? map->own_x_lo * plane : 0, own_hi = tiled ? map->own_x_hi * plane : grid;
         if (tiled) {
             hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th, map->dirty,
-                               (const int64_t*)map->latent_vecs_pos, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, map->grid_bits,
-                               (const int*)C, own_lo, own_hi);
+                               (const int64_t*)map->latent_vecs_pos, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, bits,
+                               n_slots, own_lo, own_hi);
             DIF_CHECK_LAUNCH();
         }
         DirtyFunctor f{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels, g, map->ignore_count_th,
-                       map->indexer, map->voxel_obs_count, map->grid_bits, own_lo, own_hi};
-        if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+                       map->indexer, map->voxel_obs_count, bits, own_lo, own_hi};
+        if (launch_scan(f, n_slots, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     }
     {
-        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
+        OccFunctor f{bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
         int nwords = (int)((grid + 31) / 32);
         if (launch_scan(f, nullptr, nwords, nwords, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     }
@@ -656,6 +673,8 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
         rc = launch_decode(A, w, buf->max_voxels * (int64_t)((R3 + 31) / 32), s);
         if (rc != DIF_OK) return rc;
     }
+    // nothing below reads latents, observation counts or dirty flags: the next frame's k_fuse may go ahead
+    if (decode_done && hipEventRecord(decode_done, s) != hipSuccess) return DIF_ELAUNCH;
     // marching cubes (map.py:689-691)
     McArgs a = {};
     a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
@@ -680,6 +699,16 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
                        C, buf->max_triangles, buf->cache_capacity);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
+}
+
+int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
+                float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
+    return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, false, nullptr, stream_);
+}
+
+int dif_extract_overlapped(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
+                           float max_std, int32_t no_cache, int32_t scale_vertices, void* decode_done_event, void* stream_) {
+    return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, true, (hipEvent_t)decode_done_event, stream_);
 }
 
 int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,

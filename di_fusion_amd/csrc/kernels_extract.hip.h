@@ -32,9 +32,9 @@ __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float
 // which neighbours are in the batch, mc_interp_kernel.cu:17-24).
 __global__ void __launch_bounds__(DIF_BLOCK) k_mark_halo_dirty(Geo g, float ignore_th, uint8_t* __restrict__ dirty, const int64_t* __restrict__ pos,
                                                              const int64_t* __restrict__ indexer, const float* __restrict__ obs,
-                                                             uint32_t* __restrict__ bits, const int* __restrict__ counters, int64_t own_lo,
+                                                             uint32_t* __restrict__ bits, const int* __restrict__ n_ptr, int64_t own_lo,
                                                              int64_t own_hi) {
-    const int n = counters[DIF_C_N_OCCUPIED];
+    const int n = *n_ptr;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         if (!dirty[s]) continue;
         const int64_t p = pos[s];

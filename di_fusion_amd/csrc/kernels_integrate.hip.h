@@ -309,5 +309,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
     int tu = block_sum(updated, smem);
     int tr = block_sum(rows, smem);
     if (threadIdx.x == 0 && tu) { atomicAdd(counters + DIF_C_C, tu); atomicAdd(counters + DIF_C_M, tr); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_N_FUSED] = n_occ;     // the slots an overlapped extract may look at
 }
 

@@ -144,6 +144,7 @@ class DenseIndexedMap:
             self._indexer = torch.full((self._grid,), -1, device=device, dtype=torch.long)
             self._frame_count = torch.zeros((self._grid,), device=device, dtype=torch.int32)
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
+            self._grid_bits_x = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)   # dif_extract_overlapped's own
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
         self._capacity = 0
         self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
@@ -200,6 +201,7 @@ class DenseIndexedMap:
         m.counters = _lib.ptr(self._counters)
         m.frame_count = _lib.ptr(self._frame_count)
         m.grid_bits = _lib.ptr(self._grid_bits)
+        m.grid_bits_extract = _lib.ptr(self._grid_bits_x)
         m.vbm = _lib.ptr(vbm)
         m.seg_start = _lib.ptr(seg_start)
         m.seg_cnt = _lib.ptr(seg_cnt)
@@ -298,6 +300,7 @@ class DenseIndexedMap:
         self._obs[:n] = cv["voxel_obs_count"][:n]
         self._counters.zero_()
         self._counters[_lib.C_N_OCCUPIED] = n
+        self._counters[_lib.C_N_FUSED] = n
         self._n_occ_ub = n
         self.mesh_cache.clear_all()
 

@@ -52,6 +52,7 @@ enum {
     DIF_C_WORK = 15,        /* scratch                                                                    */
     DIF_C_CACHE_DEAD = 16,  /* dead entries in the mesh-cache log (replaced triangles awaiting compaction)  */
     DIF_C_CACHE_LIVE = 17,  /* triangles written by the last dif_mesh_cache_compact                        */
+    DIF_C_N_FUSED = 18,     /* n_occupied as of the last completed integrate (what an overlapped extract looks at)   */
     DIF_C_COUNT = 32
 };
 
@@ -83,6 +84,7 @@ typedef struct dif_map {
      * voxel lies outside [own_x_lo - halo, own_x_hi + halo) are ignored by integrate, and only owned voxels are meshed.
      * 0, nx, 0 = the whole grid (single-map behaviour). */
     int32_t own_x_lo, own_x_hi, halo;
+    uint32_t* grid_bits_extract;    /* [ceil(nx*ny*nz/32)] idle 0 : private bitmap of dif_extract_overlapped (NULL: share grid_bits) */
 } dif_map_t;
 
 /* Network weights packed for the MFMA kernels by di_fusion_amd/network/packing.py (layout documented there). */
@@ -202,6 +204,20 @@ typedef struct dif_extract_buffers {
  * (map.py:698) instead of voxel units.  Triangles come out in canonical order (dirty voxel, cell, table order). */
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution,
                 int32_t fast, float max_std, int32_t no_cache, int32_t scale_vertices, void* stream);
+
+/* ---- frame overlap: extract of frame i on one stream while frame i+1 integrates on another (no reference counterpart) ----
+ * The only state the two halves share is what k_fuse writes (latents, observation counts, dirty flags) and what the decode
+ * reads.  dif_extract_overlapped records `decode_done_event` (a hipEvent_t) on its stream after the last kernel that reads
+ * them; dif_integrate_gated makes its stream wait for `gate_event` right before the one kernel that writes them.  Everything
+ * else the extract looks at is private to it: the slot count of the last COMPLETED integrate (DIF_C_N_FUSED), its own bitmap
+ * (map->grid_bits_extract, required), vbm / tri_* / the mesh-cache log.  Slots allocated concurrently are invisible to it
+ * (not dirty, observation count 0, vbm -1), so the result is bit-identical to running the two calls back to back.
+ * Call order on the host (also under stream capture): dif_extract_overlapped first, then dif_integrate_gated. */
+int dif_extract_overlapped(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution,
+                           int32_t fast, float max_std, int32_t no_cache, int32_t scale_vertices, void* decode_done_event,
+                           void* stream);
+int dif_integrate_gated(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N,
+                        uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* gate_event, void* stream);
 
 /* Materialise the live cache entries in log order into (out_tri, out_id, out_std); count -> counters[DIF_C_CACHE_LIVE].
  * scratch: int32 [4096]. */
