@@ -6,11 +6,12 @@ There is no CPU fallback: every compute entry point of this package goes through
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_uint8, c_void_p
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libdifusion.so"
+LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "libdifusion.so"    # DIF_LIB: instrumented builds (tools/)
 
 # counters (difusion.h)
 C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_N_FUSED = range(19)

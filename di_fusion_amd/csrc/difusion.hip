@@ -701,6 +701,12 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     return DIF_OK;
 }
 
+#ifdef DIF_TRACE
+int dif_trace_read(unsigned long long* out, int64_t n) {      // host copy of g_vd_trace (n <= 2048*8)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vd_trace), (size_t)n * 8) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+}
+#endif
+
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                 float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, false, nullptr, stream_);

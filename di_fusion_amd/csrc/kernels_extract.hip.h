@@ -323,9 +323,18 @@ struct VoxelDecodeArgs {
 #define VD_MAX_R2 64
 #define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3)      /* low sdf + low std */
 
+#ifdef DIF_TRACE            // tools/trace_decode.py: per-wave phase timestamps (100 MHz wall clock) of the last k_decode_voxels launch
+__device__ unsigned long long g_vd_trace[2048 * 8];
+#define VD_STAMP(slot) do { if (lane_id() == 0) g_vd_trace[((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define VD_STAMP(slot) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    VD_STAMP(0);
     stage_weights(lds, wblob, DEC_LDS_FLOATS);
+    VD_STAMP(1);
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
     float* w_low_sdf = lds + ((DEC_LDS_FLOATS + 3) & ~3) + wid * VD_WAVE_LDS_FLOATS;
@@ -358,6 +367,7 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        VD_STAMP(2);
         // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z ----
         const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
         unsigned sel = 0;
@@ -376,6 +386,7 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
                 if (fabsf(sv) < 0.05f) sel |= 1u << jz;
             }
         }
+        VD_STAMP(3);
         const int c = __popc(sel);
         const int incl = wave_incl_scan(c);
         const int total = __shfl(incl, 63);
@@ -391,6 +402,8 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
             }
         }
         __builtin_amdgcn_wave_barrier();
+        VD_STAMP(4);
     }
+    VD_STAMP(5);
 }
 
