@@ -120,39 +120,42 @@ struct TopK {
     }
 };
 
-// pcproc.cu:21-96 (eigenvector of the smallest eigenvalue of a symmetric 3x3 matrix, trigonometric closed form).  The phase
-// shift is added and its cosine taken in double precision there (M_PI is a double constant), mirrored here.
-__device__ inline void sym3eig_min(float a11, float a12, float a13, float a21, float a22, float a23, float a31, float a32, float a33,
-                                   float& nx, float& ny, float& nz) {
-    const float p1 = a12 * a12 + a13 * a13 + a23 * a23;
-    const float q = (a11 + a22 + a33) / 3.0f;
-    const float p2 = (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) + (a33 - q) * (a33 - q) + 2 * p1;
-    const float p = sqrtf(p2 / 6.0f);
+// Unit eigenvector of the smallest eigenvalue of a symmetric 3x3 matrix M (rows m0, m1, m2), as pcproc.cu:21-96 computes it:
+// eigenvalue by the trigonometric closed form on B = (M - q I) / p, eigenvector = the largest of the three pairwise cross products
+// of the rows of (M - lambda I).  Operation order follows the reference so that results agree to the last few ulps; its phase shift
+// and cosine are evaluated in double precision (M_PI is a double constant there), mirrored here.
+struct Row3 { float x, y, z; };
+
+__device__ __forceinline__ Row3 cross3(const Row3& u, const Row3& v) {
+    return Row3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+}
+
+__device__ __forceinline__ float norm2_3(const Row3& u) { return u.x * u.x + u.y * u.y + u.z * u.z; }
+
+__device__ inline Row3 smallest_eigenvector(Row3 m0, Row3 m1, Row3 m2) {
+    const float off2 = m0.y * m0.y + m0.z * m0.z + m1.z * m1.z;
+    const float q = (m0.x + m1.y + m2.z) / 3.0f;
+    const float dev2 = (m0.x - q) * (m0.x - q) + (m1.y - q) * (m1.y - q) + (m2.z - q) * (m2.z - q) + 2 * off2;
+    const float p = sqrtf(dev2 / 6.0f);
     const float ip = 1.0f / p;
-    const float b11 = ip * (a11 - q), b12 = ip * a12, b13 = ip * a13;
-    const float b21 = ip * a21, b22 = ip * (a22 - q), b23 = ip * a23;
-    const float b31 = ip * a31, b32 = ip * a32, b33 = ip * (a33 - q);
-    float r = b11 * b22 * b33 + b12 * b23 * b31 + b13 * b21 * b32 - b13 * b22 * b31 - b12 * b21 * b33 - b11 * b23 * b32;
-    r = r / 2.0f;
+    const Row3 b0{ip * (m0.x - q), ip * m0.y, ip * m0.z}, b1{ip * m1.x, ip * (m1.y - q), ip * m1.z}, b2{ip * m2.x, ip * m2.y, ip * (m2.z - q)};
+    float half_det = b0.x * b1.y * b2.z + b0.y * b1.z * b2.x + b0.z * b1.x * b2.y - b0.z * b1.y * b2.x - b0.y * b1.x * b2.z - b0.x * b1.z * b2.y;
+    half_det = half_det / 2.0f;
+    const double third_turn = 2 * 3.14159265358979323846 / 3;
     float phi;
-    if (r <= -1) phi = (float)(3.14159265358979323846 / 3.0);
-    else if (r >= 1) phi = 0;
-    else phi = acosf(r) / 3.0f;
-    const float ev = (float)((double)q + (double)(2 * p) * cos((double)phi + (2 * 3.14159265358979323846 / 3)));
-    a11 -= ev; a22 -= ev; a33 -= ev;
-    const float r12_1 = a12 * a23 - a13 * a22, r12_2 = a13 * a21 - a11 * a23, r12_3 = a11 * a22 - a12 * a21;
-    const float r13_1 = a12 * a33 - a13 * a32, r13_2 = a13 * a31 - a11 * a33, r13_3 = a11 * a32 - a12 * a31;
-    const float r23_1 = a22 * a33 - a23 * a32, r23_2 = a23 * a31 - a21 * a33, r23_3 = a21 * a32 - a22 * a31;
-    const float d1 = r12_1 * r12_1 + r12_2 * r12_2 + r12_3 * r12_3;
-    const float d2 = r13_1 * r13_1 + r13_2 * r13_2 + r13_3 * r13_3;
-    const float d3 = r23_1 * r23_1 + r23_2 * r23_2 + r23_3 * r23_3;
-    float d_max = d1;
-    int i_max = 0;
-    if (d2 > d_max) { d_max = d2; i_max = 1; }
-    if (d3 > d_max) i_max = 2;
-    if (i_max == 0) { float s = sqrtf(d1); nx = r12_1 / s; ny = r12_2 / s; nz = r12_3 / s; }
-    else if (i_max == 1) { float s = sqrtf(d2); nx = r13_1 / s; ny = r13_2 / s; nz = r13_3 / s; }
-    else { float s = sqrtf(d3); nx = r23_1 / s; ny = r23_2 / s; nz = r23_3 / s; }
+    if (half_det <= -1) phi = (float)(3.14159265358979323846 / 3.0);
+    else if (half_det >= 1) phi = 0;
+    else phi = acosf(half_det) / 3.0f;
+    const float lambda = (float)((double)q + (double)(2 * p) * cos((double)phi + third_turn));
+    m0.x -= lambda; m1.y -= lambda; m2.z -= lambda;
+    const Row3 c01 = cross3(m0, m1), c02 = cross3(m0, m2), c12 = cross3(m1, m2);
+    const float n01 = norm2_3(c01), n02 = norm2_3(c02), n12 = norm2_3(c12);
+    // pick order of the reference: c02 replaces c01 when longer; c12 wins whenever it is longer than the better of those two
+    const bool take02 = n02 > n01;
+    const bool take12 = n12 > (take02 ? n02 : n01);
+    const Row3 c = take12 ? c12 : (take02 ? c02 : c01);
+    const float len = sqrtf(take12 ? n12 : (take02 ? n02 : n01));
+    return Row3{c.x / len, c.y / len, c.z / len};
 }
 
 enum { CLOUD_KNN = 0, CLOUD_OUTLIER = 1, CLOUD_NORMAL = 2 };
@@ -249,8 +252,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
                 c31 += pz * px; c32 += pz * py; c33 += pz * pz;
             }
         }
-        float nx, ny, nz;
-        sym3eig_min(c11, c12, c13, c21, c22, c23, c31, c32, c33, nx, ny, nz);
+        const Row3 nv = smallest_eigenvector(Row3{c11, c12, c13}, Row3{c21, c22, c23}, Row3{c31, c32, c33});
+        float nx = nv.x, ny = nv.y, nz = nv.z;
         const float* self = pc + (size_t)qi * stride;
         const float dt = nx * (self[0] - out.cam[0]) + ny * (self[1] - out.cam[1]) + nz * (self[2] - out.cam[2]);
         if (dt > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
