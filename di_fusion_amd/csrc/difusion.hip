@@ -403,8 +403,9 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     }
     // k_fuse is the only kernel of an integrate that writes what an extract reads (latents, observation counts, dirty flags)
     if (gate && hipStreamWaitEvent(s, gate, 0) != hipSuccess) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.partial,
-                       (const int*)map->item_start, map->seg_cnt, map->seg_start, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for(ws.max_items * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.partial,
+                       (const int*)map->item_start, (const int*)ws.item_slot, map->seg_cnt, map->seg_start, map->latent_vecs, map->voxel_obs_count,
+                       map->dirty, C);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

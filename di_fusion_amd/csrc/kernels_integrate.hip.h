@@ -274,18 +274,20 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
 }
 
 // a10: fusion update (map.py:448-452).  One 32-lane group per slot.
-__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ partial, const int* __restrict__ item_start, int* __restrict__ seg_cnt,
-                                                  int* __restrict__ seg_cursor, float* __restrict__ latent, float* __restrict__ obs,
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ partial, const int* __restrict__ item_start, const int* __restrict__ item_slot,
+                                                  int* __restrict__ seg_cnt, int* __restrict__ seg_cursor, float* __restrict__ latent, float* __restrict__ obs,
                                                   uint8_t* __restrict__ dirty, int* __restrict__ counters) {
     __shared__ int smem[8];
-    const int n_occ = counters[DIF_C_N_OCCUPIED];
+    const int n_items = counters[DIF_C_ITEMS];
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
     const int f = threadIdx.x & 31;
     int updated = 0, rows = 0;
-    for (int s = grp; s < n_occ; s += ngrp) {
-        int cnt = seg_cnt[s];
-        if (cnt <= 0) continue;
-        int it0 = item_start[s], nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
+    // walk the work items (a few thousand) instead of every allocated slot: the first item of a slot fuses the whole slot
+    for (int it0 = grp; it0 < n_items; it0 += ngrp) {
+        const int s = item_slot[it0];
+        if (item_start[s] != it0) continue;
+        const int cnt = seg_cnt[s];
+        const int nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
         if (f < L) {
             long long Si = 0;
             for (int k = 0; k < nit; ++k) Si += partial[(int64_t)(it0 + k) * 32 + f];
@@ -309,6 +311,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
     int tu = block_sum(updated, smem);
     int tr = block_sum(rows, smem);
     if (threadIdx.x == 0 && tu) { atomicAdd(counters + DIF_C_C, tu); atomicAdd(counters + DIF_C_M, tr); }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_N_FUSED] = n_occ;     // the slots an overlapped extract may look at
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_N_FUSED] = counters[DIF_C_N_OCCUPIED];   // the slots an overlapped extract may look at
 }
 
