@@ -20,7 +20,8 @@ constexpr int L = DIF_LATENT_DIM;     // 29
 constexpr int ITEM_ROWS = 32;         // gathered rows per encoder work item = one MFMA tile of 32 points (finest load balance)
 
 __device__ __constant__ int c_mc_edge_table[256];
-__device__ __constant__ signed char c_mc_tri_table[256][16];
+// triangle table rows packed into 16 nibbles (edge id 0..11, 0xF = end): one 8-byte load per cell instead of a table walk in memory
+__device__ __constant__ unsigned long long c_mc_tri_packed[256];
 bool g_tables_uploaded[64] = {};
 
 int upload_tables() {
@@ -28,7 +29,13 @@ int upload_tables() {
     if (hipGetDevice(&dev) != hipSuccess) return DIF_ELAUNCH;
     if (dev < 64 && g_tables_uploaded[dev]) return DIF_OK;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_mc_edge_table), k_mc_edge_table, sizeof(k_mc_edge_table)) != hipSuccess) return DIF_ELAUNCH;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri_table), k_mc_tri_table, sizeof(k_mc_tri_table)) != hipSuccess) return DIF_ELAUNCH;
+    static unsigned long long packed[256];
+    for (int c = 0; c < 256; ++c) {
+        unsigned long long row = 0;
+        for (int i = 0; i < 16; ++i) row |= (unsigned long long)(k_mc_tri_table[c][i] < 0 ? 0xF : (k_mc_tri_table[c][i] & 0xF)) << (4 * i);
+        packed[c] = row;
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri_packed), packed, sizeof(packed)) != hipSuccess) return DIF_ELAUNCH;
     if (dev < 64) g_tables_uploaded[dev] = true;
     return DIF_OK;
 }

@@ -112,19 +112,25 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
         if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): nb[] visible to the whole wave
+        bool any_neg = false, any_pos = false;
         for (int c = lane; c < nc; c += 64) {
             float s, d;
             bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, s, d);
             c_sdf[c] = ok ? s : __builtin_nanf("");
             c_std[c] = ok ? d : 0.0f;
+            any_neg |= ok && s < 0.0f;
+            any_pos |= ok && !(s < 0.0f);
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
         int voxel_total = 0;
-        for (int s0 = 0; s0 < r3; s0 += 64) {
+        // a cell needs corners of both signs to produce a triangle: most dirty voxels off the surface stop here
+        const bool crossing = __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
+        for (int s0 = 0; crossing && s0 < r3; s0 += 64) {
             const int s = s0 + lane;
             int ntri = 0;
             int cube_type = 0;
+            unsigned long long tri_row = ~0ull;
             if (s < r3) {
                 const int rx = s / (r * r), ry = (s / r) % r, rz = s % r;
                 float val[8], sdv[8], pts[8][3];
@@ -148,9 +154,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 #pragma unroll
                         for (int e = 0; e < 12; ++e)
                             if (edge_config & (1 << e)) vl[e * 64] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
-                        for (int i = 0; c_mc_tri_table[cube_type][i] != -1; i += 3) {
-                            float w0 = vl[c_mc_tri_table[cube_type][i] * 64].w, w1 = vl[c_mc_tri_table[cube_type][i + 1] * 64].w,
-                                  w2 = vl[c_mc_tri_table[cube_type][i + 2] * 64].w;
+                        tri_row = c_mc_tri_packed[cube_type];
+                        for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
+                            float w0 = vl[(int)(t3 & 0xF) * 64].w, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].w, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].w;
                             if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
                             ++ntri;
                         }
@@ -166,8 +172,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
             if (EMIT && ntri > 0) {
                 int64_t tl = (int64_t)a.tri_offset[k] + voxel_total + (incl - ntri);      // index among this call's triangles
                 int64_t t = tl + (a.base_ptr ? (int64_t)(*a.base_ptr) : 0);
-                for (int i = 0; c_mc_tri_table[cube_type][i] != -1; i += 3) {
-                    V4 v0 = vl[c_mc_tri_table[cube_type][i] * 64], v1 = vl[c_mc_tri_table[cube_type][i + 1] * 64], v2 = vl[c_mc_tri_table[cube_type][i + 2] * 64];
+                for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
+                    V4 v0 = vl[(int)(t3 & 0xF) * 64], v1 = vl[(int)((t3 >> 4) & 0xF) * 64], v2 = vl[(int)((t3 >> 8) & 0xF) * 64];
                     if (v0.w > a.max_std || v1.w > a.max_std || v2.w > a.max_std) continue;
                     if (tl < a.new_limit && t < a.max_triangles) {
                         V4 vv[3] = {v0, v1, v2};
