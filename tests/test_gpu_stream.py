@@ -117,3 +117,41 @@ def test_frame_descriptor_entry_point_bit_exact(gpu_model):
     nan = lambda x: torch.nan_to_num(x, nan=123.0)
     assert torch.equal(nan(a_xyz), nan(b_xyz)) and torch.equal(nan(a_n), nan(b_n))
     assert lib.dif_unproject_transform_frame(None, _lib.ptr(b_xyz), _lib.ptr(b_n), H, W, 1.0, 1.0, 0.0, 0.0, _lib.stream_ptr()) != 0
+
+
+def test_c3_full_size_invariants(gpu_model):
+    """BASELINE config C3 at full size (128^3 grid, 640x480 frames): no oracle run is affordable here, so pin size-independent
+    properties: slot <-> voxel bijection, conservation of the observation count, idempotence of extract, vertices inside their voxel,
+    and run-to-run bit-identity."""
+    from di_fusion_amd.stream import FusionStream
+    scene, cfg = S.config_c3()
+    finals = []
+    for rep in range(2):
+        st = FusionStream(gpu_model, scene, cfg, S.Intrinsic(), DEV, 5, deg_per_frame=0.5)
+        rows = 0
+        for i in range(5):
+            st.step(i, d2h="none")
+            rows += st.stats[-1]["M"]
+        m = st.map
+        n = m.n_occupied
+        assert n > 15000
+        pos = m.latent_vecs_pos[:n]
+        idx = m.indexer.view(-1)
+        assert torch.equal(idx[pos], torch.arange(n, device=DEV))                     # indexer[pos[s]] == s
+        assert int((idx >= 0).sum()) == n and int(idx.max()) == n - 1                  # and nothing else is allocated
+        assert float(m.voxel_obs_count[:n].double().sum()) == float(rows)              # every gathered row is counted exactly once
+        tri, tid, tstd = m.mesh_cache_tensors()
+        assert tri.shape[0] > 100000
+        vox = torch.stack([tid // (128 * 128), (tid // 128) % 128, tid % 128], -1).float()
+        lo = torch.tensor(cfg.bound_min, device=DEV) + vox * cfg.voxel_size
+        eps = 1e-4
+        assert bool(((tri >= (lo - eps)[:, None, :]) & (tri <= (lo + cfg.voxel_size + eps)[:, None, :])).all())
+        assert bool((tstd <= 0.15).all())                                               # max_std gate (mc_interp_kernel.cu:304)
+        assert bool((idx[tid] >= 0).all())                                              # triangles belong to allocated voxels
+        # nothing is dirty any more: another extract is a no-op
+        before = tri.clone()
+        m.extract_mesh_arrays(4, int(4e6), max_std=0.15, to_host=False)
+        assert m.last_counters["K"] == 0 and m.last_counters["T"] == 0
+        assert torch.equal(m.mesh_cache_tensors()[0], before)
+        finals.append((m.latent_vecs[:n].clone(), before, tid.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(finals[0], finals[1]))
