@@ -99,24 +99,28 @@ struct AllocFunctor {
 __device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
 
 // Wave-aggregated "fetch-add 1" on counter[key] for every lane whose key is valid; returns the lane's unique offset
-// (base + rank among the lanes of the wave that share the key).  One atomic per distinct key per wave.
+// (base + rank among the lanes of the wave that share the key).  One atomic per distinct key per wave, and all of a wave's atomics
+// are in flight together: the grouping loop is pure ALU, the leaders then issue their atomics in ONE instruction and the wave waits
+// for a single round trip however many distinct keys it holds.
 __device__ __forceinline__ int wave_grouped_fetch_add(int* __restrict__ counter, uint32_t key, bool valid) {
     const int lane = lane_id();
-    int result = 0;
+    int my_leader = lane, my_rank = 0, my_group = 0;
     unsigned long long todo = __ballot(valid);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
         const unsigned long long same = __ballot(valid && key == k0);
         if (valid && key == k0) {
-            int base = 0;
-            if (lane == leader) base = atomicAdd(counter + k0, __popcll(same));
-            base = __shfl(base, leader);
-            result = base + __popcll(same & ((1ull << lane) - 1ull));
+            my_leader = leader;
+            my_rank = __popcll(same & ((1ull << lane) - 1ull));
+            my_group = __popcll(same);
         }
         todo &= ~same;
     }
-    return result;
+    int base = 0;
+    if (valid && lane == my_leader) base = atomicAdd(counter + key, my_group);
+    base = __shfl(base, my_leader);
+    return base + my_rank;
 }
 
 // Same grouping, fire-and-forget: nobody waits for the atomic's return value.
