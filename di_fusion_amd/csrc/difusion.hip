@@ -704,7 +704,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
     if (rc != DIF_OK) return rc;
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
-                       C, buf->max_triangles, buf->cache_capacity);
+                       C, buf->max_triangles, buf->cache_capacity, buf->counters_out);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

@@ -265,9 +265,24 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cache_reindex(const int64_t* __re
 
 // end of extract: clear the batch map, publish the log length
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
-                                                            int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
+                                                            int* __restrict__ counters, int64_t new_limit, int64_t capacity,
+                                                            int32_t* __restrict__ counters_out) {
     const int B = counters[DIF_C_B];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {      // wave 0: the frame's counters, final values, for the host (lane 0 owns the three it updates)
+        const int lane = (int)threadIdx.x;
+        int v = lane < DIF_C_COUNT ? counters[lane] : 0;
+        int64_t n_new = counters[DIF_C_T];
+        if (n_new > new_limit) n_new = new_limit;
+        const int64_t old_n = counters[DIF_C_CACHE_T];
+        int64_t tot = old_n + n_new;
+        const bool over = tot > capacity;
+        if (over) tot = capacity;
+        if (lane == DIF_C_CACHE_KEPT) v = (int)old_n;
+        if (lane == DIF_C_CACHE_T) v = (int)tot;
+        if (lane == DIF_C_OVERFLOW && over) v = 5;
+        if (counters_out && lane < DIF_C_COUNT) counters_out[lane] = v;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int64_t n_new = counters[DIF_C_T];
         if (n_new > new_limit) n_new = new_limit;

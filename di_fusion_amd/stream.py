@@ -45,6 +45,7 @@ class FusionStream:
         self._graphs = None
         self._graph_sig = None
         self._g_in = None
+        self._zc = None
         self._ov_graph = None
         self._ov_sig = None
         self._side_stream = torch.cuda.Stream(device=device)
@@ -151,27 +152,35 @@ class FusionStream:
         N = H * W
         with torch.cuda.device(dev):
             if self._g_in is None:
-                # frame descriptor (dif_frame_t: two device pointers + pose, 64 bytes) and the prune mask
                 self._g_in = (torch.zeros((64,), dtype=torch.uint8, device=dev), torch.empty((N,), dtype=torch.uint8, device=dev))
                 self._g_frame_host = [torch.zeros((64,), dtype=torch.uint8).pin_memory() for _ in range(4)]
                 self._g_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(4)]
                 self._g_seq = 0
-            frame, mask = self._g_in
+            if self._zc is None:
+                # Two captured graphs in ping-pong, each bound to its own pinned HOST slots: the first kernel reads the frame descriptor
+                # (dif_frame_t: two device pointers + pose, 64 bytes) straight out of host memory and the last kernel writes the
+                # counters into host memory — no copy kernels on the launch stream.  A slot is reused two frames later, after the host
+                # has finished the frame that used it.
+                self._zc = ([torch.zeros((64,), dtype=torch.uint8).pin_memory() for _ in range(2)],
+                            [torch.zeros((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(2)])
+            _, mask = self._g_in
             w = m.model.packed.weights_struct(dev)
-            tens, _ = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
-            graphs = []
             torch.cuda.synchronize()
-            _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                sp = _lib.stream_ptr()
-                _lib.check(lib.dif_unproject_transform_frame(_lib.ptr(frame), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
-                                                             intr.fx, intr.fy, intr.cx, intr.cy, sp), "dif_unproject_transform_frame")
-                _lib.check(lib.dif_integrate(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), N, _lib.ptr(mask),
-                                             _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate")
-                _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
-                                           0, 1, sp), "dif_extract")
-            graphs.append((g, buf))
+            graphs = []
+            for k in range(2):
+                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+                buf.counters_out = _lib.ptr(self._zc[1][k])
+                frame = self._zc[0][k]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    sp = _lib.stream_ptr()
+                    _lib.check(lib.dif_unproject_transform_frame(_lib.ptr(frame), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
+                                                                 intr.fx, intr.fy, intr.cx, intr.cy, sp), "dif_unproject_transform_frame")
+                    _lib.check(lib.dif_integrate(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), N, _lib.ptr(mask),
+                                                 _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate")
+                    _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
+                                               0, 1, sp), "dif_extract")
+                graphs.append((g, buf))
             self._graphs = graphs
             self._graph_sig = self._graph_signature()
 
@@ -199,17 +208,13 @@ class FusionStream:
             if self._copy_done is not None:
                 torch.cuda.current_stream().wait_event(self._copy_done)
                 self._copy_done = None
-            frame, mask = self._g_in
-            R, t = self.poses[i]
-            fh = self._g_frame_host[self._g_seq % 4]
-            fh.numpy()[:] = np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8)
-            frame.copy_(fh, non_blocking=True)
-            g, _ = self._graphs[0]
-            g.replay()
-            m.mesh_cache.invalidate_host_copy()
-            pc = self._g_counters[self._g_seq % 4]                 # counters read back outside the graph: alternating pinned buffers
+            k = self._g_seq % 2
             self._g_seq += 1
-            pc.copy_(m._counters, non_blocking=True)
+            R, t = self.poses[i]
+            self._zc[0][k].numpy()[:] = np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8)
+            self._graphs[k][0].replay()
+            m.mesh_cache.invalidate_host_copy()
+            pc = self._zc[1][k]                                    # written by the frame's last kernel; read after the event
             ev = torch.cuda.Event()
             ev.record()
             h = dict(event=ev, counters=pc, epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles)

@@ -196,6 +196,8 @@ typedef struct dif_extract_buffers {
     int64_t* cache_id;              /* [cache_capacity]                                                   */
     float* cache_std;               /* [cache_capacity][3]                                                */
     uint8_t* cache_alive;           /* [cache_capacity]                                                   */
+    int32_t* counters_out;          /* optional [DIF_C_COUNT]: the map's counters as of the end of this extract, written by its last
+                                     * kernel; may be device-mapped pinned HOST memory (no copy kernel, readable after a stream sync) */
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
