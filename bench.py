@@ -162,6 +162,29 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream with the mesh left resident in HBM, i.e.
+    # without the per-frame transfer of the new triangles to pinned host memory.  The difference is PCIe + cross-stream traffic, not kernels.
+    hbm_resident = None
+    if world == 1 and a.d2h != "none" and not a.overlap:
+        s2 = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))
+
+        def run2(i):
+            if a.graph and i >= 2 and (i % a.sample_every) != 0:
+                return s2.step_graph(i, "none")
+            return s2.step_pipelined(i, "none") if (a.pipeline or a.graph) else s2.step(i, "none")
+
+        lib.dif_profile_enable(0)
+        for i in range(a.warmup):
+            run2(i)
+        s2.flush("none")
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(a.warmup, n_frames):
+            run2(i)
+        s2.flush("none")
+        torch.cuda.synchronize()
+        hbm_resident = round(a.steps / (time.perf_counter() - t2), 3)
+        del s2
     # BASELINE config C4: after the independent subsequences, ONE all-gather of voxel records over RCCL and a fold into a global map
     # (identical on every rank), meshed once.  Outside the clock (it happens once per sequence, not per frame); reported, never fatal.
     merge_info = None
@@ -227,6 +250,7 @@ def main():
                           "launch": (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager") +
                                     (", extract of frame i-1 overlapped with integrate of frame i on a second stream" if a.overlap else ""),
                           "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1) for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
+                          "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
                           "global_map_merge_after_the_clock": merge_info},
                "roofline": roof}
         if not a.no_cpu_baseline and world == 1:

@@ -725,6 +725,15 @@ int dif_extract_overlapped(const dif_map_t* map, const dif_weights_t* w, const d
     return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, true, (hipEvent_t)decode_done_event, stream_);
 }
 
+int dif_mesh_cache_export(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std, void* stream) {
+    if (!buf || lo < 0 || n < 0 || lo + n > buf->cache_capacity || (n > 0 && (!out_tri || !out_id || !out_std))) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    hipLaunchKernelGGL(k_cache_export, dim3(grid_for(n * 9, DIF_BLOCK, 8)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, (const float*)buf->cache_tri,
+                       (const int64_t*)buf->cache_id, (const float*)buf->cache_std, lo, n, out_tri, out_id, out_std);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
 int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,
                            int64_t out_capacity, int32_t* scratch, void* stream) {
     if (!map || !buf || !out_tri || !out_id || !out_std || !scratch || out_capacity <= 0) return DIF_EINVAL;

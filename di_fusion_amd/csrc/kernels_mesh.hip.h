@@ -228,6 +228,17 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_log_replace(const int64_t* __rest
     if (threadIdx.x == 0 && dead) atomicAdd(counters + DIF_C_CACHE_DEAD, dead);
 }
 
+// Copies log entries [lo, lo+n) into three caller arrays with ONE launch; the destinations may be device-mapped pinned host memory
+// (a streaming caller ships each frame's new triangles this way instead of three copy-engine transfers).
+__global__ void __launch_bounds__(DIF_BLOCK) k_cache_export(const float* __restrict__ tri, const int64_t* __restrict__ id, const float* __restrict__ sd,
+                                                          int64_t lo, int64_t n, float* __restrict__ out_tri, int64_t* __restrict__ out_id,
+                                                          float* __restrict__ out_std) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t j = t0; j < n * 9; j += stride) out_tri[j] = tri[lo * 9 + j];
+    for (int64_t j = t0; j < n * 3; j += stride) out_std[j] = sd[lo * 3 + j];
+    for (int64_t j = t0; j < n; j += stride) out_id[j] = id[lo + j];
+}
+
 struct CacheLiveFunctor {       // ordered compaction of the live log entries
     const float* src_tri; const int64_t* src_id; const float* src_std; const uint8_t* alive;
     float* dst_tri; int64_t* dst_id; float* dst_std;

@@ -77,14 +77,19 @@ class FusionStream:
         self.stats.append(dict(self.map.last_counters))
         return out
 
+    def _before_frame(self):
+        """The D2H of the previous frame's triangles (side stream) reads a region of the mesh-cache LOG that later frames only append
+        behind, so the next frame does not wait for it — unless the log is about to be compacted."""
+        if self.map._gc_wanted and self._copy_done is not None:
+            self._copy_done.synchronize()
+            self._copy_done = None
+
     # ---- pipelined variant: no host wait inside the frame -----------------------------------------------------------------
     def _enqueue_frame(self, i: int):
         intr = self.intr
         R, t = self.poses[i]
         with torch.cuda.device(self.device):
-            if self._copy_done is not None:                      # the buffer this frame's extract overwrites is still being copied out
-                torch.cuda.current_stream().wait_event(self._copy_done)
-                self._copy_done = None
+            self._before_frame()
             _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(self.depth[i]), _lib.ptr(self.ncam[i]), _lib.ptr(self.xyz), _lib.ptr(self.nrm),
                                                            intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
                        "dif_unproject_transform")
@@ -101,12 +106,16 @@ class FusionStream:
                 self._pin = (torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
                              torch.empty((cap, 3), dtype=torch.float32).pin_memory())
             with torch.cuda.device(self.device):
-                # copy on a side stream so it overlaps the next frame's kernels; that frame only READS this buffer
+                # one small kernel on a side stream writes the three arrays straight into pinned host memory; it overlaps the next
+                # frame's kernels, which only READ this part of the log
                 self._copy_stream.wait_event(handle["event"])
                 with torch.cuda.stream(self._copy_stream):
-                    self._pin[0][:n].copy_(tri, non_blocking=True)
-                    self._pin[1][:n].copy_(tid, non_blocking=True)
-                    self._pin[2][:n].copy_(tstd, non_blocking=True)
+                    lo = tri.storage_offset() // 9
+                    b = self.map._cache_struct()
+                    _lib.check(_lib.load().dif_mesh_cache_export(ctypes.byref(b), lo, n, _lib.ptr(self._pin[0]), _lib.ptr(self._pin[1]),
+                                                                 _lib.ptr(self._pin[2]), _lib.stream_ptr()), "dif_mesh_cache_export")
+                    for src in (tri, tid, tstd):
+                        src.record_stream(self._copy_stream)     # the log may be re-allocated (growth) while this is in flight
                     self._copy_done = torch.cuda.Event()
                     self._copy_done.record()
             out = (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
@@ -200,14 +209,12 @@ class FusionStream:
                     out = self._finish_frame(self._pending, d2h)
                     self._pending = None
             m._ensure_capacity(may_add)
+            self._before_frame()
             if m._gc_wanted:
                 m._cache_gc()
             if self._graphs is None or self._graph_sig != self._graph_signature():
                 torch.cuda.synchronize()
                 self._capture_graphs()
-            if self._copy_done is not None:
-                torch.cuda.current_stream().wait_event(self._copy_done)
-                self._copy_done = None
             k = self._g_seq % 2
             self._g_seq += 1
             R, t = self.poses[i]
@@ -272,14 +279,12 @@ class FusionStream:
                 out = self._finish_frame(self._pending, d2h)     # make the bound exact before deciding to grow
                 self._pending = None
             m._ensure_capacity(may_add)
+            self._before_frame()
             if m._gc_wanted:
                 m._cache_gc()
             self._overlap_prepare()
             frame, mask = self._g_in
             w = m.model.packed.weights_struct(self.device)
-            if self._copy_done is not None:
-                torch.cuda.current_stream().wait_event(self._copy_done)
-                self._copy_done = None
             R, t = self.poses[i]
             fh = self._g_frame_host[self._g_seq % 4]
             fh.numpy()[:] = np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8)

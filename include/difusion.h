@@ -221,6 +221,10 @@ int dif_extract_overlapped(const dif_map_t* map, const dif_weights_t* w, const d
 int dif_integrate_gated(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N,
                         uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* gate_event, void* stream);
 
+/* Log entries [lo, lo+n) -> (out_tri, out_id, out_std) in one launch.  The destinations may be device-mapped pinned HOST memory: a
+ * streaming caller ships each call's new triangles (lo = DIF_C_CACHE_KEPT, n = DIF_C_CACHE_T - lo) without copy-engine transfers. */
+int dif_mesh_cache_export(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std,
+                          void* stream);
 /* Materialise the live cache entries in log order into (out_tri, out_id, out_std); count -> counters[DIF_C_CACHE_LIVE].
  * scratch: int32 [4096]. */
 int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,
