@@ -143,6 +143,7 @@ def main():
     if a.graph and not a.overlap and a.warmup >= 1 and stream._graphs is None:
         torch.cuda.synchronize()
         with torch.cuda.device(dev):
+            stream._graph_export = (a.d2h == "new")
             stream._capture_graphs()            # a short warmup never reached the first replay: capture outside the clock
     stats_base = len(stream.stats)
     lib.dif_profile_read((ctypes.c_double * _lib.PROF_COUNT)(), (ctypes.c_int64 * _lib.PROF_COUNT)(), 1)

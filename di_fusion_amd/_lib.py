@@ -48,7 +48,7 @@ class DifExtractBuffers(Structure):
                 ("refine_list", c_void_p), ("tri_count", c_void_p), ("tri_offset", c_void_p), ("block_tmp", c_void_p),
                 ("max_triangles", c_int64), ("cache_capacity", c_int64),
                 ("cache_tri", c_void_p), ("cache_id", c_void_p), ("cache_std", c_void_p), ("cache_alive", c_void_p),
-                ("counters_out", c_void_p)]
+                ("counters_out", c_void_p), ("out_tri", c_void_p), ("out_id", c_void_p), ("out_std", c_void_p), ("out_capacity", c_int64)]
 
 
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)

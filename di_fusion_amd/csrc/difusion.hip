@@ -533,7 +533,8 @@ static int mc_setup(const McArgs& a, size_t& lds_bytes, int& blocks, int64_t K_u
     return DIF_OK;
 }
 
-static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
+static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, bool freeze_log,
+                             hipStream_t s) {
     size_t lds_bytes; int blocks;
     int rc = mc_setup(a, lds_bytes, blocks, K_upper);
     if (rc != DIF_OK) return rc;
@@ -544,7 +545,7 @@ static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int3
         hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
     }
     DIF_CHECK_LAUNCH();
-    TriScanFunctor f{tri_count, tri_offset, counters};
+    TriScanFunctor f{tri_count, tri_offset, counters, freeze_log ? 1 : 0};
     return launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s);
 }
 
@@ -563,7 +564,7 @@ static int mc_emit(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_o
 }
 
 static int run_marching_cubes(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
-    int rc = mc_count_and_scan(a, K_upper, tri_count, tri_offset, block_tmp, counters, s);
+    int rc = mc_count_and_scan(a, K_upper, tri_count, tri_offset, block_tmp, counters, false, s);
     if (rc != DIF_OK) return rc;
     return mc_emit(a, K_upper, tri_count, tri_offset, s);
 }
@@ -687,7 +688,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     McArgs a = {};
     a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
     a.vbm = map->vbm; a.V = map->capacity; a.cube_sdf = buf->cube_sdf; a.cube_std = buf->cube_std; a.R = R; a.max_std = max_std;
-    a.max_triangles = buf->cache_capacity; a.new_limit = buf->max_triangles; a.base_ptr = C + DIF_C_CACHE_T;     // append at the log's end
+    a.max_triangles = buf->cache_capacity; a.new_limit = buf->max_triangles; a.base_ptr = C + DIF_C_CACHE_KEPT;  // append at the log's end (frozen by the scan)
     a.triangles = buf->cache_tri; a.tri_id = buf->cache_id; a.tri_std = buf->cache_std; a.tri_alive = buf->cache_alive;
     a.scale = scale_vertices ? 1 : 0; a.vs = map->voxel_size; a.bx = map->bound_min[0]; a.by = map->bound_min[1]; a.bz = map->bound_min[2];
     if (no_cache) {                                                                                               // map.py:614-616
@@ -695,7 +696,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (hipMemsetAsync(C + DIF_C_CACHE_DEAD, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
         if (hipMemsetAsync(map->tri_n, 0, sizeof(int32_t) * (size_t)map->capacity, s) != hipSuccess) return DIF_ELAUNCH;
     }
-    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, s);
+    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, true, s);
     if (rc != DIF_OK) return rc;
     hipLaunchKernelGGL(k_log_replace, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks,
                        (const int32_t*)buf->tri_count, (const int32_t*)buf->tri_offset, (const int64_t*)map->indexer, map->tri_start, map->tri_n,
@@ -704,7 +705,8 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
     if (rc != DIF_OK) return rc;
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
-                       C, buf->max_triangles, buf->cache_capacity, buf->counters_out);
+                       C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
+                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity});
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

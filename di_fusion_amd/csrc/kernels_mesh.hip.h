@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_log_replace(const int64_t* __rest
                                                          int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
     __shared__ int smem[8];
     const int K = counters[DIF_C_K];
-    const int64_t log_n = counters[DIF_C_CACHE_T];
+    const int64_t log_n = counters[DIF_C_CACHE_KEPT];     // frozen by the triangle scan
     int dead = 0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
         const int c = tri_count[k];
@@ -274,34 +274,43 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cache_reindex(const int64_t* __re
     }
 }
 
-// end of extract: clear the batch map, publish the log length
+// end of extract: clear the batch map, publish the log length, hand the call's counters and (optionally) its new triangles to the caller.
+// Everything here reads DIF_C_CACHE_KEPT (the log length BEFORE this call, frozen by TriScanFunctor::finish) and DIF_C_T; only the last
+// statement moves DIF_C_CACHE_T, so workgroups may start in any order.
+struct ExtractOut {
+    int32_t* counters_out;          // [DIF_C_COUNT] or NULL
+    float* tri; int64_t* id; float* sd; int64_t capacity;      // this call's new triangles (first `capacity` of them) or NULL
+};
+
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
                                                             int* __restrict__ counters, int64_t new_limit, int64_t capacity,
-                                                            int32_t* __restrict__ counters_out) {
+                                                            const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
+                                                            const float* __restrict__ log_std, ExtractOut out) {
     const int B = counters[DIF_C_B];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
-    if (blockIdx.x == 0 && threadIdx.x < 64) {      // wave 0: the frame's counters, final values, for the host (lane 0 owns the three it updates)
+    const int64_t kept = counters[DIF_C_CACHE_KEPT];
+    int64_t n_new = counters[DIF_C_T];
+    if (n_new > new_limit) n_new = new_limit;
+    int64_t tot = kept + n_new;
+    const bool over = tot > capacity;
+    if (over) { tot = capacity; n_new = capacity - kept; }
+    if (out.tri) {                                  // destinations may be device-mapped pinned host memory: coalesced, one pass
+        const int64_t n = n_new < out.capacity ? n_new : out.capacity;
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (int64_t j = t0; j < n * 9; j += stride) out.tri[j] = log_tri[kept * 9 + j];
+        for (int64_t j = t0; j < n * 3; j += stride) out.sd[j] = log_std[kept * 3 + j];
+        for (int64_t j = t0; j < n; j += stride) out.id[j] = log_id[kept + j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {      // wave 0: the call's counters with their final values, then the update itself
         const int lane = (int)threadIdx.x;
         int v = lane < DIF_C_COUNT ? counters[lane] : 0;
-        int64_t n_new = counters[DIF_C_T];
-        if (n_new > new_limit) n_new = new_limit;
-        const int64_t old_n = counters[DIF_C_CACHE_T];
-        int64_t tot = old_n + n_new;
-        const bool over = tot > capacity;
-        if (over) tot = capacity;
-        if (lane == DIF_C_CACHE_KEPT) v = (int)old_n;
         if (lane == DIF_C_CACHE_T) v = (int)tot;
         if (lane == DIF_C_OVERFLOW && over) v = 5;
-        if (counters_out && lane < DIF_C_COUNT) counters_out[lane] = v;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int64_t n_new = counters[DIF_C_T];
-        if (n_new > new_limit) n_new = new_limit;
-        const int64_t old_n = counters[DIF_C_CACHE_T];
-        int64_t tot = old_n + n_new;
-        if (tot > capacity) { tot = capacity; counters[DIF_C_OVERFLOW] = 5; }
-        counters[DIF_C_CACHE_KEPT] = (int)old_n;
-        counters[DIF_C_CACHE_T] = (int)tot;
+        if (out.counters_out && lane < DIF_C_COUNT) out.counters_out[lane] = v;
+        if (lane == 0) {
+            if (over) counters[DIF_C_OVERFLOW] = 5;
+            counters[DIF_C_CACHE_T] = (int)tot;
+        }
     }
 }
 
@@ -309,9 +318,13 @@ struct TriScanFunctor {
     const int32_t* tri_count;
     int32_t* tri_offset;
     int* counters;
+    int freeze_log_length;      // the mesh-cache path: DIF_C_CACHE_KEPT = log length before this call (read by everything after the scan)
     __device__ int count(int k) const { return tri_count[k]; }
     __device__ void emit(int k, int offset) const { tri_offset[k] = offset; }
-    __device__ void finish(int total) const { counters[DIF_C_T] = total; }
+    __device__ void finish(int total) const {
+        counters[DIF_C_T] = total;
+        if (freeze_log_length) counters[DIF_C_CACHE_KEPT] = counters[DIF_C_CACHE_T];
+    }
 };
 
 // =================================================================================================================

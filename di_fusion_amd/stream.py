@@ -44,6 +44,7 @@ class FusionStream:
         self._copy_done = None
         self._graphs = None
         self._graph_sig = None
+        self._graph_export = True                                # captured graphs also hand each frame's new triangles to the host
         self._g_in = None
         self._zc = None
         self._ov_graph = None
@@ -96,29 +97,40 @@ class FusionStream:
         self.map.integrate_keyframe(self.xyz, self.nrm)
         return self.map.extract_mesh_enqueue(self.resolution, self.max_n_triangles, max_std=self.max_std)
 
+    HOST_OUT_TRIANGLES = 1 << 18                                 # pinned staging per graph: 14 MB; larger updates fall back to _export_new
+
+    def _export_new(self, handle, tri, tid, tstd):
+        """Eager frames (and oversized updates): one small kernel on a side stream writes the three arrays straight into pinned host
+        memory; it overlaps the next frame's kernels, which only READ this part of the log."""
+        n = tri.size(0)
+        if self._pin is None or self._pin[0].size(0) < n:
+            cap = max(1 << 18, 2 * n)
+            self._pin = (torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
+                         torch.empty((cap, 3), dtype=torch.float32).pin_memory())
+        with torch.cuda.device(self.device):
+            self._copy_stream.wait_event(handle["event"])
+            with torch.cuda.stream(self._copy_stream):
+                lo = tri.storage_offset() // 9
+                b = self.map._cache_struct()
+                _lib.check(_lib.load().dif_mesh_cache_export(ctypes.byref(b), lo, n, _lib.ptr(self._pin[0]), _lib.ptr(self._pin[1]),
+                                                             _lib.ptr(self._pin[2]), _lib.stream_ptr()), "dif_mesh_cache_export")
+                for src in (tri, tid, tstd):
+                    src.record_stream(self._copy_stream)         # the log may be re-allocated (growth) while this is in flight
+                self._copy_done = torch.cuda.Event()
+                self._copy_done.record()
+        return (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
+
     def _finish_frame(self, handle, d2h: str):
         tri, tid, tstd = self.map.extract_mesh_finish(handle)
         out = (tri, tid, tstd)
         if d2h == "new":
             n = tri.size(0)
-            if self._pin is None or self._pin[0].size(0) < n:
-                cap = max(1 << 18, 2 * n)
-                self._pin = (torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
-                             torch.empty((cap, 3), dtype=torch.float32).pin_memory())
-            with torch.cuda.device(self.device):
-                # one small kernel on a side stream writes the three arrays straight into pinned host memory; it overlaps the next
-                # frame's kernels, which only READ this part of the log
-                self._copy_stream.wait_event(handle["event"])
-                with torch.cuda.stream(self._copy_stream):
-                    lo = tri.storage_offset() // 9
-                    b = self.map._cache_struct()
-                    _lib.check(_lib.load().dif_mesh_cache_export(ctypes.byref(b), lo, n, _lib.ptr(self._pin[0]), _lib.ptr(self._pin[1]),
-                                                                 _lib.ptr(self._pin[2]), _lib.stream_ptr()), "dif_mesh_cache_export")
-                    for src in (tri, tid, tstd):
-                        src.record_stream(self._copy_stream)     # the log may be re-allocated (growth) while this is in flight
-                    self._copy_done = torch.cuda.Event()
-                    self._copy_done.record()
-            out = (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
+            k = handle.get("host_out")
+            if k is not None and n <= self.HOST_OUT_TRIANGLES:
+                hp = self._zc[2][k]                              # already there: written by the frame's last kernel
+                out = (hp[0][:n], hp[1][:n], hp[2][:n])
+            else:
+                out = self._export_new(handle, tri, tid, tstd)
         elif d2h == "full":
             mc = self.map.mesh_cache
             out = (mc.vertices, mc.vertices_flatten_id, mc.vertices_std)
@@ -151,7 +163,7 @@ class FusionStream:
     # re-allocated (capacity growth, mesh-cache garbage collection).
     def _graph_signature(self):
         m = self.map
-        return (m._capacity, m._ws.data_ptr() if m._ws is not None else 0, m._xbuf[0] if m._xbuf else None,
+        return (self._graph_export, m._capacity, m._ws.data_ptr() if m._ws is not None else 0, m._xbuf[0] if m._xbuf else None,
                 m._cache[0].data_ptr() if m._cache else 0)
 
     def _capture_graphs(self):
@@ -170,8 +182,11 @@ class FusionStream:
                 # (dif_frame_t: two device pointers + pose, 64 bytes) straight out of host memory and the last kernel writes the
                 # counters into host memory — no copy kernels on the launch stream.  A slot is reused two frames later, after the host
                 # has finished the frame that used it.
+                cap = self.HOST_OUT_TRIANGLES
                 self._zc = ([torch.zeros((64,), dtype=torch.uint8).pin_memory() for _ in range(2)],
-                            [torch.zeros((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(2)])
+                            [torch.zeros((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(2)],
+                            [(torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
+                              torch.empty((cap, 3), dtype=torch.float32).pin_memory()) for _ in range(2)])
             _, mask = self._g_in
             w = m.model.packed.weights_struct(dev)
             torch.cuda.synchronize()
@@ -179,6 +194,9 @@ class FusionStream:
             for k in range(2):
                 _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
                 buf.counters_out = _lib.ptr(self._zc[1][k])
+                if self._graph_export:                           # the frame's last kernel also writes its new triangles to pinned host memory
+                    buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in self._zc[2][k])
+                    buf.out_capacity = self.HOST_OUT_TRIANGLES
                 frame = self._zc[0][k]
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -212,6 +230,7 @@ class FusionStream:
             self._before_frame()
             if m._gc_wanted:
                 m._cache_gc()
+            self._graph_export = (d2h == "new")
             if self._graphs is None or self._graph_sig != self._graph_signature():
                 torch.cuda.synchronize()
                 self._capture_graphs()
@@ -224,7 +243,8 @@ class FusionStream:
             pc = self._zc[1][k]                                    # written by the frame's last kernel; read after the event
             ev = torch.cuda.Event()
             ev.record()
-            h = dict(event=ev, counters=pc, epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles)
+            h = dict(event=ev, counters=pc, epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
+                     host_out=(k if self._graph_export else None))
         if self._pending is not None:
             out = self._finish_frame(self._pending, d2h)
         self._pending = h

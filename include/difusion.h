@@ -198,6 +198,10 @@ typedef struct dif_extract_buffers {
     uint8_t* cache_alive;           /* [cache_capacity]                                                   */
     int32_t* counters_out;          /* optional [DIF_C_COUNT]: the map's counters as of the end of this extract, written by its last
                                      * kernel; may be device-mapped pinned HOST memory (no copy kernel, readable after a stream sync) */
+    float* out_tri;                 /* optional: this call's NEW triangles (log[DIF_C_CACHE_KEPT : DIF_C_CACHE_T], the first out_capacity   */
+    int64_t* out_id;                /* of them) copied out by the same last kernel — (n,3,3) f32, (n) i64, (n,3) f32; again, pinned host   */
+    float* out_std;                 /* memory is fine: a streaming caller gets each frame's mesh update without a transfer of its own      */
+    int64_t out_capacity;
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
