@@ -73,6 +73,8 @@ SIGNATURES = {
     "dif_integrate_workspace_bytes": (c_int64, [c_int64]),
     "dif_integrate": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_int64, c_void_p]),
+    "dif_integrate_frame": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
                               c_int32, c_int32, c_void_p]),
     "dif_extract_overlapped": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,

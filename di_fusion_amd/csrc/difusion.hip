@@ -353,8 +353,14 @@ int64_t dif_integrate_workspace_bytes(int64_t N) {
     return ws.total_bytes;
 }
 
+struct FrameSource {            // integrate straight from a depth frame: the first kernel also produces xyz / normal
+    const dif_frame_t* frame;
+    int H, W;
+    float fx, fy, cx, cy;
+};
+
 static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
-                          void* wsp, int64_t ws_bytes, hipEvent_t gate, void* stream_) {
+                          void* wsp, int64_t ws_bytes, hipEvent_t gate, const FrameSource* src, void* stream_) {
     if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0) return DIF_EINVAL;
     if (N == 0) return DIF_OK;
     if (!xyz || !normal || !unq_mask || !wsp) return DIF_EINVAL;
@@ -371,8 +377,12 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
 
     // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
     const int own_lo = map->own_x_hi > map->own_x_lo ? map->own_x_lo : 0, own_hi = map->own_x_hi > map->own_x_lo ? map->own_x_hi : map->nx;
-    hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C, own_lo - map->halo,
-                       own_hi + map->halo);
+    if (src)
+        hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, src->frame, src->H, src->W, src->fx, src->fy, src->cx, src->cy,
+                           const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C, own_lo - map->halo, own_hi + map->halo);
+    else
+        hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C, own_lo - map->halo,
+                           own_hi + map->halo);
     hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
                        (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, map->grid_bits, C);
     DIF_CHECK_LAUNCH();
@@ -419,13 +429,20 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
 
 int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
                   void* wsp, int64_t ws_bytes, void* stream_) {
-    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, nullptr, stream_);
+    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, nullptr, nullptr, stream_);
+}
+
+int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_frame_t* frame_dev, int32_t H, int32_t W, float fx, float fy, float cx,
+                        float cy, float* xyz_world, float* normal_world, uint8_t* unq_mask, void* wsp, int64_t ws_bytes, void* stream_) {
+    if (!frame_dev || H <= 0 || W <= 0 || !xyz_world || !normal_world) return DIF_EINVAL;
+    FrameSource src{frame_dev, H, W, fx, fy, cx, cy};
+    return integrate_impl(map, w, xyz_world, normal_world, (int64_t)H * W, unq_mask, wsp, ws_bytes, nullptr, &src, stream_);
 }
 
 int dif_integrate_gated(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
                         void* wsp, int64_t ws_bytes, void* gate_event, void* stream_) {
     if (!gate_event) return DIF_EINVAL;
-    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, (hipEvent_t)gate_event, stream_);
+    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, (hipEvent_t)gate_event, nullptr, stream_);
 }
 
 // ---- decoder launches ------------------------------------------------------------------------------------------
@@ -533,8 +550,8 @@ static int mc_setup(const McArgs& a, size_t& lds_bytes, int& blocks, int64_t K_u
     return DIF_OK;
 }
 
-static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, bool freeze_log,
-                             hipStream_t s) {
+static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters,
+                             TriScanFunctor f, hipStream_t s) {
     size_t lds_bytes; int blocks;
     int rc = mc_setup(a, lds_bytes, blocks, K_upper);
     if (rc != DIF_OK) return rc;
@@ -545,7 +562,7 @@ static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int3
         hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
     }
     DIF_CHECK_LAUNCH();
-    TriScanFunctor f{tri_count, tri_offset, counters, freeze_log ? 1 : 0};
+    f.tri_count = tri_count; f.tri_offset = tri_offset; f.counters = counters;
     return launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s);
 }
 
@@ -564,7 +581,7 @@ static int mc_emit(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_o
 }
 
 static int run_marching_cubes(McArgs a, int64_t K_upper, int32_t* tri_count, int32_t* tri_offset, int32_t* block_tmp, int* counters, hipStream_t s) {
-    int rc = mc_count_and_scan(a, K_upper, tri_count, tri_offset, block_tmp, counters, false, s);
+    int rc = mc_count_and_scan(a, K_upper, tri_count, tri_offset, block_tmp, counters, TriScanFunctor{}, s);
     if (rc != DIF_OK) return rc;
     return mc_emit(a, K_upper, tri_count, tri_offset, s);
 }
@@ -696,12 +713,12 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (hipMemsetAsync(C + DIF_C_CACHE_DEAD, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
         if (hipMemsetAsync(map->tri_n, 0, sizeof(int32_t) * (size_t)map->capacity, s) != hipSuccess) return DIF_ELAUNCH;
     }
-    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, true, s);
+    a.log_counters = C;
+    TriScanFunctor ts{};
+    ts.valid_blocks = buf->valid_blocks; ts.indexer = map->indexer; ts.tri_start = map->tri_start; ts.tri_n = map->tri_n; ts.alive = buf->cache_alive;
+    ts.new_limit = buf->max_triangles; ts.capacity = buf->cache_capacity;
+    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, ts, s);
     if (rc != DIF_OK) return rc;
-    hipLaunchKernelGGL(k_log_replace, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int64_t*)buf->valid_blocks,
-                       (const int32_t*)buf->tri_count, (const int32_t*)buf->tri_offset, (const int64_t*)map->indexer, map->tri_start, map->tri_n,
-                       buf->cache_alive, C, buf->max_triangles, buf->cache_capacity);
-    DIF_CHECK_LAUNCH();
     rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
     if (rc != DIF_OK) return rc;
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,

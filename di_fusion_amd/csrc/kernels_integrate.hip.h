@@ -4,17 +4,17 @@
 // =================================================================================================================
 // a3..a6 : voxel ids, prune, allocate   (map.py:366-387)
 // =================================================================================================================
-// K1: per-point voxel id + per-voxel point count of this frame.  Adjacent pixels mostly fall in the same voxel, so
-// equal-id runs inside a wave are aggregated with a ballot before touching memory (1 atomic per run, not per point).
-__global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* __restrict__ xyz, int64_t N, int* __restrict__ pt_lin,
-                                                         int* __restrict__ frame_count, int* __restrict__ counters, int px_lo, int px_hi) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // grid covers N rounded up to a wave
-    int lane = lane_id();
+// K1: per-point voxel id + per-voxel point count of this frame.
+// Per-voxel point counts of the frame (map.py:374) with wave-run aggregation: pixels of a row that fall into the same voxel are
+// neighbours in the wave, so one atomic per run of equal ids.  Also zeroes the per-call counters.
+__device__ __forceinline__ void voxel_count_point(const Geo& g, bool in_range, float x, float y, float z, int64_t i, int* __restrict__ pt_lin,
+                                                  int* __restrict__ frame_count, int* __restrict__ counters, int px_lo, int px_hi) {
+    const int lane = lane_id();
     if (i < 4) counters[DIF_C_ALLOC_NEW + i] = 0;                   // ALLOC_NEW, M, C, ITEMS of this call
     int lin = -2;                                                    // -2: beyond N, -1: invalid point
-    if (i < N) {
+    if (in_range) {
         float xn, yn, zn; int ix, iy, iz;
-        bool ok = voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        bool ok = voxel_of(g, x, y, z, xn, yn, zn, ix, iy, iz);
         ok = ok && ix >= px_lo && ix < px_hi;                         // spatial tiling: own slab + halo only
         lin = ok ? linearize(g, ix, iy, iz) : -1;
         pt_lin[i] = lin;
@@ -27,6 +27,36 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* _
         int run = above ? __ffsll((long long)above) : (64 - lane);
         atomicAdd(frame_count + lin, run);
     }
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* __restrict__ xyz, int64_t N, int* __restrict__ pt_lin,
+                                                         int* __restrict__ frame_count, int* __restrict__ counters, int px_lo, int px_hi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // grid covers N rounded up to a wave
+    const bool in = i < N;
+    voxel_count_point(g, in, in ? xyz[i * 3 + 0] : 0.f, in ? xyz[i * 3 + 1] : 0.f, in ? xyz[i * 3 + 2] : 0.f, i, pt_lin, frame_count, counters, px_lo, px_hi);
+}
+
+// a1 + a2 + a3 in one pass for a streaming caller: depth pixel -> world point and normal (written out for the later stages) -> voxel id
+// and per-voxel count, without re-reading the points.
+__global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(Geo g, const dif_frame_t* __restrict__ frame, int H, int W, float fx, float fy,
+                                                                   float cx, float cy, float* __restrict__ xyz, float* __restrict__ nrm,
+                                                                   int* __restrict__ pt_lin, int* __restrict__ frame_count, int* __restrict__ counters,
+                                                                   int px_lo, int px_hi) {
+    const int64_t N = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < N;
+    float p[3] = {0.f, 0.f, 0.f}, nv[3];
+    if (in) {
+        Pose P;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) P.r[k] = frame->pose[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P.t[k] = frame->pose[9 + k];
+        unproject_point(frame->depth, frame->normal_cam, i, W, fx, fy, cx, cy, P, p, nv);
+        xyz[i * 3 + 0] = p[0]; xyz[i * 3 + 1] = p[1]; xyz[i * 3 + 2] = p[2];
+        nrm[i * 3 + 0] = nv[0]; nrm[i * 3 + 1] = nv[1]; nrm[i * 3 + 2] = nv[2];
+    }
+    voxel_count_point(g, in, p[0], p[1], p[2], i, pt_lin, frame_count, counters, px_lo, px_hi);
 }
 
 // K2: prune mask + candidate voxels.  mask[i] = count(voxel of i) > prune_min_vox_obs (map.py:375).  A kept point whose

@@ -14,6 +14,7 @@ struct McArgs {
     float* triangles; int64_t* tri_id; float* tri_std; uint8_t* tri_alive;
     int32_t* tri_count; const int32_t* tri_offset;
     const int* base_ptr;            // device: first output triangle index (mesh-cache append), or NULL
+    int* log_counters;              // mesh-cache path: the count pass freezes DIF_C_CACHE_KEPT = DIF_C_CACHE_T (log length before this call)
     int64_t new_limit;              // triangles this call may emit (max_n_triangles)
     int scale; float vs, bx, by, bz;
 };
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     // 8-tap blends), not memory bound.
     V4* vl = reinterpret_cast<V4*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
     const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
+    if (!EMIT && a.log_counters && blockIdx.x == 0 && threadIdx.x == 0) a.log_counters[DIF_C_CACHE_KEPT] = a.log_counters[DIF_C_CACHE_T];
     const float sbs = 1.0f / (float)r;
     for (int64_t k = (int64_t)blockIdx.x * wpb + wid; k < K; k += (int64_t)gridDim.x * wpb) {
         const int64_t vb = a.valid_blocks[k];
@@ -201,32 +203,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 
 // ---- a16 : device-resident mesh cache as an append-only log (map.py:703-714) -----------------------------------------
 // A voxel that produced >= 1 new triangle replaces its previous batch (the reference drops cached triangles whose voxel id
-// occurs among the new ones, map.py:708-709): mark the old batch dead, point the voxel at its new batch.
-__global__ void __launch_bounds__(DIF_BLOCK) k_log_replace(const int64_t* __restrict__ valid_blocks, const int32_t* __restrict__ tri_count,
-                                                         const int32_t* __restrict__ tri_offset, const int64_t* __restrict__ indexer,
-                                                         int32_t* __restrict__ tri_start, int32_t* __restrict__ tri_n, uint8_t* __restrict__ alive,
-                                                         int* __restrict__ counters, int64_t new_limit, int64_t capacity) {
-    __shared__ int smem[8];
-    const int K = counters[DIF_C_K];
-    const int64_t log_n = counters[DIF_C_CACHE_KEPT];     // frozen by the triangle scan
-    int dead = 0;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        const int c = tri_count[k];
-        if (c <= 0) continue;
-        const int64_t slot = indexer[valid_blocks[k]];
-        const int old_n = tri_n[slot], old_s = tri_start[slot];
-        for (int j = 0; j < old_n; ++j) alive[old_s + j] = 0;
-        dead += old_n;
-        int64_t off = tri_offset[k];
-        int64_t n_new = c;
-        if (off + n_new > new_limit) n_new = new_limit > off ? new_limit - off : 0;          // truncated by max_n_triangles
-        if (log_n + off + n_new > capacity) n_new = capacity > log_n + off ? capacity - (log_n + off) : 0;
-        tri_start[slot] = (int)(log_n + off);
-        tri_n[slot] = (int)n_new;
-    }
-    dead = block_sum(dead, smem);
-    if (threadIdx.x == 0 && dead) atomicAdd(counters + DIF_C_CACHE_DEAD, dead);
-}
+// occurs among the new ones, map.py:708-709): TriScanFunctor::emit marks the old batch dead and points the voxel at its new one.
 
 // Copies log entries [lo, lo+n) into three caller arrays with ONE launch; the destinations may be device-mapped pinned host memory
 // (a streaming caller ships each frame's new triangles this way instead of three copy-engine transfers).
@@ -314,17 +291,34 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
     }
 }
 
-struct TriScanFunctor {
+struct TriScanFunctor {         // exclusive scan of the per-voxel triangle counts; on the mesh-cache path also the log bookkeeping
     const int32_t* tri_count;
     int32_t* tri_offset;
     int* counters;
-    int freeze_log_length;      // the mesh-cache path: DIF_C_CACHE_KEPT = log length before this call (read by everything after the scan)
+    // mesh-cache path (valid_blocks != NULL): needs DIF_C_CACHE_KEPT frozen by the marching-cubes count pass
+    const int64_t* valid_blocks; const int64_t* indexer;
+    int32_t* tri_start; int32_t* tri_n; uint8_t* alive;
+    int64_t new_limit, capacity;
     __device__ int count(int k) const { return tri_count[k]; }
-    __device__ void emit(int k, int offset) const { tri_offset[k] = offset; }
-    __device__ void finish(int total) const {
-        counters[DIF_C_T] = total;
-        if (freeze_log_length) counters[DIF_C_CACHE_KEPT] = counters[DIF_C_CACHE_T];
+    __device__ void emit(int k, int offset) const {          // only called for voxels with >= 1 new triangle
+        tri_offset[k] = offset;
+        if (!valid_blocks) return;
+        const int64_t log_n = counters[DIF_C_CACHE_KEPT];
+        const int64_t slot = indexer[valid_blocks[k]];
+        const int old_n = tri_n[slot], old_s = tri_start[slot];
+        for (int j = 0; j < old_n; ++j) alive[old_s + j] = 0;
+        int64_t n_new = tri_count[k];
+        if (offset + n_new > new_limit) n_new = new_limit > offset ? new_limit - offset : 0;          // truncated by max_n_triangles
+        if (log_n + offset + n_new > capacity) n_new = capacity > log_n + offset ? capacity - (log_n + offset) : 0;
+        tri_start[slot] = (int)(log_n + offset);
+        tri_n[slot] = (int)n_new;
+        // dead-entry count: one atomic per wave, summed over the lanes that are in here together
+        const unsigned long long here = __ballot(1);
+        int dead = 0;
+        for (unsigned long long m = here; m; m &= m - 1) dead += __shfl(old_n, __ffsll((long long)m) - 1);
+        if (lane_id() == __ffsll((long long)here) - 1 && dead) atomicAdd(counters + DIF_C_CACHE_DEAD, dead);
     }
+    __device__ void finish(int total) const { counters[DIF_C_T] = total; }
 };
 
 // =================================================================================================================

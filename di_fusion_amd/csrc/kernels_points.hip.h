@@ -25,6 +25,30 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_unproject(const float* __restrict
 
 struct Pose { float r[9]; float t[3]; };
 
+// One pixel: back-projection (imgproc.cu:18-20 op order) and pose transform ((r0*x + r1*y) + r2*z) + t, every op rounded
+// (synthetic.transform_points states the same order).  NaN depth -> NaN point and normal.
+__device__ __forceinline__ void unproject_point(const float* __restrict__ depth, const float* __restrict__ ncam, int64_t i, int W, float fx, float fy,
+                                                float cx, float cy, const Pose& P, float (&p)[3], float (&nv)[3]) {
+    const int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+    const float d = depth[i];
+    const float qnan = __builtin_nanf("");
+    p[0] = p[1] = p[2] = nv[0] = nv[1] = nv[2] = qnan;
+    if (d == d) {
+        const float x = ((float)u - cx) / fx * d;
+        const float y = ((float)v - cy) / fy * d;
+        const float z = d;
+        p[0] = ((P.r[0] * x + P.r[1] * y) + P.r[2] * z) + P.t[0];
+        p[1] = ((P.r[3] * x + P.r[4] * y) + P.r[5] * z) + P.t[1];
+        p[2] = ((P.r[6] * x + P.r[7] * y) + P.r[8] * z) + P.t[2];
+        if (ncam) {
+            const float a = ncam[i * 3 + 0], b = ncam[i * 3 + 1], c = ncam[i * 3 + 2];
+            nv[0] = (P.r[0] * a + P.r[1] * b) + P.r[2] * c;
+            nv[1] = (P.r[3] * a + P.r[4] * b) + P.r[5] * c;
+            nv[2] = (P.r[6] * a + P.r[7] * b) + P.r[8] * c;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* __restrict__ depth, const float* __restrict__ ncam,
                                                                  float* __restrict__ xyz, float* __restrict__ nrm, int H, int W,
                                                                  float fx, float fy, float cx, float cy, Pose P, const float* __restrict__ pose_dev,
@@ -42,27 +66,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* 
     }
     int64_t n = (int64_t)H * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
-        float d = depth[i];
-        const float qnan = __builtin_nanf("");
-        float ox = qnan, oy = qnan, oz = qnan, nx = qnan, ny = qnan, nz = qnan;
-        if (d == d) {
-            float x = ((float)u - cx) / fx * d;
-            float y = ((float)v - cy) / fy * d;
-            float z = d;
-            // ((r0*x + r1*y) + r2*z) + t, every op rounded (synthetic.transform_points states the same order)
-            ox = ((P.r[0] * x + P.r[1] * y) + P.r[2] * z) + P.t[0];
-            oy = ((P.r[3] * x + P.r[4] * y) + P.r[5] * z) + P.t[1];
-            oz = ((P.r[6] * x + P.r[7] * y) + P.r[8] * z) + P.t[2];
-            if (ncam) {
-                float a = ncam[i * 3 + 0], b = ncam[i * 3 + 1], c = ncam[i * 3 + 2];
-                nx = (P.r[0] * a + P.r[1] * b) + P.r[2] * c;
-                ny = (P.r[3] * a + P.r[4] * b) + P.r[5] * c;
-                nz = (P.r[6] * a + P.r[7] * b) + P.r[8] * c;
-            }
-        }
-        xyz[i * 3 + 0] = ox; xyz[i * 3 + 1] = oy; xyz[i * 3 + 2] = oz;
-        if (nrm) { nrm[i * 3 + 0] = nx; nrm[i * 3 + 1] = ny; nrm[i * 3 + 2] = nz; }
+        float p[3], nv[3];
+        unproject_point(depth, ncam, i, W, fx, fy, cx, cy, P, p, nv);
+        xyz[i * 3 + 0] = p[0]; xyz[i * 3 + 1] = p[1]; xyz[i * 3 + 2] = p[2];
+        if (nrm) { nrm[i * 3 + 0] = nv[0]; nrm[i * 3 + 1] = nv[1]; nrm[i * 3 + 2] = nv[2]; }
     }
 }
 

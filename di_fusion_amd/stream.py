@@ -201,10 +201,9 @@ class FusionStream:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     sp = _lib.stream_ptr()
-                    _lib.check(lib.dif_unproject_transform_frame(_lib.ptr(frame), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
-                                                                 intr.fx, intr.fy, intr.cx, intr.cy, sp), "dif_unproject_transform_frame")
-                    _lib.check(lib.dif_integrate(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), N, _lib.ptr(mask),
-                                                 _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate")
+                    _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(frame), H, W, intr.fx, intr.fy, intr.cx, intr.cy,
+                                                       _lib.ptr(self.xyz), _lib.ptr(self.nrm), _lib.ptr(mask), _lib.ptr(m._ws), m._ws.numel(), sp),
+                               "dif_integrate_frame")
                     _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
                                                0, 1, sp), "dif_extract")
                 graphs.append((g, buf))

@@ -171,6 +171,12 @@ int64_t dif_integrate_workspace_bytes(int64_t N);
 int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N,
                   uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* stream);
 
+/* a1 + a2 + a3..a10 for a streaming caller: integrate straight from a depth frame behind a device-readable descriptor (see
+ * dif_unproject_transform_frame).  The first kernel back-projects, transforms AND counts points per voxel; xyz_world / normal_world
+ * ((H*W,3) each) are outputs that the later stages read.  Same results as dif_unproject_transform_frame followed by dif_integrate. */
+int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_frame_t* frame_dev, int32_t H, int32_t W, float fx, float fy,
+                        float cx, float cy, float* xyz_world, float* normal_world, uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- a11..a16: extract_mesh (map.py:581-723) ---------------------------------------------------------------- */
 typedef struct dif_extract_buffers {
     int64_t max_voxels;             /* rows available in the per-voxel buffers below                      */
