@@ -327,7 +327,7 @@ struct IntegrateWs {
 static int64_t max_items_for(int64_t N) {
     // items = sum_s ceil(cnt_s / ITEM_ROWS) <= M/ITEM_ROWS + C with M <= 8N rows.  With pruning on, every kept point shares its
     // voxel with > prune_min_vox_obs others, so the encoded voxels (26-neighbourhoods of those) number well under 2N; anything
-    // beyond the bound is dropped by ItemFunctor with DIF_C_OVERFLOW = 4.
+    // beyond the bound is dropped by k_alloc_items with DIF_C_OVERFLOW = 4.
     return 8 * N / ITEM_ROWS + 2 * N + 64;
 }
 
@@ -395,10 +395,8 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
                        (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
                        ws.pair_key, map->seg_cnt, C, map->capacity);
     DIF_CHECK_LAUNCH();
-    {
-        ItemFunctor f{map->seg_cnt, map->item_start, ws.item_slot, C, ws.max_items};
-        if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
-    }
+    hipLaunchKernelGGL(k_alloc_items, dim3(grid_for(map->capacity, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const int*)map->seg_cnt, map->item_start,
+                       ws.item_slot, C, ws.max_items);
     {
         ProfScope prof(DIF_PROF_SORT, s);
         hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(8 * N, DIF_BLOCK, 8192)), dim3(DIF_BLOCK), 0, s, (const uint32_t*)ws.pair_key, 8 * N,
@@ -415,14 +413,14 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         }
         ProfScope prof(DIF_PROF_ENCODE, s);
         hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint32_t*)ws.row_val,
-                           (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot, (const int*)C, ws.partial);
+                           (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot, (const int*)C, ws.partial, (int)ws.max_items);
         DIF_CHECK_LAUNCH();
     }
     // k_fuse is the only kernel of an integrate that writes what an extract reads (latents, observation counts, dirty flags)
     if (gate && hipStreamWaitEvent(s, gate, 0) != hipSuccess) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(ws.max_items * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.partial,
                        (const int*)map->item_start, (const int*)ws.item_slot, map->seg_cnt, map->seg_start, map->latent_vecs, map->voxel_obs_count,
-                       map->dirty, C);
+                       map->dirty, C, (int)ws.max_items);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

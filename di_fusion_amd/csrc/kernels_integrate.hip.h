@@ -214,23 +214,31 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
     }
 }
 
-// K5: per-slot encoder work items (ceil(cnt / ITEM_ROWS)), exclusive scan over slots, item -> slot table.  A slot's rows
-// live in the row table at [item_start*ITEM_ROWS, ...) (padded to whole items), so one scan yields both.
-struct ItemFunctor {
-    const int* seg_cnt;
-    int* item_start;
-    int* item_slot;
-    int* counters;
-    int64_t max_items;
-    __device__ int count(int s) const { return (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS; }
-    __device__ void emit(int s, int offset) const {
-        int n = (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS;
-        item_start[s] = offset;
-        if ((int64_t)offset + n > max_items) { counters[DIF_C_OVERFLOW] = 4; return; }
-        for (int k = 0; k < n; ++k) item_slot[offset + k] = s;
+// K5: per-slot encoder work items (ceil(cnt / ITEM_ROWS)) and the item -> slot table.  A slot's rows live in the row table at
+// [item_start*ITEM_ROWS, ...) (padded to whole items).
+__global__ void __launch_bounds__(DIF_BLOCK) k_alloc_items(const int* __restrict__ seg_cnt, int* __restrict__ item_start, int* __restrict__ item_slot,
+                                                         int* __restrict__ counters, int64_t max_items) {
+    // Items are handed out with one atomic per workgroup instead of an ordered scan: WHICH items a voxel gets only decides where its
+    // partial sums live and which wave encodes them; k_fuse adds a voxel's partials in its own fixed order, so results do not change.
+    __shared__ int smem[8];
+    __shared__ int s_base;
+    const int n = counters[DIF_C_N_OCCUPIED];
+    for (int s0 = (int)(blockIdx.x * blockDim.x); s0 < n; s0 += (int)(gridDim.x * blockDim.x)) {
+        const int s = s0 + (int)threadIdx.x;
+        const int nit = (s < n) ? (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS : 0;
+        int total;
+        const int ex = block_excl_scan(nit, smem, total);
+        if (threadIdx.x == 0) s_base = total ? atomicAdd(counters + DIF_C_ITEMS, total) : 0;
+        __syncthreads();
+        if (nit) {
+            const int off = s_base + ex;
+            item_start[s] = off;
+            if ((int64_t)off + nit > max_items) counters[DIF_C_OVERFLOW] = 4;
+            else for (int k = 0; k < nit; ++k) item_slot[off + k] = s;
+        }
+        __syncthreads();
     }
-    __device__ void finish(int total) const { counters[DIF_C_ITEMS] = (total > max_items) ? (int)max_items : total; }
-};
+}
 
 // K6: place every valid (offset, point) pair into its slot's rows.  Order inside a slot is arrival order — harmless, because
 // the per-voxel sum is accumulated in exact fixed point (order-independent, see k_encode).
@@ -260,14 +268,14 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_scatter_rows(const uint32_t* __re
 __global__ void __launch_bounds__(512, 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
          const uint32_t* __restrict__ row_val, const int* __restrict__ seg_cnt, const int* __restrict__ item_start,
-         const int* __restrict__ item_slot, const int* __restrict__ counters, long long* __restrict__ partial /* [items][32] */) {
+         const int* __restrict__ item_slot, const int* __restrict__ counters, long long* __restrict__ partial /* [items][32] */, int max_items) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights(lds, wblob, ENC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
     const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int n_items = counters[DIF_C_ITEMS];
+    const int n_items = min(counters[DIF_C_ITEMS], max_items);
     for (int item = wave; item < n_items; item += nwaves) {
         const int slot = item_slot[item];
         const int chunk = item - item_start[slot];
@@ -310,9 +318,9 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
 // a10: fusion update (map.py:448-452).  One 32-lane group per slot.
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ partial, const int* __restrict__ item_start, const int* __restrict__ item_slot,
                                                   int* __restrict__ seg_cnt, int* __restrict__ seg_cursor, float* __restrict__ latent, float* __restrict__ obs,
-                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters) {
+                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters, int max_items) {
     __shared__ int smem[8];
-    const int n_items = counters[DIF_C_ITEMS];
+    const int n_items = min(counters[DIF_C_ITEMS], max_items);
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
     const int f = threadIdx.x & 31;
     int updated = 0, rows = 0;
