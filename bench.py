@@ -252,6 +252,7 @@ def main():
                                     (", extract of frame i-1 overlapped with integrate of frame i on a second stream" if a.overlap else ""),
                           "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1) for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
+                          "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info},
                "roofline": roof}
         if not a.no_cpu_baseline and world == 1:

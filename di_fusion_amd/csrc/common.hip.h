@@ -189,4 +189,12 @@ inline int launch_scan(F f, const int* n_ptr, int n_static, int64_t n_upper, int
     return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }
 
+// One launch whatever the static bound: for lists that are short in practice (a frame's dirty voxels) even though their capacity is
+// large.  Cost grows with n / 1024 per thread, so only for scans whose n rarely passes a few ten thousand.
+template <class F>
+inline int launch_scan_one_block(F f, const int* n_ptr, int n_static, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(1024), 0, s, f, n_ptr, n_static);
+    return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+}
+
 }  // namespace dif

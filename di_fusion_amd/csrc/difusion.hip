@@ -561,6 +561,8 @@ static int mc_count_and_scan(McArgs a, int64_t K_upper, int32_t* tri_count, int3
     }
     DIF_CHECK_LAUNCH();
     f.tri_count = tri_count; f.tri_offset = tri_offset; f.counters = counters;
+    // K = dirty voxels of the call: hundreds per frame in a stream; only a map with a huge capacity can make the one-block scan long
+    if (K_upper <= ((int64_t)1 << 18)) return launch_scan_one_block(f, a.K_ptr, (int)a.K_static, s);
     return launch_scan(f, a.K_ptr, (int)a.K_static, K_upper, block_tmp, s);
 }
 

@@ -45,6 +45,7 @@ class FusionStream:
         self._graphs = None
         self._graph_sig = None
         self._graph_export = True                                # captured graphs also hand each frame's new triangles to the host
+        self.n_captures = 0
         self._g_in = None
         self._zc = None
         self._ov_graph = None
@@ -209,6 +210,7 @@ class FusionStream:
                 graphs.append((g, buf))
             self._graphs = graphs
             self._graph_sig = self._graph_signature()
+            self.n_captures += 1
 
     def step_graph(self, i: int, d2h: str = "new"):
         """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: a 64-byte

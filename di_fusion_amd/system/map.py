@@ -419,8 +419,10 @@ class DenseIndexedMap:
     def _cache_gc(self):
         """Drop the dead entries: the compacted copy becomes the log (same content and order as before for the live part)."""
         n = self._cache_compact()
-        self._cache, self._cache_out = self._cache_out, self._cache
         with torch.cuda.device(self.device):
+            # copied back rather than swapped in: the log keeps its addresses, so launch graphs captured over it stay valid
+            for dst, src in zip(self._cache[:3], self._cache_out[:3]):
+                dst[:n].copy_(src[:n])
             b = self._cache_struct()
             _lib.check(_lib.load().dif_mesh_cache_reindex(ctypes.byref(self._cmap), ctypes.byref(b), n, _lib.stream_ptr()), "dif_mesh_cache_reindex")
         self._gc_epoch += 1
