@@ -509,7 +509,8 @@ class DenseIndexedMap:
         if c["K"] > 0:
             self._cache_any = True
         cap = self._cache[0].size(0)
-        if c["cache_dead"] > max(1 << 20, c["cache_T"] // 2) or c["cache_T"] + 2 * handle["max_n_triangles"] > cap:
+        # compaction is a host-synchronous safe point: amortise it over millions of dead entries (they cost 57 B each, HBM is plentiful)
+        if c["cache_dead"] > max(1 << 22, c["cache_T"] // 2) or c["cache_T"] + 2 * handle["max_n_triangles"] > cap:
             self._gc_wanted = True                                # performed at the next enqueue (a safe point)
         tri, tid, tstd, _ = self._cache
         lo, hi = c["cache_kept"], c["cache_T"]

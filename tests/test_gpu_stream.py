@@ -63,6 +63,8 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     torch.cuda.synchronize()
     got.append(per_frame[0])
     for i in range(1, N_FRAMES):
+        if i == 3:
+            st.map._gc_wanted = True                        # force a mesh-log compaction in mid-stream, with a frame still in flight
         o = st.step_graph(i, d2h="new")
         if o is not None:
             torch.cuda.synchronize()
@@ -70,6 +72,7 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     o = st.flush()
     got.append(tuple(x.clone() for x in o))
     outs["graph"] = snapshot(st)
+    assert st.map._gc_epoch == 1 and st.n_captures == 1     # compacted once, and the captured graphs survived it
     assert len(got) == N_FRAMES
     for a, b in zip(per_frame[1:], got[1:]):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
