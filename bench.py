@@ -41,6 +41,7 @@ def parse():
                     "eagerly with HIP events around the MFMA kernels (the roofline sample)")
     ap.add_argument("--sample-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra run with the mesh left in HBM (keeps profiler traces to one stream)")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.5, help="image scale of the CPU-baseline sample frame")
     return ap.parse_args()
 
@@ -166,7 +167,7 @@ def main():
     # Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream with the mesh left resident in HBM, i.e.
     # without the per-frame transfer of the new triangles to pinned host memory.  The difference is PCIe + cross-stream traffic, not kernels.
     hbm_resident = None
-    if world == 1 and a.d2h != "none" and not a.overlap:
+    if world == 1 and a.d2h != "none" and not a.overlap and not a.no_secondary:
         s2 = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))
 
         def run2(i):

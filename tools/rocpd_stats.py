@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / % — the `--stats` table.
-Usage: python tools/rocpd_stats.py gpurun_out/prof/bench_results.db [--last N] > profiles/rNN_kernel_stats.md"""
+Usage: python tools/rocpd_stats.py gpurun_out/prof/bench_results.db [--after-nth KERNEL N [--frames F]] > profiles/rNN_kernel_stats.md"""
 import re
 import sqlite3
 import sys
@@ -30,8 +30,13 @@ def main():
         marker, nth = sys.argv[i + 1], int(sys.argv[i + 2])
         starts = [s for n, s, e in rows if marker in n]
         t0 = starts[nth]
-        rows = [r for r in rows if r[1] >= t0]
-        print(f"(restricted to dispatches at/after dispatch #{nth} of `{marker}`: the timed region, {len(starts) - nth} frames)\n")
+        t1 = None
+        if "--frames" in sys.argv:          # ... and stop before the (nth + frames)-th one
+            nf = int(sys.argv[sys.argv.index("--frames") + 1])
+            t1 = starts[nth + nf] if nth + nf < len(starts) else None
+        rows = [r for r in rows if r[1] >= t0 and (t1 is None or r[1] < t1)]
+        nfr = (len([s for s in starts if s >= t0 and (t1 is None or s < t1)]))
+        print(f"(restricted to dispatches from dispatch #{nth} of `{marker}` on: the timed region, {nfr} frames)\n")
     agg = {}
     for n, s, e in rows:
         k = short(n)
