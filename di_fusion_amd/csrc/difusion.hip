@@ -393,7 +393,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     }
     hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
                        (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
-                       ws.pair_key, map->seg_cnt, C, map->capacity);
+                       ws.pair_key, map->seg_cnt, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0);
     DIF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_alloc_items, dim3(grid_for(map->capacity, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const int*)map->seg_cnt, map->item_start,
                        ws.item_slot, C, ws.max_items);

@@ -166,12 +166,47 @@ __device__ __forceinline__ void wave_grouped_add(int* __restrict__ counter, uint
     }
 }
 
+// Workgroup-level version: the wave groups go into a small LDS table first, one global atomic per distinct key per WORKGROUP.
+// Same-address global atomics are what bounds the row counting (hundreds per voxel per frame, ~12 ns each on one L2 channel).
+#define FG_TABLE 256
+__device__ __forceinline__ void block_grouped_add_lds(unsigned* __restrict__ tkey, int* __restrict__ tcnt, uint32_t key, bool valid) {
+    const int lane = lane_id();
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+        const unsigned long long same = __ballot(valid && key == k0);
+        if (lane == leader) {
+            unsigned h = (k0 * 2654435761u) >> 24;                     // FG_TABLE = 256 slots; a workgroup holds far fewer distinct keys
+            while (true) {
+                const unsigned old = atomicCAS(tkey + h, DIF_INVALID_KEY, k0);
+                if (old == DIF_INVALID_KEY || old == k0) break;
+                h = (h + 1) & (FG_TABLE - 1);
+            }
+            atomicAdd(tcnt + h, __popcll(same));
+        }
+        todo &= ~same;
+    }
+}
+
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
                                                           uint32_t* __restrict__ pair_key, int* __restrict__ seg_cnt,
-                                                          int* __restrict__ counters, int64_t capacity) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole waves
+                                                          int* __restrict__ counters, int64_t capacity, int img_w) {
+    __shared__ unsigned tkey[FG_TABLE];
+    __shared__ int tcnt[FG_TABLE];
+    tkey[threadIdx.x] = DIF_INVALID_KEY;                             // DIF_BLOCK == FG_TABLE
+    tcnt[threadIdx.x] = 0;
+    // Points of a frame (img_w > 0, N = H * img_w with both multiples of 16) are walked in 16 x 16 pixel tiles: a workgroup then touches
+    // ~10 voxels instead of the ~90 that a 256-pixel piece of an image row does, so its rows collapse into few counters.
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole workgroups
+    if (img_w > 0) {
+        const int tiles_x = img_w >> 4;
+        const int ty = (int)(blockIdx.x / tiles_x), tx = (int)(blockIdx.x % tiles_x);
+        i = (int64_t)(ty * 16 + (int)(threadIdx.x >> 4)) * img_w + tx * 16 + (int)(threadIdx.x & 15);
+    }
+    __syncthreads();
     if (i == 0) {
         int n = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (n > capacity) { n = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
@@ -181,37 +216,54 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
     uint32_t key[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) key[o] = DIF_INVALID_KEY;
-    if (lin >= 0) {
-        frame_count[lin] = 0;
-        if (unq_mask[i]) {
-            float xn, yn, zn; int ix, iy, iz;
-            voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
-            // get_pruned_surface: own voxel in expand(encode set) <=> own voxel or an in-grid 6-neighbour is in the set
-            bool focus = in_encode_set(indexer[lin], obs, enc_th);
-            if (!focus && ix > 0) focus = in_encode_set(indexer[lin - g.ny * g.nz], obs, enc_th);
-            if (!focus && ix < g.nx - 1) focus = in_encode_set(indexer[lin + g.ny * g.nz], obs, enc_th);
-            if (!focus && iy > 0) focus = in_encode_set(indexer[lin - g.nz], obs, enc_th);
-            if (!focus && iy < g.ny - 1) focus = in_encode_set(indexer[lin + g.nz], obs, enc_th);
-            if (!focus && iz > 0) focus = in_encode_set(indexer[lin - 1], obs, enc_th);
-            if (!focus && iz < g.nz - 1) focus = in_encode_set(indexer[lin + 1], obs, enc_th);
-            if (focus) {
+    // get_pruned_surface: own voxel in expand(encode set) <=> own voxel or an in-grid 6-neighbour is in the set.  That is a property of the
+    // VOXEL, and neighbouring pixels share voxels: the first lane of every run of equal ids does the seven look-ups, the rest of the run
+    // takes its answer (in steady state ~97 % of the points fail this test, so it is most of the kernel's gathers).
+    const int lane = lane_id();
+    const bool kept = lin >= 0 && unq_mask[i];
+    if (lin >= 0) frame_count[lin] = 0;
+    const int prev = __shfl_up(lin, 1);
+    const bool head = (lane == 0) || (prev != lin);
+    const unsigned long long heads = __ballot(head);
+    bool focus = false;
+    if (head && kept) {
+        int ix, iy, iz;
+        unlinearize(g, lin, ix, iy, iz);
+        // all seven indexer entries first, then all seven observation counts: two dependent loads deep instead of fourteen
+        const int plane = g.ny * g.nz;
+        const int nl[7] = {lin, lin - plane, lin + plane, lin - g.nz, lin + g.nz, lin - 1, lin + 1};
+        const bool in_grid[7] = {true, ix > 0, ix < g.nx - 1, iy > 0, iy < g.ny - 1, iz > 0, iz < g.nz - 1};
+        int64_t slot[7];
 #pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;   // map.py:186-189
-                    int gx = clampi((int)(ceilf(xn + ox) - 1.0f), 0, g.nx - 1);                                   // map.py:422-424
-                    int gy = clampi((int)(ceilf(yn + oy) - 1.0f), 0, g.ny - 1);
-                    int gz = clampi((int)(ceilf(zn + oz) - 1.0f), 0, g.nz - 1);
-                    int64_t slot = indexer[linearize(g, gx, gy, gz)];
-                    if (in_encode_set(slot, obs, enc_th)) key[o] = (uint32_t)slot;
-                }
-            }
+        for (int q = 0; q < 7; ++q) slot[q] = in_grid[q] ? indexer[nl[q]] : -1;
+        float w[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) w[q] = slot[q] >= 0 ? obs[slot[q]] : enc_th;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) focus |= w[q] < enc_th;
+    }
+    const int my_head = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));      // nearest run start at or below this lane
+    focus = __shfl((int)focus, my_head) != 0;
+    if (kept && focus) {
+        float xn, yn, zn; int ix, iy, iz;
+        voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;   // map.py:186-189
+            int gx = clampi((int)(ceilf(xn + ox) - 1.0f), 0, g.nx - 1);                                   // map.py:422-424
+            int gy = clampi((int)(ceilf(yn + oy) - 1.0f), 0, g.ny - 1);
+            int gz = clampi((int)(ceilf(zn + oz) - 1.0f), 0, g.nz - 1);
+            int64_t slot = indexer[linearize(g, gx, gy, gz)];
+            if (in_encode_set(slot, obs, enc_th)) key[o] = (uint32_t)slot;
         }
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         if (i < N) pair_key[(int64_t)o * N + i] = key[o];
-        wave_grouped_add(seg_cnt, key[o], key[o] != DIF_INVALID_KEY);
+        block_grouped_add_lds(tkey, tcnt, key[o], key[o] != DIF_INVALID_KEY);
     }
+    __syncthreads();
+    if (tkey[threadIdx.x] != DIF_INVALID_KEY) atomicAdd(seg_cnt + tkey[threadIdx.x], tcnt[threadIdx.x]);
 }
 
 // K5: per-slot encoder work items (ceil(cnt / ITEM_ROWS)) and the item -> slot table.  A slot's rows live in the row table at
