@@ -149,6 +149,9 @@ def main():
     stats_base = len(stream.stats)
     lib.dif_profile_read((ctypes.c_double * _lib.PROF_COUNT)(), (ctypes.c_int64 * _lib.PROF_COUNT)(), 1)
     lib.dif_profile_enable(1)
+    import gc
+    gc.collect()
+    gc.disable()            # a generation-2 collection in the middle of a 75 ms timed region shows up as a 20 % outlier
     barrier()
     t0 = time.perf_counter()
     for i in range(a.warmup, n_frames):
@@ -156,6 +159,7 @@ def main():
     drain()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     lib.dif_profile_enable(0)
     ms = (ctypes.c_double * _lib.PROF_COUNT)()
     nl = (ctypes.c_int64 * _lib.PROF_COUNT)()

@@ -343,7 +343,15 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
     const float scale = (float)(l - 1) / (float)(R - 1);
     const int B = A.counters[DIF_C_B];
     const int wave = (int)(wid * gridDim.x + blockIdx.x), nwaves = (int)(gridDim.x * (blockDim.x >> 6));   // spread over CUs first
-    for (int b = wave; b < B; b += nwaves) {
+    // uniform trip count: the refine-list reservation below is a workgroup-wide step (one global atomic per workgroup and round
+    // instead of one per voxel — 900 same-address atomics at the end of the launch queued up for ~5 us)
+    __shared__ int s_tot[8], s_base;
+    const int rounds = (B + nwaves - 1) / nwaves;
+    for (int round = 0; round < rounds; ++round) {
+        const int b = wave + round * nwaves;
+        unsigned sel = 0;
+        const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
+        if (b < B) {
         const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
         f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
 #pragma unroll
@@ -369,8 +377,6 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
         __builtin_amdgcn_s_waitcnt(0xc07f);
         VD_STAMP(2);
         // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z ----
-        const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
-        unsigned sel = 0;
         if (lane < R2) {
             const int jx = lane / R, jy = lane % R;
             int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
@@ -386,22 +392,29 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
                 if (fabsf(sv) < 0.05f) sel |= 1u << jz;
             }
         }
+        }   // b < B
         VD_STAMP(3);
         const int c = __popc(sel);
         const int incl = wave_incl_scan(c);
         const int total = __shfl(incl, 63);
+        if (lane == 0) s_tot[wid] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sum = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += s_tot[w];
+            s_base = sum ? atomicAdd(A.counters + DIF_C_VH, sum) : 0;
+        }
+        __syncthreads();
         if (total > 0) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(A.counters + DIF_C_VH, total);
-            base = __shfl(base, 0);
-            int o = base + incl - c;
+            int o = s_base + incl - c;
+            for (int w = 0; w < wid; ++w) o += s_tot[w];
             while (sel) {
                 const int jz = __ffs((int)sel) - 1;
                 sel &= sel - 1;
                 A.refine_list[o++] = (int32_t)(e0 + jz);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();                        // s_tot / s_base are rewritten by the next round
         VD_STAMP(4);
     }
     VD_STAMP(5);
