@@ -352,47 +352,47 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
         unsigned sel = 0;
         const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
         if (b < B) {
-        const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
-        f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int k = 2 * t + half;
-            xlat[t] = (k < L) ? lat_row[k] : 0.0f;
-        }
-        // ---- low lattice -> LDS (map.py:644-653) ----
-        for (int t0 = 0; t0 < l3; t0 += 32) {
-            const int s = t0 + col;
-            const bool live = s < l3;
-            const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
-            f16v xin = xlat;
-            if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }        // k = 29 (x), 30 (y), 31 (z)
-            float sdf, sd;
-            decoder_tile(lds, wfwd, xin, lane, sdf, sd);
-            if (live) {
-                if (half == 0) w_low_sdf[s] = sdf;
-                else w_low_std[s] = sd;
+            const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+            f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
+    #pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int k = 2 * t + half;
+                xlat[t] = (k < L) ? lat_row[k] : 0.0f;
+            }
+            // ---- low lattice -> LDS (map.py:644-653) ----
+            for (int t0 = 0; t0 < l3; t0 += 32) {
+                const int s = t0 + col;
+                const bool live = s < l3;
+                const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
+                f16v xin = xlat;
+                if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }        // k = 29 (x), 30 (y), 31 (z)
+                float sdf, sd;
+                decoder_tile(lds, wfwd, xin, lane, sdf, sd);
+                if (live) {
+                    if (half == 0) w_low_sdf[s] = sdf;
+                    else w_low_std[s] = sd;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            VD_STAMP(2);
+            // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z ----
+            if (lane < R2) {
+                const int jx = lane / R, jy = lane % R;
+                int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
+                tri_axis(jx, l, scale, x0, x1, wx0, wx1);
+                tri_axis(jy, l, scale, y0, y1, wy0, wy1);
+                for (int jz = 0; jz < R; ++jz) {
+                    int z0, z1; float wz0, wz1;
+                    tri_axis(jz, l, scale, z0, z1, wz0, wz1);
+                    float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                    float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                    A.cube_sdf[e0 + jz] = -sv;
+                    A.cube_std[e0 + jz] = dv;
+                    if (fabsf(sv) < 0.05f) sel |= 1u << jz;
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        VD_STAMP(2);
-        // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z ----
-        if (lane < R2) {
-            const int jx = lane / R, jy = lane % R;
-            int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
-            tri_axis(jx, l, scale, x0, x1, wx0, wx1);
-            tri_axis(jy, l, scale, y0, y1, wy0, wy1);
-            for (int jz = 0; jz < R; ++jz) {
-                int z0, z1; float wz0, wz1;
-                tri_axis(jz, l, scale, z0, z1, wz0, wz1);
-                float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                A.cube_sdf[e0 + jz] = -sv;
-                A.cube_std[e0 + jz] = dv;
-                if (fabsf(sv) < 0.05f) sel |= 1u << jz;
-            }
-        }
-        }   // b < B
         VD_STAMP(3);
         const int c = __popc(sel);
         const int incl = wave_incl_scan(c);

@@ -47,7 +47,7 @@ def main():
     buf = (ctypes.c_ulonglong * (2048 * 8))()
     assert lib.dif_trace_read(buf, 2048 * 8) == 0
     t = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8).astype(np.int64)
-    act = t[:, 4] > t[:, 0]                               # waves that decoded a voxel in the LAST launch (older stamps are stale)
+    act = t[:, 2] > t[:, 0]                               # waves that decoded a voxel in the LAST launch (stamp 2 sits inside the b < B branch)
     t0 = t[:, 0][t[:, 0] > 0].min()
     us = lambda x: (x - t0) / 100.0
     out = {"B": int(B), "waves_with_work": int(act.sum()),
