@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
         if (b < B) {
             const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
             f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
-    #pragma unroll
+#pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int k = 2 * t + half;
                 xlat[t] = (k < L) ? lat_row[k] : 0.0f;
