@@ -320,11 +320,21 @@ __device__ __forceinline__ void decoder_tile_grad(const float* __restrict__ W /*
     gz = dt * gxv[15];
 }
 
-// cooperative global -> LDS copy of `n_floats` (multiple of 4) by the whole block
+// cooperative global -> LDS copy of `n_floats` (multiple of 4) by the whole block.  Eight 16-byte loads are in flight per thread before
+// the first LDS write: the copy is latency-bound (134 KB per CU is ~1 us of L2 bandwidth), so batching the loads is what shortens it.
 __device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ g, int n_floats) {
-    const f4v* src = reinterpret_cast<const f4v*>(g);
+    const f4v* __restrict__ src = reinterpret_cast<const f4v*>(g);
     f4v* dst = reinterpret_cast<f4v*>(lds);
-    for (int i = threadIdx.x; i < n_floats / 4; i += blockDim.x) dst[i] = src[i];
+    const int n4 = n_floats / 4, step = (int)blockDim.x;
+    int i = (int)threadIdx.x;
+    for (; i + 7 * step < n4; i += 8 * step) {
+        f4v v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[i + k * step];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[i + k * step] = v[k];
+    }
+    for (; i < n4; i += step) dst[i] = src[i];
     __syncthreads();
 }
 
