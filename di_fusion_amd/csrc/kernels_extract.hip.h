@@ -17,13 +17,20 @@ __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float
     cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
     cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
     cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
+    // three rounds of independent loads (slots, observation counts, bitmap words) instead of seven dependent chains
+    int64_t slot[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) slot[c] = indexer[cand[c]];
+    float w[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? obs[slot[c]] : ignore_th;
+    uint32_t word[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) word[c] = (w[c] > ignore_th) ? bits[cand[c] >> 5] : 0xFFFFFFFFu;
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
-        int v = cand[c];
-        int64_t slot = indexer[v];
-        if (slot < 0 || !(obs[slot] > ignore_th)) continue;
-        uint32_t b = 1u << (v & 31);
-        if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
+        const uint32_t b = 1u << (cand[c] & 31);
+        if (!(word[c] & b)) atomicOr(bits + (cand[c] >> 5), b);
     }
 }
 
