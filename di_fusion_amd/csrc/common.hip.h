@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(1024) k_scan_single(F f, const int* n_ptr, int
 }
 
 inline int scan_blocks(int64_t n_upper) {
-    int64_t b = (n_upper + 4 * DIF_BLOCK - 1) / (4 * DIF_BLOCK);
+    int64_t b = (n_upper + DIF_BLOCK - 1) / DIF_BLOCK;      // one 256-element chunk per workgroup while that fits 1024 workgroups: shortest chain
     if (b < 1) b = 1;
     if (b > 1024) b = 1024;
     return (int)b;
