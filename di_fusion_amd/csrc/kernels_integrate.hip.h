@@ -69,11 +69,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, 
     int lane = lane_id();
     int lin = (i < N) ? pt_lin[i] : -2;
     bool keep = false;
-    if (lin >= 0) keep = (prune_min > 0) ? (frame_count[lin] > prune_min) : true;
+    const int cnt = (lin >= 0) ? frame_count[lin] : 0;            // both look-ups hang off `lin` only: issued together
+    const int64_t own = (lin >= 0) ? indexer[lin] : 0;
+    if (lin >= 0) keep = (prune_min > 0) ? (cnt > prune_min) : true;
     if (i < N) unq_mask[i] = keep ? 1 : 0;
     int prev = __shfl_up(lin, 1);
     bool head = (lane == 0) || (prev != lin);
-    if (head && keep && indexer[lin] == -1) {
+    if (head && keep && own == -1) {
         int ix, iy, iz;
         unlinearize(g, lin, ix, iy, iz);
         int cand[7];
@@ -247,15 +249,21 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
     if (kept && focus) {
         float xn, yn, zn; int ix, iy, iz;
         voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        int64_t slot[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;   // map.py:186-189
             int gx = clampi((int)(ceilf(xn + ox) - 1.0f), 0, g.nx - 1);                                   // map.py:422-424
             int gy = clampi((int)(ceilf(yn + oy) - 1.0f), 0, g.ny - 1);
             int gz = clampi((int)(ceilf(zn + oz) - 1.0f), 0, g.nz - 1);
-            int64_t slot = indexer[linearize(g, gx, gy, gz)];
-            if (in_encode_set(slot, obs, enc_th)) key[o] = (uint32_t)slot;
+            slot[o] = indexer[linearize(g, gx, gy, gz)];
         }
+        float w[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) w[o] = slot[o] >= 0 ? obs[slot[o]] : enc_th;      // all eight counts in flight together
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (w[o] < enc_th) key[o] = (uint32_t)slot[o];
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
