@@ -714,6 +714,10 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (hipMemsetAsync(map->tri_n, 0, sizeof(int32_t) * (size_t)map->capacity, s) != hipSuccess) return DIF_ELAUNCH;
     }
     a.log_counters = C;
+    if (2 * (r + 1) * (r + 1) * (r + 1) <= R3) {         // the refine list is idle from here on: it carries the blended corners between the passes
+        a.corner_cache = reinterpret_cast<float*>(buf->refine_list);
+        a.corner_stride = R3;
+    }
     TriScanFunctor ts{};
     ts.valid_blocks = buf->valid_blocks; ts.indexer = map->indexer; ts.tri_start = map->tri_start; ts.tri_n = map->tri_n; ts.alive = buf->cache_alive;
     ts.new_limit = buf->max_triangles; ts.capacity = buf->cache_capacity;

@@ -14,6 +14,7 @@ struct McArgs {
     float* triangles; int64_t* tri_id; float* tri_std; uint8_t* tri_alive;
     int32_t* tri_count; const int32_t* tri_offset;
     const int* base_ptr;            // device: first output triangle index (mesh-cache append), or NULL
+    float* corner_cache; int64_t corner_stride;   // optional [K][corner_stride >= 2(r+1)^3]: the count pass parks the blended corners here, the emit pass picks them up
     int* log_counters;              // mesh-cache path: the count pass freezes DIF_C_CACHE_KEPT = DIF_C_CACHE_T (log length before this call)
     int64_t new_limit;              // triangles this call may emit (max_n_triangles)
     int scale; float vs, bx, by, bz;
@@ -109,25 +110,36 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     if (!EMIT && a.log_counters && blockIdx.x == 0 && threadIdx.x == 0) a.log_counters[DIF_C_CACHE_KEPT] = a.log_counters[DIF_C_CACHE_T];
     const float sbs = 1.0f / (float)r;
     for (int64_t k = (int64_t)blockIdx.x * wpb + wid; k < K; k += (int64_t)gridDim.x * wpb) {
+        if (EMIT && a.tri_count[k] == 0) continue;          // nothing to write for this voxel: the count pass has already said so
         const int64_t vb = a.valid_blocks[k];
         const int bx = (int)((vb / ((int64_t)a.ny * a.nz)) % a.nx), by = (int)((vb / a.nz) % a.ny), bz = (int)(vb % a.nz);
-        if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): nb[] visible to the whole wave
-        bool any_neg = false, any_pos = false;
-        for (int c = lane; c < nc; c += 64) {
-            float s, d;
-            bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, s, d);
-            c_sdf[c] = ok ? s : __builtin_nanf("");
-            c_std[c] = ok ? d : 0.0f;
-            any_neg |= ok && s < 0.0f;
-            any_pos |= ok && !(s < 0.0f);
+        bool any_neg = true, any_pos = true;
+        if (EMIT && a.corner_cache) {                        // blended corners as the count pass left them (c_sdf and c_std are contiguous)
+            const float* cc = a.corner_cache + k * a.corner_stride;
+            for (int c = lane; c < 2 * nc; c += 64) c_sdf[c] = cc[c];
+        } else {
+            if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): nb[] visible to the whole wave
+            any_neg = false; any_pos = false;
+            for (int c = lane; c < nc; c += 64) {
+                float s, d;
+                bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, s, d);
+                c_sdf[c] = ok ? s : __builtin_nanf("");
+                c_std[c] = ok ? d : 0.0f;
+                any_neg |= ok && s < 0.0f;
+                any_pos |= ok && !(s < 0.0f);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
         int voxel_total = 0;
         // a cell needs corners of both signs to produce a triangle: most dirty voxels off the surface stop here
         const bool crossing = __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
+        if (!EMIT && a.corner_cache && crossing) {
+            float* cc = a.corner_cache + k * a.corner_stride;
+            for (int c = lane; c < 2 * nc; c += 64) cc[c] = c_sdf[c];
+        }
         for (int s0 = 0; crossing && s0 < r3; s0 += 64) {
             const int s = s0 + lane;
             int ntri = 0;
