@@ -285,10 +285,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_alloc_items(const int* __restrict
     const int n = counters[DIF_C_N_OCCUPIED];
     for (int s0 = (int)(blockIdx.x * blockDim.x); s0 < n; s0 += (int)(gridDim.x * blockDim.x)) {
         const int s = s0 + (int)threadIdx.x;
-        const int nit = (s < n) ? (seg_cnt[s] + ITEM_ROWS - 1) / ITEM_ROWS : 0;
+        const int cnt = (s < n) ? seg_cnt[s] : 0;
+        const int nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
         int total;
         const int ex = block_excl_scan(nit, smem, total);
-        if (threadIdx.x == 0) s_base = total ? atomicAdd(counters + DIF_C_ITEMS, total) : 0;
+        const int rows = block_sum(cnt, smem), vox = block_sum(cnt > 0 ? 1 : 0, smem);      // M and C of map.py:434-437
+        if (threadIdx.x == 0) {
+            s_base = total ? atomicAdd(counters + DIF_C_ITEMS, total) : 0;
+            if (vox) { atomicAdd(counters + DIF_C_C, vox); atomicAdd(counters + DIF_C_M, rows); }
+        }
         __syncthreads();
         if (nit) {
             const int off = s_base + ex;
@@ -379,11 +384,9 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ partial, const int* __restrict__ item_start, const int* __restrict__ item_slot,
                                                   int* __restrict__ seg_cnt, int* __restrict__ seg_cursor, float* __restrict__ latent, float* __restrict__ obs,
                                                   uint8_t* __restrict__ dirty, int* __restrict__ counters, int max_items) {
-    __shared__ int smem[8];
     const int n_items = min(counters[DIF_C_ITEMS], max_items);
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
     const int f = threadIdx.x & 31;
-    int updated = 0, rows = 0;
     // walk the work items (a few thousand) instead of every allocated slot: the first item of a slot fuses the whole slot
     for (int it0 = grp; it0 < n_items; it0 += ngrp) {
         const int s = item_slot[it0];
@@ -406,13 +409,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
             dirty[s] = 1;                                    // map.py:452
             seg_cnt[s] = 0;
             seg_cursor[s] = 0;
-            ++updated;
-            rows += cnt;
         }
     }
-    int tu = block_sum(updated, smem);
-    int tr = block_sum(rows, smem);
-    if (threadIdx.x == 0 && tu) { atomicAdd(counters + DIF_C_C, tu); atomicAdd(counters + DIF_C_M, tr); }
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_N_FUSED] = counters[DIF_C_N_OCCUPIED];   // the slots an overlapped extract may look at
 }
 
