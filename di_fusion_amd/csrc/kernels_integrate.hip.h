@@ -313,9 +313,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_scatter_rows(const uint32_t* __re
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_pad; j += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t key = (j < n_pairs) ? pair_key[j] : DIF_INVALID_KEY;
         const bool valid = key != DIF_INVALID_KEY;
+        const int first_item = valid ? item_start[key] : 0;          // in flight together with the atomics below
         const int r = wave_grouped_fetch_add(seg_cursor, key, valid);
         if (valid) {
-            const int64_t pos = (int64_t)item_start[key] * ITEM_ROWS + r;
+            const int64_t pos = (int64_t)first_item * ITEM_ROWS + r;
             if (pos < max_rows) row_val[pos] = (uint32_t)j;
         }
     }
