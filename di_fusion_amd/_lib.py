@@ -39,7 +39,8 @@ class DifMap(Structure):
 class DifWeights(Structure):
     _fields_ = [("enc_packed", c_void_p), ("enc_packed_floats", c_int64),
                 ("dec_packed", c_void_p), ("dec_packed_floats", c_int64),
-                ("dec_bwd_packed", c_void_p), ("dec_bwd_packed_floats", c_int64)]
+                ("dec_bwd_packed", c_void_p), ("dec_bwd_packed_floats", c_int64),
+                ("dec_fold_packed", c_void_p), ("dec_fold_packed_floats", c_int64)]
 
 
 class DifExtractBuffers(Structure):
@@ -48,7 +49,8 @@ class DifExtractBuffers(Structure):
                 ("refine_list", c_void_p), ("tri_count", c_void_p), ("tri_offset", c_void_p), ("block_tmp", c_void_p),
                 ("max_triangles", c_int64), ("cache_capacity", c_int64),
                 ("cache_tri", c_void_p), ("cache_id", c_void_p), ("cache_std", c_void_p), ("cache_alive", c_void_p),
-                ("counters_out", c_void_p), ("out_tri", c_void_p), ("out_id", c_void_p), ("out_std", c_void_p), ("out_capacity", c_int64)]
+                ("counters_out", c_void_p), ("out_tri", c_void_p), ("out_id", c_void_p), ("out_std", c_void_p), ("out_capacity", c_int64),
+                ("fold_table", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)

@@ -649,6 +649,8 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         VoxelDecodeArgs V = {};
         V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std; V.counters = C;
         V.refine_list = buf->refine_list; V.R = R;
+        const bool fold = w->dec_fold_packed && w->dec_fold_packed_floats == DECF_FLOATS && buf->fold_table;
+        V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
         V.low.res = l; V.low.a = (float)sample_a; V.low.vsize = (l > 1) ? (float)((sample_b - sample_a) / (l - 1)) : 0.0f;
         const size_t lds_bytes = ((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 8 * VD_WAVE_LDS_FLOATS) * 4;
         static bool attr_set[64] = {};
@@ -667,6 +669,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         DecodeArgs Rf = {};
         Rf.mode = 1; Rf.n_ptr = C + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
         Rf.lat.res = R; Rf.lat.a = (float)sample_a; Rf.lat.vsize = (float)((sample_b - sample_a) / (R - 1));
+        Rf.fold_table = fold ? buf->fold_table : nullptr;
         Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
         rc = launch_decode(Rf, w, buf->max_voxels * (int64_t)(R3 / 32), s);
         if (rc != DIF_OK) return rc;

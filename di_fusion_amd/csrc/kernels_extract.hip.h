@@ -140,6 +140,7 @@ struct DecodeArgs {
     float* out_grad;                // GRAD kernels: (n,3) d sdf / d xyz (world units), mode 3 (or d sdf / d x0[29..31] for mode 2)
     const float* wbwd;              // GRAD kernels: transposed-layer blob
     float grad_scale;               // 1 / voxel_size (mode 3), 1 (mode 2)
+    const float* fold_table;        // mode 1, optional: [batch voxel][256] constants written by k_decode_voxels (decoder_tile_folded)
 };
 
 // GRAD: 256 threads = one wave per SIMD with the full 512-register budget (forward + reverse chain keep ~300 values live)
@@ -218,7 +219,10 @@ __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(Decod
             xin[t] = v;
         }
         float sdf, sd;
-        if (GRAD) {
+        if (!GRAD && A.mode == 1 && A.fold_table) {          // refine rows: the voxel's latent terms come ready-made from the lattice pass
+            const int b = live ? A.list[tile * 32 + col] / res3 : 0;
+            decoder_tile_folded(lds, wfwd, FoldInitGlobal{A.fold_table + (int64_t)b * 256}, px, py, pz, lane, sdf, sd);
+        } else if (GRAD) {
             float gx, gy, gz;
             decoder_tile_grad(lds, wfwd, wbwd, xin, lane, sdf, sd, gx, gy, gz);
             if (live && half == 1) {
@@ -324,11 +328,13 @@ struct VoxelDecodeArgs {
     float* cube_std;
     int32_t* refine_list;
     int* counters;
+    const float* fold_w;            // packing.py:pack_decoder_fold, or NULL (latent carried through the MFMAs)
+    float* fold_table;              // [batch voxel][256] out, for the refine pass
 };
 
 #define VD_MAX_L3 64
 #define VD_MAX_R2 64
-#define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3)      /* low sdf + low std */
+#define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3 + 256) /* low sdf + low std + the voxel's folded decoder constants */
 
 #ifdef DIF_TRACE            // tools/trace_decode.py: per-wave phase timestamps (100 MHz wall clock) of the last k_decode_voxels launch
 __device__ unsigned long long g_vd_trace[2048 * 8];
@@ -346,6 +352,7 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
     const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
     float* w_low_sdf = lds + ((DEC_LDS_FLOATS + 3) & ~3) + wid * VD_WAVE_LDS_FLOATS;
     float* w_low_std = w_low_sdf + VD_MAX_L3;
+    float* w_fold = w_low_std + VD_MAX_L3;                   // [c0 | c3], see decoder_fold_consts
     const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
     const float scale = (float)(l - 1) / (float)(R - 1);
     const int B = A.counters[DIF_C_B];
@@ -360,24 +367,41 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
         const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
         if (b < B) {
             const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
-            f16v xlat;                                          // latent part of the B operand: the same for every sample of the voxel
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int k = 2 * t + half;
-                xlat[t] = (k < L) ? lat_row[k] : 0.0f;
-            }
             // ---- low lattice -> LDS (map.py:644-653) ----
-            for (int t0 = 0; t0 < l3; t0 += 32) {
-                const int s = t0 + col;
-                const bool live = s < l3;
-                const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
-                f16v xin = xlat;
-                if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }        // k = 29 (x), 30 (y), 31 (z)
-                float sdf, sd;
-                decoder_tile(lds, wfwd, xin, lane, sdf, sd);
-                if (live) {
-                    if (half == 0) w_low_sdf[s] = sdf;
-                    else w_low_std[s] = sd;
+            if (A.fold_w) {
+                // the voxel's latent goes through lin0 / lin3 once (VALU), every sample then only adds its coordinate columns (MFMA)
+                decoder_fold_consts(lds, A.fold_w, lat_row, w_fold, lane);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                float* rec = A.fold_table + (int64_t)b * 256;            // the refine pass picks the constants up from here
+                for (int p = lane; p < 256; p += 64) rec[p] = w_fold[p];
+                for (int t0 = 0; t0 < l3; t0 += 32) {
+                    const int s = t0 + col;
+                    float sdf, sd;
+                    decoder_tile_folded(lds, wfwd, FoldInitLds{w_fold}, A.low.coord(s / (l * l)), A.low.coord((s / l) % l), A.low.coord(s % l), lane, sdf, sd);
+                    if (s < l3) {
+                        if (half == 0) w_low_sdf[s] = sdf;
+                        else w_low_std[s] = sd;
+                    }
+                }
+            } else {
+                f16v xlat;                                      // latent part of the B operand: the same for every sample of the voxel
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int k = 2 * t + half;
+                    xlat[t] = (k < L) ? lat_row[k] : 0.0f;
+                }
+                for (int t0 = 0; t0 < l3; t0 += 32) {
+                    const int s = t0 + col;
+                    const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
+                    f16v xin = xlat;
+                    if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }        // k = 29 (x), 30 (y), 31 (z)
+                    float sdf, sd;
+                    decoder_tile(lds, wfwd, xin, lane, sdf, sd);
+                    if (s < l3) {
+                        if (half == 0) w_low_sdf[s] = sdf;
+                        else w_low_std[s] = sd;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -208,6 +208,106 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W /* LDS 
     stdv = 0.05f + 0.5f * sp;                                              // di_decoder.py:68
 }
 
+// ---- decoder with the latent folded into per-voxel constants -----------------------------------------------------------------
+// Every sample row of a voxel shares the voxel's latent z, which enters the decoder twice: through lin0 (x0 = [z | xyz]) and through the
+// skip connection of lin3.  c0 = b0 + W0[:, :29] z and c3 = b3 + W3[:, 96:125] z are therefore computed ONCE per voxel
+// (decoder_fold_consts: 2 x 128 dot products of length 29 on the VALU, weights from packing.py:pack_decoder_fold) and become the
+// accumulators' initial values; the MFMAs only add the three coordinate columns (k = 29, 30, 31: the last two k-steps of the
+// natural-order block).  656 MFMAs per 32-row tile instead of 768.  The sums are associated differently from decoder_tile (latent
+// terms first), so results agree to rounding (~1e-7 relative), not bit for bit.
+#define DECF_FLOATS (2 * 29 * 128)
+
+// c (256 floats, wave-private LDS): [c0 | c3] in accumulator-fragment order.  lat_row is the same for the whole wave.
+__device__ __forceinline__ void decoder_fold_consts(const float* __restrict__ W /* LDS */, const float* __restrict__ fold /* global */,
+                                                    const float* __restrict__ lat_row, float* __restrict__ c, int lane) {
+    float a0 = W[DEC_B0 + lane], a1 = W[DEC_B0 + lane + 64], a2 = W[DEC_B3 + lane], a3 = W[DEC_B3 + lane + 64];
+    const float* w0 = fold + lane;
+    const float* w3 = fold + 29 * 128 + lane;
+#pragma unroll 4                                      // a few iterations' loads in flight; fully unrolled the 116 loads get hoisted and spill
+    for (int k = 0; k < 29; ++k) {
+        const float zk = lat_row[k];
+        a0 = fmaf(w0[k * 128], zk, a0);
+        a1 = fmaf(w0[k * 128 + 64], zk, a1);
+        a2 = fmaf(w3[k * 128], zk, a2);
+        a3 = fmaf(w3[k * 128 + 64], zk, a3);
+    }
+    c[lane] = a0;
+    c[lane + 64] = a1;
+    c[128 + lane] = a2;
+    c[128 + lane + 64] = a3;
+}
+
+// acc init for (layer, out-block mb): from the wave's LDS record, or from a per-lane record in global memory (rows of different voxels)
+struct FoldInitLds {
+    const float* c;
+    __device__ __forceinline__ f16v load(int layer, int mb, int half) const { return load_bias16(c + layer * 128 + mb * 32, half); }
+};
+struct FoldInitGlobal {
+    const float* rec;               // this lane's voxel record (256 floats)
+    __device__ __forceinline__ f16v load(int layer, int mb, int half) const { return load_bias16(rec + layer * 128 + mb * 32, half); }
+};
+
+// One 32-point tile; (px, py, pz) = voxel-local coordinates of point (lane & 31).
+template <class INIT>
+__device__ __forceinline__ void decoder_tile_folded(const float* __restrict__ W /* LDS */, __amdgpu_buffer_rsrc_t Wg /* global blob */, const INIT& init,
+                                                    float px, float py, float pz, int lane, float& sdf, float& stdv) {
+    const int half = lane >> 5;
+    const float b14 = half ? px : 0.0f;             // k-step 14 contracts features (28, 29): the latent's last entry is folded away
+    const float b15 = half ? pz : py;               // k-step 15: features (30, 31)
+    f16v h0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = init.load(0, mb, half);
+        const f4v a = reinterpret_cast<const f4v*>(W + DEC_A0)[(mb * 4 + 3) * 64 + lane];
+        acc = mfma32(a.z, b14, acc);
+        acc = mfma32(a.w, b15, acc);
+        h0[mb] = relu16(acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f16v h1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = load_bias16(W + DEC_B1 + mb * 32, half);
+        acc = block_mm<4>(reinterpret_cast<const f4v*>(W + DEC_A1) + (mb * 16) * 64, h0, acc, lane);
+        h1[mb] = relu16(acc);
+    }
+    f16v h2[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        f16v acc = load_bias16(W + DEC_B2 + mb * 32, half);
+        acc = block_mm<4>(reinterpret_cast<const f4v*>(W + DEC_A2) + (mb * 16) * 64, h1, acc, lane);
+        h2[mb] = relu16(acc);
+    }
+    int off3 = DEC_A3 * 4;
+    asm volatile("" : "+s"(off3) : : "memory");
+    float ps = 0.0f, pu = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = init.load(1, mb, half);
+        const BufA src{Wg, off3 + mb * 16 * 1024};
+        const f4v ax = src.load(15, lane);          // the k-group that holds the coordinate columns of the skip block
+        acc = block_mm_src<3>(src, h2, acc, lane);
+        acc = mfma32(ax.z, b14, acc);
+        acc = mfma32(ax.w, b15, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = relu16(acc);
+        f16v ws = load_bias16(W + DEC_HW + mb * 32, half);
+        f16v wu = load_bias16(W + DEC_HU + mb * 32, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ps = fmaf(acc[r], ws[r], ps);
+            pu = fmaf(acc[r], wu[r], pu);
+        }
+    }
+    ps += __shfl_xor(ps, 32);
+    pu += __shfl_xor(pu, 32);
+    ps += W[DEC_HB + 0];
+    pu += W[DEC_HB + 1];
+    sdf = tanhf(ps);                                                       // di_decoder.py:84
+    float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));                       // F.softplus (beta=1, threshold=20)
+    stdv = 0.05f + 0.5f * sp;                                              // di_decoder.py:68
+}
+
 // ---- decoder with input gradient (get_sdf for the tracker: d sdf / d xyz, reference tracker.py:186-192) -------------------
 // Backward blob (global memory, packing.py:pack_decoder_backward): transposed layers, k order = D-fragment order of the
 // forward layer's OUTPUT blocks, so the masked upstream gradient fragments are again ready-made B operands.

@@ -23,6 +23,7 @@ ENC_FLOATS = 27264
 DEC_LDS_FLOATS = 33508
 DEC_FLOATS = 49892
 DECB_FLOATS = 49152
+DECF_FLOATS = 2 * 29 * 128
 
 
 def _frag_feature(r: int, half: int) -> int:
@@ -135,4 +136,24 @@ def pack_decoder_backward(w: Dict[str, np.ndarray]) -> np.ndarray:
              pack_A(np.ascontiguousarray(Ws[0].T), 1, 16, kmap_dfrag)]      # (32 in: latent 29 | xyz 3) x (128 out)
     blob = np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
     assert blob.shape[0] == DECB_FLOATS, blob.shape
+    return blob
+
+
+def pack_decoder_fold(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """Latent columns of the two decoder layers that see the input (lin0: x0[:29]; lin3: the skip part, columns 96..124), transposed
+    to [layer][k][p] with p running over the accumulator-fragment positions (p = mb*32 + half*16 + r <-> feature mb*32 + f(r, half)).
+    The latent of a voxel is the same for every sample of that voxel, so  c = bias + W[:, latent] z  is computed once per voxel
+    (`decoder_fold_consts`, mlp.hip.h) and used as the accumulator's initial value; only the three coordinate columns are left to the
+    MFMAs (2 k-steps per out-block instead of 16)."""
+    Ws, bs, Wu, bu = fold_decoder(w)
+    out = np.zeros((2, 29, 128), dtype=np.float32)
+    for layer, (W, c0) in enumerate(((Ws[0], 0), (Ws[3], 96))):
+        for mb in range(4):
+            for half in range(2):
+                for r in range(16):
+                    p = mb * 32 + half * 16 + r
+                    f = mb * 32 + _frag_feature(r, half)
+                    out[layer, :, p] = W[f, c0:c0 + 29]
+    blob = out.reshape(-1)
+    assert blob.shape[0] == DECF_FLOATS
     return blob

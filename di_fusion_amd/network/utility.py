@@ -29,6 +29,7 @@ class _PackedNet:
         self._enc_blob = packing.pack_encoder(raw)
         self._dec_blob = packing.pack_decoder(raw)
         self._decb_blob = packing.pack_decoder_backward(raw)
+        self._decf_blob = packing.pack_decoder_fold(raw)
         self._dev = {}
 
     def weights_struct(self, device: torch.device):
@@ -38,8 +39,9 @@ class _PackedNet:
             enc = torch.from_numpy(self._enc_blob).to(device)
             dec = torch.from_numpy(self._dec_blob).to(device)
             decb = torch.from_numpy(self._decb_blob).to(device)
-            w = _lib.DifWeights(_lib.ptr(enc), enc.numel(), _lib.ptr(dec), dec.numel(), _lib.ptr(decb), decb.numel())
-            self._dev[key] = (w, enc, dec, decb)
+            decf = torch.from_numpy(self._decf_blob).to(device)
+            w = _lib.DifWeights(_lib.ptr(enc), enc.numel(), _lib.ptr(dec), dec.numel(), _lib.ptr(decb), decb.numel(), _lib.ptr(decf), decf.numel())
+            self._dev[key] = (w, enc, dec, decb, decf)
         return self._dev[key][0]
 
 

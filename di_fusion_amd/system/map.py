@@ -463,7 +463,8 @@ class DenseIndexedMap:
                      refine_list=torch.empty((max_vox * R ** 3,), dtype=torch.int32, device=dev),
                      tri_count=torch.empty((max_vox,), dtype=torch.int32, device=dev),
                      tri_offset=torch.empty((max_vox,), dtype=torch.int32, device=dev),
-                     block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev))
+                     block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev),
+                     fold_table=torch.empty((max_vox, 256), dtype=torch.float32, device=dev))
             self._xbuf = (key, t)
         t = self._xbuf[1]
         # the log must always have room for two calls' worth of output beyond what the host last saw (counters lag one frame

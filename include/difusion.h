@@ -95,6 +95,9 @@ typedef struct dif_weights {
     int64_t dec_packed_floats;
     const float* dec_bwd_packed;    /* decoder, transposed layers for d sdf / d xyz (may be NULL if gradients are never asked) */
     int64_t dec_bwd_packed_floats;
+    const float* dec_fold_packed;   /* decoder, latent columns of lin0 / lin3 for the per-voxel constant folding (packing.py:pack_decoder_fold);
+                                     * NULL: every sample row carries the latent through the MFMAs */
+    int64_t dec_fold_packed_floats;
 } dif_weights_t;
 
 int dif_version(void);
@@ -208,6 +211,8 @@ typedef struct dif_extract_buffers {
     int64_t* out_id;                /* of them) copied out by the same last kernel — (n,3,3) f32, (n) i64, (n,3) f32; again, pinned host   */
     float* out_std;                 /* memory is fine: a streaming caller gets each frame's mesh update without a transfer of its own      */
     int64_t out_capacity;
+    float* fold_table;              /* optional [max_voxels][256]: per-voxel decoder constants handed from the lattice decode to the refine
+                                     * decode (used when dif_weights_t.dec_fold_packed is set) */
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
