@@ -221,15 +221,15 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W /* LDS 
 __device__ __forceinline__ void decoder_fold_consts(const float* __restrict__ W /* LDS */, const float* __restrict__ fold /* global */,
                                                     const float* __restrict__ lat_row, float* __restrict__ c, int lane) {
     float a0 = W[DEC_B0 + lane], a1 = W[DEC_B0 + lane + 64], a2 = W[DEC_B3 + lane], a3 = W[DEC_B3 + lane + 64];
-    const float* w0 = fold + lane;
-    const float* w3 = fold + 29 * 128 + lane;
-#pragma unroll 4                                      // a few iterations' loads in flight; fully unrolled the 116 loads get hoisted and spill
+    const f4v* wk = reinterpret_cast<const f4v*>(fold) + lane;       // [k][lane] -> (lin0: p = lane, lane + 64; lin3: p = lane, lane + 64)
+#pragma unroll 8                                      // a batch of loads in flight; fully unrolled they get hoisted en masse and spill
     for (int k = 0; k < 29; ++k) {
         const float zk = lat_row[k];
-        a0 = fmaf(w0[k * 128], zk, a0);
-        a1 = fmaf(w0[k * 128 + 64], zk, a1);
-        a2 = fmaf(w3[k * 128], zk, a2);
-        a3 = fmaf(w3[k * 128 + 64], zk, a3);
+        const f4v wv = wk[k * 64];
+        a0 = fmaf(wv.x, zk, a0);
+        a1 = fmaf(wv.y, zk, a1);
+        a2 = fmaf(wv.z, zk, a2);
+        a3 = fmaf(wv.w, zk, a3);
     }
     c[lane] = a0;
     c[lane + 64] = a1;

@@ -141,7 +141,7 @@ def pack_decoder_backward(w: Dict[str, np.ndarray]) -> np.ndarray:
 
 def pack_decoder_fold(w: Dict[str, np.ndarray]) -> np.ndarray:
     """Latent columns of the two decoder layers that see the input (lin0: x0[:29]; lin3: the skip part, columns 96..124), transposed
-    to [layer][k][p] with p running over the accumulator-fragment positions (p = mb*32 + half*16 + r <-> feature mb*32 + f(r, half)).
+    to positions p of the accumulator fragments (p = mb*32 + half*16 + r <-> feature mb*32 + f(r, half)), stored [k][lane][4].
     The latent of a voxel is the same for every sample of that voxel, so  c = bias + W[:, latent] z  is computed once per voxel
     (`decoder_fold_consts`, mlp.hip.h) and used as the accumulator's initial value; only the three coordinate columns are left to the
     MFMAs (2 k-steps per out-block instead of 16)."""
@@ -154,6 +154,8 @@ def pack_decoder_fold(w: Dict[str, np.ndarray]) -> np.ndarray:
                     p = mb * 32 + half * 16 + r
                     f = mb * 32 + _frag_feature(r, half)
                     out[layer, :, p] = W[f, c0:c0 + 29]
-    blob = out.reshape(-1)
+    # device order [k][lane][4]: the four positions a lane owns (lin0: lane, lane+64; lin3: lane, lane+64) in one 16-byte load
+    dev = np.stack([out[0, :, :64], out[0, :, 64:], out[1, :, :64], out[1, :, 64:]], axis=-1)     # (29, 64, 4)
+    blob = np.ascontiguousarray(dev).reshape(-1).astype(np.float32)
     assert blob.shape[0] == DECF_FLOATS
     return blob
