@@ -99,6 +99,28 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
         same(outs["eager"], snapshot(st))
 
 
+def test_graph_mode_host_staging_overflow_falls_back(gpu_model):
+    """A frame with more new triangles than the pinned staging area of the captured graph holds must still hand back all of them
+    (through the side-stream export)."""
+    ref = make_stream(gpu_model)
+    want = [tuple(x.clone() for x in ref.step(i, d2h="new")) for i in range(4)]
+    st = make_stream(gpu_model)
+    st.HOST_OUT_TRIANGLES = 64                               # instance attribute shadows the class default before the first capture
+    st.step(0, d2h="new")
+    got = [want[0]]
+    for i in range(1, 4):
+        o = st.step_graph(i, d2h="new")
+        if o is not None:
+            torch.cuda.synchronize()
+            got.append(tuple(x.clone() for x in o))
+    o = st.flush()
+    torch.cuda.synchronize()
+    got.append(tuple(x.clone() for x in o))
+    assert len(got) == 4 and min(g[0].shape[0] for g in got) > 64
+    for a, b in zip(want, got):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_frame_descriptor_entry_point_bit_exact(gpu_model):
     import ctypes
     import struct
