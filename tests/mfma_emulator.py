@@ -92,3 +92,41 @@ def decoder_tile(blob, rows):
     ps = ps + ps[LANES ^ 32] + blob[DEC["HB"]]
     pu = pu + pu[LANES ^ 32] + blob[DEC["HB"] + 1]
     return ps[:32], pu[:32]
+
+
+def decoder_tile_folded(blob, fold_blob, latent, pts):
+    """The folded chain of mlp.hip.h (`decoder_fold_consts` + `decoder_tile_folded`): one voxel latent (29,), 32 sample coordinates
+    pts (32,3) -> pre-activation (sdf_lin (32,), std_lin (32,)).  fold_blob is packing.pack_decoder_fold's [k][lane][4] array."""
+    half = LANES >> 5
+    col = LANES & 31
+    wk = fold_blob.reshape(29, 64, 4)
+    # c[p], p = accumulator-fragment position: lane owns p = lane, lane + 64 of each layer
+    c = np.zeros((2, 128))
+    c[0, :64] = blob[DEC["B0"]:DEC["B0"] + 64]; c[0, 64:] = blob[DEC["B0"] + 64:DEC["B0"] + 128]
+    c[1, :64] = blob[DEC["B3"]:DEC["B3"] + 64]; c[1, 64:] = blob[DEC["B3"] + 64:DEC["B3"] + 128]
+    for k in range(29):
+        c[0, :64] += wk[k, :, 0] * latent[k]; c[0, 64:] += wk[k, :, 1] * latent[k]
+        c[1, :64] += wk[k, :, 2] * latent[k]; c[1, 64:] += wk[k, :, 3] * latent[k]
+    b14 = np.where(half == 1, pts[col, 0], 0.0)
+    b15 = np.where(half == 1, pts[col, 2], pts[col, 1])
+    h0 = []
+    for mb in range(4):
+        acc = bias16(c[0], mb * 32)
+        a4 = blob[DEC["A0"] + (mb * 4 + 3) * 256: DEC["A0"] + (mb * 4 + 4) * 256].reshape(64, 4)
+        acc = mfma(a4[:, 2], b14, acc)
+        acc = mfma(a4[:, 3], b15, acc)
+        h0.append(np.maximum(acc, 0))
+    h1 = [np.maximum(block_mm(blob, DEC["A1"] + mb * 16 * 256, h0, bias16(blob, DEC["B1"] + mb * 32)), 0) for mb in range(4)]
+    h2 = [np.maximum(block_mm(blob, DEC["A2"] + mb * 16 * 256, h1, bias16(blob, DEC["B2"] + mb * 32)), 0) for mb in range(3)]
+    ps = np.zeros(64); pu = np.zeros(64)
+    for mb in range(4):
+        acc = block_mm(blob, DEC["A3"] + mb * 16 * 256, h2, bias16(c[1], mb * 32))
+        a4 = blob[DEC["A3"] + (mb * 16 + 15) * 256: DEC["A3"] + (mb * 16 + 16) * 256].reshape(64, 4)
+        acc = mfma(a4[:, 2], b14, acc)
+        acc = mfma(a4[:, 3], b15, acc)
+        acc = np.maximum(acc, 0)
+        ps += (acc * bias16(blob, DEC["HW"] + mb * 32)).sum(1)
+        pu += (acc * bias16(blob, DEC["HU"] + mb * 32)).sum(1)
+    ps = ps + ps[LANES ^ 32] + blob[DEC["HB"]]
+    pu = pu + pu[LANES ^ 32] + blob[DEC["HB"] + 1]
+    return ps[:32], pu[:32]
