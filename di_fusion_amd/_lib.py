@@ -72,7 +72,7 @@ SIGNATURES = {
     "dif_estimate_normals": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, POINTER(c_float), c_void_p, c_void_p, c_int64,
                                        c_void_p]),
     "dif_groupby_sum": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
-    "dif_integrate_workspace_bytes": (c_int64, [c_int64]),
+    "dif_integrate_workspace_bytes": (c_int64, [c_int64, c_int32]),
     "dif_integrate": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_int64, c_void_p]),
     "dif_integrate_frame": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float,

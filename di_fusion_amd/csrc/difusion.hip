@@ -324,17 +324,23 @@ struct IntegrateWs {
 };
 
 
-static int64_t max_items_for(int64_t N) {
-    // items = sum_s ceil(cnt_s / ITEM_ROWS) <= M/ITEM_ROWS + C with M <= 8N rows.  With pruning on, every kept point shares its
-    // voxel with > prune_min_vox_obs others, so the encoded voxels (26-neighbourhoods of those) number well under 2N; anything
-    // beyond the bound is dropped by k_alloc_items with DIF_C_OVERFLOW = 4.
-    return 8 * N / ITEM_ROWS + 2 * N + 64;
+static int64_t max_items_for(int64_t N, int prune_min_vox_obs) {
+    // items = sum_s ceil(cnt_s / ITEM_ROWS) <= M / ITEM_ROWS + C, with M <= 8N gathered rows and C updated voxels.  Every kept point lives in
+    // a voxel holding > prune_min_vox_obs points of the frame, so there are at most N / (prune + 1) such voxels and the updated ones sit in
+    // their 27-neighbourhoods; without pruning every (point, offset) pair may hit its own voxel: C <= 8N.  Anything beyond the bound would
+    // be dropped by k_alloc_items with DIF_C_OVERFLOW = 4.
+    int64_t c_max = 8 * N;
+    if (prune_min_vox_obs > 0) {
+        const int64_t by_prune = 27 * (N / ((int64_t)prune_min_vox_obs + 1) + 1);
+        if (by_prune < c_max) c_max = by_prune;
+    }
+    return 8 * N / ITEM_ROWS + c_max + 64;
 }
 
-static int carve_integrate(int64_t N, void* base, IntegrateWs& ws) {
+static int carve_integrate(int64_t N, int prune_min_vox_obs, void* base, IntegrateWs& ws) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    ws.max_items = max_items_for(N);
+    ws.max_items = max_items_for(N, prune_min_vox_obs);
     size_t o_lin = take((size_t)N * 4), o_key = take((size_t)8 * N * 4), o_row = take((size_t)ws.max_items * ITEM_ROWS * 4);
     size_t o_islot = take((size_t)ws.max_items * 4), o_part = take((size_t)ws.max_items * 32 * 8), o_tmp = take(4096 * 4);
     ws.total_bytes = (int64_t)off;
@@ -346,10 +352,10 @@ static int carve_integrate(int64_t N, void* base, IntegrateWs& ws) {
     return DIF_OK;
 }
 
-int64_t dif_integrate_workspace_bytes(int64_t N) {
+int64_t dif_integrate_workspace_bytes(int64_t N, int32_t prune_min_vox_obs) {
     if (N <= 0) N = 1;
     IntegrateWs ws;
-    if (carve_integrate(N, nullptr, ws) != DIF_OK) return -1;
+    if (carve_integrate(N, prune_min_vox_obs, nullptr, ws) != DIF_OK) return -1;
     return ws.total_bytes;
 }
 
@@ -369,7 +375,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     if (grid >= ((int64_t)1 << 31)) return DIF_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     IntegrateWs ws;
-    if (carve_integrate(N, wsp, ws) != DIF_OK) return DIF_ELAUNCH;
+    if (carve_integrate(N, (int)map->prune_min_vox_obs, wsp, ws) != DIF_OK) return DIF_ELAUNCH;
     if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
     Geo g = geo_of(map);
     int* C = map->counters;

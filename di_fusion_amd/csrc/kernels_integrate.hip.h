@@ -159,7 +159,8 @@ __device__ __forceinline__ int wave_grouped_fetch_add(int* __restrict__ counter,
 // per WORKGROUP.
 // Same-address global atomics are what bounds the row counting (hundreds per voxel per frame, ~12 ns each on one L2 channel).
 #define FG_TABLE 256
-__device__ __forceinline__ void block_grouped_add_lds(unsigned* __restrict__ tkey, int* __restrict__ tcnt, uint32_t key, bool valid) {
+__device__ __forceinline__ void block_grouped_add_lds(unsigned* __restrict__ tkey, int* __restrict__ tcnt, int* __restrict__ counter, uint32_t key,
+                                                      bool valid) {
     const int lane = lane_id();
     unsigned long long todo = __ballot(valid);
     while (todo) {
@@ -167,13 +168,15 @@ __device__ __forceinline__ void block_grouped_add_lds(unsigned* __restrict__ tke
         const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
         const unsigned long long same = __ballot(valid && key == k0);
         if (lane == leader) {
-            unsigned h = (k0 * 2654435761u) >> 24;                     // FG_TABLE = 256 slots; a workgroup holds far fewer distinct keys
-            while (true) {
+            unsigned h = (k0 * 2654435761u) >> 24;                     // FG_TABLE = 256 slots; a workgroup normally holds far fewer distinct keys
+            int probes = 0;
+            for (; probes < FG_TABLE; ++probes) {
                 const unsigned old = atomicCAS(tkey + h, DIF_INVALID_KEY, k0);
                 if (old == DIF_INVALID_KEY || old == k0) break;
                 h = (h + 1) & (FG_TABLE - 1);
             }
-            atomicAdd(tcnt + h, __popcll(same));
+            if (probes < FG_TABLE) atomicAdd(tcnt + h, __popcll(same));
+            else atomicAdd(counter + k0, __popcll(same));             // table full (a workgroup spanning > 256 voxels): count directly
         }
         todo &= ~same;
     }
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         if (i < N) pair_key[(int64_t)o * N + i] = key[o];
-        block_grouped_add_lds(tkey, tcnt, key[o], key[o] != DIF_INVALID_KEY);
+        block_grouped_add_lds(tkey, tcnt, seg_cnt, key[o], key[o] != DIF_INVALID_KEY);
     }
     __syncthreads();
     if (tkey[threadIdx.x] != DIF_INVALID_KEY) atomicAdd(seg_cnt + tkey[threadIdx.x], tcnt[threadIdx.x]);

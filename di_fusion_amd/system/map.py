@@ -322,7 +322,7 @@ class DenseIndexedMap:
             prune = int(self.args.prune_min_vox_obs)
             self._ensure_capacity(7 * (N // (prune + 1)) if prune > 0 else 7 * N)
             if self._ws is None or self._ws_n < N:
-                nb = int(lib.dif_integrate_workspace_bytes(N))
+                nb = int(lib.dif_integrate_workspace_bytes(N, prune))
                 if nb < 0:
                     raise RuntimeError("dif_integrate_workspace_bytes failed")
                 self._ws = torch.empty((nb,), dtype=torch.uint8, device=self.device)

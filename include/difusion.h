@@ -166,8 +166,9 @@ int dif_groupby_sum(const float* values, const int64_t* indices, int64_t N, int3
                     int64_t C, void* stream);
 
 /* ---- a3..a10: integrate_keyframe (map.py:340-519, do_optimize=False) --------------------------------------- */
-/* Bytes of scratch `ws` needed for N points. */
-int64_t dif_integrate_workspace_bytes(int64_t N);
+/* Bytes of scratch `ws` needed for N points by a map with this `prune_min_vox_obs` (the pruning bounds how many voxels a frame can
+ * update, hence the number of encoder work items; <= 0: no pruning, up to 8N voxels). */
+int64_t dif_integrate_workspace_bytes(int64_t N, int32_t prune_min_vox_obs);
 /* xyz, normal: (N,3) f32.  unq_mask: (N) u8 out (map.py:375; all-valid-points when prune_min_vox_obs<=0).
  * Points with NaN coordinates or outside [bound_min, bound_max) are masked out (the reference indexes out of
  * bounds there, map.py:313; documented divergence). */

@@ -166,6 +166,29 @@ def test_edge_cases(gpu_model):
         m.integrate_keyframe(torch.zeros((4, 3)), torch.zeros((4, 3)))
 
 
+def test_scattered_points_without_pruning_vs_oracle(gpu_model, oracle_net):
+    """Points in random order, pruning off: consecutive points share no voxel, a 256-point workgroup touches ~2,000 distinct voxels
+    (more than its LDS row-count table holds: the overflow path), every voxel gets only a handful of rows.  State must still be
+    bit-exact against the oracle."""
+    from oracle import difusion_oracle as O
+    cfg = syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.1, prune_min_vox_obs=0)
+    g = torch.Generator().manual_seed(7)
+    xyz = ((torch.rand((6000, 3), generator=g) - 0.5) * 3.0).float()
+    nrm = torch.nn.functional.normalize(torch.randn((6000, 3), generator=g), dim=1).float()
+    m = make_map(gpu_model, cfg)
+    om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size, prune_min_vox_obs=0)
+    for rep in range(2):                                   # second pass: voxels already allocated, running average
+        mask = m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV))
+        omask = om.integrate_keyframe(xyz.numpy(), nrm.numpy())
+        assert mask is None or np.array_equal(mask.cpu().numpy(), omask)
+        n = m.n_occupied
+        assert n == om.n_occupied and n > 5000
+        assert np.array_equal(m.indexer.cpu().numpy().reshape(-1), om.indexer.reshape(-1))
+        assert np.array_equal(m.voxel_obs_count[:n].cpu().numpy(), om.voxel_obs_count[:n])
+        assert np.abs(m.latent_vecs[:n].cpu().numpy() - om.latent_vecs[:n]).max() < 2e-5
+        assert m.last_counters["M"] == om.last_stats["M"]
+
+
 def test_capacity_growth_and_save_load(gpu_model, tmp_path):
     scene, cfg, intr = CASES["seq_room16"]
     g = np.load(GOLDEN / "seq_room16.npz")
