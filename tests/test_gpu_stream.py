@@ -147,7 +147,7 @@ def test_frame_descriptor_entry_point_bit_exact(gpu_model):
 def test_c3_full_size_invariants(gpu_model):
     """BASELINE config C3 at full size (128^3 grid, 640x480 frames): no oracle run is affordable here, so pin size-independent
     properties: slot <-> voxel bijection, conservation of the observation count, idempotence of extract, vertices inside their voxel,
-    and run-to-run bit-identity."""
+    and bit-identity between an eager run and a hipGraph run (which walks the frame in 16x16 pixel tiles)."""
     from di_fusion_amd.stream import FusionStream
     scene, cfg = S.config_c3()
     finals = []
@@ -155,8 +155,12 @@ def test_c3_full_size_invariants(gpu_model):
         st = FusionStream(gpu_model, scene, cfg, S.Intrinsic(), DEV, 5, deg_per_frame=0.5)
         rows = 0
         for i in range(5):
-            st.step(i, d2h="none")
-            rows += st.stats[-1]["M"]
+            if rep == 1 and i >= 1:                     # second run: hipGraph replay through dif_integrate_frame (16x16 pixel tiles)
+                st.step_graph(i, d2h="none")
+            else:
+                st.step(i, d2h="none")
+        st.flush("none")
+        rows = sum(s["M"] for s in st.stats)
         m = st.map
         n = m.n_occupied
         assert n > 15000
