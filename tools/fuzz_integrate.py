@@ -1,5 +1,5 @@
 """Differential fuzzing of integrate + extract against the oracle on random small problems (grid size, voxel size, pruning on/off, point
-order, NaNs, out-of-bounds points, repeated frames).  Bit-exact integer state, latents within 2e-5, triangle counts equal.
+order, NaNs, out-of-bounds points, repeated frames).  Bit-exact integer state, latents within 2e-5, dirty / batch counts equal; then random point queries (mask exact, values within 5e-5).
 Usage: python tools/fuzz_integrate.py [--cases 20] [--seed 0]      (GPU; a few seconds per case, the oracle is the slow side)"""
 import argparse
 import sys
@@ -79,6 +79,15 @@ def main():
                 assert m.last_counters["K"] == 0, (case, frame, "K")
             else:
                 assert m.last_counters["K"] == len(oa["valid_blocks"]) and m.last_counters["B"] == len(oa["occupied_vec_id"]), (case, frame, "K/B")
+        # point queries inside the grid (get_sdf, map.py:559-579): validity mask exact, values within 5e-5
+        lo = np.asarray(cfg.bound_min, np.float32)
+        hi = lo + np.asarray(om.n_xyz, np.float32) * np.float32(vs)
+        q = (lo + (hi - lo) * rng.random((4000, 3)).astype(np.float32) * 0.999 + 1e-4).astype(np.float32)
+        sdf, std, qm = m.get_sdf(torch.from_numpy(q).to(dev))
+        osdf, ostd, oqm = om.get_sdf(q)
+        assert np.array_equal(qm.cpu().numpy(), oqm), (case, "query mask")
+        if oqm.any():
+            assert np.abs(sdf.cpu().numpy() - osdf).max() < 5e-5 and np.abs(std.cpu().numpy() - ostd).max() < 5e-5, (case, "query values")
         print(f"case {case}: grid {n}^3 vs {vs} prune {prune} {kind}: n_occupied {m.n_occupied} triangles {0 if out is None else out[0].shape[0]} ok", flush=True)
     print("fuzz ok")
 
