@@ -77,7 +77,113 @@ def flush_c_stdio():
         pass
 
 
+WORKLOADS = {"c1": "C1 32^3 grid 0.1 m, sphere", "c2": "C2 64^3 grid 0.1 m, room",
+             "c3": "C3 128^3 grid 0.05 m, ScanNet-shape 6 m room with boxes"}
+
+
+def prime_process(FusionStream, syn, model, intr, dev, d2h):
+    """One-time process costs (code-object load, kernel attributes, pinned-memory pools, graph machinery) are paid on a throwaway 32^3
+    map, so that they do not land in the timed region when the caller asks for little or no warmup.  Its allocator blocks are given
+    back: leaving them cached costs 9 % of throughput (buffer placement matters at 0.35 ms per frame)."""
+    import gc
+    s1, c1 = syn.config_c1()
+    prime = FusionStream(model, s1, c1, intr, dev, 4, deg_per_frame=0.5)
+    prime.step(0, d2h)
+    prime.step_pipelined(1, d2h)
+    prime.step_graph(2, d2h)
+    prime.step_graph(3, d2h)
+    prime.flush(d2h)
+    torch.cuda.synchronize()
+    del prime
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def frame_runner(stream, a, d2h):
+    """(run(i), drain()) for the chosen way of driving a frame."""
+    def run(i):
+        if a.overlap and i >= 1:
+            return stream.step_overlap(i, d2h, graph=bool(a.graph and (i % a.sample_every) != 0))
+        if a.graph and i >= 2 and (i % a.sample_every) != 0:
+            return stream.step_graph(i, d2h)
+        return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
+
+    def drain():
+        if a.overlap:
+            stream.flush_overlap(d2h)           # includes the extract of the last integrated frame: nothing is left outside the clock
+        else:
+            stream.flush(d2h)
+    return run, drain
+
+
+def rate_with_mesh_left_in_hbm(make_stream, a, n_frames):
+    """Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream without the per-frame hand-over of
+    the new triangles to pinned host memory.  The difference is PCIe traffic, not kernels."""
+    s2 = make_stream()
+    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "overlap": 0, "sample_every": 1 << 30}), "none")
+    for i in range(a.warmup):
+        run2(i)
+    drain2()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for i in range(a.warmup, n_frames):
+        run2(i)
+    drain2()
+    torch.cuda.synchronize()
+    return round(a.steps / (time.perf_counter() - t2), 3)
+
+
+def global_map_merge(stream, model, cfg, dev, barrier):
+    """BASELINE config C4: after the independent subsequences, ONE all-gather of voxel records over RCCL and a fold into a global map
+    (identical on every rank), meshed once.  Outside the clock (once per sequence, not per frame); reported, never fatal."""
+    try:
+        from di_fusion_amd import parallel
+        from di_fusion_amd.system.map import DenseIndexedMap
+        barrier()
+        tm = time.perf_counter()
+        gmap = parallel.build_global_map(stream.map, lambda: DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1 << 17))
+        torch.cuda.synchronize()
+        t_merge = time.perf_counter() - tm
+        gmesh = gmap.extract_mesh_arrays(4, int(8e6), max_std=0.15, no_cache=True, to_host=False)
+        torch.cuda.synchronize()
+        return {"all_gather_and_fold_ms": round(t_merge * 1e3, 2), "global_voxels": int(gmap.n_occupied),
+                "local_voxels_rank0": int(stream.map.n_occupied), "global_mesh_triangles": int(gmesh[0].shape[0]) if gmesh else 0,
+                "extract_global_ms": round((time.perf_counter() - tm - t_merge) * 1e3, 2)}
+    except Exception as e:      # the headline number must survive a failure of the optional epilogue
+        return {"error": repr(e)[:200]}
+
+
+def roofline_block(prof, sst):
+    """`roofline` for the MFMA kernel with the longest average launch.  prof: name -> (ms, launches) from the library's HIP events;
+    sst: the counters of the frames those events bracketed (rows per launch come from there)."""
+    rows = {"encode": (sum(s["M"] for s in sst), ENC_FLOP_PER_ROW), "decode_lattice": (sum(s["B"] * 64 for s in sst), DEC_FLOP_PER_ROW),
+            "decode_points": (sum(s["VH"] for s in sst), DEC_FLOP_PER_ROW)}
+    kern = {}
+    for name, (n_rows, flop) in rows.items():
+        t_ms, n = prof[name]
+        if n > 0 and t_ms > 0:
+            kern[name] = dict(ms_per_launch=t_ms / n, rows_per_launch=n_rows / n, tflops=n_rows * flop / (t_ms * 1e-3) / 1e12)
+    if not kern:
+        return None
+    dom = max(kern, key=lambda k: kern[k]["ms_per_launch"])
+    pmc = {}
+    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs; see profiles/README.md)
+        pmc = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_hbm.json"))[-1].read_text())["kernels"]
+    except Exception:
+        pass
+    kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode<false>"}[dom]
+    return {"bound": "mfma", "kernel": kname,
+            "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
+            "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
+            "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
+            "event_timed_frames": len(sst),
+            "other_ms_per_frame": {k: round(prof[k][0] / max(1, len(sst)), 4) for k in ("mc_count", "mc_emit", "sort")}}
+
+
 def main():
+    import gc
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -103,21 +209,14 @@ def main():
     intr = syn.Intrinsic()
     model = net_util.networks_from_arrays(net_util.load_weights_npz())
     n_frames = a.warmup + a.steps
-    # every rank walks its own arc of the orbit (independent subsequence)
-    stream = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))
-    lib = _lib.load()
 
-    # One-time process costs (code-object load, kernel attributes, pinned-memory pools, graph machinery) are paid on a throwaway
-    # 32^3 map, so that they do not land in the timed region when the caller asks for little or no warmup.
+    def make_stream():      # every rank walks its own arc of the orbit (independent subsequence)
+        return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))
+
+    stream = make_stream()
+    lib = _lib.load()
     if os.environ.get("DIF_BENCH_NO_PRIME") != "1":
-        s1, c1 = syn.config_c1()
-        prime = FusionStream(model, s1, c1, intr, dev, 4, deg_per_frame=0.5)
-        prime.step(0, a.d2h); prime.step_pipelined(1, a.d2h); prime.step_graph(2, a.d2h); prime.step_graph(3, a.d2h); prime.flush(a.d2h)
-        torch.cuda.synchronize()
-        del prime
-        import gc
-        gc.collect()
-        torch.cuda.empty_cache()
+        prime_process(FusionStream, syn, model, intr, dev, a.d2h)
 
     def barrier():
         torch.cuda.synchronize()
@@ -125,19 +224,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(i):
-        if a.overlap and i >= 1:
-            return stream.step_overlap(i, a.d2h, graph=bool(a.graph and (i % a.sample_every) != 0))
-        if a.graph and i >= 2 and (i % a.sample_every) != 0:
-            return stream.step_graph(i, a.d2h)
-        return stream.step_pipelined(i, a.d2h) if (a.pipeline or a.graph) else stream.step(i, a.d2h)
-
-    def drain():
-        if a.overlap:
-            stream.flush_overlap(a.d2h)         # includes the extract of the last integrated frame: nothing is left outside the clock
-        else:
-            stream.flush(a.d2h)
-
+    run, drain = frame_runner(stream, a, a.d2h)
     for i in range(a.warmup):
         run(i)
     drain()
@@ -149,9 +236,8 @@ def main():
     stats_base = len(stream.stats)
     lib.dif_profile_read((ctypes.c_double * _lib.PROF_COUNT)(), (ctypes.c_int64 * _lib.PROF_COUNT)(), 1)
     lib.dif_profile_enable(1)
-    import gc
     gc.collect()
-    gc.disable()            # a generation-2 collection in the middle of a 75 ms timed region shows up as a 20 % outlier
+    gc.disable()            # a generation-2 collection in the middle of a 70 ms timed region shows up as a 20 % outlier
     barrier()
     t0 = time.perf_counter()
     for i in range(a.warmup, n_frames):
@@ -168,98 +254,35 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    # Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream with the mesh left resident in HBM, i.e.
-    # without the per-frame transfer of the new triangles to pinned host memory.  The difference is PCIe + cross-stream traffic, not kernels.
     hbm_resident = None
     if world == 1 and a.d2h != "none" and not a.overlap and not a.no_secondary:
-        s2 = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))
+        hbm_resident = rate_with_mesh_left_in_hbm(make_stream, a, n_frames)
+    merge_info = global_map_merge(stream, model, cfg, dev, barrier) if use_dist else None
 
-        def run2(i):
-            if a.graph and i >= 2 and (i % a.sample_every) != 0:
-                return s2.step_graph(i, "none")
-            return s2.step_pipelined(i, "none") if (a.pipeline or a.graph) else s2.step(i, "none")
-
-        lib.dif_profile_enable(0)
-        for i in range(a.warmup):
-            run2(i)
-        s2.flush("none")
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for i in range(a.warmup, n_frames):
-            run2(i)
-        s2.flush("none")
-        torch.cuda.synchronize()
-        hbm_resident = round(a.steps / (time.perf_counter() - t2), 3)
-        del s2
-    # BASELINE config C4: after the independent subsequences, ONE all-gather of voxel records over RCCL and a fold into a global map
-    # (identical on every rank), meshed once.  Outside the clock (it happens once per sequence, not per frame); reported, never fatal.
-    merge_info = None
-    if use_dist:
-        try:
-            from di_fusion_amd import parallel
-            from di_fusion_amd.system.map import DenseIndexedMap
-            barrier()
-            tm = time.perf_counter()
-            gmap = parallel.build_global_map(stream.map, lambda: DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1 << 17))
-            torch.cuda.synchronize()
-            t_merge = time.perf_counter() - tm
-            gmesh = gmap.extract_mesh_arrays(4, int(8e6), max_std=0.15, no_cache=True, to_host=False)
-            torch.cuda.synchronize()
-            merge_info = {"all_gather_and_fold_ms": round(t_merge * 1e3, 2), "global_voxels": int(gmap.n_occupied),
-                          "local_voxels_rank0": int(stream.map.n_occupied), "global_mesh_triangles": int(gmesh[0].shape[0]) if gmesh else 0,
-                          "extract_global_ms": round((time.perf_counter() - tm - t_merge) * 1e3, 2)}
-            del gmap, gmesh
-        except Exception as e:      # the headline number must survive a failure of the optional epilogue
-            merge_info = {"error": repr(e)[:200]}
-
+    out = None
     if rank == 0:
         st = stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
         timed_idx = [j for j in range(a.steps) if not (a.graph and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
         if a.overlap:   # unit j = integrate of frame j beside the extract of frame j-1; the flush adds one extract-only entry
             timed_idx = [j for j in timed_idx if j < len(st)]
-        sst = [st[j] for j in timed_idx]
-        rows_enc = sum(s["M"] for s in sst)
-        rows_dec_lat = sum(s["B"] * 64 for s in sst)
-        rows_dec_pts = sum(s["VH"] for s in sst)
         prof = {n: (ms[i], nl[i]) for i, n in enumerate(_lib.PROF_NAMES)}
-        kern = {}
-        for name, rows, flop in (("encode", rows_enc, ENC_FLOP_PER_ROW), ("decode_lattice", rows_dec_lat, DEC_FLOP_PER_ROW),
-                                 ("decode_points", rows_dec_pts, DEC_FLOP_PER_ROW)):
-            t_ms, n = prof[name]
-            if n > 0 and t_ms > 0:
-                kern[name] = dict(ms_per_launch=t_ms / n, rows_per_launch=rows / n, tflops=rows * flop / (t_ms * 1e-3) / 1e12)
-        dom = max(kern, key=lambda k: kern[k]["ms_per_launch"]) if kern else None
-        roof = None
-        pmc = {}
-        try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs; see profiles/README.md)
-            pmc = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_hbm.json"))[-1].read_text())["kernels"]
-        except Exception:
-            pass
-        if dom:
-            kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode<false>"}[dom]
-            roof = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
-                    "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
-                    "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
-                    "event_timed_frames": len(sst),
-                    "other_ms_per_frame": {k: round(prof[k][0] / max(1, len(sst)), 4) for k in ("mc_count", "mc_emit", "sort")}}
+        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager") + \
+                 (", extract of frame i-1 overlapped with integrate of frame i on a second stream" if a.overlap else "")
         out = {"metric": "frames/s integrate+decode+mesh, 640x480 synthetic stream", "value": round(world * a.steps / dt, 3),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": {"c1": "C1 32^3 grid 0.1 m, sphere", "c2": "C2 64^3 grid 0.1 m, room",
-                                       "c3": "C3 128^3 grid 0.05 m, ScanNet-shape 6 m room with boxes"}[a.config] +
-                          ", 640x480 orbit stream 0.5 deg/frame, all 307200 pixels integrated and meshed every frame, resolution 4, fast decode, max_std 0.15",
-                          "points_per_frame": intr.width * intr.height, "parallelism": f"{world} independent subsequences (one map per GPU)", "d2h_per_frame": a.d2h, "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1,
-                          "launch": (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager") +
-                                    (", extract of frame i-1 overlapped with integrate of frame i on a second stream" if a.overlap else ""),
-                          "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1) for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
+               "config": {"workload": WORKLOADS[a.config] + ", 640x480 orbit stream 0.5 deg/frame, all 307200 pixels integrated and meshed "
+                                                            "every frame, resolution 4, fast decode, max_std 0.15",
+                          "points_per_frame": intr.width * intr.height,
+                          "parallelism": f"{world} independent subsequences (one map per GPU)", "d2h_per_frame": a.d2h,
+                          "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1, "launch": launch,
+                          "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1)
+                                            for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info},
-               "roofline": roof}
+               "roofline": roofline_block(prof, [st[j] for j in timed_idx])}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_scale)
     if use_dist:
