@@ -6,12 +6,13 @@
  * `pytorch/system/map.py` (integrate_keyframe :340-519, extract_mesh :581-723, get_sdf :559-579) bind to.
  *
  * Conventions (all entry points):
- *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host] (a few outputs and the frame descriptor
+ *     may also live in device-mapped pinned host memory: said where it applies);
  *   - all buffers are caller-owned (the Python façade allocates them as torch tensors); no hidden allocation;
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, nothing synchronises except dif_read_counters();
  *   - return 0 on success, a negative DIF_E* code on a bad argument / launch failure (no exceptions, no exit);
  *   - element counts that are only known on the device (#voxels allocated, #rows gathered, #triangles) stay on the
- *     device in `dif_counters_t`; kernels read them there, the host reads them only at the end of extract.
+ *     device in the map's `counters` array (DIF_C_*); kernels read them there, the host reads them only at the end of extract.
  *
  * Linear voxel id:  lin = z + nz*y + nz*ny*x  of  ceil((p - bound_min)/voxel_size) - 1   (map.py:287-292,366-369).
  */
