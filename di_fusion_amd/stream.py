@@ -158,10 +158,10 @@ class FusionStream:
             self._copy_stream.synchronize()
         return out
 
-    # ---- hipGraph variant: the ~22 launches of a frame are captured once and replayed --------------------------------------
-    # Everything a frame launches has host-independent shapes (device counters carry the sizes), so a frame is a static graph:
-    # stage depth / normals / pose into fixed buffers, replay, read the counters one frame later.  Re-captured only when a buffer is
-    # re-allocated (capacity growth, mesh-cache garbage collection).
+    # ---- hipGraph variant: the 19 launches of a frame are captured once and replayed ----------------------------------------
+    # Everything a frame launches has host-independent shapes (device counters carry the sizes), so a frame is a static graph: write the
+    # frame descriptor (input pointers + pose) into pinned host memory, replay, read the counters and the new triangles out of pinned
+    # host memory one frame later.  Re-captured only when a buffer is re-allocated (capacity growth).
     def _graph_signature(self):
         m = self.map
         return (self._graph_export, m._capacity, m._ws.data_ptr() if m._ws is not None else 0, m._xbuf[0] if m._xbuf else None,
@@ -213,8 +213,8 @@ class FusionStream:
             self.n_captures += 1
 
     def step_graph(self, i: int, d2h: str = "new"):
-        """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: a 64-byte
-        frame descriptor upload (input pointers + pose) and one graph launch)."""
+        """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: writing a 64-byte frame descriptor
+        into pinned memory and one graph launch)."""
         m = self.map
         N = self.intr.height * self.intr.width
         prune = int(m.args.prune_min_vox_obs)
