@@ -103,8 +103,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     // edge vertices of the lane's cell, [edge][lane] x (x,y,z,std): indexed by the triangle table at run time, so they live in
     // LDS — as a per-lane array they were spilled to scratch memory (13 KB of scratch traffic per voxel).  Measured alternatives
     // on 2.1 M voxels (count + emit ms): scratch array 9.4 + 18.2, this 11.3 + 14.2, vertices recomputed per triangle 11.9 + 19.2,
-    // LDS-staged neighbour samples instead of gathers 14.2 + 16.7 — the kernel is VALU-issue bound (divergent triangle loop,
-    // 8-tap blends), not memory bound.
+    // LDS-staged neighbour samples instead of gathers 14.2 + 16.7.  PMC (profiles/r01_pmc_sq_stress.json): the waves sit parked on
+    // memory 54-67 % of their cycles at ~3 waves per SIMD — latency-bound; these 12 KB per wave are what caps the occupancy.
     V4* vl = reinterpret_cast<V4*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
     const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
     if (!EMIT && a.log_counters && blockIdx.x == 0 && threadIdx.x == 0) a.log_counters[DIF_C_CACHE_KEPT] = a.log_counters[DIF_C_CACHE_T];
