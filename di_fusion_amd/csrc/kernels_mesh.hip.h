@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __rest
             float pay = __int_as_float(rec[i * 32 + 3 + f]);
             float z = latent[s * L + f];
             if (assign) latent[s * L + f] = pay;
-            else if (w_new > 0.0f) latent[s * L + f] = (z * w_old + pay) / w_new;
+            else if (w_r > 0.0f) latent[s * L + f] = (z * w_old + pay) / w_new;      // a weight-0 record only allocates (allocate_block): no re-rounding of z
         }
         __builtin_amdgcn_wave_barrier();
         if (f == 31) {

@@ -70,9 +70,12 @@ def pack_vec(b: np.ndarray, MB: int) -> np.ndarray:
 def fold_decoder(w: Dict[str, np.ndarray]):
     Ws, bs = [], []
     for i in range(5):
-        v = w[f"decoder.lin{i}.weight_v"].astype(np.float64)
-        g = w[f"decoder.lin{i}.weight_g"].astype(np.float64)
-        Ws.append((v * (g / np.linalg.norm(v, axis=1, keepdims=True))).astype(np.float32))
+        if f"decoder.lin{i}.weight_v" in w:           # nn.utils.weight_norm (di_decoder.py:37-40): W = g * v / |v|_row
+            v = w[f"decoder.lin{i}.weight_v"].astype(np.float64)
+            g = w[f"decoder.lin{i}.weight_g"].astype(np.float64)
+            Ws.append((v * (g / np.linalg.norm(v, axis=1, keepdims=True))).astype(np.float32))
+        else:                                         # "weight_norm": false in network_specs
+            Ws.append(w[f"decoder.lin{i}.weight"].astype(np.float32))
         bs.append(w[f"decoder.lin{i}.bias"].astype(np.float32))
     return Ws, bs, w["decoder.uncertainty_layer.weight"].astype(np.float32), w["decoder.uncertainty_layer.bias"].astype(np.float32)
 

@@ -18,7 +18,7 @@ import torch
 from .. import _lib
 from . import packing
 
-DEFAULT_WEIGHTS = Path(__file__).resolve().parent.parent.parent / "tests" / "golden" / "weights_default.npz"
+DEFAULT_WEIGHTS = Path(__file__).resolve().parent / "weights_default.npz"      # ckpt/default of the reference, as arrays
 
 
 class _PackedNet:
@@ -155,9 +155,15 @@ def load_model(training_hyper_path: str, use_epoch: int = -1):
         raise NotImplementedError("libdifusion is specialised to the shipped di_decoder/di_encoder topology")
     raw = {}
     for k, v in torch.load(args.checkpoint, map_location="cpu")["model_state"].items():
-        raw["decoder." + k] = v.numpy()
+        raw["decoder." + k] = v.detach().cpu().numpy()
     for k, v in torch.load(exp_dir / f"encoder_{use_epoch}.pth.tar", map_location="cpu")["model_state"].items():
-        raw["encoder." + k] = v.numpy()
+        raw["encoder." + k] = v.detach().cpu().numpy()
+    # A weight-normed Linear pickled with its hook-computed `weight` still attached (what the reference's
+    # `fix_weight_norm_pickle`, utility.py:211-220, strips before pickling) carries a stale copy next to weight_g / weight_v:
+    # g and v are the parameters, the copy is dropped.  (`packing.fold_decoder` folds g * v / |v|; a checkpoint trained without
+    # weight_norm has only `weight` and is used as is.)
+    for k in [k for k in raw if k.endswith(".weight") and k[:-len("weight")] + "weight_v" in raw]:
+        del raw[k]
     return networks_from_arrays(raw), args
 
 
@@ -178,28 +184,21 @@ def forward_model(model, network_input: torch.Tensor = None, latent_input: torch
 
 
 def get_samples(r: int, device: torch.device, a: float = 0.0, b: float = None):
-    """reference `network/utility.py:129-149` (plain tensor arithmetic; the kernels generate this lattice in registers)."""
-    overall_index = torch.arange(0, r ** 3, 1, device=device, dtype=torch.long)
+    """The sample lattice of reference `network/utility.py:129-149`: (r^3, 3) float32, x slowest, coordinate fl(fl(i) * vsize) + a per
+    axis (the kernels generate the same values in registers, `csrc/kernels_extract.hip.h:Lattice`)."""
     r = int(r)
     if b is None:
         b = 1. - 1. / r
-    vsize = (b - a) / (r - 1)
-    samples = torch.zeros(r ** 3, 3, device=device, dtype=torch.float32)
-    samples[:, 0] = (overall_index // (r * r)) * vsize + a
-    samples[:, 1] = ((overall_index // r) % r) * vsize + a
-    samples[:, 2] = (overall_index % r) * vsize + a
-    return samples
+    axis = torch.arange(r, device=device, dtype=torch.float32) * ((b - a) / (r - 1)) + a
+    return torch.stack(torch.meshgrid(axis, axis, axis, indexing="ij"), dim=-1).reshape(-1, 3)
 
 
 def groupby_reduce(sample_indexer: torch.Tensor, sample_values: torch.Tensor, op: str = "max"):
-    """reference `network/utility.py:186-208` ('sum' and 'mean'; 'max' raises there too)."""
+    """reference `network/utility.py:186-208` on top of `dif_groupby_sum`: per-group 'sum' or 'mean' of the rows of `sample_values`
+    (groups 0 .. max index); any other op raises, as there."""
     from ..system.ext import groupby_sum
-    C = int(sample_indexer.max().item()) + 1
+    if op not in ("sum", "mean"):
+        raise NotImplementedError
     assert sample_indexer.size(0) == sample_values.size(0), "Indexer and Values must agree on sample count!"
-    if op == "mean":
-        values_sum, values_count = groupby_sum(sample_values, sample_indexer, C)
-        return values_sum / values_count.unsqueeze(-1)
-    elif op == "sum":
-        values_sum, _ = groupby_sum(sample_values, sample_indexer, C)
-        return values_sum
-    raise NotImplementedError
+    total, count = groupby_sum(sample_values, sample_indexer, int(sample_indexer.max().item()) + 1)
+    return total if op == "sum" else total / count.unsqueeze(-1)

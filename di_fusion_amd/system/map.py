@@ -3,7 +3,9 @@ backed by libdifusion.so (hand-written HIP for gfx950).  Same constructor, attri
 the tensors behind the properties live on the GPU and are owned here, the kernels receive raw pointers.
 
 Differences a caller can observe (all documented in DESIGN.md):
-  * no host round trip inside `integrate_keyframe` (the reference syncs 4 times, `map.py:382,441-444`);
+  * `integrate_keyframe` makes no host round trip (the reference syncs 4 times, `map.py:382,441-444`) as long as the host-side
+    upper bound of `n_occupied` stays below the capacity; the bound is made exact by every finished extract (async pinned copy of
+    the counters) and, failing that, by one blocking counter read before the buffers are doubled;
   * `n_occupied` is a device counter — reading the property synchronises;
   * `latent_vecs`, `latent_vecs_pos`, `voxel_obs_count`, `voxel_optimized` are views of larger pre-allocated buffers,
     sliced to the capacity the reference's doubling rule (`map.py:263-285`) would have reached;
@@ -97,6 +99,10 @@ class _GetSdfFn(torch.autograd.Function):
         return out, None
 
 
+_OVERFLOW_WHAT = {1: "more voxels than latent rows", 2: "more dirty voxels than extract buffers", 3: "more decoded voxels than extract buffers",
+                  4: "more encoder work items than workspace", 5: "mesh-cache log full", 6: "more records than the export buffer"}
+
+
 def _next_pow2(n: int) -> int:
     p = 1
     while p < n:
@@ -125,6 +131,9 @@ class DenseIndexedMap:
         self.device = device
         self.extract_mesh_std_range = None
         self.modifying_lock = threading.Lock()
+        # host-side bookkeeping (allocation bound, counter snapshots) is touched by the meshing thread and by the integrating thread
+        self._state_lock = threading.RLock()
+        self._integrate_done = None         # event recorded behind the last integrate on ITS stream: extracts wait for it
         self.meshing_thread = None
         self.meshing_thread_id = -1
         self.meshing_stream = torch.cuda.Stream(device=device)
@@ -136,6 +145,7 @@ class DenseIndexedMap:
         self._gc_epoch = 0
         self._gc_log_len = 0
         self._gc_wanted = False
+        self._cache_call_limit = 0          # max_n_triangles of the latest extract (what one more call may append to the log)
 
         self._grid = int(np.prod(self.n_xyz))
         if self._grid >= 2 ** 31:
@@ -212,8 +222,16 @@ class DenseIndexedMap:
         self._cmap = m
 
     def _publish_counters(self, c, add_total_at_read):
+        with self._state_lock:
+            return self._publish_counters_locked(c, add_total_at_read)
+
+    def _publish_counters_locked(self, c, add_total_at_read):
         if c[_lib.C_OVERFLOW] != 0:
-            raise RuntimeError(f"libdifusion: device buffer overflow (code {c[_lib.C_OVERFLOW]}); the map state is incomplete")
+            # reported once: the device flag is cleared so that the session can go on (e.g. with a no_cache re-extraction)
+            with torch.cuda.device(self.device):
+                self._counters[_lib.C_OVERFLOW:_lib.C_OVERFLOW + 1].zero_()
+            raise RuntimeError(f"libdifusion: device buffer overflow (code {c[_lib.C_OVERFLOW]}: "
+                               f"{_OVERFLOW_WHAT.get(c[_lib.C_OVERFLOW], '?')}); the result of that call is incomplete")
         # exact n_occupied at the time the counters were read + whatever later calls may have allocated since
         self._n_occ_ub = c[_lib.C_N_OCCUPIED] + (self._add_total - add_total_at_read)
         self.last_counters = dict(n_occupied=c[_lib.C_N_OCCUPIED], alloc_new=c[_lib.C_ALLOC_NEW], M=c[_lib.C_M], C=c[_lib.C_C],
@@ -223,17 +241,24 @@ class DenseIndexedMap:
         return self.last_counters
 
     def _read_counters(self):
-        with torch.cuda.device(self.device):
+        """Blocking read of the device counters on the current stream.  Every integrate is enqueued completely while `_state_lock` is
+        held, so with the lock taken and — when a second thread / stream is in play — the whole device drained, no allocation that
+        `_add_total` already accounts for can still be missing from the value read here."""
+        with self._state_lock, torch.cuda.device(self.device):
+            if self.meshing_thread is not None or threading.current_thread() is not threading.main_thread():
+                torch.cuda.synchronize(self.device)
             _lib.check(_lib.load().dif_read_counters(ctypes.byref(self._cmap), self._host_counters, _lib.stream_ptr()), "dif_read_counters")
-        return self._publish_counters(list(self._host_counters), self._add_total)
+            return self._publish_counters_locked(list(self._host_counters), self._add_total)
 
     def _ensure_capacity(self, may_add: int):
-        if self._n_occ_ub + may_add > self._capacity:
-            self._read_counters()                                  # make the bound exact
+        """Called with `_state_lock` held by whoever is about to enqueue work that may allocate up to `may_add` voxels."""
+        with self._state_lock:
             if self._n_occ_ub + may_add > self._capacity:
-                self._alloc_state(_next_pow2(self._n_occ_ub + may_add))
-        self._n_occ_ub += may_add
-        self._add_total += may_add
+                self._read_counters()                              # make the bound exact
+                if self._n_occ_ub + may_add > self._capacity:
+                    self._alloc_state(_next_pow2(self._n_occ_ub + may_add))
+            self._n_occ_ub += may_add
+            self._add_total += may_add
 
     def _ref_capacity(self) -> int:
         """Buffer length the reference would have after the same allocations (doubling from 1, map.py:263-268)."""
@@ -317,7 +342,7 @@ class DenseIndexedMap:
         nrm = surface_normal.contiguous().float()
         N = xyz.size(0)
         lib = _lib.load()
-        with self.modifying_lock, torch.cuda.device(self.device):
+        with self.modifying_lock, self._state_lock, torch.cuda.device(self.device):
             torch.cuda.current_stream().wait_stream(self.meshing_stream)
             prune = int(self.args.prune_min_vox_obs)
             self._ensure_capacity(7 * (N // (prune + 1)) if prune > 0 else 7 * N)
@@ -331,14 +356,20 @@ class DenseIndexedMap:
             w = self.model.packed.weights_struct(self.device)
             _lib.check(lib.dif_integrate(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), _lib.ptr(nrm), N, _lib.ptr(mask),
                                          _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "dif_integrate")
+            if self._integrate_done is None:
+                self._integrate_done = torch.cuda.Event()
+            self._integrate_done.record()                          # on the integrating stream, whichever it is
         return mask.view(torch.bool) if int(self.args.prune_min_vox_obs) > 0 else None
 
     def allocate_block(self, idx: torch.Tensor):
         """reference `map.py:310-319`.  Slots are handed out in ASCENDING linear-id order (the only order the reference's
-        own caller ever passes, `map.py:383-387`)."""
+        own caller ever passes, `map.py:383-387`); ids that are already allocated are left untouched (weight-0 records)."""
         if idx.ndimension() == 2 and idx.size(1) == 3:
             idx = idx[:, 2] + self.n_xyz[-1] * idx[:, 1] + (self.n_xyz[-1] * self.n_xyz[-2]) * idx[:, 0]
         idx = idx.to(self.device).long().contiguous()
+        if idx.numel() > 1 and not bool((idx[1:] > idx[:-1]).all()):
+            raise NotImplementedError("allocate_block: pass sorted, unique linear ids (slots are numbered in ascending id order; the "
+                                      "reference numbers them in the caller's order, map.py:317-319, and its only caller passes torch.unique output)")
         rec = torch.zeros((idx.size(0), 32), dtype=torch.int32, device=self.device)
         rec[:, 0] = idx.to(torch.int32)          # grid < 2^31 (checked in __init__), high word stays 0
         self.merge_records(rec)
@@ -429,6 +460,11 @@ class DenseIndexedMap:
         self._gc_log_len = n
         self._gc_wanted = False
         self._read_counters()
+        # the reference's host cache grows without bound (map.py:703-714): if even the compacted log leaves no room for two more
+        # calls' worth of triangles, double it (the pointers change: captured launch graphs are re-captured by their owner)
+        need = n + 2 * self._cache_call_limit
+        if need > self._cache[0].size(0):
+            self._ensure_cache(_next_pow2(2 * need))
 
     def mesh_cache_tensors(self, new_only: bool = False):
         """Device views of the mesh cache: (vertices (T,3,3) f32 world units, vertices_flatten_id (T,) i64, vertices_std (T,3)) — the
@@ -469,6 +505,7 @@ class DenseIndexedMap:
         t = self._xbuf[1]
         # the log must always have room for two calls' worth of output beyond what the host last saw (counters lag one frame
         # in the pipelined driver); it is garbage-collected in extract_mesh_finish before it gets there
+        self._cache_call_limit = int(max_n_triangles)
         self._ensure_cache(max(3 * int(max_n_triangles), 1 << 16))
         b = self._cache_struct()
         b.max_voxels = max_vox
@@ -485,7 +522,11 @@ class DenseIndexedMap:
         lib = _lib.load()
         if self._gc_wanted and self._cache is not None:
             self._cache_gc()                                      # safe point: at most one (the latest) extract is still pending
-        with self.modifying_lock, torch.cuda.device(self.device):
+        with self.modifying_lock, self._state_lock, torch.cuda.device(self.device):
+            # Whatever stream this extract runs on (the meshing thread uses `meshing_stream`), it starts behind the last integrate,
+            # which was enqueued completely under the same lock (the reference drains the device instead, map.py:625).
+            if self._integrate_done is not None:
+                torch.cuda.current_stream().wait_event(self._integrate_done)
             tens, buf = self._extract_buffers(voxel_resolution, max_n_triangles)
             w = self.model.packed.weights_struct(self.device)
             _lib.check(lib.dif_extract(ctypes.byref(self._cmap), ctypes.byref(w), ctypes.byref(buf), int(voxel_resolution), 1 if fast else 0,
@@ -578,10 +619,8 @@ class DenseIndexedMap:
                 return None
 
         def do_meshing():
-            with torch.cuda.device(self.device):
-                self.meshing_stream.wait_stream(torch.cuda.default_stream(self.device))
-                with torch.cuda.stream(self.meshing_stream):
-                    self.extract_mesh_arrays(voxel_resolution, max_n_triangles, fast, max_std, no_cache)
+            with torch.cuda.device(self.device), torch.cuda.stream(self.meshing_stream):
+                self.extract_mesh_arrays(voxel_resolution, max_n_triangles, fast, max_std, no_cache)     # ordered behind the integrates inside
 
         if extract_async:
             self.meshing_thread = threading.Thread(target=do_meshing, daemon=True)
@@ -622,11 +661,14 @@ class DenseIndexedMap:
         n = rec.size(0)
         if n == 0:
             return
-        with self.modifying_lock, torch.cuda.device(self.device):
+        with self.modifying_lock, self._state_lock, torch.cuda.device(self.device):
             self._ensure_capacity(n)
             scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
             _lib.check(_lib.load().dif_merge_records(ctypes.byref(self._cmap), _lib.ptr(rec), n, 1 if assign else 0, _lib.ptr(scratch),
                                                      _lib.stream_ptr()), "dif_merge_records")
+            if self._integrate_done is None:
+                self._integrate_done = torch.cuda.Event()
+            self._integrate_done.record()                          # writes latents like an integrate: later extracts wait for it
 
     # ---- visualisers: out of scope (need Open3D) ---------------------------------------
     def get_fast_preview_visuals(self):

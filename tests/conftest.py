@@ -30,7 +30,8 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def raw_weights():
     import numpy as np
-    return {k: v for k, v in np.load(GOLDEN / "weights_default.npz").items()}
+    from di_fusion_amd.network import utility as net_util
+    return {k: v for k, v in np.load(net_util.DEFAULT_WEIGHTS).items()}
 
 
 @pytest.fixture(scope="session")

@@ -105,13 +105,14 @@ def sha(a: np.ndarray) -> str:
 
 
 def export_weights(model):
-    """Raw checkpoint tensors -> weights_default.npz (data, not code)."""
+    """Raw checkpoint tensors -> di_fusion_amd/network/weights_default.npz (data, not code): the
+    package's default weights, which the tests also use."""
     out = {}
     for k, v in model.decoder.state_dict().items():
         out["decoder." + k] = v.detach().cpu().numpy()
     for k, v in model.encoder.state_dict().items():
         out["encoder." + k] = v.detach().cpu().numpy()
-    np.savez_compressed(HERE / "weights_default.npz", **out)
+    np.savez_compressed(REPO / "di_fusion_amd" / "network" / "weights_default.npz", **out)
     print("weights:", len(out), "tensors")
 
 
@@ -230,10 +231,26 @@ def save_reference_map(model):
     print("ref_map_small.pt:", (HERE / "ref_map_small.pt").stat().st_size, "bytes, keys", sorted(m.cold_vars.keys()))
 
 
+def full_size_sequences(model, which):
+    """BASELINE configs C2 (64^3) and C3 (128^3) at their real size: two full 640x480 frames of the bench stream (room scene,
+    0.5 deg per frame), whole map state after every integrate, a strided subset of the decoded cubes."""
+    if "seq_c2" in which:
+        scene, cfg = syn.config_c2()
+        run_sequence(model, "seq_c2", scene, cfg, syn.Intrinsic(), n_frames=2, deg_per_frame=0.5,
+                     store_inputs=False, store_cubes=False)
+    if "seq_c3" in which:
+        scene, cfg = syn.config_c3()
+        run_sequence(model, "seq_c3", scene, cfg, syn.Intrinsic(), n_frames=2, deg_per_frame=0.5,
+                     store_inputs=False, store_cubes=False)
+
+
 def main():
     model, hyper = load_reference_model()
     if "--map-only" in sys.argv:
         save_reference_map(model)
+        return
+    if "--only" in sys.argv:
+        full_size_sequences(model, sys.argv[sys.argv.index("--only") + 1].split(","))
         return
     export_weights(model)
     golden_networks(model)
@@ -254,6 +271,7 @@ def main():
     run_sequence(model, "seq_c1", scene, cfg, syn.Intrinsic(), n_frames=1, deg_per_frame=0.5,
                  store_inputs=False, store_cubes=False)
     save_reference_map(model)
+    full_size_sequences(model, ("seq_c2", "seq_c3"))
 
 
 if __name__ == "__main__":

@@ -18,6 +18,9 @@ VERT_TOL = 2e-4          # voxel units, away from the 1e-5 epsilon branches of s
 CASES = {
     "seq_small": (syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6,) * 3, (1.6,) * 3, 0.4), syn.Intrinsic().scaled(0.125)),
     "seq_room16": (syn.default_room(), syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4), syn.Intrinsic().scaled(0.25)),
+    # BASELINE configs C2 (64^3) and C3 (128^3) at their real size: two full 640x480 frames of the bench stream each
+    "seq_c2": (*syn.config_c2(), syn.Intrinsic()),
+    "seq_c3": (*syn.config_c3(), syn.Intrinsic()),
 }
 
 
@@ -58,7 +61,7 @@ def sort_tris(tri, tid):
     return np.lexsort((c[:, 2], c[:, 1], c[:, 0], tid))
 
 
-@pytest.mark.parametrize("name", ["seq_small", "seq_room16"])
+@pytest.mark.parametrize("name", ["seq_small", "seq_room16", "seq_c2", "seq_c3"])
 def test_sequence_vs_golden_and_oracle(name, gpu_model, oracle_net):
     from oracle import difusion_oracle as O
     scene, cfg, intr = CASES[name]
@@ -117,33 +120,38 @@ def test_sequence_vs_golden_and_oracle(name, gpu_model, oracle_net):
 
 def test_mesh_cache_replace_by_voxel(gpu_model, oracle_net):
     """map.py:703-714: triangles of voxels that produced new triangles are replaced, the rest of the cache is kept
-    (including the reference's quirk that a re-meshed voxel which now yields NO triangle keeps its stale ones)."""
+    (including the reference's quirk that a re-meshed voxel which now yields NO triangle keeps its stale ones).
+    Expected cache = the reference's host-side rule applied to the C oracle's marching cubes of the GPU's OWN cubes (so a
+    refinement-threshold flip in the decode cannot blur the comparison): same length, same voxel id at every position, same order
+    (kept old triangles, then the new ones), vertices within 1e-5."""
     from oracle import difusion_oracle as O
     scene, cfg, intr = CASES["seq_small"]
     g = np.load(GOLDEN / "seq_small.npz")
     m = make_map(gpu_model, cfg)
     om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
     cache = None
+    replaced = 0
     for f in range(3):
         xyz, nrm = frame_inputs(g, "seq_small", f)
         m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
         om.integrate_keyframe(xyz, nrm)
         v, vid, vs = m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
-        ov, oid, ostd = om.extract_mesh(4, int(4e6), max_std=0.15)
+        B = m.last_counters["B"]
+        oa = om.extract_prepare(4)
+        assert np.array_equal(m._xbuf[1]["valid_blocks"][:m.last_counters["K"]].cpu().numpy(), oa["valid_blocks"])
+        cs, cd = m._xbuf[1]["cube_sdf"][:B].cpu().numpy(), m._xbuf[1]["cube_std"][:B].cpu().numpy()
+        wt, oid, ostd = O.marching_cubes_interp(oa["indexer"], oa["valid_blocks"], oa["vec_batch_mapping"], cs, cd, int(4e6), om.n_xyz, 0.15)
+        ov = (wt * np.float32(cfg.voxel_size)).astype(np.float32) + om.bound_min                  # map.py:698
         if cache is None:
             cache = [ov, oid, ostd]
         else:                                                     # the reference's host-side rule, restated
             keep = ~np.isin(cache[1], np.unique(oid))
+            replaced += int((~keep).sum())
             cache = [np.concatenate([cache[0][keep], ov]), np.concatenate([cache[1][keep], oid]), np.concatenate([cache[2][keep], ostd])]
-        assert v.shape[0] == vid.shape[0] == vs.shape[0]
-        # the oracle's fast-decode may flip a threshold sample, so compare as sets with a small slack
-        assert abs(v.shape[0] - cache[0].shape[0]) <= 8, (f, v.shape, cache[0].shape)
-        if v.shape[0] == cache[0].shape[0]:
-            a, b = sort_tris(v, vid), sort_tris(cache[0], cache[1])
-            assert np.array_equal(vid[a], cache[1][b])
-            close = np.abs(v[a] - cache[0][b]).reshape(len(a), -1).max(axis=1) < VERT_TOL * cfg.voxel_size
-            assert close.mean() > 0.99, close.mean()
-    assert len(np.unique(vid)) > 10
+        assert v.shape[0] == vid.shape[0] == vs.shape[0] == cache[0].shape[0], (f, v.shape, cache[0].shape)
+        assert np.array_equal(vid, cache[1])
+        assert np.abs(v - cache[0]).max() < 1e-5 and np.abs(vs - cache[2]).max() < 1e-5
+    assert replaced > 0 and len(np.unique(vid)) > 10
     mesh = m.extract_mesh(4, int(4e6), max_std=0.15)
     assert mesh is not None and mesh.triangles.shape[0] == v.shape[0]
 
@@ -451,3 +459,84 @@ def test_mesh_cache_log_garbage_collection(gpu_model):
     a = m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
     b = m2.extract_mesh_arrays(4, int(4e6), max_std=0.15)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_mesh_cache_log_grows_with_a_small_per_call_limit(gpu_model):
+    """A caller that passes a small `max_n_triangles` per call on a map whose mesh keeps growing: the reference's host cache simply grows
+    (map.py:703-714).  The device log starts at max(3 * limit, 65536) entries and must be compacted / doubled on the way, never
+    overflow, and hold — entry for entry, in the same order — what the same sequence yields with a log that never needs to grow."""
+    scene, cfg = syn.config_c2()
+    intr = syn.Intrinsic().scaled(0.5)
+    small, big = make_map(gpu_model, cfg), make_map(gpu_model, cfg)
+    limit = 80000                       # above any single call's output here, far below the whole mesh
+    caps = set()
+    for f in range(12):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=30.0)
+        xyz, nrm = xyz.to(DEV), nrm.to(DEV)
+        outs = []
+        for m, lim in ((small, limit), (big, int(4e6))):
+            m.integrate_keyframe(xyz, nrm)
+            outs.append(m.extract_mesh_arrays(4, lim, max_std=0.15, to_host=False))
+        assert small.last_counters["T"] <= limit, "this test wants untruncated calls"
+        caps.add(small._cache[0].size(0))
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.equal(x, y), f
+    assert outs[0][0].size(0) > 3 * limit and len(caps) > 1, (outs[0][0].shape, caps)  # the log had to grow beyond its first size
+    assert small._gc_epoch > 0 and big._gc_epoch == 0
+
+
+def test_extract_async_is_ordered_behind_the_integrates(gpu_model):
+    """`extract_mesh(extract_async=True)` (reference map.py:716-720) on the meshing thread / stream while the main thread goes on
+    integrating: the extract must see exactly the state of the integrates enqueued before it.  Compared with the same schedule run
+    synchronously, over several rounds."""
+    scene, cfg, intr = CASES["seq_room16"]
+    frames = [tuple(t.to(DEV) for t in syn.frame_points(scene, f, intr, deg_per_frame=15.0)) for f in range(6)]
+
+    def run(async_):
+        m = make_map(gpu_model, cfg)
+        meshes = []
+        for f in range(0, 6, 2):
+            m.integrate_keyframe(*frames[f])
+            if async_:
+                assert m.extract_mesh(4, int(4e6), max_std=0.15, extract_async=True) is None
+                m.integrate_keyframe(*frames[f + 1])              # races with the meshing thread unless the streams are ordered
+                mesh = m.extract_mesh(4, int(4e6), max_std=0.15, extract_async=False)       # joins the thread, returns its mesh
+                assert m.meshing_thread is None or not m.meshing_thread.is_alive()
+                m.meshing_thread = None
+            else:
+                mesh = m.extract_mesh(4, int(4e6), max_std=0.15)
+                m.integrate_keyframe(*frames[f + 1])
+            meshes.append(np.asarray(mesh.vertices).copy())
+        torch.cuda.synchronize()
+        n = m.n_occupied
+        return meshes, m.latent_vecs[:n].clone(), m.voxel_obs_count[:n].clone()
+
+    a, za, wa = run(False)
+    b, zb, wb = run(True)
+    assert torch.equal(za, zb) and torch.equal(wa, wb)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and x.shape[0] > 0 and np.array_equal(x, y)
+
+
+def test_allocate_block(gpu_model):
+    """reference map.py:310-319 as an external entry point: new ids get slots in ascending order, ids that are already allocated keep
+    their slot and their latent bits."""
+    scene, cfg, intr = CASES["seq_small"]
+    g = np.load(GOLDEN / "seq_small.npz")
+    m = make_map(gpu_model, cfg)
+    xyz, nrm = frame_inputs(g, "seq_small", 0)
+    m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+    n0 = m.n_occupied
+    z0, w0, idx0 = m.latent_vecs[:n0].clone(), m.voxel_obs_count[:n0].clone(), m.indexer.clone()
+    free = torch.nonzero(idx0 == -1).flatten()[:5]
+    taken = torch.nonzero(idx0 != -1).flatten()[:5]
+    ids = torch.sort(torch.cat([free, taken]))[0]
+    m.allocate_block(ids)
+    assert m.n_occupied == n0 + 5
+    assert torch.equal(m.indexer[free].cpu(), torch.arange(n0, n0 + 5))
+    assert torch.equal(m.latent_vecs_pos[n0:n0 + 5].cpu(), free.cpu())
+    assert torch.equal(m.indexer[taken], idx0[taken])
+    assert torch.equal(m.latent_vecs[:n0], z0) and torch.equal(m.voxel_obs_count[:n0], w0)      # bit for bit
+    assert float(m.voxel_obs_count[n0:n0 + 5].abs().sum()) == 0.0
+    with pytest.raises(NotImplementedError):
+        m.allocate_block(torch.flip(ids, [0]))

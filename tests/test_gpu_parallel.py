@@ -47,26 +47,35 @@ def test_export_merge_records_vs_oracle(gpu_model, oracle_net):
     assert v.shape[0] > 0
 
 
-def test_spatial_tiling_matches_single_map_bit_for_bit(gpu_model):
-    """C5: two x-slabs with halo exchange (emulated in one process, same kernels and record path as the RCCL version) reproduce
+TILING_CASES = {
+    # 16^3 grid, quarter-resolution frames, large yaw: allocation, the 600-count gate and re-meshing all happen across the cut
+    "room16_2slabs": (syn.default_room(), syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4), 0.25, 2, 4, 15.0),
+    # BASELINE config C5: ONE 1280x960 stream (1.23 M points per frame) on the C3 grid (128^3, 0.05 m), cut into 2 and into 8 x-slabs
+    "c5_1280x960_2slabs": (*syn.config_c3(), 2.0, 2, 2, 0.5),
+    "c5_1280x960_8slabs": (*syn.config_c3(), 2.0, 8, 2, 0.5),
+}
+
+
+@pytest.mark.parametrize("case", list(TILING_CASES))
+def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
+    """C5: x-slabs with halo exchange (emulated in one process, same kernels and record path as the RCCL version) reproduce
     the single-map state of every owned voxel BIT FOR BIT, and the union of the slab meshes equals the single-map mesh."""
     from di_fusion_amd import parallel
     from di_fusion_amd.system.map import DenseIndexedMap
-    cfg = syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4)          # 16^3
-    intr = syn.Intrinsic().scaled(0.25)
-    scene = syn.default_room()
+    scene, cfg, scale, world, n_frames, deg = TILING_CASES[case]
+    intr = syn.Intrinsic().scaled(scale)
     full = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=2048)
     nx = full.n_xyz[0]
-    world = 2
     slabs = []
     for r in range(world):
         m = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=2048)
         m.set_ownership(*parallel.slab_range(nx, r, world), halo=parallel.HALO)
         slabs.append(m)
     plane = full.n_xyz[1] * full.n_xyz[2]
-    for f in range(4):
-        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=15.0)
+    for f in range(n_frames):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg)
         xyz, nrm = xyz.to(DEV), nrm.to(DEV)
+        assert scale != 2.0 or xyz.size(0) > 1_100_000         # a 1280x960 frame
         full.integrate_keyframe(xyz, nrm)
         for m in slabs:
             m.integrate_keyframe(xyz, nrm)
@@ -103,8 +112,9 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(gpu_model):
         tris, ids = [], []
         for m in slabs:
             m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
-            t, i, _ = m.mesh_cache_tensors(new_only=True)
-            tris.append(t.cpu().numpy()); ids.append(i.cpu().numpy())
+            new = m.mesh_cache_tensors(new_only=True)
+            if new is not None:                                    # a slab the camera has not reached yet has no mesh
+                tris.append(new[0].cpu().numpy()); ids.append(new[1].cpu().numpy())
         tS, iS = np.concatenate(tris), np.concatenate(ids)
         tF, iF = newF[0].cpu().numpy(), newF[1].cpu().numpy()
         assert tS.shape == tF.shape, (f, tS.shape, tF.shape)

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from di_fusion_amd import synthetic as syn
-from tests.conftest import GOLDEN
+from tests.conftest import GOLDEN, ROOT
 
 
 def _free_port():
@@ -20,7 +20,7 @@ def _free_port():
 
 def _build_rank_map(rank):
     from oracle import difusion_oracle as O
-    net = O.OracleNetworks({k: v for k, v in np.load(GOLDEN / "weights_default.npz").items()})
+    net = O.OracleNetworks({k: v for k, v in np.load(ROOT / "di_fusion_amd" / "network" / "weights_default.npz").items()})
     cfg = syn.MapConfig((-1.6,) * 3, (1.6,) * 3, 0.4)
     om = O.OracleMap(net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
     intr = syn.Intrinsic().scaled(0.125)

@@ -13,11 +13,8 @@ from di_fusion_amd.system import ext                             # noqa: E402
 from oracle import difusion_oracle as O                          # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=30)
-    ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+def run(cases: int, seed: int = 0):
+    a = argparse.Namespace(cases=cases, seed=seed)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
     for case in range(a.cases):
@@ -60,6 +57,14 @@ def main():
             assert np.array_equal(np.isnan(got[:, 0]), np.isnan(want[:, 0])), (case, kind, n, k, radius, "normal nan pattern")
         print(f"case {case}: {kind} n={n} stride={stride} k={k} r={radius:.4g} ok", flush=True)
     print("fuzz ok")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    run(a.cases, a.seed)
 
 
 if __name__ == "__main__":

@@ -15,11 +15,8 @@ from di_fusion_amd.system.map import DenseIndexedMap             # noqa: E402
 from oracle import difusion_oracle as O                          # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=20)
-    ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+def run(cases: int, seed: int = 0):
+    a = argparse.Namespace(cases=cases, seed=seed)
     dev = torch.device("cuda:0")
     raw = net_util.load_weights_npz()
     model = net_util.networks_from_arrays(raw)
@@ -90,6 +87,14 @@ def main():
             assert np.abs(sdf.cpu().numpy() - osdf).max() < 5e-5 and np.abs(std.cpu().numpy() - ostd).max() < 5e-5, (case, "query values")
         print(f"case {case}: grid {n}^3 vs {vs} prune {prune} {kind}: n_occupied {m.n_occupied} triangles {0 if out is None else out[0].shape[0]} ok", flush=True)
     print("fuzz ok")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    run(a.cases, a.seed)
 
 
 if __name__ == "__main__":

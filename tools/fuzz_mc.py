@@ -13,11 +13,8 @@ from di_fusion_amd.system import ext                             # noqa: E402
 from oracle import difusion_oracle as O                          # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=40)
-    ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+def run(cases: int, seed: int = 0):
+    a = argparse.Namespace(cases=cases, seed=seed)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
@@ -65,6 +62,14 @@ def main():
             assert np.abs(tstd.cpu().numpy() - ws).max() < 1e-5, (case, "std")
         print(f"case {case}: grid {n} r={r} V={V} B={B} K={K} max_std={max_std}: {wt.shape[0]} triangles ok", flush=True)
     print("fuzz ok")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    run(a.cases, a.seed)
 
 
 if __name__ == "__main__":
