@@ -35,8 +35,6 @@ def parse():
     ap.add_argument("--noise", type=int, default=0)
     ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
-    ap.add_argument("--overlap", type=int, default=0, help="1: the extract of frame i-1 runs beside the integrate of frame i (two streams, one gate "
-                    "event; bit-identical results); needs --graph 1")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the frame's launches from a captured hipGraph; every --sample-every-th frame runs "
                     "eagerly with HIP events around the MFMA kernels (the roofline sample)")
     ap.add_argument("--sample-every", type=int, default=8)
@@ -102,17 +100,12 @@ def prime_process(FusionStream, syn, model, intr, dev, d2h):
 def frame_runner(stream, a, d2h):
     """(run(i), drain()) for the chosen way of driving a frame."""
     def run(i):
-        if a.overlap and i >= 1:
-            return stream.step_overlap(i, d2h, graph=bool(a.graph and (i % a.sample_every) != 0))
         if a.graph and i >= 2 and (i % a.sample_every) != 0:
             return stream.step_graph(i, d2h)
         return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
 
     def drain():
-        if a.overlap:
-            stream.flush_overlap(d2h)           # includes the extract of the last integrated frame: nothing is left outside the clock
-        else:
-            stream.flush(d2h)
+        stream.flush(d2h)
     return run, drain
 
 
@@ -120,7 +113,7 @@ def rate_with_mesh_left_in_hbm(make_stream, a, n_frames):
     """Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream without the per-frame hand-over of
     the new triangles to pinned host memory.  The difference is PCIe traffic, not kernels."""
     s2 = make_stream()
-    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "overlap": 0, "sample_every": 1 << 30}), "none")
+    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30}), "none")
     for i in range(a.warmup):
         run2(i)
     drain2()
@@ -179,7 +172,7 @@ def roofline_block(prof, sst):
             "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
             "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
             "event_timed_frames": len(sst),
-            "other_ms_per_frame": {k: round(prof[k][0] / max(1, len(sst)), 4) for k in ("mc_count", "mc_emit", "sort")}}
+            "other_ms_per_frame": {k: round(prof[k][0] / max(1, len(sst)), 4) for k in ("mc_count", "mc_emit")}}
 
 
 def main():
@@ -228,7 +221,7 @@ def main():
     for i in range(a.warmup):
         run(i)
     drain()
-    if a.graph and not a.overlap and a.warmup >= 1 and stream._graphs is None:
+    if a.graph and a.warmup >= 1 and stream._graphs is None:
         torch.cuda.synchronize()
         with torch.cuda.device(dev):
             stream._graph_export = (a.d2h == "new")
@@ -255,7 +248,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     hbm_resident = None
-    if world == 1 and a.d2h != "none" and not a.overlap and not a.no_secondary:
+    if world == 1 and a.d2h != "none" and not a.no_secondary:
         hbm_resident = rate_with_mesh_left_in_hbm(make_stream, a, n_frames)
     merge_info = global_map_merge(stream, model, cfg, dev, barrier) if use_dist else None
 
@@ -264,11 +257,8 @@ def main():
         st = stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
         timed_idx = [j for j in range(a.steps) if not (a.graph and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
-        if a.overlap:   # unit j = integrate of frame j beside the extract of frame j-1; the flush adds one extract-only entry
-            timed_idx = [j for j in timed_idx if j < len(st)]
         prof = {n: (ms[i], nl[i]) for i, n in enumerate(_lib.PROF_NAMES)}
-        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager") + \
-                 (", extract of frame i-1 overlapped with integrate of frame i on a second stream" if a.overlap else "")
+        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager")
         out = {"metric": "frames/s integrate+decode+mesh, 640x480 synthetic stream", "value": round(world * a.steps / dt, 3),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

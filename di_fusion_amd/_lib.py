@@ -14,9 +14,9 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "libdifusion.so"    # DIF_LIB: instrumented builds (tools/)
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_N_FUSED = range(19)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE = range(18)
 C_COUNT = 32
-PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "sort"]
+PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit"]
 PROF_COUNT = 8
 LATENT_DIM = 29
 
@@ -31,9 +31,9 @@ class DifMap(Structure):
                 ("indexer", c_void_p), ("latent_vecs", c_void_p), ("latent_vecs_pos", c_void_p),
                 ("voxel_obs_count", c_void_p), ("dirty", c_void_p), ("counters", c_void_p),
                 ("frame_count", c_void_p), ("grid_bits", c_void_p), ("vbm", c_void_p),
-                ("seg_start", c_void_p), ("seg_cnt", c_void_p), ("item_start", c_void_p),
+                ("rec_head", c_void_p), ("upd_list", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
-                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("grid_bits_extract", c_void_p)]
+                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32)]
 
 
 class DifWeights(Structure):
@@ -72,17 +72,13 @@ SIGNATURES = {
     "dif_estimate_normals": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, POINTER(c_float), c_void_p, c_void_p, c_int64,
                                        c_void_p]),
     "dif_groupby_sum": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
-    "dif_integrate_workspace_bytes": (c_int64, [c_int64, c_int32]),
+    "dif_integrate_workspace_bytes": (c_int64, [c_int64]),
     "dif_integrate": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_int64, c_void_p]),
     "dif_integrate_frame": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
                               c_int32, c_int32, c_void_p]),
-    "dif_extract_overlapped": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
-                                         c_int32, c_int32, c_void_p, c_void_p]),
-    "dif_integrate_gated": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                      c_int64, c_void_p, c_void_p]),
     "dif_mesh_cache_export": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dif_mesh_cache_compact": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "dif_mesh_cache_reindex": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_int64, c_void_p]),

@@ -7,7 +7,7 @@
 
 #define DIF_WAVE 64
 #define DIF_BLOCK 256
-#define DIF_INVALID_KEY 0x00FFFFFFu   // sort key of a (point, offset) pair that contributes to no voxel (24-bit keys)
+#define DIF_INVALID_KEY 0xFFFFFFFFu   // slot key of a (point, offset) pair that contributes to no voxel
 
 #define DIF_CHECK_LAUNCH()                                   \
     do {                                                     \

@@ -17,7 +17,6 @@ using namespace dif;
 namespace {
 
 constexpr int L = DIF_LATENT_DIM;     // 29
-constexpr int ITEM_ROWS = 32;         // gathered rows per encoder work item = one MFMA tile of 32 points (finest load balance)
 
 __device__ __constant__ int c_mc_edge_table[256];
 // triangle table rows packed into 16 nibbles (edge id 0..11, 0xF = end): one 8-byte load per cell instead of a table walk in memory
@@ -313,49 +312,33 @@ int dif_estimate_normals(const float* pc, int64_t n, int32_t stride, int32_t max
 // ---- integrate ------------------------------------------------------------------------------------------------
 // workspace carve (all offsets 256-byte aligned)
 struct IntegrateWs {
-    int* pt_lin;            // [N]
-    uint32_t* pair_key;     // [8N]
-    uint32_t* row_val;      // [max_items * ITEM_ROWS]
-    int* item_slot;         // [max_items]
-    long long* partial;     // [max_items][32]
+    int* pt_lin;            // [N]     linear voxel id per point
+    uint2* pair_list;       // [8N]    compacted (slot, offset*N + point) entries; M of them are written
+    int* rec_next;          // [8N]    chain link per run record
+    long long* rec;         // [8N][32] run records, written sparsely at tile*32 + run rank (~3 per tile in a stream)
     int* block_tmp;         // [4096]
-    int64_t max_items;
     int64_t total_bytes;
 };
 
-
-static int64_t max_items_for(int64_t N, int prune_min_vox_obs) {
-    // items = sum_s ceil(cnt_s / ITEM_ROWS) <= M / ITEM_ROWS + C, with M <= 8N gathered rows and C updated voxels.  Every kept point lives in
-    // a voxel holding > prune_min_vox_obs points of the frame, so there are at most N / (prune + 1) such voxels and the updated ones sit in
-    // their 27-neighbourhoods; without pruning every (point, offset) pair may hit its own voxel: C <= 8N.  Anything beyond the bound would
-    // be dropped by k_alloc_items with DIF_C_OVERFLOW = 4.
-    int64_t c_max = 8 * N;
-    if (prune_min_vox_obs > 0) {
-        const int64_t by_prune = 27 * (N / ((int64_t)prune_min_vox_obs + 1) + 1);
-        if (by_prune < c_max) c_max = by_prune;
-    }
-    return 8 * N / ITEM_ROWS + c_max + 64;
-}
-
-static int carve_integrate(int64_t N, int prune_min_vox_obs, void* base, IntegrateWs& ws) {
+static int carve_integrate(int64_t N, void* base, IntegrateWs& ws) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    ws.max_items = max_items_for(N, prune_min_vox_obs);
-    size_t o_lin = take((size_t)N * 4), o_key = take((size_t)8 * N * 4), o_row = take((size_t)ws.max_items * ITEM_ROWS * 4);
-    size_t o_islot = take((size_t)ws.max_items * 4), o_part = take((size_t)ws.max_items * 32 * 8), o_tmp = take(4096 * 4);
+    // 8N bounds the gathered rows (map.py:419-435), hence tiles * 32 and the run records: a run holds at least one row
+    const size_t rows = (size_t)(8 * N + 32);
+    size_t o_lin = take((size_t)N * 4), o_list = take(rows * 8), o_next = take(rows * 4), o_rec = take(rows * DIF_REC_WORDS * 8), o_tmp = take(4096 * 4);
     ws.total_bytes = (int64_t)off;
     if (base) {
         char* b = (char*)base;
-        ws.pt_lin = (int*)(b + o_lin); ws.pair_key = (uint32_t*)(b + o_key); ws.row_val = (uint32_t*)(b + o_row);
-        ws.item_slot = (int*)(b + o_islot); ws.partial = (long long*)(b + o_part); ws.block_tmp = (int*)(b + o_tmp);
+        ws.pt_lin = (int*)(b + o_lin); ws.pair_list = (uint2*)(b + o_list); ws.rec_next = (int*)(b + o_next);
+        ws.rec = (long long*)(b + o_rec); ws.block_tmp = (int*)(b + o_tmp);
     }
     return DIF_OK;
 }
 
-int64_t dif_integrate_workspace_bytes(int64_t N, int32_t prune_min_vox_obs) {
+int64_t dif_integrate_workspace_bytes(int64_t N) {
     if (N <= 0) N = 1;
     IntegrateWs ws;
-    if (carve_integrate(N, prune_min_vox_obs, nullptr, ws) != DIF_OK) return -1;
+    if (carve_integrate(N, nullptr, ws) != DIF_OK) return -1;
     return ws.total_bytes;
 }
 
@@ -366,16 +349,16 @@ struct FrameSource {            // integrate straight from a depth frame: the fi
 };
 
 static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
-                          void* wsp, int64_t ws_bytes, hipEvent_t gate, const FrameSource* src, void* stream_) {
+                          void* wsp, int64_t ws_bytes, const FrameSource* src, void* stream_) {
     if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0) return DIF_EINVAL;
     if (N == 0) return DIF_OK;
     if (!xyz || !normal || !unq_mask || !wsp) return DIF_EINVAL;
-    if (8 * N >= (int64_t)1 << 31 || map->capacity >= (int64_t)DIF_INVALID_KEY) return DIF_EINVAL;
+    if (8 * N + 64 >= (int64_t)1 << 31 || map->capacity >= (int64_t)1 << 31) return DIF_EINVAL;      // record ids and slots are int32
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     if (grid >= ((int64_t)1 << 31)) return DIF_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     IntegrateWs ws;
-    if (carve_integrate(N, (int)map->prune_min_vox_obs, wsp, ws) != DIF_OK) return DIF_ELAUNCH;
+    if (carve_integrate(N, wsp, ws) != DIF_OK) return DIF_ELAUNCH;
     if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
     Geo g = geo_of(map);
     int* C = map->counters;
@@ -399,15 +382,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     }
     hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
                        (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
-                       ws.pair_key, map->seg_cnt, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0);
-    DIF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_alloc_items, dim3(grid_for(map->capacity, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, (const int*)map->seg_cnt, map->item_start,
-                       ws.item_slot, C, ws.max_items);
-    {
-        ProfScope prof(DIF_PROF_SORT, s);
-        hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(8 * N, DIF_BLOCK, 8192)), dim3(DIF_BLOCK), 0, s, (const uint32_t*)ws.pair_key, 8 * N,
-                           (const int*)map->item_start, map->seg_start /* row cursors, idle 0 */, ws.row_val, ws.max_items * ITEM_ROWS);
-    }
+                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0);
     DIF_CHECK_LAUNCH();
     {
         const size_t lds_bytes = (size_t)ENC_FLOATS * 4;
@@ -418,35 +393,26 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
             attr_set[dev] = true;
         }
         ProfScope prof(DIF_PROF_ENCODE, s);
-        hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint32_t*)ws.row_val,
-                           (const int*)map->seg_cnt, (const int*)map->item_start, (const int*)ws.item_slot, (const int*)C, ws.partial, (int)ws.max_items);
+        hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint2*)ws.pair_list,
+                           map->rec_head, ws.rec_next, ws.rec, map->upd_list, C);
         DIF_CHECK_LAUNCH();
     }
-    // k_fuse is the only kernel of an integrate that writes what an extract reads (latents, observation counts, dirty flags)
-    if (gate && hipStreamWaitEvent(s, gate, 0) != hipSuccess) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_fuse, dim3(grid_for(ws.max_items * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.partial,
-                       (const int*)map->item_start, (const int*)ws.item_slot, map->seg_cnt, map->seg_start, map->latent_vecs, map->voxel_obs_count,
-                       map->dirty, C, (int)ws.max_items);
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.rec, (const int*)ws.rec_next,
+                       map->rec_head, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
 
 int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
                   void* wsp, int64_t ws_bytes, void* stream_) {
-    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, nullptr, nullptr, stream_);
+    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, nullptr, stream_);
 }
 
 int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_frame_t* frame_dev, int32_t H, int32_t W, float fx, float fy, float cx,
                         float cy, float* xyz_world, float* normal_world, uint8_t* unq_mask, void* wsp, int64_t ws_bytes, void* stream_) {
     if (!frame_dev || H <= 0 || W <= 0 || !xyz_world || !normal_world) return DIF_EINVAL;
     FrameSource src{frame_dev, H, W, fx, fy, cx, cy};
-    return integrate_impl(map, w, xyz_world, normal_world, (int64_t)H * W, unq_mask, wsp, ws_bytes, nullptr, &src, stream_);
-}
-
-int dif_integrate_gated(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
-                        void* wsp, int64_t ws_bytes, void* gate_event, void* stream_) {
-    if (!gate_event) return DIF_EINVAL;
-    return integrate_impl(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, (hipEvent_t)gate_event, nullptr, stream_);
+    return integrate_impl(map, w, xyz_world, normal_world, (int64_t)H * W, unq_mask, wsp, ws_bytes, &src, stream_);
 }
 
 // ---- decoder launches ------------------------------------------------------------------------------------------
@@ -611,12 +577,10 @@ int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t n
 
 // ---- extract ---------------------------------------------------------------------------------------------------
 static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
-                        float max_std, int32_t no_cache, int32_t scale_vertices, bool overlapped, hipEvent_t decode_done, void* stream_) {
+                        float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
-    if (overlapped && (!map->grid_bits_extract || !decode_done || no_cache)) return DIF_EINVAL;
-    // what an overlapped extract may look at while the next integrate runs: the slots of the last COMPLETED integrate, its own bitmap
-    const int* n_slots = map->counters + (overlapped ? DIF_C_N_FUSED : DIF_C_N_OCCUPIED);
-    uint32_t* const bits = overlapped ? map->grid_bits_extract : map->grid_bits;
+    const int* n_slots = map->counters + DIF_C_N_OCCUPIED;
+    uint32_t* const bits = map->grid_bits;
     if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_tri || !buf->cache_id || !buf->cache_std || !buf->cache_alive)
         return DIF_EINVAL;
     if (!map->tri_start || !map->tri_n) return DIF_EINVAL;
@@ -708,8 +672,6 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         rc = launch_decode(A, w, buf->max_voxels * (int64_t)((R3 + 31) / 32), s);
         if (rc != DIF_OK) return rc;
     }
-    // nothing below reads latents, observation counts or dirty flags: the next frame's k_fuse may go ahead
-    if (decode_done && hipEventRecord(decode_done, s) != hipSuccess) return DIF_ELAUNCH;
     // marching cubes (map.py:689-691)
     McArgs a = {};
     a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
@@ -749,12 +711,7 @@ int dif_trace_read(unsigned long long* out, int64_t n) {      // host copy of g_
 
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                 float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
-    return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, false, nullptr, stream_);
-}
-
-int dif_extract_overlapped(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
-                           float max_std, int32_t no_cache, int32_t scale_vertices, void* decode_done_event, void* stream_) {
-    return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, true, (hipEvent_t)decode_done_event, stream_);
+    return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, stream_);
 }
 
 int dif_mesh_cache_export(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std, void* stream) {

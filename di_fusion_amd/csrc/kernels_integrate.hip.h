@@ -124,82 +124,29 @@ struct AllocFunctor {
 };
 
 // K4: (i) commit n_occupied += newly allocated (all pass-2 blocks of K3 have read the old value by now),
-// (ii) restore frame_count to zero, (iii) focus mask + 8-offset gather keys (map.py:389-433).
-// Key of pair (offset o, point i), stored at o*N + i (the reference's concatenation order): slot of the neighbour voxel
-// if that voxel is in the encode set {obs_count < encoder_count_th}, else DIF_INVALID_KEY.  Rows per slot are counted here
-// (seg_cnt = the reference's `pcounts`, map.py:437-439) with one atomic per distinct slot per wave.
+// (ii) restore frame_count to zero, (iii) focus mask + 8-offset gather (map.py:389-433), written as a COMPACTED list of the valid
+// (offset o, point i) pairs: entry = (slot of the neighbour voxel, o*N + i) for every pair whose neighbour voxel is in the encode set
+// {obs_count < encoder_count_th}.  In steady state ~3 % of the 8N pairs are valid, so nothing 8N-sized is written or read again.
+// List order: (workgroup, wave, offset, lane) — a wave's pairs for one offset are neighbours in the list, and neighbouring pixels
+// share voxels, so the list is made of long runs of equal slots (which is what k_encode's per-tile run reduction feeds on).  Which
+// workgroup gets which list range is decided by one atomic per workgroup; the order only decides which tile a row is encoded in,
+// and the per-voxel sums are exact integer sums, so results do not depend on it.
 __device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
-
-// Wave-aggregated "fetch-add 1" on counter[key] for every lane whose key is valid; returns the lane's unique offset
-// (base + rank among the lanes of the wave that share the key).  One atomic per distinct key per wave, and all of a wave's atomics
-// are in flight together: the grouping loop is pure ALU, the leaders then issue their atomics in ONE instruction and the wave waits
-// for a single round trip however many distinct keys it holds.
-__device__ __forceinline__ int wave_grouped_fetch_add(int* __restrict__ counter, uint32_t key, bool valid) {
-    const int lane = lane_id();
-    int my_leader = lane, my_rank = 0, my_group = 0;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
-        const unsigned long long same = __ballot(valid && key == k0);
-        if (valid && key == k0) {
-            my_leader = leader;
-            my_rank = __popcll(same & ((1ull << lane) - 1ull));
-            my_group = __popcll(same);
-        }
-        todo &= ~same;
-    }
-    int base = 0;
-    if (valid && lane == my_leader) base = atomicAdd(counter + key, my_group);
-    base = __shfl(base, my_leader);
-    return base + my_rank;
-}
-
-// Fire-and-forget counting at workgroup level: the wave's groups go into a small LDS table first, one global atomic per distinct key
-// per WORKGROUP.
-// Same-address global atomics are what bounds the row counting (hundreds per voxel per frame, ~12 ns each on one L2 channel).
-#define FG_TABLE 256
-__device__ __forceinline__ void block_grouped_add_lds(unsigned* __restrict__ tkey, int* __restrict__ tcnt, int* __restrict__ counter, uint32_t key,
-                                                      bool valid) {
-    const int lane = lane_id();
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
-        const unsigned long long same = __ballot(valid && key == k0);
-        if (lane == leader) {
-            unsigned h = (k0 * 2654435761u) >> 24;                     // FG_TABLE = 256 slots; a workgroup normally holds far fewer distinct keys
-            int probes = 0;
-            for (; probes < FG_TABLE; ++probes) {
-                const unsigned old = atomicCAS(tkey + h, DIF_INVALID_KEY, k0);
-                if (old == DIF_INVALID_KEY || old == k0) break;
-                h = (h + 1) & (FG_TABLE - 1);
-            }
-            if (probes < FG_TABLE) atomicAdd(tcnt + h, __popcll(same));
-            else atomicAdd(counter + k0, __popcll(same));             // table full (a workgroup spanning > 256 voxels): count directly
-        }
-        todo &= ~same;
-    }
-}
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
-                                                          uint32_t* __restrict__ pair_key, int* __restrict__ seg_cnt,
-                                                          int* __restrict__ counters, int64_t capacity, int img_w) {
-    __shared__ unsigned tkey[FG_TABLE];
-    __shared__ int tcnt[FG_TABLE];
-    tkey[threadIdx.x] = DIF_INVALID_KEY;                             // DIF_BLOCK == FG_TABLE
-    tcnt[threadIdx.x] = 0;
-    // Points of a frame (img_w > 0, N = H * img_w with both multiples of 16) are walked in 16 x 16 pixel tiles: a workgroup then touches
-    // ~10 voxels instead of the ~90 that a 256-pixel piece of an image row does, so its rows collapse into few counters.
+                                                          uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w) {
+    __shared__ int s_wave_tot[DIF_BLOCK / 64];
+    __shared__ int s_base;
+    // Points of a frame (img_w > 0, N = H * img_w with both multiples of 16) are walked in 16 x 16 pixel tiles: a wave then covers a
+    // 16 x 4 pixel patch (2-6 voxels) instead of a 64-pixel piece of an image row, which makes the runs of equal slots longer.
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole workgroups
     if (img_w > 0) {
         const int tiles_x = img_w >> 4;
         const int ty = (int)(blockIdx.x / tiles_x), tx = (int)(blockIdx.x % tiles_x);
         i = (int64_t)(ty * 16 + (int)(threadIdx.x >> 4)) * img_w + tx * 16 + (int)(threadIdx.x & 15);
     }
-    __syncthreads();
     if (i == 0) {
         int n = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (n > capacity) { n = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
@@ -212,7 +159,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
     // get_pruned_surface: own voxel in expand(encode set) <=> own voxel or an in-grid 6-neighbour is in the set.  That is a property of the
     // VOXEL, and neighbouring pixels share voxels: the first lane of every run of equal ids does the seven look-ups, the rest of the run
     // takes its answer (in steady state ~97 % of the points fail this test, so it is most of the kernel's gathers).
-    const int lane = lane_id();
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     const bool kept = lin >= 0 && unq_mask[i];
     if (lin >= 0) frame_count[lin] = 0;
     const int prev = __shfl_up(lin, 1);
@@ -256,90 +203,78 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
         for (int o = 0; o < 8; ++o)
             if (w[o] < enc_th) key[o] = (uint32_t)slot[o];
     }
+    // ---- compaction: ballots per offset, one list reservation per workgroup ----
+    unsigned long long valid[8];
+    int wave_total = 0;
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-        if (i < N) pair_key[(int64_t)o * N + i] = key[o];
-        block_grouped_add_lds(tkey, tcnt, seg_cnt, key[o], key[o] != DIF_INVALID_KEY);
+        valid[o] = __ballot(key[o] != DIF_INVALID_KEY);
+        wave_total += __popcll(valid[o]);
+    }
+    if (lane == 0) s_wave_tot[wid] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < DIF_BLOCK / 64; ++w) tot += s_wave_tot[w];
+        s_base = tot ? atomicAdd(counters + DIF_C_M, tot) : 0;      // M of map.py:434-435
     }
     __syncthreads();
-    if (tkey[threadIdx.x] != DIF_INVALID_KEY) atomicAdd(seg_cnt + tkey[threadIdx.x], tcnt[threadIdx.x]);
-}
-
-// K5: per-slot encoder work items (ceil(cnt / ITEM_ROWS)) and the item -> slot table.  A slot's rows live in the row table at
-// [item_start*ITEM_ROWS, ...) (padded to whole items).
-__global__ void __launch_bounds__(DIF_BLOCK) k_alloc_items(const int* __restrict__ seg_cnt, int* __restrict__ item_start, int* __restrict__ item_slot,
-                                                         int* __restrict__ counters, int64_t max_items) {
-    // Items are handed out with one atomic per workgroup instead of an ordered scan: WHICH items a voxel gets only decides where its
-    // partial sums live and which wave encodes them; k_fuse adds a voxel's partials in its own fixed order, so results do not change.
-    __shared__ int smem[8];
-    __shared__ int s_base;
-    const int n = counters[DIF_C_N_OCCUPIED];
-    for (int s0 = (int)(blockIdx.x * blockDim.x); s0 < n; s0 += (int)(gridDim.x * blockDim.x)) {
-        const int s = s0 + (int)threadIdx.x;
-        const int cnt = (s < n) ? seg_cnt[s] : 0;
-        const int nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
-        int total;
-        const int ex = block_excl_scan(nit, smem, total);
-        const int rows = block_sum(cnt, smem), vox = block_sum(cnt > 0 ? 1 : 0, smem);      // M and C of map.py:434-437
-        if (threadIdx.x == 0) {
-            s_base = total ? atomicAdd(counters + DIF_C_ITEMS, total) : 0;
-            if (vox) { atomicAdd(counters + DIF_C_C, vox); atomicAdd(counters + DIF_C_M, rows); }
-        }
-        __syncthreads();
-        if (nit) {
-            const int off = s_base + ex;
-            item_start[s] = off;
-            if ((int64_t)off + nit > max_items) counters[DIF_C_OVERFLOW] = 4;
-            else for (int k = 0; k < nit; ++k) item_slot[off + k] = s;
-        }
-        __syncthreads();
-    }
-}
-
-// K6: place every valid (offset, point) pair into its slot's rows.  Order inside a slot is arrival order — harmless, because
-// the per-voxel sum is accumulated in exact fixed point (order-independent, see k_encode).
-__global__ void __launch_bounds__(DIF_BLOCK) k_scatter_rows(const uint32_t* __restrict__ pair_key, int64_t n_pairs, const int* __restrict__ item_start,
-                                                          int* __restrict__ seg_cursor, uint32_t* __restrict__ row_val, int64_t max_rows) {
-    const int64_t n_pad = (n_pairs + 63) / 64 * 64;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_pad; j += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t key = (j < n_pairs) ? pair_key[j] : DIF_INVALID_KEY;
-        const bool valid = key != DIF_INVALID_KEY;
-        const int first_item = valid ? item_start[key] : 0;          // in flight together with the atomics below
-        const int r = wave_grouped_fetch_add(seg_cursor, key, valid);
-        if (valid) {
-            const int64_t pos = (int64_t)first_item * ITEM_ROWS + r;
-            if (pos < max_rows) row_val[pos] = (uint32_t)j;
-        }
+    if (wave_total == 0) return;
+    int off = s_base;
+    for (int w = 0; w < wid; ++w) off += s_wave_tot[w];
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (key[o] != DIF_INVALID_KEY) pair_list[off + __popcll(valid[o] & below)] = make_uint2(key[o], (uint32_t)((int64_t)o * N + i));
+        off += __popcll(valid[o]);
     }
 }
 
 // =================================================================================================================
 // a7..a9 : gather + encoder (MFMA) + per-voxel sums
 // =================================================================================================================
-// Persistent: one 512-thread workgroup per CU keeps the 107 KB of packed encoder weights in LDS; each wave pulls work
-// items (slot, 32 rows), runs the tile through the MFMA chain and reduces the 29 output features over the rows.
-// The reduction is done in 2^-30 FIXED POINT (int64): integer addition is associative, so the per-voxel sum does not
-// depend on row order, tile grouping or the order partials are added in => bit-reproducible, and more accurate than an
-// fp32 running sum (the reference sums with float atomics in arbitrary order, indexing.cu:59-71).
+// Persistent: one 512-thread workgroup per CU keeps the 107 KB of packed encoder weights in LDS; each wave pulls tiles of 32
+// CONSECUTIVE list entries (every tile full: no per-voxel padding, no sort), runs them through the MFMA chain and reduces the 29
+// output features over each RUN of equal slots inside the tile with one segmented wave scan.  Every run leaves a 256-byte record
+// (32 x int64: the 29 feature sums, the run length in the spare position 29) at a fixed place, rec[tile*32 + rank of the run], and
+// is pushed onto its slot's record chain with ONE atomic exchange (rec_head[slot], idle 0 = empty; the first run of a slot also
+// appends the slot to the frame's update list).  k_fuse walks the chains.
+// The sums are kept in 2^-30 FIXED POINT (int64): integer addition is associative, so the per-voxel sum does not depend on list
+// order, tile boundaries or chain order => bit-reproducible, and more accurate than an fp32 running sum (the reference sums with
+// float atomics in arbitrary order, indexing.cu:59-71).
 #define DIF_FIX_SCALE 1073741824.0f          /* 2^30: |enc| < 2^12 and < 2^21 rows per voxel keep the sum inside int64 */
+#define DIF_REC_WORDS 32                     /* int64 per record */
+#define DIF_REC_COUNT_POS 29                 /* record position that carries the run length (feature 29 is a zero row of the MFMA tile) */
+
 __global__ void __launch_bounds__(512, 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
-         const uint32_t* __restrict__ row_val, const int* __restrict__ seg_cnt, const int* __restrict__ item_start,
-         const int* __restrict__ item_slot, const int* __restrict__ counters, long long* __restrict__ partial /* [items][32] */, int max_items) {
+         const uint2* __restrict__ pair_list, int* __restrict__ rec_head, int* __restrict__ rec_next, long long* __restrict__ rec,
+         int* __restrict__ upd_list, int* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights(lds, wblob, ENC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
-    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
+    // tile t goes to wave (t / #blocks) of block (t % #blocks): a partly filled launch spreads over all CUs and SIMDs first
     const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int n_items = min(counters[DIF_C_ITEMS], max_items);
-    for (int item = wave; item < n_items; item += nwaves) {
-        const int slot = item_slot[item];
-        const int chunk = item - item_start[slot];
-        const bool live = chunk * ITEM_ROWS + col < seg_cnt[slot];
+    const int M = counters[DIF_C_M];
+    const int n_tiles = (M + 31) >> 5;
+    for (int tile = wave; tile < n_tiles; tile += nwaves) {
+        const int row = tile * 32 + col;
+        const bool live = row < M;
+        uint2 e = make_uint2(DIF_INVALID_KEY, 0u);
+        if (live) e = pair_list[row];
+        const uint32_t key = e.x;
+        // runs of equal slots (both halves of the wave hold the same 32 rows and compute the same run structure)
+        const uint32_t key_prev = (uint32_t)__shfl_up((int)key, 1), key_next = (uint32_t)__shfl_down((int)key, 1);
+        const bool run_head = (col == 0) || (key_prev != key);
+        const bool run_tail = (col == 31) || (key_next != key);
+        const uint32_t heads32 = (uint32_t)(__ballot(run_head) >> (half * 32));
+        const int my_head = 31 - __clz((int)(heads32 & ((2u << col) - 1u)));      // column where this lane's run starts
+        const int rec_id = tile * 32 + __popc(heads32 & ((2u << col) - 1u)) - 1;  // record of this lane's run
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         if (live) {
-            uint32_t v = row_val[(int64_t)item * ITEM_ROWS + col];
+            const uint32_t v = e.y;
             int o = 0;
 #pragma unroll
             for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
@@ -357,37 +292,51 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
             x1 = half ? nxv : rz;
             x2 = half ? nzv : nyv;
         }
+        // push the run onto its slot's chain.  Issued after the gathers above have been consumed and before the MFMA chain, used after
+        // it: the round trip hides behind ~11 us of matrix work.
+        int chain_prev = 0;
+        const bool pusher = live && run_tail && half == 0;
+        if (pusher) chain_prev = atomicExch(rec_head + key, rec_id + 1);
         f16v out = encoder_tile(lds, x0, x1, x2, lane);
-        long long* p = partial + (int64_t)item * 32;
+        long long* p = rec + (int64_t)rec_id * DIF_REC_WORDS + half * 16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             long long v = live ? __float2ll_rn(out[r] * DIF_FIX_SCALE) : 0ll;
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 16);
-            if (col == 0) p[(r & 3) + 8 * (r >> 2) + 4 * half] = v;
+            if (half == 1 && r == 13) v = live ? 1ll : 0ll;          // feature 29 (a zero row): carries the run length instead
+            // segmented inclusive scan along the 32 columns: a lane adds the value `d` columns below if that column is still in its run
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const long long u = __shfl_up(v, d, 32);
+                if (col - d >= my_head) v += u;
+            }
+            if (live && run_tail) p[r] = v;
+        }
+        if (pusher) {
+            rec_next[rec_id] = chain_prev;
+            if (chain_prev == 0) upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;      // first run of this slot in the frame (C of map.py:437)
         }
     }
 }
 
-// a10: fusion update (map.py:448-452).  One 32-lane group per slot.
-__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ partial, const int* __restrict__ item_start, const int* __restrict__ item_slot,
-                                                  int* __restrict__ seg_cnt, int* __restrict__ seg_cursor, float* __restrict__ latent, float* __restrict__ obs,
-                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters, int max_items) {
-    const int n_items = min(counters[DIF_C_ITEMS], max_items);
+// a10: fusion update (map.py:448-452).  One 32-lane group per updated slot: sum the slot's record chain, fuse, reset the chain.
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_head,
+                                                  const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
+                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters) {
+    const int n_upd = counters[DIF_C_C];
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
     const int f = threadIdx.x & 31;
-    // walk the work items (a few thousand) instead of every allocated slot: the first item of a slot fuses the whole slot
-    for (int it0 = grp; it0 < n_items; it0 += ngrp) {
-        const int s = item_slot[it0];
-        if (item_start[s] != it0) continue;
-        const int cnt = seg_cnt[s];
-        const int nit = (cnt + ITEM_ROWS - 1) / ITEM_ROWS;
+    // where feature f sits in a record: the accumulator-fragment order of the tile's two halves (mlp.hip.h)
+    const int pos = ((f >> 2) & 1) * 16 + (f & 3) + 4 * (f >> 3);
+    for (int u = grp; u < n_upd; u += ngrp) {
+        const int s = upd_list[u];
+        long long Si = 0;
+        int cnt = 0;
+        for (int id = rec_head[s]; id != 0; id = rec_next[id - 1]) {
+            const long long* r = rec + (int64_t)(id - 1) * DIF_REC_WORDS;
+            Si += r[pos];
+            cnt += (int)r[DIF_REC_COUNT_POS];
+        }
         if (f < L) {
-            long long Si = 0;
-            for (int k = 0; k < nit; ++k) Si += partial[(int64_t)(it0 + k) * 32 + f];
             float S = (float)Si * (1.0f / DIF_FIX_SCALE);    // one rounding: exact integer sum -> nearest float
             float w_old = obs[s];
             float z_old = latent[(int64_t)s * L + f];
@@ -399,10 +348,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
         if (f == 31) {                                       // after every lane of the group has read obs[s]
             obs[s] = obs[s] + (float)cnt;
             dirty[s] = 1;                                    // map.py:452
-            seg_cnt[s] = 0;
-            seg_cursor[s] = 0;
+            rec_head[s] = 0;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_N_FUSED] = counters[DIF_C_N_OCCUPIED];   // the slots an overlapped extract may look at
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_ITEMS] = (counters[DIF_C_M] + 31) >> 5;   // encoder tiles of this frame
 }
 

@@ -405,7 +405,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __rest
         int no = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (no > capacity) { no = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
         counters[DIF_C_N_OCCUPIED] = no;
-        counters[DIF_C_N_FUSED] = no;
         counters[DIF_C_ALLOC_NEW] = 0;
     }
     const int64_t total = n * 32;

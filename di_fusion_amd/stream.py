@@ -48,10 +48,6 @@ class FusionStream:
         self.n_captures = 0
         self._g_in = None
         self._zc = None
-        self._ov_graph = None
-        self._ov_sig = None
-        self._side_stream = torch.cuda.Stream(device=device)
-        self._gate = None                                        # event: "frame i's decode is done" -> frame i+1's k_fuse may run
 
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
@@ -250,104 +246,3 @@ class FusionStream:
             out = self._finish_frame(self._pending, d2h)
         self._pending = h
         return out
-
-    # ---- overlapped variant: extract of frame i-1 runs beside integrate of frame i ----------------------------------------------
-    # One unit of work = [dif_extract_overlapped of what the previous frame left dirty] on a side stream, beside
-    # [unproject+transform, dif_integrate_gated of frame i] on the main stream.  The two only meet at one event: k_fuse(i) waits for
-    # the decode of frame i-1 (include/difusion.h explains why nothing else is shared).  Same kernels, same results bit for bit, but the
-    # low-occupancy tails of one half (marching cubes, scans) fill the gaps of the other.  The mesh handed back lags one more frame.
-    def _overlap_unit(self, frame, mask, buf, w):
-        m, intr, lib = self.map, self.intr, _lib.load()
-        H, W = intr.height, intr.width
-        main = torch.cuda.current_stream()
-        side = self._side_stream
-        side.wait_stream(main)                                   # fork
-        with torch.cuda.stream(side):
-            _lib.check(lib.dif_extract_overlapped(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1,
-                                                  float(self.max_std), 0, 1, ctypes.c_void_p(self._gate.cuda_event), _lib.stream_ptr()),
-                       "dif_extract_overlapped")
-        _lib.check(lib.dif_unproject_transform_frame(_lib.ptr(frame), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H, W,
-                                                     intr.fx, intr.fy, intr.cx, intr.cy, _lib.stream_ptr()), "dif_unproject_transform_frame")
-        _lib.check(lib.dif_integrate_gated(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(self.xyz), _lib.ptr(self.nrm), H * W, _lib.ptr(mask),
-                                           _lib.ptr(m._ws), m._ws.numel(), ctypes.c_void_p(self._gate.cuda_event), _lib.stream_ptr()),
-                   "dif_integrate_gated")
-        main.wait_stream(side)                                   # join
-
-    def _overlap_prepare(self):
-        m, intr, dev = self.map, self.intr, self.device
-        N = intr.height * intr.width
-        if self._g_in is None:
-            self._g_in = (torch.zeros((64,), dtype=torch.uint8, device=dev), torch.empty((N,), dtype=torch.uint8, device=dev))
-            self._g_frame_host = [torch.zeros((64,), dtype=torch.uint8).pin_memory() for _ in range(4)]
-            self._g_counters = [torch.empty((_lib.C_COUNT,), dtype=torch.int32).pin_memory() for _ in range(4)]
-            self._g_seq = 0
-        if self._gate is None:
-            self._gate = torch.cuda.Event()
-            self._gate.record()                                  # creates the underlying hipEvent_t
-
-    def step_overlap(self, i: int, d2h: str = "new", graph: bool = True):
-        """Integrate frame i while the mesh of frame i-1 is extracted (see above).  Returns the mesh of the frame before the previous
-        call's frame (None while the pipeline fills); `flush()` drains it."""
-        m = self.map
-        N = self.intr.height * self.intr.width
-        prune = int(m.args.prune_min_vox_obs)
-        may_add = 7 * (N // (prune + 1)) if prune > 0 else 7 * N
-        out = None
-        with torch.cuda.device(self.device):
-            if m._ws is None or m._xbuf is None or m._cache is None:
-                raise RuntimeError("run at least one eager step before step_overlap (buffers are sized there)")
-            if m._n_occ_ub + may_add > m._capacity and self._pending is not None:
-                out = self._finish_frame(self._pending, d2h)     # make the bound exact before deciding to grow
-                self._pending = None
-            m._ensure_capacity(may_add)
-            self._before_frame()
-            if m._gc_wanted:
-                m._cache_gc()
-            self._overlap_prepare()
-            frame, mask = self._g_in
-            w = m.model.packed.weights_struct(self.device)
-            R, t = self.poses[i]
-            fh = self._g_frame_host[self._g_seq % 4]
-            fh.numpy()[:] = np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8)
-            frame.copy_(fh, non_blocking=True)
-            if graph:
-                sig = self._graph_signature()
-                if self._ov_graph is None or self._ov_sig != sig:
-                    torch.cuda.synchronize()
-                    _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._overlap_unit(frame, mask, buf, w)
-                    self._ov_graph, self._ov_sig = (g, buf), self._graph_signature()
-                self._ov_graph[0].replay()
-            else:
-                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
-                self._overlap_unit(frame, mask, buf, w)
-            self._extract_owed = True                            # frame i is integrated but not meshed yet
-            m.mesh_cache.invalidate_host_copy()
-            pc = self._g_counters[self._g_seq % 4]
-            self._g_seq += 1
-            pc.copy_(m._counters, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            h = dict(event=ev, counters=pc, epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles)
-        if self._pending is not None:
-            out = self._finish_frame(self._pending, d2h)
-        self._pending = h
-        return out
-
-    def flush_overlap(self, d2h: str = "new"):
-        """Drain `step_overlap`: finish the pending unit, then mesh the last integrated frame.  Returns the list of the meshes that
-        were still in flight, oldest first (copies, when d2h == "new": the pinned staging buffer is reused)."""
-        outs = []
-        out = self.flush(d2h)
-        if out is not None:
-            outs.append(tuple(x.clone() for x in out))
-        if getattr(self, "_extract_owed", False):
-            self._extract_owed = False
-            h = self.map.extract_mesh_enqueue(self.resolution, self.max_n_triangles, max_std=self.max_std)
-            out = self._finish_frame(h, d2h)
-            with torch.cuda.device(self.device):
-                self._copy_stream.synchronize()
-            outs.append(tuple(x.clone() for x in out))
-        return outs

@@ -154,7 +154,6 @@ class DenseIndexedMap:
             self._indexer = torch.full((self._grid,), -1, device=device, dtype=torch.long)
             self._frame_count = torch.zeros((self._grid,), device=device, dtype=torch.int32)
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
-            self._grid_bits_x = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)   # dif_extract_overlapped's own
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
         self._capacity = 0
         self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
@@ -177,9 +176,8 @@ class DenseIndexedMap:
             obs = torch.zeros((capacity,), dtype=torch.float32, device=dev)
             dirty = torch.zeros((capacity,), dtype=torch.uint8, device=dev)
             vbm = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
-            seg_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
-            seg_cnt = torch.zeros((capacity,), dtype=torch.int32, device=dev)
-            item_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            rec_head = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            upd_list = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_n = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             if self._capacity > 0:
@@ -192,7 +190,7 @@ class DenseIndexedMap:
                 tri_n[:c] = self._tri_n
         self._latent, self._pos, self._obs, self._dirty = lat, pos, obs, dirty
         self._tri_start, self._tri_n = tri_start, tri_n
-        self._vbm, self._seg_start, self._seg_cnt, self._item_start = vbm, seg_start, seg_cnt, item_start
+        self._vbm, self._rec_head, self._upd_list = vbm, rec_head, upd_list
         self._capacity = capacity
         m = _lib.DifMap()
         m.nx, m.ny, m.nz = self.n_xyz
@@ -211,11 +209,9 @@ class DenseIndexedMap:
         m.counters = _lib.ptr(self._counters)
         m.frame_count = _lib.ptr(self._frame_count)
         m.grid_bits = _lib.ptr(self._grid_bits)
-        m.grid_bits_extract = _lib.ptr(self._grid_bits_x)
         m.vbm = _lib.ptr(vbm)
-        m.seg_start = _lib.ptr(seg_start)
-        m.seg_cnt = _lib.ptr(seg_cnt)
-        m.item_start = _lib.ptr(item_start)
+        m.rec_head = _lib.ptr(rec_head)
+        m.upd_list = _lib.ptr(upd_list)
         m.tri_start = _lib.ptr(tri_start)
         m.tri_n = _lib.ptr(tri_n)
         m.own_x_lo, m.own_x_hi, m.halo = getattr(self, "_ownership", (0, self.n_xyz[0], 0))
@@ -325,7 +321,6 @@ class DenseIndexedMap:
         self._obs[:n] = cv["voxel_obs_count"][:n]
         self._counters.zero_()
         self._counters[_lib.C_N_OCCUPIED] = n
-        self._counters[_lib.C_N_FUSED] = n
         self._n_occ_ub = n
         self.mesh_cache.clear_all()
 
@@ -347,7 +342,7 @@ class DenseIndexedMap:
             prune = int(self.args.prune_min_vox_obs)
             self._ensure_capacity(7 * (N // (prune + 1)) if prune > 0 else 7 * N)
             if self._ws is None or self._ws_n < N:
-                nb = int(lib.dif_integrate_workspace_bytes(N, prune))
+                nb = int(lib.dif_integrate_workspace_bytes(N))
                 if nb < 0:
                     raise RuntimeError("dif_integrate_workspace_bytes failed")
                 self._ws = torch.empty((nb,), dtype=torch.uint8, device=self.device)

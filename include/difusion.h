@@ -36,11 +36,11 @@ extern "C" {
 /* Device-resident counters (one per map).  int32 each; indices into the `counters` array. */
 enum {
     DIF_C_N_OCCUPIED = 0,   /* map.py:200  n_occupied                                                   */
-    DIF_C_OVERFLOW = 1,     /* set !=0 when an allocation exceeded `capacity` (checked by the façade)     */
+    DIF_C_OVERFLOW = 1,     /* set !=0 when a device-side buffer was too small (checked by the façade)    */
     DIF_C_ALLOC_NEW = 2,    /* voxels allocated by the last integrate                                     */
     DIF_C_M = 3,            /* gathered (point, offset) rows of the last integrate  (map.py:434-435)      */
     DIF_C_C = 4,            /* voxels updated by the encoder in the last integrate  (map.py:437)          */
-    DIF_C_ITEMS = 5,        /* encoder work items of the last integrate                                   */
+    DIF_C_ITEMS = 5,        /* encoder tiles (32 gathered rows each) of the last integrate                */
     DIF_C_K = 6,            /* dirty voxels handed to marching cubes ("valid_blocks", map.py:627)         */
     DIF_C_B = 7,            /* confident voxels decoded ("occupied_vec_id", map.py:631)                   */
     DIF_C_VH = 8,           /* refine rows of the fast two-level decode (map.py:667)                      */
@@ -53,7 +53,6 @@ enum {
     DIF_C_WORK = 15,        /* scratch                                                                    */
     DIF_C_CACHE_DEAD = 16,  /* dead entries in the mesh-cache log (replaced triangles awaiting compaction)  */
     DIF_C_CACHE_LIVE = 17,  /* triangles written by the last dif_mesh_cache_compact                        */
-    DIF_C_N_FUSED = 18,     /* n_occupied as of the last completed integrate (what an overlapped extract looks at)   */
     DIF_C_COUNT = 32
 };
 
@@ -76,16 +75,14 @@ typedef struct dif_map {
     int32_t* frame_count;           /* [nx*ny*nz] idle 0  : points of the current frame per voxel (map.py:374) */
     uint32_t* grid_bits;            /* [ceil(nx*ny*nz/32)] idle 0 : candidate / occupied voxel bitmap          */
     int32_t* vbm;                   /* [capacity] idle -1 : vec_id_batch_mapping (map.py:633-635)              */
-    int32_t* seg_start;             /* [capacity] idle 0  : row cursor of the slot while rows are placed             */
-    int32_t* seg_cnt;               /* [capacity] idle 0  : rows gathered for the slot (pcounts, map.py:439)   */
-    int32_t* item_start;            /* [capacity] first encoder work item of the slot                          */
+    int32_t* rec_head;              /* [capacity] idle 0  : head of the slot's chain of encoder run records (id + 1) */
+    int32_t* upd_list;              /* [capacity] slots updated by the current integrate (unique_pinds, map.py:437) */
     int32_t* tri_start;             /* [capacity] mesh-cache log position of the slot's live triangle batch     */
     int32_t* tri_n;                 /* [capacity] idle 0 when the voxel has no cached triangles                 */
     /* Spatial tiling (SURVEY.md section 8e "C5"): this map OWNS the voxels with x index in [own_x_lo, own_x_hi); points whose own
      * voxel lies outside [own_x_lo - halo, own_x_hi + halo) are ignored by integrate, and only owned voxels are meshed.
      * 0, nx, 0 = the whole grid (single-map behaviour). */
     int32_t own_x_lo, own_x_hi, halo;
-    uint32_t* grid_bits_extract;    /* [ceil(nx*ny*nz/32)] idle 0 : private bitmap of dif_extract_overlapped (NULL: share grid_bits) */
 } dif_map_t;
 
 /* Network weights packed for the MFMA kernels by di_fusion_amd/network/packing.py (layout documented there). */
@@ -167,9 +164,9 @@ int dif_groupby_sum(const float* values, const int64_t* indices, int64_t N, int3
                     int64_t C, void* stream);
 
 /* ---- a3..a10: integrate_keyframe (map.py:340-519, do_optimize=False) --------------------------------------- */
-/* Bytes of scratch `ws` needed for N points by a map with this `prune_min_vox_obs` (the pruning bounds how many voxels a frame can
- * update, hence the number of encoder work items; <= 0: no pruning, up to 8N voxels). */
-int64_t dif_integrate_workspace_bytes(int64_t N, int32_t prune_min_vox_obs);
+/* Bytes of scratch `ws` needed for N points: the point ids, the compacted list of gathered (voxel, offset, point) rows (at most 8N,
+ * map.py:419-435) and the encoder's per-run partial sums (at most one 256-byte record per row; written sparsely). */
+int64_t dif_integrate_workspace_bytes(int64_t N);
 /* xyz, normal: (N,3) f32.  unq_mask: (N) u8 out (map.py:375; all-valid-points when prune_min_vox_obs<=0).
  * Points with NaN coordinates or outside [bound_min, bound_max) are masked out (the reference indexes out of
  * bounds there, map.py:313; documented divergence). */
@@ -224,20 +221,6 @@ typedef struct dif_extract_buffers {
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution,
                 int32_t fast, float max_std, int32_t no_cache, int32_t scale_vertices, void* stream);
 
-/* ---- frame overlap: extract of frame i on one stream while frame i+1 integrates on another (no reference counterpart) ----
- * The only state the two halves share is what k_fuse writes (latents, observation counts, dirty flags) and what the decode
- * reads.  dif_extract_overlapped records `decode_done_event` (a hipEvent_t) on its stream after the last kernel that reads
- * them; dif_integrate_gated makes its stream wait for `gate_event` right before the one kernel that writes them.  Everything
- * else the extract looks at is private to it: the slot count of the last COMPLETED integrate (DIF_C_N_FUSED), its own bitmap
- * (map->grid_bits_extract, required), vbm / tri_* / the mesh-cache log.  Slots allocated concurrently are invisible to it
- * (not dirty, observation count 0, vbm -1), so the result is bit-identical to running the two calls back to back.
- * Call order on the host (also under stream capture): dif_extract_overlapped first, then dif_integrate_gated. */
-int dif_extract_overlapped(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution,
-                           int32_t fast, float max_std, int32_t no_cache, int32_t scale_vertices, void* decode_done_event,
-                           void* stream);
-int dif_integrate_gated(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N,
-                        uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* gate_event, void* stream);
-
 /* Log entries [lo, lo+n) -> (out_tri, out_id, out_std) in one launch.  The destinations may be device-mapped pinned HOST memory: a
  * streaming caller ships each call's new triangles (lo = DIF_C_CACHE_KEPT, n = DIF_C_CACHE_T - lo) without copy-engine transfers. */
 int dif_mesh_cache_export(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std,
@@ -284,7 +267,7 @@ int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, i
 /* ---- per-kernel timing for bench.py's roofline leg ---------------------------------------------------------- */
 /* When enabled, a hipEvent pair is recorded around each launch of the named kernels ON THE STREAM THEY RUN ON. */
 enum { DIF_PROF_ENCODE = 0, DIF_PROF_DECODE_LATTICE = 1, DIF_PROF_DECODE_POINTS = 2, DIF_PROF_MC_COUNT = 3, DIF_PROF_MC_EMIT = 4,
-       DIF_PROF_SORT = 5, DIF_PROF_COUNT = 8 };
+       DIF_PROF_COUNT = 8 };
 int dif_profile_enable(int32_t on);
 /* Sum of elapsed milliseconds and number of launches per kernel since the last reset; synchronises on the events. */
 int dif_profile_read(double* ms /* [DIF_PROF_COUNT], host */, int64_t* launches /* [DIF_PROF_COUNT], host */, int32_t reset);
