@@ -127,20 +127,26 @@ struct AllocFunctor {
 // (ii) restore frame_count to zero, (iii) focus mask + 8-offset gather (map.py:389-433), written as a COMPACTED list of the valid
 // (offset o, point i) pairs: entry = (slot of the neighbour voxel, o*N + i) for every pair whose neighbour voxel is in the encode set
 // {obs_count < encoder_count_th}.  In steady state ~3 % of the 8N pairs are valid, so nothing 8N-sized is written or read again.
-// List order: (workgroup, wave, offset, lane) — a wave's pairs for one offset are neighbours in the list, and neighbouring pixels
-// share voxels, so the list is made of long runs of equal slots (which is what k_encode's per-tile run reduction feeds on).  Which
-// workgroup gets which list range is decided by one atomic per workgroup; the order only decides which tile a row is encoded in,
-// and the per-voxel sums are exact integer sums, so results do not depend on it.
+// A workgroup's pairs are GROUPED BY SLOT before they are written (a counting sort through a 256-entry LDS hash table: the pairs
+// of a 16 x 16 pixel tile hit 10-30 voxels), so every (workgroup, slot) combination is one contiguous run of the list — which is
+// what keeps the number of run records per voxel small in k_encode / k_fuse.  Which list range a workgroup gets is decided by one
+// atomic per workgroup, and the order inside a run by LDS atomics; neither affects results (per-voxel sums are exact integer sums).
 __device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
 
+#define FG_TABLE 256            /* == DIF_BLOCK: one table entry per thread in the scan below */
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
                                                           uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w) {
-    __shared__ int s_wave_tot[DIF_BLOCK / 64];
-    __shared__ int s_base;
-    // Points of a frame (img_w > 0, N = H * img_w with both multiples of 16) are walked in 16 x 16 pixel tiles: a wave then covers a
-    // 16 x 4 pixel patch (2-6 voxels) instead of a 64-pixel piece of an image row, which makes the runs of equal slots longer.
+    __shared__ unsigned tkey[FG_TABLE];
+    __shared__ int tcnt[FG_TABLE];        // rows per table entry, then (after the scan) the entry's first list position within the workgroup
+    __shared__ int smem[8];
+    __shared__ int s_loose, s_base;
+    tkey[threadIdx.x] = DIF_INVALID_KEY;
+    tcnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_loose = 0;
+    // Points of a frame (img_w > 0, N = H * img_w with both multiples of 16) are walked in 16 x 16 pixel tiles: a workgroup then
+    // touches 10-30 voxels instead of the ~90 that a 256-pixel piece of an image row does.
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole workgroups
     if (img_w > 0) {
         const int tiles_x = img_w >> 4;
@@ -203,32 +209,35 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
         for (int o = 0; o < 8; ++o)
             if (w[o] < enc_th) key[o] = (uint32_t)slot[o];
     }
-    // ---- compaction: ballots per offset, one list reservation per workgroup ----
-    unsigned long long valid[8];
-    int wave_total = 0;
+    // ---- group by slot inside the workgroup, then one list reservation per workgroup ----
+    bool any = false;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) any |= key[o] != DIF_INVALID_KEY;
+    if (!__syncthreads_or((int)any)) return;                   // (also orders the table initialisation before its first use)
+    int where[8], rank[8];                                       // table entry (-1: table full, "loose" row) and rank inside it
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-        valid[o] = __ballot(key[o] != DIF_INVALID_KEY);
-        wave_total += __popcll(valid[o]);
+        where[o] = -1; rank[o] = 0;
+        if (key[o] == DIF_INVALID_KEY) continue;
+        unsigned h = (key[o] * 2654435761u) >> 24;
+        for (int probes = 0; probes < FG_TABLE; ++probes) {
+            const unsigned old = atomicCAS(tkey + h, DIF_INVALID_KEY, key[o]);
+            if (old == DIF_INVALID_KEY || old == key[o]) { where[o] = (int)h; break; }
+            h = (h + 1) & (FG_TABLE - 1);
+        }
+        rank[o] = atomicAdd(where[o] >= 0 ? tcnt + where[o] : &s_loose, 1);      // > 256 voxels in one workgroup (scattered points): ungrouped tail
     }
-    if (lane == 0) s_wave_tot[wid] = wave_total;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < DIF_BLOCK / 64; ++w) tot += s_wave_tot[w];
-        s_base = tot ? atomicAdd(counters + DIF_C_M, tot) : 0;      // M of map.py:434-435
-    }
+    int grouped;
+    const int first = block_excl_scan(tcnt[threadIdx.x], smem, grouped);
     __syncthreads();
-    if (wave_total == 0) return;
-    int off = s_base;
-    for (int w = 0; w < wid; ++w) off += s_wave_tot[w];
-    const unsigned long long below = (1ull << lane) - 1ull;
+    tcnt[threadIdx.x] = first;
+    if (threadIdx.x == 0) s_base = atomicAdd(counters + DIF_C_M, grouped + s_loose);      // M of map.py:434-435
+    __syncthreads();
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        if (key[o] != DIF_INVALID_KEY) pair_list[off + __popcll(valid[o] & below)] = make_uint2(key[o], (uint32_t)((int64_t)o * N + i));
-        off += __popcll(valid[o]);
-    }
+    for (int o = 0; o < 8; ++o)
+        if (key[o] != DIF_INVALID_KEY)
+            pair_list[s_base + (where[o] >= 0 ? tcnt[where[o]] : grouped) + rank[o]] = make_uint2(key[o], (uint32_t)((int64_t)o * N + i));
 }
 
 // =================================================================================================================
@@ -238,18 +247,21 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
 // CONSECUTIVE list entries (every tile full: no per-voxel padding, no sort), runs them through the MFMA chain and reduces the 29
 // output features over each RUN of equal slots inside the tile with one segmented wave scan.  Every run leaves a 256-byte record
 // (32 x int64: the 29 feature sums, the run length in the spare position 29) at a fixed place, rec[tile*32 + rank of the run], and
-// is pushed onto its slot's record chain with ONE atomic exchange (rec_head[slot], idle 0 = empty; the first run of a slot also
-// appends the slot to the frame's update list).  k_fuse walks the chains.
+// enters its slot's record DIRECTORY with one atomic (rec_dir[slot][16]: word 0 = number of records, idle 0; words 2..15 = the
+// first 14 record ids, which k_fuse fetches in parallel; further ones are chained through word 1 / rec_next).  The first run of a
+// slot also appends the slot to the frame's update list.
 // The sums are kept in 2^-30 FIXED POINT (int64): integer addition is associative, so the per-voxel sum does not depend on list
 // order, tile boundaries or chain order => bit-reproducible, and more accurate than an fp32 running sum (the reference sums with
 // float atomics in arbitrary order, indexing.cu:59-71).
 #define DIF_FIX_SCALE 1073741824.0f          /* 2^30: |enc| < 2^12 and < 2^21 rows per voxel keep the sum inside int64 */
 #define DIF_REC_WORDS 32                     /* int64 per record */
 #define DIF_REC_COUNT_POS 29                 /* record position that carries the run length (feature 29 is a zero row of the MFMA tile) */
+#define DIF_DIR_WORDS 16                     /* int32 per slot directory: count | overflow chain head | 14 record ids */
+#define DIF_DIR_IDS (DIF_DIR_WORDS - 2)
 
 __global__ void __launch_bounds__(512, 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
-         const uint2* __restrict__ pair_list, int* __restrict__ rec_head, int* __restrict__ rec_next, long long* __restrict__ rec,
+         const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
          int* __restrict__ upd_list, int* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_weights(lds, wblob, ENC_FLOATS);
@@ -292,11 +304,12 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
             x1 = half ? nxv : rz;
             x2 = half ? nzv : nyv;
         }
-        // push the run onto its slot's chain.  Issued after the gathers above have been consumed and before the MFMA chain, used after
-        // it: the round trip hides behind ~11 us of matrix work.
-        int chain_prev = 0;
+        // enter the run in its slot's directory.  Asked after the gathers above have been consumed and before the MFMA chain, answered
+        // after it: the round trip hides behind ~11 us of matrix work.
+        int dir_pos = 0;
         const bool pusher = live && run_tail && half == 0;
-        if (pusher) chain_prev = atomicExch(rec_head + key, rec_id + 1);
+        int* dir = rec_dir + (int64_t)key * DIF_DIR_WORDS;
+        if (pusher) dir_pos = atomicAdd(dir, 1);
         f16v out = encoder_tile(lds, x0, x1, x2, lane);
         long long* p = rec + (int64_t)rec_id * DIF_REC_WORDS + half * 16;
 #pragma unroll
@@ -312,14 +325,16 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
             if (live && run_tail) p[r] = v;
         }
         if (pusher) {
-            rec_next[rec_id] = chain_prev;
-            if (chain_prev == 0) upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;      // first run of this slot in the frame (C of map.py:437)
+            if (dir_pos < DIF_DIR_IDS) dir[2 + dir_pos] = rec_id;
+            else rec_next[rec_id] = atomicExch(dir + 1, rec_id + 1);                        // a voxel fed by many workgroups: chained
+            if (dir_pos == 0) upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;        // first run of this slot in the frame (C of map.py:437)
         }
     }
 }
 
-// a10: fusion update (map.py:448-452).  One 32-lane group per updated slot: sum the slot's record chain, fuse, reset the chain.
-__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_head,
+// a10: fusion update (map.py:448-452).  One 32-lane group per updated slot: sum the slot's run records (directory entries fetched
+// together, overflow chain walked), fuse, return the directory to its idle state.
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                                   const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
                                                   uint8_t* __restrict__ dirty, int* __restrict__ counters) {
     const int n_upd = counters[DIF_C_C];
@@ -329,13 +344,23 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
     const int pos = ((f >> 2) & 1) * 16 + (f & 3) + 4 * (f >> 3);
     for (int u = grp; u < n_upd; u += ngrp) {
         const int s = upd_list[u];
+        int* dir = rec_dir + (int64_t)s * DIF_DIR_WORDS;
+        const int n_rec = dir[0];
+        const int my_id = (f < DIF_DIR_IDS && f < n_rec) ? dir[2 + f] : -1;       // lane f fetches directory entry f
         long long Si = 0;
         int cnt = 0;
-        for (int id = rec_head[s]; id != 0; id = rec_next[id - 1]) {
-            const long long* r = rec + (int64_t)(id - 1) * DIF_REC_WORDS;
+        const int n_dir = n_rec < DIF_DIR_IDS ? n_rec : DIF_DIR_IDS;
+        for (int j = 0; j < n_dir; ++j) {                       // independent loads: all in flight together
+            const long long* r = rec + (int64_t)__shfl(my_id, j, 32) * DIF_REC_WORDS;
             Si += r[pos];
             cnt += (int)r[DIF_REC_COUNT_POS];
         }
+        if (n_rec > DIF_DIR_IDS)
+            for (int id = dir[1]; id != 0; id = rec_next[id - 1]) {
+                const long long* r = rec + (int64_t)(id - 1) * DIF_REC_WORDS;
+                Si += r[pos];
+                cnt += (int)r[DIF_REC_COUNT_POS];
+            }
         if (f < L) {
             float S = (float)Si * (1.0f / DIF_FIX_SCALE);    // one rounding: exact integer sum -> nearest float
             float w_old = obs[s];
@@ -348,7 +373,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
         if (f == 31) {                                       // after every lane of the group has read obs[s]
             obs[s] = obs[s] + (float)cnt;
             dirty[s] = 1;                                    // map.py:452
-            rec_head[s] = 0;
+            dir[0] = 0;
+            dir[1] = 0;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_ITEMS] = (counters[DIF_C_M] + 31) >> 5;   // encoder tiles of this frame

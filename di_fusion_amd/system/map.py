@@ -176,7 +176,7 @@ class DenseIndexedMap:
             obs = torch.zeros((capacity,), dtype=torch.float32, device=dev)
             dirty = torch.zeros((capacity,), dtype=torch.uint8, device=dev)
             vbm = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
-            rec_head = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            rec_dir = torch.zeros((capacity, 16), dtype=torch.int32, device=dev)
             upd_list = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_n = torch.zeros((capacity,), dtype=torch.int32, device=dev)
@@ -190,7 +190,7 @@ class DenseIndexedMap:
                 tri_n[:c] = self._tri_n
         self._latent, self._pos, self._obs, self._dirty = lat, pos, obs, dirty
         self._tri_start, self._tri_n = tri_start, tri_n
-        self._vbm, self._rec_head, self._upd_list = vbm, rec_head, upd_list
+        self._vbm, self._rec_dir, self._upd_list = vbm, rec_dir, upd_list
         self._capacity = capacity
         m = _lib.DifMap()
         m.nx, m.ny, m.nz = self.n_xyz
@@ -210,7 +210,7 @@ class DenseIndexedMap:
         m.frame_count = _lib.ptr(self._frame_count)
         m.grid_bits = _lib.ptr(self._grid_bits)
         m.vbm = _lib.ptr(vbm)
-        m.rec_head = _lib.ptr(rec_head)
+        m.rec_dir = _lib.ptr(rec_dir)
         m.upd_list = _lib.ptr(upd_list)
         m.tri_start = _lib.ptr(tri_start)
         m.tri_n = _lib.ptr(tri_n)

@@ -75,7 +75,7 @@ typedef struct dif_map {
     int32_t* frame_count;           /* [nx*ny*nz] idle 0  : points of the current frame per voxel (map.py:374) */
     uint32_t* grid_bits;            /* [ceil(nx*ny*nz/32)] idle 0 : candidate / occupied voxel bitmap          */
     int32_t* vbm;                   /* [capacity] idle -1 : vec_id_batch_mapping (map.py:633-635)              */
-    int32_t* rec_head;              /* [capacity] idle 0  : head of the slot's chain of encoder run records (id + 1) */
+    int32_t* rec_dir;               /* [capacity][16] idle 0 (words 0,1): the slot's encoder run records of the current integrate */
     int32_t* upd_list;              /* [capacity] slots updated by the current integrate (unique_pinds, map.py:437) */
     int32_t* tri_start;             /* [capacity] mesh-cache log position of the slot's live triangle batch     */
     int32_t* tri_n;                 /* [capacity] idle 0 when the voxel has no cached triangles                 */
