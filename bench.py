@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of integrate + decode + mesh on a synthetic 640x480 depth stream (BASELINE.json metric).
 
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`); every rank fuses its own
-subsequence of the orbit into its own map (weak scaling, no data-path collective; SURVEY.md section 8e "C4").
+One process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks come from the
+environment; a bare `python bench.py --gpus N` (N > 1) starts that launcher itself; a WORLD_SIZE that disagrees with --gpus is an error.
+  --mode c4 (default): every rank fuses its own subsequence of the orbit into its own map (weak scaling, no data-path collective;
+                       SURVEY.md section 8e "C4"; one all-gather merge of the maps after the clock);
+  --mode tiled       : BASELINE config C5 — ONE 1280x960 stream, the grid cut into N x-slabs, halo exchange with the ring neighbours
+                       (RCCL send/recv) after every integrate (strong scaling: the work per frame is fixed).
 A "step" = one frame: unproject+transform -> integrate_keyframe -> extract_mesh (decode, marching cubes, D2H, mesh cache).
 Inputs (depth + camera-frame normals) are rendered before the timed region and stay resident in HBM.
 Prints ONE JSON line on rank 0.
@@ -32,6 +36,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"])
+    ap.add_argument("--mode", default="c4", choices=["c4", "tiled"], help="c4: independent subsequences per GPU; tiled: one 1280x960 stream "
+                    "spatially tiled across the GPUs (BASELINE config C5)")
     ap.add_argument("--noise", type=int, default=0)
     ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
@@ -40,30 +46,87 @@ def parse():
     ap.add_argument("--sample-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra run with the mesh left in HBM (keeps profiler traces to one stream)")
-    ap.add_argument("--cpu-sample-scale", type=float, default=0.5, help="image scale of the CPU-baseline sample frame")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed per thread setting by the CPU baseline (after 2 warm-ups)")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg_name, scale):
-    """The oracle (numpy port of the reference path + C marching cubes) on ONE subsampled frame of the same workload."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(stream, cfg_name, scene, cfg, intr, first_frame, n_timed, deg_per_frame=0.5):
+    """the parity-checked CPU restatement (the numpy oracle + the C marching cubes; the reference's Python cannot
+    travel to this box) on FULL-resolution frames of the same stream, continuing from the map state the GPU run reached after its
+    warm-up frames (copied into the oracle before the clock, so the CPU frames are the steady-state frames the GPU number is quoted on,
+    not the heavy map-building ones).  Per thread setting (1 thread, 16 threads, all host cores): 2 warm-up frames, then the median of
+    `n_timed` frames, stages timed separately; `value` is the best setting's end-to-end rate and `cores` the threads it used (on a
+    256-core host the small per-frame matmuls run fastest on ONE thread).  Baseline only — says nothing about kernel quality."""
+    import threadpoolctl
     from di_fusion_amd import synthetic as syn
     from di_fusion_amd.network import utility as net_util
     from oracle import difusion_oracle as O
-    scene, cfg = getattr(syn, f"config_{cfg_name}")()
-    intr = syn.Intrinsic().scaled(scale)
-    xyz, nrm = syn.frame_points(scene, 0, intr)
-    om = O.OracleMap(O.OracleNetworks(net_util.load_weights_npz()), cfg.bound_min, cfg.bound_max, cfg.voxel_size)
     O.build_mc_oracle()
-    t0 = time.perf_counter()
-    om.integrate_keyframe(xyz.numpy(), nrm.numpy())
-    t1 = time.perf_counter()
-    om.extract_mesh(4, int(4e6), max_std=0.15)
-    t2 = time.perf_counter()
-    frac = (intr.width * intr.height) / (640 * 480)
-    return {"value": round(frac / (t2 - t0), 5), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"frame 0 of the {cfg_name} stream rendered at {intr.width}x{intr.height} ({frac:.3f} of the pixels, "
-                      f"{xyz.shape[0]} points): oracle integrate {t1 - t0:.2f}s + decode/MC {t2 - t1:.2f}s; value = pixel fraction / time; "
-                      "numpy/OpenBLAS matmuls use all host cores, the rest is single-threaded"}
+    net = O.OracleNetworks(net_util.load_weights_npz())
+    m = stream.map
+    n = m.n_occupied
+    state = dict(indexer=m.indexer.cpu().numpy().reshape(-1).copy(), pos=m.latent_vecs_pos[:n].cpu().numpy().copy(),
+                 w=m.voxel_obs_count[:n].cpu().numpy().copy(), z=m.latent_vecs[:n].cpu().numpy().copy())
+
+    def fresh():
+        om = O.OracleMap(net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+        cap = 1
+        while cap < max(n, 1):
+            cap *= 2
+        om.indexer = state["indexer"].copy()
+        om.latent_vecs = np.zeros((cap, 29), np.float32); om.latent_vecs[:n] = state["z"]
+        om.latent_vecs_pos = -np.ones((cap,), np.int64); om.latent_vecs_pos[:n] = state["pos"]
+        om.voxel_obs_count = np.zeros((cap,), np.float32); om.voxel_obs_count[:n] = state["w"]
+        om.n_occupied = n
+        return om
+
+    frames = []
+    for i in range(first_frame, first_frame + 2 + n_timed):
+        R, t = syn.orbit_pose(i, 0.3, deg_per_frame, 0.0)
+        depth, ncam = syn.render_frame(scene, R, t, intr, torch.device("cpu"))
+        frames.append((depth.numpy(), ncam.numpy().reshape(-1, 3), np.asarray(R, np.float64).astype(np.float32), np.asarray(t, np.float64).astype(np.float32)))
+    cores = os.cpu_count() or 1
+    legs = {}
+    for threads in sorted({1, min(16, cores), cores}):
+        om = fresh()
+        rows = []
+        with threadpoolctl.threadpool_limits(limits=threads):
+            for k, (depth, ncam, R, t) in enumerate(frames):
+                t0 = time.perf_counter()
+                pc = O.unproject_depth(depth, intr.fx, intr.fy, intr.cx, intr.cy).reshape(-1, 3)          # a1
+                ok = ~np.isnan(pc[:, 0])
+                xyz = (pc[ok] @ R.T + t).astype(np.float32)                                               # a2
+                nrm = (ncam[ok] @ R.T).astype(np.float32)
+                t1 = time.perf_counter()
+                om.integrate_keyframe(xyz, nrm)                                                           # a3-a10
+                t2 = time.perf_counter()
+                a = om.extract_prepare(4)                                                                 # a11-a14
+                t3 = time.perf_counter()
+                if a is not None:                                                                         # a15
+                    O.marching_cubes_interp(a["indexer"], a["valid_blocks"], a["vec_batch_mapping"], a["cube_sdf"], a["cube_std"], int(4e6), om.n_xyz, 0.15)
+                    om.updated_vec_id = np.zeros((0,), np.int64)
+                t4 = time.perf_counter()
+                if k >= 2:
+                    rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0))
+        med = np.median(np.asarray(rows), axis=0)
+        legs[threads] = dict(zip(("unproject_s", "integrate_s", "decode_s", "marching_cubes_s", "frame_s"), (round(float(v), 4) for v in med)))
+    best = min(legs, key=lambda k: legs[k]["frame_s"])
+    return {"value": round(1.0 / legs[best]["frame_s"], 4), "unit": "frames/s", "cores": best, "kind": "port",
+            "cpu_model": cpu_model_name(), "host_cores": cores,
+            "sample": f"frames {first_frame + 2}..{first_frame + 1 + n_timed} of the {cfg_name} stream at {intr.width}x{intr.height} (all pixels), oracle map "
+                      f"initialised from the GPU map after {first_frame} frames ({n} voxels); median of {n_timed} frames after 2 warm-ups per thread "
+                      "setting; numpy/OpenBLAS threads limited with threadpoolctl, the C marching cubes and the index arithmetic are single-threaded",
+            "per_thread_setting": {str(k): v for k, v in legs.items()}}
 
 
 def flush_c_stdio():
@@ -146,41 +209,83 @@ def global_map_merge(stream, model, cfg, dev, barrier):
         return {"error": repr(e)[:200]}
 
 
-def roofline_block(prof, sst):
-    """`roofline` for the MFMA kernel with the longest average launch.  prof: name -> (ms, launches) from the library's HIP events;
-    sst: the counters of the frames those events bracketed (rows per launch come from there)."""
+def roofline_of(records, sst):
+    """records: [(kernel name, ms)] of the event-timed launches of the frames whose counters are `sst`."""
     rows = {"encode": (sum(s["M"] for s in sst), ENC_FLOP_PER_ROW), "decode_lattice": (sum(s["B"] * 64 for s in sst), DEC_FLOP_PER_ROW),
             "decode_points": (sum(s["VH"] for s in sst), DEC_FLOP_PER_ROW)}
     kern = {}
     for name, (n_rows, flop) in rows.items():
-        t_ms, n = prof[name]
-        if n > 0 and t_ms > 0:
-            kern[name] = dict(ms_per_launch=t_ms / n, rows_per_launch=n_rows / n, tflops=n_rows * flop / (t_ms * 1e-3) / 1e12)
+        ts = [ms for k, ms in records if k == name]
+        if ts and sum(ts) > 0:
+            kern[name] = dict(ms_per_launch=sum(ts) / len(ts), rows_per_launch=n_rows / len(ts), tflops=n_rows * flop / (sum(ts) * 1e-3) / 1e12)
+    return kern
+
+
+def roofline_block(per_frame, sst):
+    """`roofline` for the MFMA kernel with the longest average launch.  per_frame: for every event-timed frame the [(kernel, ms)] list
+    from the library's HIP events (recorded on the launch stream); sst: the counters of those frames (rows per launch come from there).
+    The same figures are also given for the first and the second half of the timed frames: a short run sits in the map-building
+    transient (thousands of voxels decoded per frame), a long one ends in steady state (~900), and the fraction differs."""
+    kern = roofline_of([r for f in per_frame for r in f], sst)
     if not kern:
         return None
     dom = max(kern, key=lambda k: kern[k]["ms_per_launch"])
-    pmc = {}
-    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs; see profiles/README.md)
-        pmc = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_hbm.json"))[-1].read_text())["kernels"]
+    pmc, pmc_file = {}, None
+    try:    # HBM bytes per launch: NOT measured by this run (PMC needs rocprofv3) — the committed summary of separate --pmc passes
+        pmc_file = sorted((ROOT / "profiles").glob("r*_pmc_hbm.json"))[-1]
+        pmc = json.loads(pmc_file.read_text())["kernels"]
     except Exception:
         pass
     kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode<false>"}[dom]
+    half = len(per_frame) // 2
+    phases = {}
+    if half >= 1:
+        for label, lo, hi in (("first_half_of_timed_frames", 0, half), ("second_half_of_timed_frames", half, len(per_frame))):
+            k = roofline_of([r for f in per_frame[lo:hi] for r in f], sst[lo:hi])
+            phases[label] = {n: {"frac": round(v["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(v["ms_per_launch"], 4),
+                                 "rows_per_launch": round(v["rows_per_launch"], 1)} for n, v in k.items()}
+    other = {}
+    for name in ("mc_count", "mc_emit"):
+        ts = [ms for f in per_frame for k, ms in f if k == name]
+        other[name] = round(sum(ts) / max(1, len(per_frame)), 4)
     return {"bound": "mfma", "kernel": kname,
             "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
             "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
+            "traffic_source": (f"static: profiles/{pmc_file.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --graph 0`, "
+                               "FETCH_SIZE doubled as the gfx950 guide prescribes); not measured by this run") if pmc_file else None,
             "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
             "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
-            "event_timed_frames": len(sst),
-            "other_ms_per_frame": {k: round(prof[k][0] / max(1, len(sst)), 4) for k in ("mc_count", "mc_emit")}}
+            "event_timed_frames": len(sst), "by_phase": phases,
+            "other_ms_per_frame": other}
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks on this node and pass its output on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     import gc
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        if torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        spawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
@@ -198,18 +303,24 @@ def main():
     from di_fusion_amd.network import utility as net_util
     from di_fusion_amd.stream import FusionStream
 
+    tiled = a.mode == "tiled"
     scene, cfg = getattr(syn, f"config_{a.config}")()
-    intr = syn.Intrinsic()
+    intr = syn.Intrinsic().scaled(2.0) if tiled else syn.Intrinsic()          # C5: one 1280x960 stream
     model = net_util.networks_from_arrays(net_util.load_weights_npz())
     n_frames = a.warmup + a.steps
+    if tiled and world > 1:
+        a.graph = 0                         # the halo exchange sits between the kernels of a frame: eager, host one frame ahead
 
-    def make_stream():      # every rank walks its own arc of the orbit (independent subsequence)
-        return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))
+    def make_stream():
+        if tiled:           # every rank renders the same stream and owns one x-slab of the grid
+            return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, noise=bool(a.noise), initial_capacity=1 << 18,
+                                tiling=(rank, world, None))
+        return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))   # own arc of the orbit
 
     stream = make_stream()
     lib = _lib.load()
     if os.environ.get("DIF_BENCH_NO_PRIME") != "1":
-        prime_process(FusionStream, syn, model, intr, dev, a.d2h)
+        prime_process(FusionStream, syn, model, syn.Intrinsic(), dev, a.d2h)
 
     def barrier():
         torch.cuda.synchronize()
@@ -227,7 +338,9 @@ def main():
             stream._graph_export = (a.d2h == "new")
             stream._capture_graphs()            # a short warmup never reached the first replay: capture outside the clock
     stats_base = len(stream.stats)
-    lib.dif_profile_read((ctypes.c_double * _lib.PROF_COUNT)(), (ctypes.c_int64 * _lib.PROF_COUNT)(), 1)
+    cap = 1 << 16
+    p_which, p_ms = (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
+    lib.dif_profile_dump(p_which, p_ms, cap, 1)
     lib.dif_profile_enable(1)
     gc.collect()
     gc.disable()            # a generation-2 collection in the middle of a 70 ms timed region shows up as a 20 % outlier
@@ -240,9 +353,9 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     lib.dif_profile_enable(0)
-    ms = (ctypes.c_double * _lib.PROF_COUNT)()
-    nl = (ctypes.c_int64 * _lib.PROF_COUNT)()
-    _lib.check(lib.dif_profile_read(ms, nl, 1), "dif_profile_read")
+    n_rec = int(lib.dif_profile_dump(p_which, p_ms, cap, 1))
+    if n_rec < 0:
+        raise SystemExit("dif_profile_dump failed")
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -250,31 +363,44 @@ def main():
     hbm_resident = None
     if world == 1 and a.d2h != "none" and not a.no_secondary:
         hbm_resident = rate_with_mesh_left_in_hbm(make_stream, a, n_frames)
-    merge_info = global_map_merge(stream, model, cfg, dev, barrier) if use_dist else None
+    merge_info = global_map_merge(stream, model, cfg, dev, barrier) if (use_dist and not tiled) else None
 
     out = None
     if rank == 0:
         st = stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
         timed_idx = [j for j in range(a.steps) if not (a.graph and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
-        prof = {n: (ms[i], nl[i]) for i, n in enumerate(_lib.PROF_NAMES)}
-        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager")
-        out = {"metric": "frames/s integrate+decode+mesh, 640x480 synthetic stream", "value": round(world * a.steps / dt, 3),
-               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": WORKLOADS[a.config] + ", 640x480 orbit stream 0.5 deg/frame, all 307200 pixels integrated and meshed "
+        # the event records come in launch order, one k_encode per event-timed frame: cut the list into frames there
+        per_frame = []
+        for k in range(n_rec):
+            name = _lib.PROF_NAMES[p_which[k]] if p_which[k] < len(_lib.PROF_NAMES) else "?"
+            if name == "encode" or not per_frame:
+                per_frame.append([])
+            per_frame[-1].append((name, float(p_ms[k])))
+        if len(per_frame) != len(timed_idx):        # (an empty frame launches no encoder) fall back to one group
+            per_frame, timed_idx = [[r for f in per_frame for r in f]], timed_idx[:1] if timed_idx else []
+        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager, host one frame ahead")
+        pixels = intr.width * intr.height
+        value = (a.steps if tiled else world * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
+        out = {"metric": f"frames/s integrate+decode+mesh, {intr.width}x{intr.height} synthetic stream", "value": round(value, 3),
+               "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if use_dist else 0, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": WORKLOADS[a.config] + f", {intr.width}x{intr.height} orbit stream 0.5 deg/frame, all {pixels} pixels integrated and meshed "
                                                             "every frame, resolution 4, fast decode, max_std 0.15",
-                          "points_per_frame": intr.width * intr.height,
-                          "parallelism": f"{world} independent subsequences (one map per GPU)", "d2h_per_frame": a.d2h,
+                          "mode": a.mode, "points_per_frame": pixels,
+                          "parallelism": (f"one stream, grid cut into {world} x-slabs, halo exchange (RCCL send/recv, 3 boundary layers) after every integrate"
+                                          if tiled else f"{world} independent subsequences (one map per GPU)"),
+                          "d2h_per_frame": a.d2h,
                           "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1, "launch": launch,
-                          "avg_per_frame": {k: round(float(np.mean([s[k] for s in st])), 1)
-                                            for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
+                          "avg_per_frame_rank0": {k: round(float(np.mean([s[k] for s in st])), 1)
+                                                  for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info},
-               "roofline": roofline_block(prof, [st[j] for j in timed_idx])}
+               "roofline": roofline_block(per_frame, [st[j] for j in timed_idx])}
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_sample_scale)
+            out["cpu_baseline"] = cpu_baseline(stream, a.config, scene, cfg, intr, n_frames, a.cpu_frames)
     if use_dist:
         flush_c_stdio()
         dist.barrier()                      # every rank has flushed whatever it had to say before rank 0 prints the one JSON line

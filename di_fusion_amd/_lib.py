@@ -91,8 +91,11 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "dif_export_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "dif_merge_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "dif_export_halo": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "dif_merge_halo": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p, c_void_p]),
     "dif_profile_enable": (c_int32, [c_int32]),
     "dif_profile_read": (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
+    "dif_profile_dump": (c_int64, [POINTER(c_int32), POINTER(c_float), c_int64, c_int32]),
     "dif_read_counters": (c_int32, [POINTER(DifMap), POINTER(c_int32), c_void_p]),
 }
 

@@ -5,6 +5,7 @@
 // reference's operation order and compiled without FMA contraction; fmaf() is used only where the reference's own
 // CPU build fuses (trilinear upsample) or where the order is ours to choose (MLP accumulation = the MFMA's fmaf chain).
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include <hip/hip_runtime.h>
 
@@ -52,13 +53,19 @@ int num_cus() {
 }
 
 // ---- optional per-kernel timing (dif_profile_*) -----------------------------------------------------------------
+// The record list is shared by every thread that launches through the library (the meshing thread and the integrating thread may both
+// be inside a ProfScope): guarded by one mutex; the events themselves are recorded on the caller's stream.
 struct ProfRec { hipEvent_t a, b; int which; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
 struct ProfScope {
     hipStream_t s; int which; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(int which_, hipStream_t s_) : s(s_), which(which_) {
-        if (!g_prof_on || g_prof.size() >= 65536) return;
+        {
+            std::lock_guard<std::mutex> lock(g_prof_mu);
+            if (!g_prof_on || g_prof.size() >= 65536) return;
+        }
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;      // never put events into a captured graph
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
@@ -67,6 +74,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!a) return;
         (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lock(g_prof_mu);
         g_prof.push_back(ProfRec{a, b, which});
     }
 };
@@ -758,55 +766,92 @@ int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz
 }
 
 // ---- multi-GPU merge -------------------------------------------------------------------------------------------
-int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t raw, int32_t* scratch,
-                       void* stream) {
+static int export_impl(const dif_map_t* map, int32_t* records, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t raw, int32_t* header,
+                       int32_t* scratch, void* stream) {
     if (!map || !records || !scratch || max_records <= 0) return DIF_EINVAL;
     if (x_lo < 0) x_lo = 0;
     if (x_hi > map->nx) x_hi = map->nx;
     const int64_t plane = (int64_t)map->ny * map->nz;
     ExportFunctor f{map->latent_vecs_pos, map->voxel_obs_count, map->latent_vecs, map->dirty, records, max_records, x_lo * plane, (x_hi > x_lo ? x_hi : x_lo) * plane,
-                    raw ? 1 : 0, map->counters};
+                    raw ? 1 : 0, map->counters, header};
     return launch_scan(f, map->counters + DIF_C_N_OCCUPIED, 0, map->capacity, scratch, (hipStream_t)stream);
 }
 
-int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t assign, int32_t* scratch, void* stream_) {
+int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t raw, int32_t* scratch,
+                       void* stream) {
+    return export_impl(map, records, max_records, x_lo, x_hi, raw, nullptr, scratch, stream);
+}
+
+int dif_export_halo(const dif_map_t* map, int32_t* message, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t* scratch, void* stream) {
+    if (!message) return DIF_EINVAL;
+    return export_impl(map, message + 32, max_records, x_lo, x_hi, 1, message, scratch, stream);      // row 0 = header, word 0 = record count
+}
+
+static int merge_impl(const dif_map_t* map, const int32_t* records, int64_t n, const int32_t* n_dev, int32_t assign, int32_t* scratch, void* stream_) {
     if (!map || n < 0) return DIF_EINVAL;
     if (n == 0) return DIF_OK;
     if (!records || !scratch) return DIF_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     if (hipMemsetAsync(map->counters + DIF_C_ALLOC_NEW, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, records, n, (const int64_t*)map->indexer, map->grid_bits, grid);
+    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, records, n, n_dev, (const int64_t*)map->indexer, map->grid_bits, grid);
     DIF_CHECK_LAUNCH();
     AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, map->counters, map->capacity};
     int nwords = (int)((grid + 31) / 32);
     if (launch_scan(f, nullptr, nwords, nwords, scratch, s) != DIF_OK) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, records, n, (const int64_t*)map->indexer,
+    hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, records, n, n_dev, (const int64_t*)map->indexer,
                        map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
 
+int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t assign, int32_t* scratch, void* stream_) {
+    return merge_impl(map, records, n, nullptr, assign, scratch, stream_);
+}
+
+int dif_merge_halo(const dif_map_t* map, const int32_t* message, int64_t max_records, int32_t* scratch, void* stream_) {
+    if (!message || max_records <= 0) return DIF_EINVAL;
+    return merge_impl(map, message + 32, max_records, message, 1, scratch, stream_);
+}
+
 int dif_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on = on != 0;
     return DIF_OK;
 }
 
-int dif_profile_read(double* ms, int64_t* launches, int32_t reset) {
-    if (!ms || !launches) return DIF_EINVAL;
-    for (int i = 0; i < DIF_PROF_COUNT; ++i) { ms[i] = 0.0; launches[i] = 0; }
+// elapsed time of every recorded launch, in launch order (synchronises on the events)
+static int prof_collect(std::vector<std::pair<int, float>>& out, bool reset) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) {
         if (hipEventSynchronize(r.b) != hipSuccess) return DIF_ELAUNCH;
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return DIF_ELAUNCH;
-        ms[r.which] += t;
-        launches[r.which] += 1;
+        out.emplace_back(r.which, t);
     }
     if (reset) {
         for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         g_prof.clear();
     }
     return DIF_OK;
+}
+
+int dif_profile_read(double* ms, int64_t* launches, int32_t reset) {
+    if (!ms || !launches) return DIF_EINVAL;
+    for (int i = 0; i < DIF_PROF_COUNT; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    std::vector<std::pair<int, float>> recs;
+    if (prof_collect(recs, reset != 0) != DIF_OK) return DIF_ELAUNCH;
+    for (auto& r : recs) { ms[r.first] += r.second; launches[r.first] += 1; }
+    return DIF_OK;
+}
+
+int64_t dif_profile_dump(int32_t* which, float* ms, int64_t capacity, int32_t reset) {
+    if (!which || !ms || capacity < 0) return DIF_EINVAL;
+    std::vector<std::pair<int, float>> recs;
+    if (prof_collect(recs, reset != 0) != DIF_OK) return DIF_ELAUNCH;
+    int64_t n = (int64_t)recs.size() < capacity ? (int64_t)recs.size() : capacity;
+    for (int64_t i = 0; i < n; ++i) { which[i] = recs[i].first; ms[i] = recs[i].second; }
+    return n;
 }
 
 int dif_read_counters(const dif_map_t* map, int32_t* host_out, void* stream) {

@@ -368,6 +368,7 @@ struct ExportFunctor {       // ordered compaction over slots: allocated voxels 
     int64_t lin_lo, lin_hi;
     int raw;
     int* counters;
+    int32_t* header;             // optional: record-count word that travels with the records (device-side variable length)
     __device__ int count(int s) const { int64_t p = pos[s]; return (p >= lin_lo && p < lin_hi) ? 1 : 0; }
     __device__ void emit(int s, int offset) const {
         if (offset >= max_records) return;
@@ -385,11 +386,13 @@ struct ExportFunctor {       // ordered compaction over slots: allocated voxels 
     __device__ void finish(int total) const {
         if (total > max_records) { total = (int)max_records; counters[DIF_C_OVERFLOW] = 6; }
         counters[DIF_C_EXPORT_N] = total;
+        if (header) header[0] = total;
     }
 };
 
-__global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
-                                                        uint32_t* __restrict__ bits, int64_t grid) {
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n_static, const int32_t* __restrict__ n_ptr,
+                                                        const int64_t* __restrict__ indexer, uint32_t* __restrict__ bits, int64_t grid) {
+    const int64_t n = n_ptr ? min((int64_t)*n_ptr, n_static) : n_static;       // a device-side count is bounded by the buffer's capacity
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t lin = rec[i * 32];
         if (lin < 0 || lin >= grid) continue;
@@ -398,9 +401,11 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restr
 }
 
 // records of one call carry distinct lin ids => plain read-modify-write, deterministic
-__global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __restrict__ rec, int64_t n, const int64_t* __restrict__ indexer,
-                                                         float* __restrict__ latent, float* __restrict__ obs, uint8_t* __restrict__ dirty,
-                                                         int* __restrict__ counters, int64_t grid, int64_t capacity, int assign) {
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __restrict__ rec, int64_t n_static, const int32_t* __restrict__ n_ptr,
+                                                         const int64_t* __restrict__ indexer, float* __restrict__ latent, float* __restrict__ obs,
+                                                         uint8_t* __restrict__ dirty, int* __restrict__ counters, int64_t grid, int64_t capacity,
+                                                         int assign) {
+    const int64_t n = n_ptr ? min((int64_t)*n_ptr, n_static) : n_static;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int no = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (no > capacity) { no = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }

@@ -62,6 +62,10 @@ def build_global_map(local_map, make_map, group=None):
 # Halo voxels are updated locally from incomplete data and are overwritten by the owner's exact (w, z, dirty flag) right after;
 # the dirty flag matters because a dirty neighbour pulls ITS neighbourhood into the decoded batch, and marching cubes blends a
 # corner over whichever neighbours are in the batch (mc_interp_kernel.cu:17-24).
+#
+# Exchange volume: a message holds HALO * ny * nz records of 128 bytes (6.3 MB on the 128^3 grid) whatever the occupancy — the price
+# of keeping the frame free of host synchronisation (a variable-length transfer needs its length on the host first); at ~153 GB/s
+# per xGMI link that is ~40 us per direction, both directions and both neighbours in flight together.
 HALO = 3
 
 
@@ -69,15 +73,30 @@ def slab_range(nx: int, rank: int, world: int):
     return (rank * nx) // world, ((rank + 1) * nx) // world
 
 
-def exchange_halo(m, rank: int, world: int, group=None):
-    """Refresh the halo layers of `m` (a DenseIndexedMap with `set_ownership`) from the neighbouring slabs' owners.
-    Two small variable-length all-gathers of raw (w, z) records; ring neighbours are directly xGMI-linked."""
+def exchange_halo(m, rank: int, world: int, group=None, buffers: Optional[dict] = None):
+    """Refresh the halo layers of `m` (a map with `set_ownership`) from the neighbouring slabs' owners: one send and one receive per
+    neighbour (`ncclSend` / `ncclRecv` grouped by `batch_isend_irecv`; ring neighbours are directly xGMI-linked), nothing else.
+    The messages have a fixed size (HALO x-layers, every voxel allocated) and carry their record count in a header row, so the
+    exchange needs no host round trip: export, transfers and merge are all enqueued on the stream, and every frame moves the same
+    bytes.  `buffers`: dict reused across frames (message tensors), filled on first use."""
     lo, hi = m._ownership[0], m._ownership[1]
-    left = m.export_records(lo, lo + HALO, raw=True)            # what rank-1 needs
-    right = m.export_records(hi - HALO, hi, raw=True)           # what rank+1 needs
-    gl = all_gather_records(left, group)
-    gr = all_gather_records(right, group)
-    if rank > 0:
-        m.merge_records(gr[rank - 1], assign=True)
-    if rank < world - 1:
-        m.merge_records(gl[rank + 1], assign=True)
+    buffers = {} if buffers is None else buffers
+    rows = m.halo_message_rows(HALO)
+    ops = []
+    for name, peer, x0 in (("left", rank - 1, lo), ("right", rank + 1, hi - HALO)):
+        if peer < 0 or peer >= world:
+            continue
+        out = m.export_halo(x0, x0 + HALO, out=buffers.get("out_" + name))       # what that neighbour's halo mirrors
+        buffers["out_" + name] = out
+        inp = buffers.get("in_" + name)
+        if inp is None:
+            inp = buffers["in_" + name] = torch.zeros((1 + rows, 32), dtype=torch.int32, device=out.device)
+        ops.append(dist.P2POp(dist.isend, out, peer, group))
+        ops.append(dist.P2POp(dist.irecv, inp, peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()                      # RCCL: orders the current stream behind the transfer; the host does not block
+    for name, peer in (("left", rank - 1), ("right", rank + 1)):
+        if 0 <= peer < world:
+            m.merge_halo(buffers["in_" + name])
+    return buffers

@@ -21,11 +21,20 @@ class FusionStream:
     def __init__(self, model, scene: syn.Scene, cfg: syn.MapConfig, intr: syn.Intrinsic, device: torch.device,
                  n_frames: int, deg_per_frame: float = 0.5, phase_deg: float = 0.0, orbit_radius: float = 0.3,
                  noise: bool = False, resolution: int = 4, max_n_triangles: int = int(4e6), max_std: float = 0.15,
-                 initial_capacity: int = 1 << 16):
+                 initial_capacity: int = 1 << 16, tiling=None):
+        """tiling = (rank, world, group): BASELINE config C5 — the grid is cut into `world` x-slabs, this stream's map owns slab `rank`,
+        every rank is offered the whole frame and the 3 boundary layers are refreshed from the ring neighbours after every integrate
+        (`parallel.exchange_halo`: one send + one receive per neighbour over RCCL / xGMI).  Eager / pipelined stepping only."""
         self.device = device
         self.intr = intr
         self.resolution, self.max_n_triangles, self.max_std = resolution, max_n_triangles, max_std
         self.map = DenseIndexedMap(model, cfg.namespace(), 29, device, initial_capacity=initial_capacity)
+        self.tiling = tiling if (tiling is not None and tiling[1] > 1) else None
+        self._halo_buffers = {}
+        if self.tiling is not None:
+            from . import parallel
+            rank, world, _ = self.tiling
+            self.map.set_ownership(*parallel.slab_range(self.map.n_xyz[0], rank, world), halo=parallel.HALO)
         self.poses, self.depth, self.ncam = [], [], []
         for i in range(n_frames):
             R, t = syn.orbit_pose(i, orbit_radius, deg_per_frame, phase_deg)
@@ -60,6 +69,7 @@ class FusionStream:
                                                            intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
                        "dif_unproject_transform")
         self.map.integrate_keyframe(self.xyz, self.nrm)
+        self._exchange_halo()
         out = self.map.extract_mesh_arrays(self.resolution, self.max_n_triangles, max_std=self.max_std, to_host=(d2h == "full"))
         if d2h == "new" and out is not None:
             tri, tid, tstd = self.map.mesh_cache_tensors(new_only=True)
@@ -74,6 +84,13 @@ class FusionStream:
             out = (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
         self.stats.append(dict(self.map.last_counters))
         return out
+
+    def _exchange_halo(self):
+        if self.tiling is not None:
+            from . import parallel
+            rank, world, group = self.tiling
+            with torch.cuda.device(self.device):
+                parallel.exchange_halo(self.map, rank, world, group, self._halo_buffers)
 
     def _before_frame(self):
         """The D2H of the previous frame's triangles (side stream) reads a region of the mesh-cache LOG that later frames only append
@@ -92,6 +109,7 @@ class FusionStream:
                                                            intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
                        "dif_unproject_transform")
         self.map.integrate_keyframe(self.xyz, self.nrm)
+        self._exchange_halo()
         return self.map.extract_mesh_enqueue(self.resolution, self.max_n_triangles, max_std=self.max_std)
 
     HOST_OUT_TRIANGLES = 1 << 18                                 # pinned staging per graph: 14 MB; larger updates fall back to _export_new
@@ -212,6 +230,8 @@ class FusionStream:
         """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: writing a 64-byte frame descriptor
         into pinned memory and one graph launch)."""
         m = self.map
+        if self.tiling is not None:
+            raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
         N = self.intr.height * self.intr.width
         prune = int(m.args.prune_min_vox_obs)
         may_add = 7 * (N // (prune + 1)) if prune > 0 else 7 * N

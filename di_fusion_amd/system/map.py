@@ -145,6 +145,7 @@ class DenseIndexedMap:
         self._gc_epoch = 0
         self._gc_log_len = 0
         self._gc_wanted = False
+        self._halo_scratch = None
         self._cache_call_limit = 0          # max_n_triangles of the latest extract (what one more call may append to the log)
 
         self._grid = int(np.prod(self.n_xyz))
@@ -648,6 +649,38 @@ class DenseIndexedMap:
         self._read_counters()
         n = int(self._host_counters[_lib.C_EXPORT_N])
         return rec[:n]
+
+    def halo_message_rows(self, layers: int) -> int:
+        """Records a halo message of `layers` x-layers can hold (every voxel of the layers allocated)."""
+        return int(layers) * self.n_xyz[1] * self.n_xyz[2]
+
+    def export_halo(self, x_lo: int, x_hi: int, out: torch.Tensor = None) -> torch.Tensor:
+        """Fixed-size halo message for the x-layers [x_lo, x_hi): (1 + rows, 32) int32 on the device, row 0 = header (word 0 = number of
+        records), then raw (w, z, dirty) records in slot order.  Nothing comes back to the host: the length travels in the message."""
+        rows = self.halo_message_rows(max(0, min(self.n_xyz[0], int(x_hi)) - max(0, int(x_lo))))
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.zeros((1 + max(rows, 1), 32), dtype=torch.int32, device=self.device)
+            if self._halo_scratch is None:
+                self._halo_scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
+            _lib.check(_lib.load().dif_export_halo(ctypes.byref(self._cmap), _lib.ptr(out), out.size(0) - 1, int(x_lo), int(x_hi),
+                                                   _lib.ptr(self._halo_scratch), _lib.stream_ptr()), "dif_export_halo")
+        return out
+
+    def merge_halo(self, msg: torch.Tensor):
+        """Overwrite (w, z, dirty) of the voxels named in a halo message (allocating the unseen ones, ascending id); the record count is
+        read on the device."""
+        _lib.require_cuda(msg)
+        rows = msg.size(0) - 1
+        with self.modifying_lock, self._state_lock, torch.cuda.device(self.device):
+            self._ensure_capacity(rows)
+            if self._halo_scratch is None:
+                self._halo_scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
+            _lib.check(_lib.load().dif_merge_halo(ctypes.byref(self._cmap), _lib.ptr(msg), rows, _lib.ptr(self._halo_scratch), _lib.stream_ptr()),
+                       "dif_merge_halo")
+            if self._integrate_done is None:
+                self._integrate_done = torch.cuda.Event()
+            self._integrate_done.record()
 
     def merge_records(self, rec: torch.Tensor, assign: bool = False):
         """Fold records with DISTINCT lin ids into this map: accumulate (one rank's `export_records()`), or `assign`

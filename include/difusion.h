@@ -264,6 +264,15 @@ int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_recor
  * scratch: int32 [4096]. */
 int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t assign, int32_t* scratch, void* stream);
 
+/* Halo messages for the spatially tiled mode (C5): fixed-capacity buffers whose LENGTH travels inside them, so a frame's exchange needs
+ * no host round trip (no counter read-back between export, send/recv and merge) and always moves the same number of bytes.
+ *   message = int32 [1 + max_records][32]: row 0 = header (word 0 = number of records that follow), rows 1.. = raw records
+ *   (lin | flags | w | z[29], as dif_export_records with raw != 0) of the allocated voxels with x index in [x_lo, x_hi), slot order.
+ * dif_merge_halo folds a received message with assign semantics (w = w_r, z = z_r, dirty = flags & 1), reading the count on the
+ * device (clamped to max_records).  scratch: int32 [4096]. */
+int dif_export_halo(const dif_map_t* map, int32_t* message, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t* scratch, void* stream);
+int dif_merge_halo(const dif_map_t* map, const int32_t* message, int64_t max_records, int32_t* scratch, void* stream);
+
 /* ---- per-kernel timing for bench.py's roofline leg ---------------------------------------------------------- */
 /* When enabled, a hipEvent pair is recorded around each launch of the named kernels ON THE STREAM THEY RUN ON. */
 enum { DIF_PROF_ENCODE = 0, DIF_PROF_DECODE_LATTICE = 1, DIF_PROF_DECODE_POINTS = 2, DIF_PROF_MC_COUNT = 3, DIF_PROF_MC_EMIT = 4,
@@ -271,6 +280,9 @@ enum { DIF_PROF_ENCODE = 0, DIF_PROF_DECODE_LATTICE = 1, DIF_PROF_DECODE_POINTS 
 int dif_profile_enable(int32_t on);
 /* Sum of elapsed milliseconds and number of launches per kernel since the last reset; synchronises on the events. */
 int dif_profile_read(double* ms /* [DIF_PROF_COUNT], host */, int64_t* launches /* [DIF_PROF_COUNT], host */, int32_t reset);
+/* The same per launch, in launch order: which[i] (DIF_PROF_*), ms[i]; returns the number of records written (<= capacity) or a
+ * negative DIF_E* code.  Thread-safe with respect to concurrent launches (the record list is mutex-guarded). */
+int64_t dif_profile_dump(int32_t* which /* host */, float* ms /* host */, int64_t capacity, int32_t reset);
 
 /* Copy the counters to the host; the only synchronising call (hipStreamSynchronize on `stream`). */
 int dif_read_counters(const dif_map_t* map, int32_t* host_out /* [DIF_C_COUNT], host */, void* stream);

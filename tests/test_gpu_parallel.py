@@ -80,13 +80,14 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
         for m in slabs:
             m.integrate_keyframe(xyz, nrm)
         # halo exchange (what parallel.exchange_halo does over RCCL)
-        lefts = [m.export_records(m._ownership[0], m._ownership[0] + parallel.HALO, raw=True).clone() for m in slabs]
-        rights = [m.export_records(m._ownership[1] - parallel.HALO, m._ownership[1], raw=True).clone() for m in slabs]
+        # the same fixed-size messages with a device-side record count, only handed over inside the process
+        lefts = [m.export_halo(m._ownership[0], m._ownership[0] + parallel.HALO) for m in slabs]
+        rights = [m.export_halo(m._ownership[1] - parallel.HALO, m._ownership[1]) for m in slabs]
         for r, m in enumerate(slabs):
             if r > 0:
-                m.merge_records(rights[r - 1], assign=True)
+                m.merge_halo(rights[r - 1])
             if r < world - 1:
-                m.merge_records(lefts[r + 1], assign=True)
+                m.merge_halo(lefts[r + 1])
         # ---- state of owned voxels ----
         nF = full.n_occupied
         posF = full.latent_vecs_pos[:nF].cpu().numpy()
@@ -122,3 +123,64 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
         kF = np.lexsort(tuple(tF.reshape(len(tF), -1).T[::-1]) + (iF,))
         assert np.array_equal(iS[kS], iF[kF])
         assert np.array_equal(tS[kS], tF[kF])                  # bit-identical vertices
+
+
+def _tiled_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from di_fusion_amd.network import utility as net_util
+    from di_fusion_amd.stream import FusionStream
+    model = net_util.networks_from_arrays(net_util.load_weights_npz())
+    scene, cfg = syn.default_room(), syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4)
+    st = FusionStream(model, scene, cfg, syn.Intrinsic().scaled(0.25), dev, 4, deg_per_frame=15.0, tiling=(rank, world, None))
+    tris = []
+    for i in range(4):
+        st.step_pipelined(i, d2h="none")
+    st.flush("none")
+    torch.cuda.synchronize()
+    m = st.map
+    n = m.n_occupied
+    q.put((rank, m._ownership, m.latent_vecs_pos[:n].cpu().numpy(), m.voxel_obs_count[:n].cpu().numpy(), m.latent_vecs[:n].cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL send/recv between ring neighbours)")
+def test_spatial_tiling_two_processes_rccl(gpu_model):
+    """C5 as it runs in production: one process per GPU, `FusionStream(tiling=...)`, halo exchange over RCCL.  Owned voxels of both
+    ranks must equal the single-map stream bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from di_fusion_amd.stream import FusionStream
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tiled_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4)
+    full = FusionStream(gpu_model, syn.default_room(), cfg, syn.Intrinsic().scaled(0.25), DEV, 4, deg_per_frame=15.0)
+    for i in range(4):
+        full.step(i, d2h="none")
+    nF = full.map.n_occupied
+    posF = full.map.latent_vecs_pos[:nF].cpu().numpy()
+    wF, zF = full.map.voxel_obs_count[:nF].cpu().numpy(), full.map.latent_vecs[:nF].cpu().numpy()
+    plane = full.map.n_xyz[1] * full.map.n_xyz[2]
+    covered = 0
+    for rank, (lo, hi, _), pos, w, z in res:
+        own_f, own_s = (posF >= lo * plane) & (posF < hi * plane), (pos >= lo * plane) & (pos < hi * plane)
+        of, os_ = np.argsort(posF[own_f]), np.argsort(pos[own_s])
+        assert np.array_equal(pos[own_s][os_], posF[own_f][of])
+        assert np.array_equal(w[own_s][os_], wF[own_f][of]) and np.array_equal(z[own_s][os_], zF[own_f][of])
+        covered += own_f.sum()
+    assert covered == nF

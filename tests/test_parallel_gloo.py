@@ -89,48 +89,66 @@ def test_merge_equals_weighted_mean():
             assert np.abs(g.latent_vecs[sg] - want).max() < 1e-5
 
 
-class _FakeSlabMap:
-    """Stands in for DenseIndexedMap in the exchange plumbing test: records are kept as a dict lin -> (w, z)."""
+class _OracleSlabMap:
+    """The surface `parallel.exchange_halo` needs from a map (ownership, fixed-size halo messages in the layout of
+    `dif_export_halo` / `dif_merge_halo`), played by the numpy oracle on CPU tensors."""
 
-    def __init__(self, nx, ny, nz, lo, hi):
-        self.n_xyz = [nx, ny, nz]
+    def __init__(self, O, om, lo, hi):
+        self.O, self.om = O, om
+        self.n_xyz = om.n_xyz
         self._ownership = (lo, hi, 3)
-        self.store = {}
 
-    def export_records(self, x_lo, x_hi, raw=False):
-        plane = self.n_xyz[1] * self.n_xyz[2]
-        rows = []
-        for lin in sorted(self.store):
-            if x_lo * plane <= lin < x_hi * plane:
-                w, z = self.store[lin]
-                r = np.zeros(32, dtype=np.int32)
-                r[0] = lin; r[2] = np.float32(w).view(np.int32); r[3:32] = z.astype(np.float32).view(np.int32)
-                rows.append(r)
-        return torch.from_numpy(np.stack(rows) if rows else np.zeros((0, 32), dtype=np.int32))
+    def halo_message_rows(self, layers):
+        return layers * self.n_xyz[1] * self.n_xyz[2]
 
-    def merge_records(self, rec, assign=False):
-        assert assign
-        for r in rec.numpy():
-            self.store[int(r[0])] = (float(r[2:3].view(np.float32)[0]), r[3:32].view(np.float32).copy())
+    def export_halo(self, x_lo, x_hi, out=None):
+        msg = torch.from_numpy(self.O.export_halo_message(self.om, x_lo, x_hi, self.halo_message_rows(x_hi - x_lo)))
+        if out is None:
+            return msg
+        out.copy_(msg)
+        return out
+
+    def merge_halo(self, msg):
+        self.O.merge_halo_message(self.om, msg.numpy())
+
+    def integrate(self, xyz, nrm):
+        """what `dif_integrate` does under `set_ownership`: points whose own voxel lies outside [lo - halo, hi + halo) are ignored"""
+        lo, hi, halo = self._ownership
+        ix = np.ceil((xyz[:, 0] - self.om.bound_min[0]) / np.float32(self.om.voxel_size)).astype(np.int64) - 1
+        keep = (ix >= lo - halo) & (ix < hi + halo)
+        self.om.integrate_keyframe(xyz[keep], nrm[keep])
+
+
+def _tiling_case():
+    from oracle import difusion_oracle as O
+    net = O.OracleNetworks({k: v for k, v in np.load(ROOT / "di_fusion_amd" / "network" / "weights_default.npz").items()})
+    cfg = syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4)          # 16^3, the case of tests/test_gpu_parallel.py
+    frames = [tuple(t.numpy() for t in syn.frame_points(syn.default_room(), f, syn.Intrinsic().scaled(0.25), deg_per_frame=15.0)) for f in range(3)]
+    return O, net, cfg, frames
 
 
 def _halo_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from di_fusion_amd import parallel
-    nx = ny = nz = 8
-    lo, hi = parallel.slab_range(nx, rank, world)
-    m = _FakeSlabMap(nx, ny, nz, lo, hi)
-    rng = np.random.default_rng(rank)
-    for x in range(lo, hi):                       # every owned voxel of column (y=1,z=2) holds rank-specific data
-        m.store[x * ny * nz + 1 * nz + 2] = (100.0 * rank + x, rng.standard_normal(29).astype(np.float32))
-    parallel.exchange_halo(m, rank, world)
-    q.put((rank, {k: (v[0], v[1].copy()) for k, v in m.store.items()}))
+    O, net, cfg, frames = _tiling_case()
+    om = O.OracleMap(net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    m = _OracleSlabMap(O, om, *parallel.slab_range(om.n_xyz[0], rank, world))
+    buffers = {}
+    for xyz, nrm in frames:
+        m.integrate(xyz, nrm)
+        parallel.exchange_halo(m, rank, world, buffers=buffers)     # send/recv with the ring neighbours, real message layout
+    n = om.n_occupied
+    q.put((rank, m._ownership, om.latent_vecs_pos[:n].copy(), om.voxel_obs_count[:n].copy(), om.latent_vecs[:n].copy(), om.updated_vec_id.copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_halo_exchange_gloo():
+    """C5 over gloo, world size 2, on the real halo-message layout: two slab maps (oracle arithmetic), the whole frame offered to
+    both, neighbour send/recv of the 3 boundary layers after every integrate.  Every OWNED voxel must end up as in the single map:
+    same set of voxels, same observation counts bit for bit, latents to fp32 rounding (the oracle's float sums are order-dependent;
+    the HIP path's fixed-point sums make this bit-exact, tests/test_gpu_parallel.py), same dirty flags."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -138,17 +156,35 @@ def test_halo_exchange_gloo():
     procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(world))
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ny = nz = 8
-    col = lambda x: x * ny * nz + 1 * nz + 2
-    # rank 0 owns x 0..3 and must now also hold rank 1's x = 4,5,6 (its left boundary, 3 layers), bit-exact; and vice versa
-    for x in (4, 5, 6):
-        assert col(x) in res[0] and res[0][col(x)][0] == res[1][col(x)][0]
-        assert np.array_equal(res[0][col(x)][1], res[1][col(x)][1])
-    assert col(7) not in res[0]
-    for x in (1, 2, 3):
-        assert col(x) in res[1] and np.array_equal(res[1][col(x)][1], res[0][col(x)][1])
-    assert col(0) not in res[1]
+    O, net, cfg, frames = _tiling_case()
+    full = O.OracleMap(net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    for xyz, nrm in frames:
+        full.integrate_keyframe(xyz, nrm)
+    nF = full.n_occupied
+    posF, wF, zF = full.latent_vecs_pos[:nF], full.voxel_obs_count[:nF], full.latent_vecs[:nF]
+    dirtyF = set(posF[full.updated_vec_id].tolist())
+    plane = full.n_xyz[1] * full.n_xyz[2]
+    covered = 0
+    for rank, (lo, hi, _), pos, w, z, upd in res:
+        own_full = (posF >= lo * plane) & (posF < hi * plane)
+        own_slab = (pos >= lo * plane) & (pos < hi * plane)
+        assert set(pos[own_slab].tolist()) == set(posF[own_full].tolist())
+        order_f, order_s = np.argsort(posF[own_full]), np.argsort(pos[own_slab])
+        assert np.array_equal(w[own_slab][order_s], wF[own_full][order_f])
+        assert np.abs(z[own_slab][order_s] - zF[own_full][order_f]).max() < 5e-6
+        assert set(p for p in pos[upd].tolist() if lo * plane <= p < hi * plane) == set(p for p in dirtyF if lo * plane <= p < hi * plane)
+        # the halo mirrors the neighbour's owned boundary exactly (bit for bit: it is a copy)
+        other = res[1 - rank]
+        for x in range(max(lo - 3, 0), lo) if rank > 0 else range(hi, min(hi + 3, full.n_xyz[0])):
+            mine = (pos >= x * plane) & (pos < (x + 1) * plane)
+            theirs = (other[2] >= x * plane) & (other[2] < (x + 1) * plane)
+            assert set(pos[mine].tolist()) >= set(other[2][theirs].tolist())
+            for lin in other[2][theirs][:40]:
+                a, b = np.nonzero(pos == lin)[0][0], np.nonzero(other[2] == lin)[0][0]
+                assert w[a] == other[3][b] and np.array_equal(z[a], other[4][b])
+        covered += own_full.sum()
+    assert covered == nF
