@@ -64,6 +64,8 @@ SIGNATURES = {
     "dif_unproject_transform_frame": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
     "dif_compute_normal_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "dif_filter_depth": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "dif_depth_frontend": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
     "dif_point_box_filter": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "dif_cloud_workspace_bytes": (c_int64, [c_int64]),

@@ -144,16 +144,33 @@ int dif_unproject_transform_frame(const dif_frame_t* frame_dev, float* xyz_world
 
 int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, int32_t W, void* stream) {
     if (!pc || !normal_weight || H <= 0 || W <= 0) return DIF_EINVAL;
-    hipLaunchKernelGGL(k_normal_weight, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, pc, normal_weight, H, W);
+    hipLaunchKernelGGL(k_normal_weight, dim3((W + FE_TILE - 1) / FE_TILE, (H + FE_TILE - 1) / FE_TILE), dim3(FE_TILE * FE_TILE), 0, (hipStream_t)stream,
+                       pc, normal_weight, H, W);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+static int launch_frontend(const FrontendArgs& a, void* stream) {
+    hipLaunchKernelGGL(k_depth_frontend, dim3((a.W + FE_TILE - 1) / FE_TILE, (a.H + FE_TILE - 1) / FE_TILE), dim3(FE_TILE * FE_TILE), 0,
+                       (hipStream_t)stream, a);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
 
 int dif_filter_depth(const float* depth_in, float* depth_out, int32_t H, int32_t W, void* stream) {
     if (!depth_in || !depth_out || H <= 0 || W <= 0) return DIF_EINVAL;
-    hipLaunchKernelGGL(k_filter_depth, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth_in, depth_out, H, W);
-    DIF_CHECK_LAUNCH();
-    return DIF_OK;
+    FrontendArgs a = {};
+    a.depth = depth_in; a.H = H; a.W = W; a.filter = 1; a.depth_out = depth_out; a.write_border = 0;      // imgproc.cu:52: the border is left alone
+    return launch_frontend(a, stream);
+}
+
+int dif_depth_frontend(const float* depth, int32_t H, int32_t W, float fx, float fy, float cx, float cy, int32_t filter, float* depth_out, float* pc,
+                       float* normal_weight, float* frame_depth, float* frame_normal, void* stream) {
+    if (!depth || H <= 0 || W <= 0 || ((frame_depth == nullptr) != (frame_normal == nullptr))) return DIF_EINVAL;
+    FrontendArgs a = {};
+    a.depth = depth; a.H = H; a.W = W; a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.filter = filter ? 1 : 0;
+    a.depth_out = depth_out; a.write_border = 1; a.pc = pc; a.normal_weight = normal_weight; a.frame_depth = frame_depth; a.frame_normal = frame_normal;
+    return launch_frontend(a, stream);
 }
 
 int dif_point_box_filter(const float* points, const float* normals, int64_t N, float voxel_size, float* out_points, float* out_normals,

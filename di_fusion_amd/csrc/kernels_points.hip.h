@@ -73,55 +73,139 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* 
     }
 }
 
-// ext/imgproc/imgproc.cu:98-141
-__global__ void __launch_bounds__(DIF_BLOCK) k_normal_weight(const float* __restrict__ pc, float* __restrict__ out, int H, int W) {
-    int64_t n = (int64_t)H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
-        float* o = out + i * 4;
-        if (v < 1 || v > H - 2 || u < 1 || u > W - 2) { o[3] = -1.0f; continue; }
-        const float* c = pc + i * 3;
-        if (c[2] <= 1e-6) { o[3] = -1.0f; continue; }
-        const float* xp = pc + (i + 1) * 3; const float* xm = pc + (i - 1) * 3;
-        const float* yp = pc + (i + W) * 3; const float* ym = pc + (i - W) * 3;
-        if (xp[2] < 1e-6 || xm[2] < 1e-6 || yp[2] < 1e-6 || ym[2] < 1e-6) { o[3] = -1.0f; continue; }
-        float dxx = xp[0] - xm[0], dxy = xp[1] - xm[1], dxz = xp[2] - xm[2];
-        float dyx = yp[0] - ym[0], dyy = yp[1] - ym[1], dyz = yp[2] - ym[2];
-        float nx = dyy * dxz - dyz * dxy, ny = dyz * dxx - dyx * dxz, nz = dyx * dxy - dyy * dxx;   // cross(diff_y, diff_x)
-        float len = sqrtf(nx * nx + ny * ny + nz * nz);
-        if (len < 1e-6) { o[3] = -1.0f; continue; }
-        nx /= len; ny /= len; nz /= len;
-        float theta = acosf(nz);
-        float td = theta / (0.5f * 3.14159f - theta);
-        float wgt = (0.0012f + 0.0019f * (c[2] - 0.4f) * (c[2] - 0.4f) + 0.0001f / sqrtf(c[2]) * td * td);
-        o[0] = nx; o[1] = ny; o[2] = nz; o[3] = 1.0f / wgt;
+// ---- 8f-2: image-space preprocessing in front of the path -----------------------------------------------------------------
+// The reference runs three one-thread-per-pixel kernels with a round trip through memory between them: filter_depth (5x5
+// bilateral filter, imgproc.cu:48-94), unproject_depth (:5-44) and compute_normal_weight (central-difference normal + noise-model
+// weight, :98-160).  Here ONE workgroup owns a 16 x 16 pixel tile: the raw depth tile with its 3-pixel apron (22 x 22) goes into LDS
+// once, the filtered depth of the tile plus a 1-pixel apron (18 x 18) is computed from it into LDS, and every thread then
+// back-projects its pixel and its four neighbours out of LDS and writes depth / point / normal+weight exactly once.  The
+// arithmetic of every stage is the reference's, operation for operation (the library is built without FMA contraction), so the
+// outputs equal the three-kernel composition bit for bit.
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 backproject(int u, int v, float d, float fx, float fy, float cx, float cy) {      // imgproc.cu:18-20
+    const float qnan = __builtin_nanf("");
+    if (!(d == d)) return V3{qnan, qnan, qnan};
+    return V3{((float)u - cx) / fx * d, ((float)v - cy) / fy * d, d};
+}
+
+// imgproc.cu:105-141 for an interior pixel: false => weight -1
+__device__ __forceinline__ bool normal_weight_of(const V3& c, const V3& xp, const V3& xm, const V3& yp, const V3& ym, float (&o)[4]) {
+    if (c.z <= 1e-6) return false;
+    if (xp.z < 1e-6 || xm.z < 1e-6 || yp.z < 1e-6 || ym.z < 1e-6) return false;
+    const float dxx = xp.x - xm.x, dxy = xp.y - xm.y, dxz = xp.z - xm.z;
+    const float dyx = yp.x - ym.x, dyy = yp.y - ym.y, dyz = yp.z - ym.z;
+    float nx = dyy * dxz - dyz * dxy, ny = dyz * dxx - dyx * dxz, nz = dyx * dxy - dyy * dxx;      // cross(diff_y, diff_x)
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    if (len < 1e-6) return false;
+    nx /= len; ny /= len; nz /= len;
+    const float theta = acosf(nz);
+    const float td = theta / (0.5f * 3.14159f - theta);
+    const float wgt = (0.0012f + 0.0019f * (c.z - 0.4f) * (c.z - 0.4f) + 0.0001f / sqrtf(c.z) * td * td);
+    o[0] = nx; o[1] = ny; o[2] = nz; o[3] = 1.0f / wgt;
+    return true;
+}
+
+#define FE_TILE 16
+#define FE_RAW (FE_TILE + 6)        /* 5x5 filter (2) behind a 4-neighbour stencil (1): 3-pixel apron */
+#define FE_FIL (FE_TILE + 2)
+
+struct FrontendArgs {
+    const float* depth; int H, W;
+    float fx, fy, cx, cy;
+    int filter;                      // 0: the stencil runs on the raw depth
+    float* depth_out; int write_border;      // filtered depth; the 2-pixel image border carries the raw depth (written only if write_border)
+    float* pc;                       // (H,W,3) back-projected (filtered) depth
+    float* normal_weight;            // (H,W,4)
+    float* frame_depth;              // (H,W): filtered depth where a normal exists, NaN elsewhere  \  what dif_frame_t wants: a depth-only
+    float* frame_normal;             // (H,W,3): that normal, NaN elsewhere                          /  stream can be integrated directly
+};
+
+__global__ void __launch_bounds__(FE_TILE * FE_TILE) k_depth_frontend(FrontendArgs a) {
+    __shared__ float raw[FE_RAW][FE_RAW + 1];
+    __shared__ float fil[FE_FIL][FE_FIL + 1];
+    const int u0 = (int)blockIdx.x * FE_TILE, v0 = (int)blockIdx.y * FE_TILE, t = (int)threadIdx.x;
+    const float qnan = __builtin_nanf("");
+    for (int k = t; k < FE_RAW * FE_RAW; k += FE_TILE * FE_TILE) {
+        const int i = k / FE_RAW, j = k % FE_RAW, v = v0 - 3 + i, u = u0 - 3 + j;
+        raw[i][j] = (v >= 0 && v < a.H && u >= 0 && u < a.W) ? a.depth[(int64_t)v * a.W + u] : qnan;
+    }
+    __syncthreads();
+    const float sig_l2 = 1.2232f * 1.2232f;                  // MEAN_SIGMA_L^2
+    for (int k = t; k < FE_FIL * FE_FIL; k += FE_TILE * FE_TILE) {
+        const int i = k / FE_FIL, j = k % FE_FIL, v = v0 - 1 + i, u = u0 - 1 + j;
+        float z = raw[i + 2][j + 2];
+        if (a.filter && v >= 2 && v < a.H - 2 && u >= 2 && u < a.W - 2) {      // imgproc.cu:52-79; border pixels keep the raw depth
+            if (z < 1e-6) {
+                z = 0.0f;
+            } else {
+                const float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
+                float w_sum = 0.0f, acc = 0.0f;
+                for (int di = -2; di <= 2; ++di)
+                    for (int dj = -2; dj <= 2; ++dj) {
+                        const float nz = raw[i + 2 + di][j + 2 + dj];
+                        if (nz < 1e-6) continue;
+                        const float dz = (nz - z) * (nz - z);
+                        const float wgt = expf(-0.5f * ((float)(abs(di) + abs(dj)) * sig_l2 + dz * sigma_z * sigma_z));
+                        w_sum += wgt;
+                        acc += wgt * nz;
+                    }
+                z = acc / w_sum;
+            }
+        }
+        fil[i][j] = z;
+    }
+    __syncthreads();
+    const int lx = t & (FE_TILE - 1), ly = t / FE_TILE, u = u0 + lx, v = v0 + ly;
+    if (u >= a.W || v >= a.H) return;
+    const int64_t px = (int64_t)v * a.W + u;
+    const float d = fil[ly + 1][lx + 1];
+    const bool interior = v >= 2 && v < a.H - 2 && u >= 2 && u < a.W - 2;
+    if (a.depth_out && (interior || a.write_border)) a.depth_out[px] = d;
+    const V3 c = backproject(u, v, d, a.fx, a.fy, a.cx, a.cy);
+    if (a.pc) { a.pc[px * 3 + 0] = c.x; a.pc[px * 3 + 1] = c.y; a.pc[px * 3 + 2] = c.z; }
+    if (!a.normal_weight && !a.frame_normal) return;
+    float o[4] = {0.0f, 0.0f, 0.0f, -1.0f};
+    bool ok = false;
+    if (!(v < 1 || v > a.H - 2 || u < 1 || u > a.W - 2))                       // imgproc.cu:102
+        ok = normal_weight_of(c, backproject(u + 1, v, fil[ly + 1][lx + 2], a.fx, a.fy, a.cx, a.cy),
+                              backproject(u - 1, v, fil[ly + 1][lx], a.fx, a.fy, a.cx, a.cy),
+                              backproject(u, v + 1, fil[ly + 2][lx + 1], a.fx, a.fy, a.cx, a.cy),
+                              backproject(u, v - 1, fil[ly][lx + 1], a.fx, a.fy, a.cx, a.cy), o);
+    if (a.normal_weight) {
+        if (ok) { a.normal_weight[px * 4 + 0] = o[0]; a.normal_weight[px * 4 + 1] = o[1]; a.normal_weight[px * 4 + 2] = o[2]; }
+        a.normal_weight[px * 4 + 3] = ok ? o[3] : -1.0f;                       // the reference writes only the weight of an invalid pixel
+    }
+    if (a.frame_normal) {
+        const bool use = ok && o[3] > 0.0f && (o[0] == o[0]) && (d == d);      // a finite normal with a valid weight on a finite depth
+        a.frame_depth[px] = use ? d : qnan;
+        a.frame_normal[px * 3 + 0] = use ? o[0] : qnan; a.frame_normal[px * 3 + 1] = use ? o[1] : qnan; a.frame_normal[px * 3 + 2] = use ? o[2] : qnan;
     }
 }
 
-// ---- 8f-2: image-space preprocessing next to the path -------------------------------------------------------------------
-// filter_depth (ext/imgproc/imgproc.cu:48-94): 5x5 bilateral filter whose range sigma follows the depth-noise model;
-// border pixels (2 px) are left untouched, depth < 1e-6 -> 0.
-__global__ void __launch_bounds__(DIF_BLOCK) k_filter_depth(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
-    const float sig_l2 = 1.2232f * 1.2232f;                  // MEAN_SIGMA_L^2
-    int64_t n = (int64_t)H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
-        if (v < 2 || v >= H - 2 || u < 2 || u >= W - 2) continue;
-        float z = in[i];
-        if (z < 1e-6) { out[i] = 0.0f; continue; }
-        float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
-        float w_sum = 0.0f, acc = 0.0f;
-        for (int di = -2; di <= 2; ++di)
-            for (int dj = -2; dj <= 2; ++dj) {
-                float nz = in[i + (int64_t)di * W + dj];
-                if (nz < 1e-6) continue;
-                float dz = (nz - z) * (nz - z);
-                float wgt = expf(-0.5f * ((float)(abs(di) + abs(dj)) * sig_l2 + dz * sigma_z * sigma_z));
-                w_sum += wgt;
-                acc += wgt * nz;
-            }
-        out[i] = acc / w_sum;
+// compute_normal_weight on an arbitrary point map (the flat op of ext/__init__.py:26): the same stencil with the point tile and its
+// 1-pixel apron staged through LDS (each point is read once instead of up to five times).
+__global__ void __launch_bounds__(FE_TILE * FE_TILE) k_normal_weight(const float* __restrict__ pc, float* __restrict__ out, int H, int W) {
+    __shared__ float tile[FE_FIL][FE_FIL][3];
+    const int u0 = (int)blockIdx.x * FE_TILE, v0 = (int)blockIdx.y * FE_TILE, t = (int)threadIdx.x;
+    for (int k = t; k < FE_FIL * FE_FIL; k += FE_TILE * FE_TILE) {
+        const int i = k / FE_FIL, j = k % FE_FIL, v = v0 - 1 + i, u = u0 - 1 + j;
+        const bool in = v >= 0 && v < H && u >= 0 && u < W;
+        const float* p = pc + ((int64_t)v * W + u) * 3;
+        tile[i][j][0] = in ? p[0] : 0.0f; tile[i][j][1] = in ? p[1] : 0.0f; tile[i][j][2] = in ? p[2] : 0.0f;
     }
+    __syncthreads();
+    const int lx = t & (FE_TILE - 1), ly = t / FE_TILE, u = u0 + lx, v = v0 + ly;
+    if (u >= W || v >= H) return;
+    float* o4 = out + ((int64_t)v * W + u) * 4;
+    float o[4];
+    bool ok = false;
+    if (!(v < 1 || v > H - 2 || u < 1 || u > W - 2)) {
+        auto at = [&](int i, int j) { return V3{tile[i][j][0], tile[i][j][1], tile[i][j][2]}; };
+        ok = normal_weight_of(at(ly + 1, lx + 1), at(ly + 1, lx + 2), at(ly + 1, lx), at(ly + 2, lx + 1), at(ly, lx + 1), o);
+    }
+    if (ok) { o4[0] = o[0]; o4[1] = o[1]; o4[2] = o[2]; }
+    o4[3] = ok ? o[3] : -1.0f;
 }
 
 // point_box_filter (system/tracker.py:13-23): mean point / mean normal per voxel_size box, boxes in ascending linear id

@@ -49,6 +49,25 @@ def groupby_sum(values: torch.Tensor, indices: torch.Tensor, C) -> List[torch.Te
     return [s, c]
 
 
+def depth_frontend(depth: torch.Tensor, fx: float, fy: float, cx: float, cy: float, filter: bool = True, want_frame: bool = False):
+    """`filter_depth` -> `unproject_depth` -> `compute_normal_weight` (reference `ext/imgproc/imgproc.cu:48-160`) in one pass over 16 x 16
+    pixel tiles (depth tile + apron in LDS), bit-identical to the three calls.  Returns (depth_filtered (H,W), pc (H,W,3),
+    normal_weight (H,W,4)) and, with `want_frame`, also (frame_depth (H,W), frame_normal (H,W,3)): NaN where no normal exists — the
+    inputs `dif_integrate_frame` takes, for streams that come without normals."""
+    _lib.require_cuda(depth)
+    H, W = depth.shape
+    dev = depth.device
+    d = torch.empty((H, W), dtype=torch.float32, device=dev)
+    pc = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    nw = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    fd = torch.empty((H, W), dtype=torch.float32, device=dev) if want_frame else None
+    fn = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if want_frame else None
+    with _dev(depth):
+        _lib.check(_lib.load().dif_depth_frontend(_lib.ptr(depth), H, W, fx, fy, cx, cy, 1 if filter else 0, _lib.ptr(d), _lib.ptr(pc), _lib.ptr(nw),
+                                                  _lib.ptr(fd), _lib.ptr(fn), _lib.stream_ptr()), "dif_depth_frontend")
+    return (d, pc, nw, fd, fn) if want_frame else (d, pc, nw)
+
+
 def pack_batch(indices: torch.Tensor, n_batch: int, n_point: int):
     """reference `ext/indexing/indexing.cu:73-86`; only reachable through `pack_samples`, which nothing on the fusion
     path calls."""

@@ -130,6 +130,15 @@ int dif_compute_normal_weight(const float* pc, float* normal_weight, int32_t H, 
 /* ext/imgproc/imgproc.cu:48-94: 5x5 bilateral depth filter (range sigma from the depth-noise model); the 2-pixel border of
  * depth_out is left untouched, depth < 1e-6 -> 0. */
 int dif_filter_depth(const float* depth_in, float* depth_out, int32_t H, int32_t W, void* stream);
+/* The three image-space kernels of ext/imgproc as ONE pass (16 x 16 pixel tiles, the depth tile and its apron staged through LDS):
+ *   depth_out     = filter_depth(depth) with the 2-pixel border copied from `depth`   (imgproc.cu:48-94; filter == 0: depth_out = depth)
+ *   pc            = unproject_depth(depth_out)                                        (imgproc.cu:5-44)
+ *   normal_weight = compute_normal_weight(pc)                                         (imgproc.cu:98-160)
+ * bit-identical to calling the three entry points one after the other.  Any of the outputs may be NULL.  frame_depth / frame_normal
+ * (both or neither): depth_out where a normal exists and NaN elsewhere, and that normal — the two arrays a dif_frame_t points at, so
+ * that a stream WITHOUT supplied normals can go straight into dif_integrate_frame. */
+int dif_depth_frontend(const float* depth, int32_t H, int32_t W, float fx, float fy, float cx, float cy, int32_t filter, float* depth_out,
+                       float* pc, float* normal_weight, float* frame_depth, float* frame_normal, void* stream);
 /* system/tracker.py:13-23 point_box_filter: mean point and mean normal per voxel_size box; boxes come out in ascending
  * linear box id (x fastest), out_count[0] (device) = number of boxes.  out_points/out_normals: (N,3) capacity.
  * bits: uint32[(max_cells+31)/32] all-zero on entry and on exit; word_rank: int32[(max_cells+31)/32]; sums: int64[N*8];

@@ -176,3 +176,79 @@ def test_point_box_filter_vs_oracle():
     assert torch.equal(fp, fp2)
     with pytest.raises(RuntimeError):
         ext.point_box_filter(xyz.to(DEV), nrm.to(DEV), 0.02, max_cells=1 << 12)
+
+
+def test_depth_frontend_equals_the_three_kernel_composition():
+    """8f-2: filter_depth -> unproject_depth -> compute_normal_weight fused into one LDS-tiled pass, at full resolution (640x480 and a
+    size that is not a multiple of the tile), on a noisy frame with NaN holes, zeros and depth discontinuities: bit-identical to the
+    three flat ops called one after the other (which are checked against the oracle above)."""
+    from di_fusion_amd.system import ext
+    from di_fusion_amd import synthetic as syn
+    for scale, seed in ((1.0, 5), (0.3, 6)):
+        intr = syn.Intrinsic().scaled(scale)
+        R, t = syn.orbit_pose(11)
+        depth, _ = syn.render_frame(syn.default_room(), R, t, intr, noise_seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        hole = torch.rand(depth.shape, generator=g)
+        depth = depth.clone()
+        depth[hole < 0.02] = float("nan")
+        depth[(hole > 0.02) & (hole < 0.04)] = 0.0
+        d = depth.to(DEV)
+        for filt in (True, False):
+            want_d = d.clone()
+            if filt:
+                ext.filter_depth(d, want_d)
+            want_pc = ext.unproject_depth(want_d, intr.fx, intr.fy, intr.cx, intr.cy)
+            want_nw = ext.compute_normal_weight(want_pc)
+            got_d, got_pc, got_nw, fd, fn = ext.depth_frontend(d, intr.fx, intr.fy, intr.cx, intr.cy, filter=filt, want_frame=True)
+            def same(x, y):         # the same bits, or NaN on both sides (which operand's NaN payload survives an operation is the compiler's choice)
+                x, y = x.contiguous(), y.contiguous()
+                return bool(((x.view(torch.int32) == y.view(torch.int32)) | (torch.isnan(x) & torch.isnan(y))).all())
+            assert same(got_d, want_d)
+            assert same(got_pc, want_pc)
+            assert same(got_nw[..., 3], want_nw[..., 3])
+            valid = want_nw[..., 3] > 0
+            assert valid.float().mean() > 0.2
+            assert same(got_nw[valid], want_nw[valid])
+            # the integrate-ready pair: depth + normal where a normal exists, NaN elsewhere
+            use = valid & ~torch.isnan(want_nw[..., 0])
+            assert torch.equal(torch.isnan(fd), ~use) and torch.equal(torch.isnan(fn[..., 0]), ~use)
+            assert torch.equal(fd[use], want_d[use]) and torch.equal(fn[use], want_nw[..., :3][use])
+
+
+def test_depth_only_stream_integrates(gpu_model):
+    """A stream that comes WITHOUT normals: depth -> `depth_frontend` -> frame descriptor -> `dif_integrate_frame` (a1 + a2 + a3..a10)."""
+    import ctypes
+    import struct
+    from di_fusion_amd import _lib, synthetic as syn
+    from di_fusion_amd.system import ext
+    from di_fusion_amd.system.map import DenseIndexedMap
+    intr = syn.Intrinsic().scaled(0.5)
+    scene, cfg = syn.config_c2()
+    R, t = syn.orbit_pose(0)
+    depth, ncam = syn.render_frame(scene, R, t, intr, DEV)
+    _, _, nw, fd, fn = ext.depth_frontend(depth, intr.fx, intr.fy, intr.cx, intr.cy, filter=False, want_frame=True)
+    ok = ~torch.isnan(fd)
+    assert ok.float().mean() > 0.9
+    dots = (fn[ok] * ncam[ok]).sum(-1)
+    assert dots.abs().median() > 0.99 and (dots > 0).float().mean() > 0.98           # same surface normal, oriented like the renderer's
+    m = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV)
+    H, W = intr.height, intr.width
+    xyz = torch.empty((H * W, 3), device=DEV); nrm = torch.empty((H * W, 3), device=DEV); mask = torch.empty((H * W,), dtype=torch.uint8, device=DEV)
+    frame = torch.from_numpy(np.frombuffer(struct.pack("<QQ12f", fd.data_ptr(), fn.data_ptr(), *[float(np.float32(v)) for v in R.reshape(-1)],
+                                                       *[float(np.float32(v)) for v in t]), dtype=np.uint8).copy()).to(DEV)
+    lib = _lib.load()
+    ws = torch.empty((int(lib.dif_integrate_workspace_bytes(H * W)),), dtype=torch.uint8, device=DEV)
+    m._ensure_capacity(7 * (H * W // 17))
+    w = gpu_model.packed.weights_struct(DEV)
+    _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(frame), H, W, intr.fx, intr.fy, intr.cx, intr.cy, _lib.ptr(xyz),
+                                       _lib.ptr(nrm), _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "dif_integrate_frame")
+    # the same points through the ordinary entry point
+    m2 = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV)
+    keep = ~torch.isnan(xyz[:, 0])
+    mask2 = m2.integrate_keyframe(xyz[keep].contiguous(), nrm[keep].contiguous())
+    n = m.n_occupied
+    assert n == m2.n_occupied and n > 500
+    assert torch.equal(m.latent_vecs[:n], m2.latent_vecs[:n]) and torch.equal(m.voxel_obs_count[:n], m2.voxel_obs_count[:n])
+    assert torch.equal(mask[keep].bool(), mask2)
+    assert m.extract_mesh_arrays(4, int(4e6), max_std=0.15, to_host=False)[0].size(0) > 1000
