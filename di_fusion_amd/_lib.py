@@ -14,7 +14,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "libdifusion.so"    # DIF_LIB: instrumented builds (tools/)
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE = range(18)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS = range(20)
 C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit"]
 PROF_COUNT = 8
@@ -29,7 +29,7 @@ class DifMap(Structure):
                 ("prune_min_vox_obs", c_int32), ("ignore_count_th", c_float), ("encoder_count_th", c_float),
                 ("capacity", c_int64),
                 ("indexer", c_void_p), ("latent_vecs", c_void_p), ("latent_vecs_pos", c_void_p),
-                ("voxel_obs_count", c_void_p), ("dirty", c_void_p), ("counters", c_void_p),
+                ("voxel_obs_count", c_void_p), ("dirty", c_void_p), ("voxel_optimized", c_void_p), ("counters", c_void_p),
                 ("frame_count", c_void_p), ("grid_bits", c_void_p), ("vbm", c_void_p),
                 ("rec_dir", c_void_p), ("upd_list", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
@@ -79,6 +79,9 @@ SIGNATURES = {
                                 c_int64, c_void_p]),
     "dif_integrate_frame": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dif_optimize_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "dif_optimize_latents": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_float,
+                                       c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
                               c_int32, c_int32, c_void_p]),
     "dif_mesh_cache_export": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

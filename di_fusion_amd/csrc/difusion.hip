@@ -91,6 +91,7 @@ inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096)
 #include "kernels_extract.hip.h"
 #include "kernels_mesh.hip.h"
 #include "kernels_cloud.hip.h"
+#include "kernels_optimize.hip.h"
 
 }  // namespace
 
@@ -438,6 +439,89 @@ int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_
     if (!frame_dev || H <= 0 || W <= 0 || !xyz_world || !normal_world) return DIF_EINVAL;
     FrameSource src{frame_dev, H, W, fx, fy, cx, cy};
     return integrate_impl(map, w, xyz_world, normal_world, (int64_t)H * W, unq_mask, wsp, ws_bytes, &src, stream_);
+}
+
+// ---- 8f-4: latent optimisation -----------------------------------------------------------------------------------
+struct OptimWs {
+    uint8_t* focus; int* row_slot; float* row_xyz; float* row_sdf;       // [N], [8N], [8N][3], [8N]
+    int* slot_flag; int* slot_u; int* uniq_slot;                          // [capacity] each (slot_flag idle 0)
+    float* z; float* m; float* v; long long* grad;                        // [capacity][32] each
+    float* loss; int* block_tmp;                                          // [64], [4096]
+    int64_t total_bytes;
+};
+
+static int carve_optimize(int64_t N, int64_t capacity, void* base, OptimWs& ws) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    const size_t rows = (size_t)(8 * N + 32), cap = (size_t)capacity;
+    size_t o_focus = take((size_t)N), o_slot = take(rows * 4), o_xyz = take(rows * 12), o_sdf = take(rows * 4), o_flag = take(cap * 4), o_u = take(cap * 4),
+           o_uniq = take(cap * 4), o_z = take(cap * 128), o_m = take(cap * 128), o_v = take(cap * 128), o_g = take(cap * 256), o_loss = take(256), o_tmp = take(4096 * 4);
+    ws.total_bytes = (int64_t)off;
+    if (base) {
+        char* b = (char*)base;
+        ws.focus = (uint8_t*)(b + o_focus); ws.row_slot = (int*)(b + o_slot); ws.row_xyz = (float*)(b + o_xyz); ws.row_sdf = (float*)(b + o_sdf);
+        ws.slot_flag = (int*)(b + o_flag); ws.slot_u = (int*)(b + o_u); ws.uniq_slot = (int*)(b + o_uniq);
+        ws.z = (float*)(b + o_z); ws.m = (float*)(b + o_m); ws.v = (float*)(b + o_v); ws.grad = (long long*)(b + o_g);
+        ws.loss = (float*)(b + o_loss); ws.block_tmp = (int*)(b + o_tmp);
+    }
+    return DIF_OK;
+}
+
+int64_t dif_optimize_workspace_bytes(int64_t N, int64_t capacity) {
+    if (N <= 0) N = 1;
+    if (capacity <= 0) return -1;
+    OptimWs ws;
+    carve_optimize(N, capacity, nullptr, ws);
+    return ws.total_bytes;
+}
+
+int dif_optimize_latents(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, const uint8_t* unq_mask,
+                         const float* noise, int32_t n_iters, float lr, float code_reg_lambda, float* loss_out, void* wsp, int64_t ws_bytes, void* stream_) {
+    if (!map || !w || !map->voxel_optimized || N < 0 || n_iters < 0 || !(lr > 0.0f) || code_reg_lambda < 0.0f) return DIF_EINVAL;
+    if (!w->dec_packed || w->dec_packed_floats != DEC_FLOATS || !w->dec_bwd_packed || w->dec_bwd_packed_floats != DECB_FLOATS) return DIF_EINVAL;
+    if (N == 0 || n_iters == 0) return DIF_OK;
+    if (!xyz || !normal || !unq_mask || !noise || !wsp || 8 * N + 64 >= (int64_t)1 << 31) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    OptimWs ws;
+    carve_optimize(N, map->capacity, wsp, ws);
+    if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
+    Geo g = geo_of(map);
+    int* C = map->counters;
+    OptimSet S{map->voxel_obs_count, map->voxel_optimized, map->latent_vecs_pos, map->encoder_count_th};
+    if (hipMemsetAsync(ws.slot_flag, 0, (size_t)map->capacity * 4, s) != hipSuccess) return DIF_ELAUNCH;
+    if (hipMemsetAsync(ws.loss, 0, 256, s) != hipSuccess) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_optim_focus, dim3(grid_for(N, DIF_BLOCK, 1 << 22)), dim3(DIF_BLOCK), 0, s, g, S, xyz, unq_mask, N, (const int64_t*)map->indexer, ws.focus, C);
+    DIF_CHECK_LAUNCH();
+    {
+        OptimGatherFunctor f{g, S, xyz, normal, ws.focus, N, map->indexer, noise, ws.row_slot, ws.row_xyz, ws.row_sdf, ws.slot_flag, C};
+        if (launch_scan(f, nullptr, (int)(8 * N), 8 * N, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    }
+    {
+        OptimUniqueFunctor f{ws.slot_flag, ws.slot_u, ws.uniq_slot, C};
+        if (launch_scan(f, C + DIF_C_N_OCCUPIED, 0, map->capacity, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+    }
+    const int small = grid_for(map->capacity * 32, DIF_BLOCK, 512);
+    hipLaunchKernelGGL(k_optim_init, dim3(small), dim3(DIF_BLOCK), 0, s, (const int*)ws.uniq_slot, (const float*)map->latent_vecs, ws.z, ws.m, ws.v, ws.grad, (const int*)C);
+    DIF_CHECK_LAUNCH();
+    const size_t lds_bytes = (size_t)DEC_LDS_FLOATS * 4;
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)k_optim_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        attr_set[dev] = true;
+    }
+    for (int it = 1; it <= n_iters; ++it) {
+        hipLaunchKernelGGL(k_optim_grad, dim3(num_cus()), dim3(256), lds_bytes, s, w->dec_packed, w->dec_bwd_packed, (const int*)ws.row_slot,
+                           (const float*)ws.row_xyz, (const float*)ws.row_sdf, (const int*)ws.slot_u, (const float*)ws.z, (unsigned long long*)ws.grad,
+                           loss_out ? ws.loss + (it - 1 < 64 ? it - 1 : 63) : nullptr, (const int*)C);
+        hipLaunchKernelGGL(k_optim_adam, dim3(small), dim3(DIF_BLOCK), 0, s, ws.z, ws.m, ws.v, ws.grad, (const int*)C, it, lr, code_reg_lambda);
+        DIF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_optim_writeback, dim3(small), dim3(DIF_BLOCK), 0, s, (const int*)ws.uniq_slot, (const float*)ws.z, map->latent_vecs, map->voxel_optimized,
+                       map->dirty, ws.slot_flag, (const int*)C);
+    DIF_CHECK_LAUNCH();
+    if (loss_out && hipMemcpyAsync(loss_out, ws.loss, 64 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return DIF_ELAUNCH;
+    return DIF_OK;
 }
 
 // ---- decoder launches ------------------------------------------------------------------------------------------

@@ -420,6 +420,98 @@ __device__ __forceinline__ void decoder_tile_grad(const float* __restrict__ W /*
     gz = dt * gxv[15];
 }
 
+// ---- decoder with the gradient of the optimiser's loss w.r.t. ALL 32 inputs (latent optimisation, reference map.py:80-113) -------------
+// Loss per row (map.py:87-96): -log N(clamp(gt, +-0.2); clamp(sdf, +-0.2), std) * inv_n.  Forward as decoder_tile_grad; the upstream
+// gradient entering lin3's output is  a * w_sdf + b * w_std  with  a = dL/d(sdf pre-activation), b = dL/d(std pre-activation), both
+// known only after the two heads — so the head weights are re-read for the reverse chain.  Returns d loss / d x0 as a D fragment
+// (register r of lane l = feature (r&3) + 8*(r>>2) + 4*(l>>5) of point l&31) and the row's loss term.
+__device__ __forceinline__ void decoder_tile_nll_grad(const float* __restrict__ W /* LDS */, __amdgpu_buffer_rsrc_t Wg /* fwd blob */,
+                                                      __amdgpu_buffer_rsrc_t Wb /* bwd blob */, const f16v& xin, int lane, float gt, float inv_n,
+                                                      float& sdf, float& stdv, float& loss, f16v& gx) {
+    const int half = lane >> 5;
+    unsigned m0[4], m1[4], m2[3], m3[4];
+    f16v hx[1];
+    hx[0] = xin;
+    f16v h0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = load_bias16(W + DEC_B0 + mb * 32, half);
+        acc = block_mm<1>(reinterpret_cast<const f4v*>(W + DEC_A0) + (mb * 4) * 64, hx, acc, lane);
+        h0[mb] = relu16_mask(acc, m0[mb]);
+    }
+    f16v h1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = load_bias16(W + DEC_B1 + mb * 32, half);
+        acc = block_mm<4>(reinterpret_cast<const f4v*>(W + DEC_A1) + (mb * 16) * 64, h0, acc, lane);
+        h1[mb] = relu16_mask(acc, m1[mb]);
+    }
+    f16v h2x[4];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        f16v acc = load_bias16(W + DEC_B2 + mb * 32, half);
+        acc = block_mm<4>(reinterpret_cast<const f4v*>(W + DEC_A2) + (mb * 16) * 64, h1, acc, lane);
+        h2x[mb] = relu16_mask(acc, m2[mb]);
+    }
+    h2x[3] = xin;
+    int off3 = DEC_A3 * 4, offb = 0;
+    asm volatile("" : "+s"(off3), "+s"(offb) : : "memory");
+    float ps = 0.0f, pu = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = load_bias16(W + DEC_B3 + mb * 32, half);
+        acc = block_mm_src<4>(BufA{Wg, off3 + mb * 16 * 1024}, h2x, acc, lane);
+        acc = relu16_mask(acc, m3[mb]);
+        f16v ws = load_bias16(W + DEC_HW + mb * 32, half);
+        f16v wu = load_bias16(W + DEC_HU + mb * 32, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ps = fmaf(acc[r], ws[r], ps);
+            pu = fmaf(acc[r], wu[r], pu);
+        }
+    }
+    ps += __shfl_xor(ps, 32);
+    pu += __shfl_xor(pu, 32);
+    ps += W[DEC_HB + 0];
+    pu += W[DEC_HB + 1];
+    sdf = tanhf(ps);
+    const float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));
+    stdv = 0.05f + 0.5f * sp;
+    // ---- loss and its derivative w.r.t. the two pre-activations ----
+    const float g = fminf(fmaxf(gt, -0.2f), 0.2f), mu = fminf(fmaxf(sdf, -0.2f), 0.2f);
+    const float diff = g - mu, var = stdv * stdv;
+    loss = (logf(stdv) + 0.918938533204672742f + diff * diff / (2.0f * var)) * inv_n;          // 0.5 * log(2 pi)
+    const float d_mu = (sdf >= -0.2f && sdf <= 0.2f) ? -diff / var : 0.0f;                      // clamp passes the gradient inside the interval
+    const float d_sigma = 1.0f / stdv - diff * diff / (var * stdv);
+    const float a = inv_n * d_mu * (1.0f - sdf * sdf);                                          // tanh'
+    const float b = inv_n * d_sigma * 0.5f * ((pu > 20.0f) ? 1.0f : 1.0f / (1.0f + expf(-pu)));   // softplus'
+    // ---- reverse chain ----
+    f16v g3[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v ws = load_bias16(W + DEC_HW + mb * 32, half);
+        f16v wu = load_bias16(W + DEC_HU + mb * 32, half);
+        f16v t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = a * ws[r] + b * wu[r];
+        g3[mb] = apply_mask16(t, m3[mb]);
+    }
+    f16v g2[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+        g2[mb] = apply_mask16(block_mm_src<4>(BufA{Wb, offb + DECB_T3 * 4 + mb * 16 * 1024}, g3, zero16(), lane), m2[mb]);
+    f16v gskip = block_mm_src<4>(BufA{Wb, offb + DECB_T3 * 4 + 3 * 16 * 1024}, g3, zero16(), lane);
+    f16v g1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+        g1[mb] = apply_mask16(block_mm_src<3>(BufA{Wb, offb + DECB_T2 * 4 + mb * 12 * 1024}, g2, zero16(), lane), m1[mb]);
+    f16v g0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+        g0[mb] = apply_mask16(block_mm_src<4>(BufA{Wb, offb + DECB_T1 * 4 + mb * 16 * 1024}, g1, zero16(), lane), m0[mb]);
+    gx = block_mm_src<4>(BufA{Wb, offb + DECB_T0 * 4}, g0, gskip, lane);
+}
+
 // cooperative global -> LDS copy of `n_floats` (multiple of 4) by the whole block.  Eight 16-byte loads are in flight per thread before
 // the first LDS write: the copy is latency-bound (134 KB per CU is ~1 us of L2 bandwidth), so batching the loads is what shortens it.
 __device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ g, int n_floats) {

@@ -11,8 +11,9 @@ Differences a caller can observe (all documented in DESIGN.md):
     sliced to the capacity the reference's doubling rule (`map.py:263-285`) would have reached;
   * points outside the map bounds / NaN points are ignored instead of indexing out of range (`map.py:313`);
   * triangles come out in a canonical order (voxel, cell, table) instead of atomic arrival order;
-  * `do_optimize=True`, the visualisers and `interpolate=False` raise NotImplementedError (out of scope / dead in the
-    reference: `system.ext.marching_cubes` does not exist there either, `map.py:693`).
+  * `do_optimize=True` runs the latent optimisation synchronously on the GPU (`async_optimize=True`, the visualisers and
+    `interpolate=False` raise NotImplementedError: out of scope / dead in the reference — `system.ext.marching_cubes` does not exist
+    there either, `map.py:693`).
 """
 from __future__ import annotations
 
@@ -146,6 +147,9 @@ class DenseIndexedMap:
         self._gc_log_len = 0
         self._gc_wanted = False
         self._halo_scratch = None
+        self._opt_ws = None
+        self.optimize_noise = None          # optional (k,) tensor of N(0,1) samples for the optimiser's perturbations (default: torch.randn)
+        self.optimize_losses = None         # device float[64]: likelihood loss before each Adam step of the last optimisation
         self._cache_call_limit = 0          # max_n_triangles of the latest extract (what one more call may append to the log)
 
         self._grid = int(np.prod(self.n_xyz))
@@ -176,6 +180,7 @@ class DenseIndexedMap:
             pos = torch.full((capacity,), -1, dtype=torch.long, device=dev)
             obs = torch.zeros((capacity,), dtype=torch.float32, device=dev)
             dirty = torch.zeros((capacity,), dtype=torch.uint8, device=dev)
+            optimized = torch.zeros((capacity,), dtype=torch.uint8, device=dev)
             vbm = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
             rec_dir = torch.zeros((capacity, 16), dtype=torch.int32, device=dev)
             upd_list = torch.zeros((capacity,), dtype=torch.int32, device=dev)
@@ -187,9 +192,10 @@ class DenseIndexedMap:
                 pos[:c] = self._pos
                 obs[:c] = self._obs
                 dirty[:c] = self._dirty
+                optimized[:c] = self._optimized
                 tri_start[:c] = self._tri_start
                 tri_n[:c] = self._tri_n
-        self._latent, self._pos, self._obs, self._dirty = lat, pos, obs, dirty
+        self._latent, self._pos, self._obs, self._dirty, self._optimized = lat, pos, obs, dirty, optimized
         self._tri_start, self._tri_n = tri_start, tri_n
         self._vbm, self._rec_dir, self._upd_list = vbm, rec_dir, upd_list
         self._capacity = capacity
@@ -207,6 +213,7 @@ class DenseIndexedMap:
         m.latent_vecs_pos = _lib.ptr(pos)
         m.voxel_obs_count = _lib.ptr(obs)
         m.dirty = _lib.ptr(dirty)
+        m.voxel_optimized = _lib.ptr(optimized)
         m.counters = _lib.ptr(self._counters)
         m.frame_count = _lib.ptr(self._frame_count)
         m.grid_bits = _lib.ptr(self._grid_bits)
@@ -233,7 +240,8 @@ class DenseIndexedMap:
         self._n_occ_ub = c[_lib.C_N_OCCUPIED] + (self._add_total - add_total_at_read)
         self.last_counters = dict(n_occupied=c[_lib.C_N_OCCUPIED], alloc_new=c[_lib.C_ALLOC_NEW], M=c[_lib.C_M], C=c[_lib.C_C],
                                   items=c[_lib.C_ITEMS], K=c[_lib.C_K], B=c[_lib.C_B], VH=c[_lib.C_VH], T=c[_lib.C_T],
-                                  query_M=c[_lib.C_QUERY_M], cache_T=c[_lib.C_CACHE_T], cache_kept=c[_lib.C_CACHE_KEPT],
+                                  query_M=c[_lib.C_QUERY_M], opt_rows=c[_lib.C_OPT_ROWS], opt_voxels=c[_lib.C_OPT_VOXELS],
+                                  cache_T=c[_lib.C_CACHE_T], cache_kept=c[_lib.C_CACHE_KEPT],
                                   cache_dead=c[_lib.C_CACHE_DEAD], cache_live=c[_lib.C_CACHE_LIVE])
         return self.last_counters
 
@@ -284,7 +292,7 @@ class DenseIndexedMap:
 
     @property
     def voxel_optimized(self) -> torch.Tensor:
-        return torch.zeros((self._ref_capacity(),), dtype=torch.bool, device=self.device)
+        return self._optimized[:self._ref_capacity()].view(torch.bool)
 
     @property
     def updated_vec_id(self) -> torch.Tensor:
@@ -297,7 +305,7 @@ class DenseIndexedMap:
         n = self.n_occupied
         c = self._ref_capacity()
         return {"n_occupied": n, "indexer": self._indexer, "latent_vecs": self._latent[:c], "latent_vecs_pos": self._pos[:c],
-                "voxel_obs_count": self._obs[:c], "voxel_optimized": torch.zeros((c,), dtype=torch.bool, device=self.device)}
+                "voxel_obs_count": self._obs[:c], "voxel_optimized": self._optimized[:c].view(torch.bool)}
 
     def save(self, path):
         """reference `map.py:239-243`: `torch.save` of the cold_vars dict (load-compatible with the reference)."""
@@ -316,7 +324,9 @@ class DenseIndexedMap:
         if n > self._capacity:
             self._alloc_state(_next_pow2(n))
         self._indexer.copy_(cv["indexer"].view(-1))
-        self._latent.zero_(); self._pos.fill_(-1); self._obs.zero_(); self._dirty.zero_()
+        self._latent.zero_(); self._pos.fill_(-1); self._obs.zero_(); self._dirty.zero_(); self._optimized.zero_()
+        if "voxel_optimized" in cv:
+            self._optimized[:n] = cv["voxel_optimized"][:n].to(torch.uint8)
         self._latent[:n] = cv["latent_vecs"][:n]
         self._pos[:n] = cv["latent_vecs_pos"][:n]
         self._obs[:n] = cv["voxel_obs_count"][:n]
@@ -332,8 +342,9 @@ class DenseIndexedMap:
         :return: unq_mask (N,) bool — points whose voxel holds more than `prune_min_vox_obs` points (None if pruning is off)."""
         assert surface_xyz.device == surface_normal.device == self.device, \
             f"Device of map {self.device} and input observation {surface_xyz.device, surface_normal.device} must be the same."
-        if do_optimize:
-            raise NotImplementedError("latent optimisation (map.py:459-513) is outside the fusion hot path")
+        if do_optimize and async_optimize:
+            raise NotImplementedError("the latent optimisation runs synchronously here (on the GPU, a few kernel launches); the reference's "
+                                      "separate optimiser process (map.py:28-78, 507-510) is not reproduced")
         xyz = surface_xyz.contiguous().float()
         nrm = surface_normal.contiguous().float()
         N = xyz.size(0)
@@ -352,10 +363,31 @@ class DenseIndexedMap:
             w = self.model.packed.weights_struct(self.device)
             _lib.check(lib.dif_integrate(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), _lib.ptr(nrm), N, _lib.ptr(mask),
                                          _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "dif_integrate")
+            if do_optimize and int(getattr(self.args, "optim_n_iters", 0)) > 0:
+                self._optimize_latents(lib, w, xyz, nrm, N, mask)
             if self._integrate_done is None:
                 self._integrate_done = torch.cuda.Event()
             self._integrate_done.record()                          # on the integrating stream, whichever it is
         return mask.view(torch.bool) if int(self.args.prune_min_vox_obs) > 0 else None
+
+    def _optimize_latents(self, lib, w, xyz, nrm, N, mask):
+        """Stage 3 of `integrate_keyframe(do_optimize=True)` (reference `map.py:459-513`, `OptimizeProcess.do_optimize` `:80-113`,
+        `_update_optimize_result_set(deintegrate_old=False)` `:321-335`): `dif_optimize_latents`.  The perturbation samples come from
+        `torch.randn` on the map's device (the reference draws them the same way); `optimize_noise`, if set, is used instead (tests feed
+        the numbers the reference drew)."""
+        nb = int(lib.dif_optimize_workspace_bytes(N, self._capacity))
+        if self._opt_ws is None or self._opt_ws.numel() < nb:
+            self._opt_ws = torch.empty((nb,), dtype=torch.uint8, device=self.device)
+        noise = self.optimize_noise
+        if noise is None:
+            noise = torch.randn((8 * N,), dtype=torch.float32, device=self.device)
+        else:
+            noise = torch.cat([noise.to(self.device).float().flatten(), torch.zeros((8 * N,), device=self.device)])[:8 * N].contiguous()
+        self.optimize_losses = torch.zeros((64,), dtype=torch.float32, device=self.device)
+        lam = float(self.args.code_reg_lambda) if getattr(self.args, "code_regularization", False) else 0.0
+        _lib.check(lib.dif_optimize_latents(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), _lib.ptr(nrm), N, _lib.ptr(mask), _lib.ptr(noise),
+                                            int(self.args.optim_n_iters), 1.0e-2, lam, _lib.ptr(self.optimize_losses), _lib.ptr(self._opt_ws),
+                                            self._opt_ws.numel(), _lib.stream_ptr()), "dif_optimize_latents")
 
     def allocate_block(self, idx: torch.Tensor):
         """reference `map.py:310-319`.  Slots are handed out in ASCENDING linear-id order (the only order the reference's

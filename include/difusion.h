@@ -53,6 +53,8 @@ enum {
     DIF_C_WORK = 15,        /* scratch                                                                    */
     DIF_C_CACHE_DEAD = 16,  /* dead entries in the mesh-cache log (replaced triangles awaiting compaction)  */
     DIF_C_CACHE_LIVE = 17,  /* triangles written by the last dif_mesh_cache_compact                        */
+    DIF_C_OPT_ROWS = 18,    /* samples gathered by the last dif_optimize_latents (n_samples, map.py:85)      */
+    DIF_C_OPT_VOXELS = 19,  /* voxels optimised by it (latent_id_subset_uniques, map.py:496)                  */
     DIF_C_COUNT = 32
 };
 
@@ -70,6 +72,7 @@ typedef struct dif_map {
     int64_t* latent_vecs_pos;       /* [capacity] lin id or -1                  map.py:206 */
     float* voxel_obs_count;         /* [capacity]                               map.py:208 */
     uint8_t* dirty;                 /* [capacity] 1 = member of mesh_cache.updated_vec_id (map.py:303-308) */
+    uint8_t* voxel_optimized;       /* [capacity]                               map.py:210 (may be NULL if dif_optimize_latents is never called) */
     int32_t* counters;              /* [DIF_C_COUNT] */
     /* scratch, restored to its idle value by every call that touches it */
     int32_t* frame_count;           /* [nx*ny*nz] idle 0  : points of the current frame per voxel (map.py:374) */
@@ -187,6 +190,20 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
  * ((H*W,3) each) are outputs that the later stages read.  Same results as dif_unproject_transform_frame followed by dif_integrate. */
 int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_frame_t* frame_dev, int32_t H, int32_t W, float fx, float fy,
                         float cx, float cy, float* xyz_world, float* normal_world, uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- 8f-4: integrate_keyframe(do_optimize=True), stage 3 (map.py:459-513, OptimizeProcess.do_optimize :80-113, write-back :321-335) ----
+ * To be called right after dif_integrate on the SAME points and with the unq_mask it produced.  Voxels with observation count >=
+ * encoder_count_th that were never optimised (and lin id > 0, as there) get `n_iters` Adam steps (lr, torch defaults otherwise) on
+ *   sum_rows -log N(clamp(gt); clamp(sdf), std) / n_rows  [+ code_reg_lambda * sum_voxels |z| / n_rows  when code_reg_lambda > 0]
+ * over the perturbed surface samples gathered around them (8 offsets; row k is displaced along its normal by 0.05 * noise[k], rows in
+ * the reference's gathering order: offset-major, then point order), then their latents are written back and they are marked optimised
+ * and dirty.  noise: device, at least 8N floats of N(0,1) samples (the reference draws them from torch.randn).  loss_out: optional
+ * device float[64], the likelihood part of the loss before each of the first 64 steps.  Counts -> DIF_C_OPT_ROWS / DIF_C_OPT_VOXELS.
+ * Nothing synchronises. */
+int64_t dif_optimize_workspace_bytes(int64_t N, int64_t capacity);
+int dif_optimize_latents(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N,
+                         const uint8_t* unq_mask, const float* noise, int32_t n_iters, float lr, float code_reg_lambda, float* loss_out,
+                         void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- a11..a16: extract_mesh (map.py:581-723) ---------------------------------------------------------------- */
 typedef struct dif_extract_buffers {

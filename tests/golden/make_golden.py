@@ -231,6 +231,47 @@ def save_reference_map(model):
     print("ref_map_small.pt:", (HERE / "ref_map_small.pt").stat().st_size, "bytes, keys", sorted(m.cold_vars.keys()))
 
 
+def optimize_sequence(model):
+    """The latent-optimisation stage (map.py:459-513, `integrate_keyframe(do_optimize=True)`, synchronous): seq_small's frames with
+    optim_n_iters = 5 and the code regulariser on.  The reference draws its sample perturbations from torch.randn; every draw is
+    recorded (in call order), so that a restatement can be fed the same numbers."""
+    intr = syn.Intrinsic().scaled(0.125)
+    scene = syn.Scene(kind="sphere", radius=1.3)
+    cfg = syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.4)
+    args = cfg.namespace()
+    args.optim_n_iters, args.code_regularization, args.code_reg_lambda = 5, True, 1.0e-2
+    m = ref_map.DenseIndexedMap(model, args, 29, torch.device("cpu"))
+    out = dict(n_frames=np.int64(4), optim_n_iters=np.int64(5), code_reg_lambda=np.float64(1.0e-2), deg_per_frame=np.float64(20.0))
+    draws = []
+    orig_randn = torch.randn
+
+    def recording_randn(*a, **k):
+        t = orig_randn(*a, **k)
+        draws.append(t.clone())
+        return t
+
+    torch.manual_seed(4321)
+    for f in range(4):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=20.0)
+        draws.clear()
+        torch.randn = recording_randn
+        try:
+            m.integrate_keyframe(xyz, nrm, do_optimize=True, async_optimize=False)
+        finally:
+            torch.randn = orig_randn
+        out[f"f{f}_noise"] = torch.cat(draws).numpy() if draws else np.zeros((0,), np.float32)
+        n = int(m.n_occupied)
+        out[f"f{f}_latent_vecs"] = m.latent_vecs[:n].numpy().copy()
+        out[f"f{f}_voxel_obs_count"] = m.voxel_obs_count[:n].numpy().copy()
+        out[f"f{f}_voxel_optimized"] = m.voxel_optimized[:n].numpy().copy()
+        out[f"f{f}_updated_vec_id"] = m.mesh_cache.updated_vec_id.numpy().copy()
+        RECORDED.clear()
+        _extract(m)
+        print(f"  seq_optim frame {f}: n_occ={n} optimised so far={int(m.voxel_optimized[:n].sum())} noise draws={out[f'f{f}_noise'].shape[0]}")
+    np.savez_compressed(HERE / "seq_optim.npz", **out)
+    print(f"seq_optim: saved ({(HERE / 'seq_optim.npz').stat().st_size / 1e6:.2f} MB)")
+
+
 def full_size_sequences(model, which):
     """BASELINE configs C2 (64^3) and C3 (128^3) at their real size: two full 640x480 frames of the bench stream (room scene,
     0.5 deg per frame), whole map state after every integrate, a strided subset of the decoded cubes."""
@@ -250,7 +291,10 @@ def main():
         save_reference_map(model)
         return
     if "--only" in sys.argv:
-        full_size_sequences(model, sys.argv[sys.argv.index("--only") + 1].split(","))
+        which = sys.argv[sys.argv.index("--only") + 1].split(",")
+        full_size_sequences(model, which)
+        if "seq_optim" in which:
+            optimize_sequence(model)
         return
     export_weights(model)
     golden_networks(model)
@@ -272,6 +316,7 @@ def main():
                  store_inputs=False, store_cubes=False)
     save_reference_map(model)
     full_size_sequences(model, ("seq_c2", "seq_c3"))
+    optimize_sequence(model)
 
 
 if __name__ == "__main__":

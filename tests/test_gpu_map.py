@@ -540,3 +540,49 @@ def test_allocate_block(gpu_model):
     assert float(m.voxel_obs_count[n0:n0 + 5].abs().sum()) == 0.0
     with pytest.raises(NotImplementedError):
         m.allocate_block(torch.flip(ids, [0]))
+
+
+def test_latent_optimisation_vs_reference_and_oracle(gpu_model, oracle_net):
+    """8f-4, `integrate_keyframe(do_optimize=True)` (map.py:459-513, :80-113, :321-335): which voxels are optimised, how many samples are
+    gathered for them, the dirty set and the observation counts must equal the reference's run bit for bit; the optimised latents agree
+    to what five Adam steps in fp32 allow — the same algorithm evaluated in float64 instead of float32 moves them by up to 2e-4 (mean
+    6e-6), the reference's own fp32 result sits 3e-4 (mean 9e-6) from the float64 one (Adam's g / sqrt(v) amplifies rounding where a
+    gradient component is near zero) — so: max 1e-3, mean 5e-5, and the likelihood loss must fall."""
+    from oracle import difusion_oracle as O
+    g = np.load(GOLDEN / "seq_optim.npz")
+    scene, cfg, intr = CASES["seq_small"]
+    args = cfg.namespace()
+    args.optim_n_iters, args.code_regularization, args.code_reg_lambda = int(g["optim_n_iters"]), True, float(g["code_reg_lambda"])
+    from di_fusion_amd.system.map import DenseIndexedMap
+    m = DenseIndexedMap(gpu_model, args, 29, DEV, initial_capacity=1024)
+    om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    om.optim_n_iters, om.code_regularization, om.code_reg_lambda = args.optim_n_iters, True, args.code_reg_lambda
+    for f in range(int(g["n_frames"])):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=float(g["deg_per_frame"]))
+        m.optimize_noise = torch.from_numpy(g[f"f{f}_noise"])
+        m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV), do_optimize=True)
+        om.integrate_keyframe(xyz.numpy(), nrm.numpy(), do_optimize=True, noise=g[f"f{f}_noise"])
+        n = m.n_occupied
+        assert m.last_counters["opt_rows"] == g[f"f{f}_noise"].shape[0] == om.last_stats["optim_rows"]
+        assert m.last_counters["opt_voxels"] == om.last_stats["optim_voxels"]
+        assert np.array_equal(m.voxel_optimized[:n].cpu().numpy(), g[f"f{f}_voxel_optimized"])
+        assert np.array_equal(m.voxel_obs_count[:n].cpu().numpy(), g[f"f{f}_voxel_obs_count"])
+        assert np.array_equal(m.updated_vec_id.cpu().numpy(), g[f"f{f}_updated_vec_id"])
+        z = m.latent_vecs[:n].cpu().numpy()
+        opt_now = g[f"f{f}_voxel_optimized"]
+        d_ref, d_or = np.abs(z - g[f"f{f}_latent_vecs"]), np.abs(z - om.latent_vecs[:n])
+        losses = m.optimize_losses.cpu().numpy()[:args.optim_n_iters]
+        print(f"  frame {f}: {m.last_counters['opt_voxels']} voxels / {m.last_counters['opt_rows']} rows optimised; latent vs reference max {d_ref.max():.2e} "
+              f"mean {d_ref[opt_now].mean():.2e}, vs oracle max {d_or.max():.2e}; likelihood loss {losses}")
+        assert d_ref.max() < 1e-3 and d_ref[opt_now].mean() < 5e-5
+        assert d_or.max() < 1e-3 and d_or[opt_now].mean() < 5e-5
+        assert d_ref[~opt_now].max() < LATENT_TOL                               # voxels the optimiser did not touch: the ordinary fusion bar
+        if m.last_counters["opt_rows"]:
+            assert losses[-1] < losses[0]
+            assert abs(losses[0] - om.last_stats["optim_losses"][0] + args.code_reg_lambda * 0) < 0.2 * abs(losses[0]) + 0.05
+        m.extract_mesh_arrays(4, int(4e6), max_std=0.15)                        # the golden sequence meshes (clears the dirty set) every frame
+        om.extract_prepare(4)
+    assert int(m.voxel_optimized.sum()) > 50
+    # without do_optimize nothing changes for the optimiser's bookkeeping, and async is declined
+    with pytest.raises(NotImplementedError):
+        m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV), do_optimize=True, async_optimize=True)
