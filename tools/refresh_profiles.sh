@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/final1; mkdir -p $O
+O=gpurun_out/${1:-final1}; mkdir -p $O
 timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python bench.py --no-cpu-baseline --no-secondary > $O/trace_bench.log 2>&1
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 200 > $O/kernel_stats.md 2>&1
@@ -11,6 +11,9 @@ timeout 900 python tools/stress_full_occupancy.py --n 128 --reps 2 > $O/stress_f
 timeout 900 python tools/stress_integrate.py > $O/stress_integrate.json 2> $O/stress_integrate.err
 timeout 300 python tools/bench_cloud.py --cpu-sample 20000 > $O/bench_cloud.json 2> $O/bench_cloud.err
 for c in c1 c2; do timeout 300 python bench.py --config $c --no-cpu-baseline --steps 50 > $O/bench_$c.json 2> $O/bench_$c.err; done
+timeout 600 python bench.py --mode tiled --no-cpu-baseline --steps 100 > $O/bench_tiled_n1.json 2> $O/bench_tiled_n1.err
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_k20.json 2> $O/bench_k20.err
+timeout 300 python tools/bench_query.py > $O/bench_query.json 2> $O/bench_query.err
 rm -rf $O/pmc_fetch $O/pmc_write
 find $O/trace -name "*.db" -size +20M -delete
 ls -la $O
