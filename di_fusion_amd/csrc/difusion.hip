@@ -712,9 +712,12 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
                                n_slots, own_lo, own_hi);
             DIF_CHECK_LAUNCH();
         }
-        DirtyFunctor f{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels, g, map->ignore_count_th,
-                       map->indexer, map->voxel_obs_count, bits, own_lo, own_hi};
-        if (launch_scan(f, n_slots, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+        DirtySet ds{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels, g, map->ignore_count_th,
+                    map->indexer, map->voxel_obs_count, bits, own_lo, own_hi, tiled};
+        {
+            DirtyFunctor f{ds};
+            if (launch_scan(f, n_slots, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+        }
     }
     {
         OccFunctor f{bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
@@ -798,16 +801,36 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         a.corner_cache = reinterpret_cast<float*>(buf->refine_list);
         a.corner_stride = R3;
     }
-    TriScanFunctor ts{};
-    ts.valid_blocks = buf->valid_blocks; ts.indexer = map->indexer; ts.tri_start = map->tri_start; ts.tri_n = map->tri_n; ts.alive = buf->cache_alive;
-    ts.new_limit = buf->max_triangles; ts.capacity = buf->cache_capacity;
-    rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, ts, s);
-    if (rc != DIF_OK) return rc;
-    rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
-    if (rc != DIF_OK) return rc;
+    const bool fused_scan = buf->chunk_sum && buf->max_voxels <= ((int64_t)1 << 24);      // three levels of 256: beyond that the scan kernel
+    int32_t* const super_sum = buf->chunk_sum ? buf->chunk_sum + (buf->max_voxels + 255) / 256 : nullptr;
+    if (fused_scan) {
+        a.chunk_sum = buf->chunk_sum; a.super_sum = super_sum; a.tri_start = map->tri_start; a.tri_n = map->tri_n;
+        a.tri_count = buf->tri_count; a.tri_offset = nullptr;
+        size_t lds_bytes; int blocks;
+        rc = mc_setup(a, lds_bytes, blocks, buf->max_voxels);
+        if (rc != DIF_OK) return rc;
+        {
+            ProfScope prof(DIF_PROF_MC_COUNT, s);
+            hipLaunchKernelGGL(k_marching_cubes<false>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+        }
+        {
+            ProfScope prof(DIF_PROF_MC_EMIT, s);
+            hipLaunchKernelGGL(k_marching_cubes<true>, dim3(blocks), dim3(DIF_BLOCK), lds_bytes, s, a);
+        }
+        DIF_CHECK_LAUNCH();
+    } else {
+        TriScanFunctor ts{};
+        ts.valid_blocks = buf->valid_blocks; ts.indexer = map->indexer; ts.tri_start = map->tri_start; ts.tri_n = map->tri_n; ts.alive = buf->cache_alive;
+        ts.new_limit = buf->max_triangles; ts.capacity = buf->cache_capacity;
+        rc = mc_count_and_scan(a, buf->max_voxels, buf->tri_count, buf->tri_offset, buf->block_tmp, C, ts, s);
+        if (rc != DIF_OK) return rc;
+        rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
+        if (rc != DIF_OK) return rc;
+    }
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
                        C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
-                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity});
+                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity},
+                       fused_scan ? buf->chunk_sum : nullptr, super_sum);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

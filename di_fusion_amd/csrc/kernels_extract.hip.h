@@ -51,12 +51,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_mark_halo_dirty(Geo g, float igno
     }
 }
 
-struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> valid_blocks (lin ids), clears flags;
-    uint8_t* dirty;         // each dirty voxel also marks the confident voxels among itself and its 6 allocated neighbours
-    const int64_t* pos;     // in the grid bitmap (map.py:628-631)
+// Ordered compaction of the dirty set -> valid_blocks (lin ids in ascending SLOT order = sorted `updated_vec_id`, map.py:303-308,627),
+// clearing it; each dirty voxel also marks the confident voxels among itself and its 6 allocated neighbours in the grid bitmap
+// (map.py:628-631).  The set is a flag per slot.
+struct DirtySet {
+    uint8_t* dirty;
+    const int64_t* pos;
     int64_t* valid_blocks;
     int* counters;
-    int no_cache;
+    int no_cache;           // map.py:614-616: every allocated voxel counts as dirty
     int64_t max_voxels;
     Geo g;
     float ignore_th;
@@ -64,21 +67,31 @@ struct DirtyFunctor {       // ordered compaction of dirty flags over slots -> v
     const float* obs;
     uint32_t* bits;
     int64_t own_lin_lo, own_lin_hi;     // only owned voxels are meshed (spatial tiling); the whole grid by default
-    __device__ int count(int s) const {
-        if (!(no_cache || dirty[s])) return 0;
+    bool tiled;
+    __device__ __forceinline__ bool owned(int s) const {
+        if (!tiled) return true;
         const int64_t p = pos[s];
-        return (p >= own_lin_lo && p < own_lin_hi) ? 1 : 0;      // halo voxels are meshed by their owner
+        return p >= own_lin_lo && p < own_lin_hi;               // halo voxels are meshed by their owner
     }
+};
+
+// The generic two-pass ordered scan with one element per SLOT: each emit marks its own voxel's neighbourhood, spread over many
+// workgroups.  (Measured and rejected: the dirty set as a bitmap over slots compacted word-wise by ONE single-workgroup launch that
+// then marks the K neighbourhoods — the ~4,000 grid-bitmap atomics of a frame issued from a single CU serialise: 46 us against
+// 12.5 us for the two passes.)
+struct DirtyFunctor {
+    DirtySet a;
+    __device__ int count(int s) const { return ((a.no_cache || a.dirty[s]) && a.owned(s)) ? 1 : 0; }
     __device__ void emit(int s, int offset) const {
-        dirty[s] = 0;
-        if (offset >= max_voxels) return;
-        const int lin = (int)pos[s];
-        valid_blocks[offset] = lin;
-        mark_confident_nbhd(g, lin, ignore_th, indexer, obs, bits);
+        a.dirty[s] = 0;
+        if (offset >= a.max_voxels) return;
+        const int lin = (int)a.pos[s];
+        a.valid_blocks[offset] = lin;
+        mark_confident_nbhd(a.g, lin, a.ignore_th, a.indexer, a.obs, a.bits);
     }
     __device__ void finish(int total) const {
-        if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 2; }
-        counters[DIF_C_K] = total;
+        if (total > a.max_voxels) { total = (int)a.max_voxels; a.counters[DIF_C_OVERFLOW] = 2; }
+        a.counters[DIF_C_K] = total;
     }
 };
 

@@ -18,6 +18,10 @@ struct McArgs {
     int* log_counters;              // mesh-cache path: the count pass freezes DIF_C_CACHE_KEPT = DIF_C_CACHE_T (log length before this call)
     int64_t new_limit;              // triangles this call may emit (max_n_triangles)
     int scale; float vs, bx, by, bz;
+    // Fused scan (mesh-cache path): the count pass adds every voxel's triangle count to chunk_sum[k >> 8] and super_sum[k >> 16]
+    // (both idle 0), the emit pass derives a voxel's output offset from < 256 super sums + < 256 chunk sums + < 256 counts and does
+    // the log bookkeeping itself — no scan launch between the two passes.
+    int32_t* chunk_sum; int32_t* super_sum; int32_t* tri_start; int32_t* tri_n;
 };
 
 // batch index of voxel (bx,by,bz) or -1   (query_sdf_raw :13-24)
@@ -108,10 +112,45 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     V4* vl = reinterpret_cast<V4*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
     const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
     if (!EMIT && a.log_counters && blockIdx.x == 0 && threadIdx.x == 0) a.log_counters[DIF_C_CACHE_KEPT] = a.log_counters[DIF_C_CACHE_T];
+    if (EMIT && a.chunk_sum && blockIdx.x == 0 && wid == 0) {        // triangles of this call = sum of all chunk sums (map.py:695 counts them on the host)
+        int tot = 0;
+        for (int c = lane; c < (int)((K + 65535) >> 16); c += 64) tot += a.super_sum[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+        if (lane == 0) a.log_counters[DIF_C_T] = tot;
+    }
     const float sbs = 1.0f / (float)r;
     for (int64_t k = (int64_t)blockIdx.x * wpb + wid; k < K; k += (int64_t)gridDim.x * wpb) {
         if (EMIT && a.tri_count[k] == 0) continue;          // nothing to write for this voxel: the count pass has already said so
         const int64_t vb = a.valid_blocks[k];
+        int voxel_offset = 0;                                // index of the voxel's first triangle among this call's triangles
+        if (EMIT) {
+            if (a.chunk_sum) {
+                const int s0 = (int)(k >> 16), c0 = (int)(k >> 8);
+                int part = 0;
+                for (int c = lane; c < s0; c += 64) part += a.super_sum[c];
+                for (int c = (s0 << 8) + lane; c < c0; c += 64) part += a.chunk_sum[c];
+                for (int j = (c0 << 8) + lane; j < (int)k; j += 64) part += a.tri_count[j];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+                voxel_offset = part;
+                // mesh-cache log: this voxel's previous batch dies, the voxel points at its new one (map.py:708-709)
+                const int64_t slot = a.indexer[vb], log_n = a.log_counters[DIF_C_CACHE_KEPT];
+                const int old_n = a.tri_n[slot], old_s = a.tri_start[slot];
+                for (int j = lane; j < old_n; j += 64) a.tri_alive[old_s + j] = 0;
+                int64_t n_new = a.tri_count[k];
+                if (voxel_offset + n_new > a.new_limit) n_new = a.new_limit > voxel_offset ? a.new_limit - voxel_offset : 0;      // truncated by max_n_triangles
+                if (log_n + voxel_offset + n_new > a.max_triangles) n_new = a.max_triangles > log_n + voxel_offset ? a.max_triangles - (log_n + voxel_offset) : 0;
+                __builtin_amdgcn_wave_barrier();             // every lane has read tri_n / tri_start
+                if (lane == 0) {
+                    a.tri_start[slot] = (int)(log_n + voxel_offset);
+                    a.tri_n[slot] = (int)n_new;
+                    if (old_n) atomicAdd(a.log_counters + DIF_C_CACHE_DEAD, old_n);
+                }
+            } else {
+                voxel_offset = a.tri_offset[k];
+            }
+        }
         const int bx = (int)((vb / ((int64_t)a.ny * a.nz)) % a.nx), by = (int)((vb / a.nz) % a.ny), bz = (int)(vb % a.nz);
         bool any_neg = true, any_pos = true;
         if (EMIT && a.corner_cache) {                        // blended corners as the count pass left them (c_sdf and c_std are contiguous)
@@ -184,7 +223,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
             const int incl = wave_incl_scan(ntri);
             const int chunk_total = __shfl(incl, 63);
             if (EMIT && ntri > 0) {
-                int64_t tl = (int64_t)a.tri_offset[k] + voxel_total + (incl - ntri);      // index among this call's triangles
+                int64_t tl = (int64_t)voxel_offset + voxel_total + (incl - ntri);         // index among this call's triangles
                 int64_t t = tl + (a.base_ptr ? (int64_t)(*a.base_ptr) : 0);
                 for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
                     V4 v0 = vl[(int)(t3 & 0xF) * 64], v1 = vl[(int)((t3 >> 4) & 0xF) * 64], v2 = vl[(int)((t3 >> 8) & 0xF) * 64];
@@ -208,7 +247,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
             }
             voxel_total += chunk_total;
         }
-        if (!EMIT && lane == 0) a.tri_count[k] = voxel_total;
+        if (!EMIT && lane == 0) {
+            a.tri_count[k] = voxel_total;
+            if (a.chunk_sum && voxel_total) { atomicAdd(a.chunk_sum + (k >> 8), voxel_total); atomicAdd(a.super_sum + (k >> 16), voxel_total); }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -274,9 +316,15 @@ struct ExtractOut {
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
                                                             int* __restrict__ counters, int64_t new_limit, int64_t capacity,
                                                             const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
-                                                            const float* __restrict__ log_std, ExtractOut out) {
+                                                            const float* __restrict__ log_std, ExtractOut out, int32_t* __restrict__ chunk_sum,
+                                                            int32_t* __restrict__ super_sum) {
     const int B = counters[DIF_C_B];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
+    if (chunk_sum)                                  // back to idle 0 (only the chunks this call's K dirty voxels could have touched)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((counters[DIF_C_K] + 255) >> 8); i += gridDim.x * blockDim.x) {
+            chunk_sum[i] = 0;
+            if (i < ((counters[DIF_C_K] + 65535) >> 16)) super_sum[i] = 0;
+        }
     const int64_t kept = counters[DIF_C_CACHE_KEPT];
     int64_t n_new = counters[DIF_C_T];
     if (n_new > new_limit) n_new = new_limit;

@@ -236,6 +236,9 @@ typedef struct dif_extract_buffers {
     int64_t* out_id;                /* of them) copied out by the same last kernel — (n,3,3) f32, (n) i64, (n,3) f32; again, pinned host   */
     float* out_std;                 /* memory is fine: a streaming caller gets each frame's mesh update without a transfer of its own      */
     int64_t out_capacity;
+    int32_t* chunk_sum;             /* optional [(max_voxels + 255) / 256 + (max_voxels + 65535) / 65536], idle 0: triangle counts per 256 and per
+                                     * 65,536 dirty voxels; with it (and max_voxels <= 2^24) marching cubes runs as two launches (count, emit)
+                                     * instead of count, scan, emit */
     float* fold_table;              /* optional [max_voxels][256]: per-voxel decoder constants handed from the lattice decode to the refine
                                      * decode (used when dif_weights_t.dec_fold_packed is set) */
 } dif_extract_buffers_t;
