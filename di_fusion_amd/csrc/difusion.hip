@@ -734,14 +734,14 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         const bool fold = w->dec_fold_packed && w->dec_fold_packed_floats == DECF_FLOATS && buf->fold_table;
         V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
         V.low.res = l; V.low.a = (float)sample_a; V.low.vsize = (l > 1) ? (float)((sample_b - sample_a) / (l - 1)) : 0.0f;
-        const size_t lds_bytes = ((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 8 * VD_WAVE_LDS_FLOATS) * 4;
+        const size_t lds_bytes = ((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 4 * VD_WAVE_LDS_FLOATS) * 4;       // four pairs of waves
         static bool attr_set[64] = {};
         int dev = 0; (void)hipGetDevice(&dev);
         if (dev < 64 && !attr_set[dev]) {
             if (hipFuncSetAttribute((const void*)k_decode_voxels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
             attr_set[dev] = true;
         }
-        int64_t blocks = (buf->max_voxels + 7) / 8;
+        int64_t blocks = (buf->max_voxels + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
         {
             ProfScope prof(DIF_PROF_DECODE_LATTICE, s);

@@ -328,10 +328,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_upsample_mark(const float* __rest
 }
 
 // Fused low-lattice decode + upsample for the fast two-level scheme (resolution <= 4, i.e. R^2 <= 64 rows = one per lane):
-// one wave owns one voxel — the l^3 low samples go through the MLP and stay in LDS, the ATen-exact trilinear x2 upsample reads
-// them from there, the cube is written once, and the |sdf| < 0.05 samples are appended to the global refine list with ONE
-// atomic per voxel (wave prefix sum of popcounts).  Work per voxel is uniform (ceil(l^3/32) tiles), so the launch is balanced;
-// the exact re-decode of the selected samples stays a separate, globally balanced launch (per-voxel counts range 0..R^3).
+// TWO waves own one voxel — each puts one 32-sample tile of the l^3 low samples through the MLP (l = 4: exactly two tiles) into the
+// pair's LDS record, then each does half of the ATen-exact trilinear x2 upsample out of LDS (lane = (x, y) row, the pair splits z),
+// writes its half of the cube and appends its |sdf| < 0.05 samples to the global refine list (space reserved once per workgroup and
+// round).  A frame decodes ~900 voxels: with one wave per voxel every SIMD ran a single wave through two tiles back to back and the
+// matrix pipe idled in that wave's gaps (bias loads, ReLU, heads: ~75 % issue rate); two co-resident waves fill each other's gaps.
+// Work per voxel is uniform, so the launch is balanced; the exact re-decode of the selected samples stays a separate, globally
+// balanced launch (per-voxel counts range 0..R^3).
 struct VoxelDecodeArgs {
     const int32_t* occ_slot;
     const float* latent;
@@ -347,7 +350,7 @@ struct VoxelDecodeArgs {
 
 #define VD_MAX_L3 64
 #define VD_MAX_R2 64
-#define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3 + 256) /* low sdf + low std + the voxel's folded decoder constants */
+#define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3 + 2 * 256) /* per PAIR of waves: low sdf + low std + each wave's copy of the voxel's folded decoder constants */
 
 #ifdef DIF_TRACE            // tools/trace_decode.py: per-wave phase timestamps (100 MHz wall clock) of the last k_decode_voxels launch
 __device__ unsigned long long g_vd_trace[2048 * 8];
@@ -363,78 +366,71 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
     VD_STAMP(1);
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
-    float* w_low_sdf = lds + ((DEC_LDS_FLOATS + 3) & ~3) + wid * VD_WAVE_LDS_FLOATS;
+    const int pair = wid >> 1, tsel = wid & 1;                 // wave `tsel` of the pair that owns the voxel
+    float* w_low_sdf = lds + ((DEC_LDS_FLOATS + 3) & ~3) + pair * VD_WAVE_LDS_FLOATS;       // shared by the pair
     float* w_low_std = w_low_sdf + VD_MAX_L3;
-    float* w_fold = w_low_std + VD_MAX_L3;                   // [c0 | c3], see decoder_fold_consts
+    float* w_fold = w_low_std + VD_MAX_L3 + tsel * 256;        // [c0 | c3], see decoder_fold_consts: each wave keeps its own copy (no barrier before the MFMAs)
     const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
     const float scale = (float)(l - 1) / (float)(R - 1);
     const int B = A.counters[DIF_C_B];
-    const int wave = (int)(wid * gridDim.x + blockIdx.x), nwaves = (int)(gridDim.x * (blockDim.x >> 6));   // spread over CUs first
-    // uniform trip count: the refine-list reservation below is a workgroup-wide step (one global atomic per workgroup and round
-    // instead of one per voxel — 900 same-address atomics at the end of the launch queued up for ~5 us)
+    const int pairs_per_block = (int)(blockDim.x >> 7), n_pairs = (int)gridDim.x * pairs_per_block;
+    const int first = pair * (int)gridDim.x + (int)blockIdx.x;  // spread over CUs first
+    // uniform trip count: the barriers below are workgroup-wide (the pair's hand-over, and the refine-list reservation: one global
+    // atomic per workgroup and round instead of one per voxel — 900 same-address atomics at the end of the launch queued up for ~5 us)
     __shared__ int s_tot[8], s_base;
-    const int rounds = (B + nwaves - 1) / nwaves;
+    const int rounds = (B + n_pairs - 1) / n_pairs;
     for (int round = 0; round < rounds; ++round) {
-        const int b = wave + round * nwaves;
+        const int b = first + round * n_pairs;
         unsigned sel = 0;
+        const int jz0 = tsel * (R >> 1), jz1 = jz0 + (R >> 1);  // this wave's share of the z samples
         const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
-        if (b < B) {
+        if (b < B && tsel * 32 < l3) {
             const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
-            // ---- low lattice -> LDS (map.py:644-653) ----
+            const int s = tsel * 32 + col;
+            const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
+            float sdf, sd;
+            // ---- this wave's tile of the low lattice -> LDS (map.py:644-653) ----
             if (A.fold_w) {
                 // the voxel's latent goes through lin0 / lin3 once (VALU), every sample then only adds its coordinate columns (MFMA)
                 decoder_fold_consts(lds, A.fold_w, lat_row, w_fold, lane);
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                float* rec = A.fold_table + (int64_t)b * 256;            // the refine pass picks the constants up from here
-                for (int p = lane; p < 256; p += 64) rec[p] = w_fold[p];
-                for (int t0 = 0; t0 < l3; t0 += 32) {
-                    const int s = t0 + col;
-                    float sdf, sd;
-                    decoder_tile_folded(lds, wfwd, FoldInitLds{w_fold}, A.low.coord(s / (l * l)), A.low.coord((s / l) % l), A.low.coord(s % l), lane, sdf, sd);
-                    if (s < l3) {
-                        if (half == 0) w_low_sdf[s] = sdf;
-                        else w_low_std[s] = sd;
-                    }
+                if (tsel == 0) {
+                    float* rec = A.fold_table + (int64_t)b * 256;          // the refine pass picks the constants up from here
+                    for (int p = lane; p < 256; p += 64) rec[p] = w_fold[p];
                 }
+                decoder_tile_folded(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
             } else {
-                f16v xlat;                                      // latent part of the B operand: the same for every sample of the voxel
+                f16v xin;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int k = 2 * t + half;
-                    xlat[t] = (k < L) ? lat_row[k] : 0.0f;
+                    xin[t] = (k < L) ? lat_row[k] : 0.0f;
                 }
-                for (int t0 = 0; t0 < l3; t0 += 32) {
-                    const int s = t0 + col;
-                    const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
-                    f16v xin = xlat;
-                    if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }        // k = 29 (x), 30 (y), 31 (z)
-                    float sdf, sd;
-                    decoder_tile(lds, wfwd, xin, lane, sdf, sd);
-                    if (s < l3) {
-                        if (half == 0) w_low_sdf[s] = sdf;
-                        else w_low_std[s] = sd;
-                    }
-                }
+                if (half) { xin[14] = px; xin[15] = pz; } else { xin[15] = py; }        // k = 29 (x), 30 (y), 31 (z)
+                decoder_tile(lds, wfwd, xin, lane, sdf, sd);
             }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            VD_STAMP(2);
-            // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z ----
-            if (lane < R2) {
-                const int jx = lane / R, jy = lane % R;
-                int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
-                tri_axis(jx, l, scale, x0, x1, wx0, wx1);
-                tri_axis(jy, l, scale, y0, y1, wy0, wy1);
-                for (int jz = 0; jz < R; ++jz) {
-                    int z0, z1; float wz0, wz1;
-                    tri_axis(jz, l, scale, z0, z1, wz0, wz1);
-                    float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                    float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                    A.cube_sdf[e0 + jz] = -sv;
-                    A.cube_std[e0 + jz] = dv;
-                    if (fabsf(sv) < 0.05f) sel |= 1u << jz;
-                }
+            if (s < l3) {
+                if (half == 0) w_low_sdf[s] = sdf;
+                else w_low_std[s] = sd;
+            }
+        }
+        __syncthreads();                        // both tiles of every pair are in LDS
+        VD_STAMP(2);
+        // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z, this wave's half of them ----
+        if (b < B && lane < R2) {
+            const int jx = lane / R, jy = lane % R;
+            int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
+            tri_axis(jx, l, scale, x0, x1, wx0, wx1);
+            tri_axis(jy, l, scale, y0, y1, wy0, wy1);
+            for (int jz = jz0; jz < jz1; ++jz) {
+                int z0, z1; float wz0, wz1;
+                tri_axis(jz, l, scale, z0, z1, wz0, wz1);
+                float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
+                A.cube_sdf[e0 + jz] = -sv;
+                A.cube_std[e0 + jz] = dv;
+                if (fabsf(sv) < 0.05f) sel |= 1u << jz;
             }
         }
         VD_STAMP(3);
@@ -458,7 +454,7 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
                 A.refine_list[o++] = (int32_t)(e0 + jz);
             }
         }
-        __syncthreads();                        // s_tot / s_base are rewritten by the next round
+        __syncthreads();                        // s_tot / s_base and the pair's LDS record are rewritten by the next round
         VD_STAMP(4);
     }
     VD_STAMP(5);
