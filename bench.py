@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--noise", type=int, default=0)
     ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
-    ap.add_argument("--graph", type=int, default=1, help="1: replay the frame's launches from a captured hipGraph; every --sample-every-th frame runs "
-                    "eagerly with HIP events around the MFMA kernels (the roofline sample)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the frame's launches from a captured hipGraph (every --sample-every-th frame runs "
+                    "eagerly with HIP events around the MFMA kernels); 0 (default): launch them directly, two C calls per frame, HIP events on every "
+                    "--sample-every-th frame — consecutive graph launches start 50-80 us apart on the GPU on this ROCm, direct launches do not")
     ap.add_argument("--sample-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra run with the mesh left in HBM (keeps profiler traces to one stream)")
@@ -152,7 +153,7 @@ def prime_process(FusionStream, syn, model, intr, dev, d2h):
     prime.step(0, d2h)
     prime.step_pipelined(1, d2h)
     prime.step_graph(2, d2h)
-    prime.step_graph(3, d2h)
+    prime.step_direct(3, d2h)
     prime.flush(d2h)
     torch.cuda.synchronize()
     del prime
@@ -162,9 +163,23 @@ def prime_process(FusionStream, syn, model, intr, dev, d2h):
 
 def frame_runner(stream, a, d2h):
     """(run(i), drain()) for the chosen way of driving a frame."""
+    lib = None
+
     def run(i):
+        nonlocal lib
         if a.graph and i >= 2 and (i % a.sample_every) != 0:
             return stream.step_graph(i, d2h)
+        if a.direct and i >= 2 and stream.tiling is None:
+            if lib is None:
+                from di_fusion_amd import _lib
+                lib = _lib.load()
+            sampled = a.timed_from is not None and i >= a.timed_from and (i % a.sample_every) == 0
+            if sampled:
+                lib.dif_profile_enable(1)               # HIP events around this frame's MFMA / marching-cubes kernels (the roofline sample)
+            out = stream.step_direct(i, d2h)
+            if sampled:
+                lib.dif_profile_enable(0)
+            return out
         return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
 
     def drain():
@@ -176,7 +191,7 @@ def rate_with_mesh_left_in_hbm(make_stream, a, n_frames):
     """Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream without the per-frame hand-over of
     the new triangles to pinned host memory.  The difference is PCIe traffic, not kernels."""
     s2 = make_stream()
-    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30}), "none")
+    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30, "timed_from": None}), "none")
     for i in range(a.warmup):
         run2(i)
     drain2()
@@ -310,6 +325,8 @@ def main():
     n_frames = a.warmup + a.steps
     if tiled and world > 1:
         a.graph = 0                         # the halo exchange sits between the kernels of a frame: eager, host one frame ahead
+    a.direct = not a.graph and a.pipeline
+    a.timed_from = None
 
     def make_stream():
         if tiled:           # every rank renders the same stream and owns one x-slab of the grid
@@ -341,7 +358,9 @@ def main():
     cap = 1 << 16
     p_which, p_ms = (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
     lib.dif_profile_dump(p_which, p_ms, cap, 1)
-    lib.dif_profile_enable(1)
+    a.timed_from = a.warmup
+    if not a.direct or stream.tiling is not None:
+        lib.dif_profile_enable(1)           # (the direct runner switches it on for the sampled frames only)
     gc.collect()
     gc.disable()            # a generation-2 collection in the middle of a 70 ms timed region shows up as a 20 % outlier
     barrier()
@@ -369,7 +388,8 @@ def main():
     if rank == 0:
         st = stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
-        timed_idx = [j for j in range(a.steps) if not (a.graph and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
+        sampled_only = a.graph or (a.direct and stream.tiling is None)
+        timed_idx = [j for j in range(a.steps) if not (sampled_only and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
         # the event records come in launch order, one k_encode per event-timed frame: cut the list into frames there
         per_frame = []
         for k in range(n_rec):
@@ -379,7 +399,9 @@ def main():
             per_frame[-1].append((name, float(p_ms[k])))
         if len(per_frame) != len(timed_idx):        # (an empty frame launches no encoder) fall back to one group
             per_frame, timed_idx = [[r for f in per_frame for r in f]], timed_idx[:1] if timed_idx else []
-        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else "eager, host one frame ahead")
+        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else
+                  f"direct launches (two C calls per frame), host one frame ahead, HIP events on 1 frame in {a.sample_every} (roofline sample)"
+                  if sampled_only else "eager, host one frame ahead")
         pixels = intr.width * intr.height
         value = (a.steps if tiled else world * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
         out = {"metric": f"frames/s integrate+decode+mesh, {intr.width}x{intr.height} synthetic stream", "value": round(value, 3),

@@ -57,6 +57,8 @@ class FusionStream:
         self.n_captures = 0
         self._g_in = None
         self._zc = None
+        self._d_slots = None
+        self._d_sig = None
 
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
@@ -142,7 +144,7 @@ class FusionStream:
             n = tri.size(0)
             k = handle.get("host_out")
             if k is not None and n <= self.HOST_OUT_TRIANGLES:
-                hp = self._zc[2][k]                              # already there: written by the frame's last kernel
+                hp = handle["host_slots"][k]["out"] if "host_slots" in handle else self._zc[2][k]      # already there: written by the frame's last kernel
                 out = (hp[0][:n], hp[1][:n], hp[2][:n])
             else:
                 out = self._export_new(handle, tri, tid, tstd)
@@ -170,6 +172,85 @@ class FusionStream:
             self._pending = None
         with torch.cuda.device(self.device):
             self._copy_stream.synchronize()
+        return out
+
+    # ---- direct variant: the frame's launches are enqueued by two C calls, the host stays ahead of the GPU ------------------------------
+    # The same per-frame protocol as `step_graph` below (frame descriptor in, counters + new triangles out through pinned host memory,
+    # written by the frame's first / last kernel; results picked up one frame later), but the ~17 kernels are launched directly:
+    # `dif_integrate_frame` + `dif_extract` enqueue them back to back in ~60 us of host time for ~230 us of GPU time, so the queue never
+    # runs dry.  A replayed hipGraph needs less host time still, but on this ROCm consecutive graph launches on one stream start
+    # 50-80 us apart on the GPU (measured: profiles/README.md), which at 0.23 ms of kernels per frame costs a fifth of the throughput.
+    DIRECT_SLOTS = 4
+
+    def _direct_prepare(self):
+        m, dev = self.map, self.device
+        H, W = self.intr.height, self.intr.width
+        if self._d_slots is None:
+            cap = self.HOST_OUT_TRIANGLES
+            self._d_slots = [dict(frame=torch.zeros((64,), dtype=torch.uint8).pin_memory(),
+                                  counters=torch.zeros((_lib.C_COUNT,), dtype=torch.int32).pin_memory(),
+                                  out=(torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
+                                       torch.empty((cap, 3), dtype=torch.float32).pin_memory()),
+                                  event=torch.cuda.Event()) for _ in range(self.DIRECT_SLOTS)]
+            for sl in self._d_slots:
+                sl["frame_np"] = sl["frame"].numpy()
+                sl["counters_np"] = sl["counters"].numpy()
+            self._d_mask = torch.empty((H * W,), dtype=torch.uint8, device=dev)
+            self._d_seq = 0
+            self._d_desc = [np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8).copy()
+                            for i, (R, t) in enumerate(self.poses)]
+        sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES)
+        if self._d_sig != sig:                       # (re)build the per-slot buffer descriptors after a re-allocation
+            self._d_bufs = []
+            for sl in self._d_slots:
+                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+                buf.counters_out = _lib.ptr(sl["counters"])
+                self._d_bufs.append(buf)
+            self._d_sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES)
+            self._d_w = m.model.packed.weights_struct(dev)
+            self._d_lib = _lib.load()
+            self._d_args = (self.intr.height, self.intr.width, self.intr.fx, self.intr.fy, self.intr.cx, self.intr.cy)
+
+    def step_direct(self, i: int, d2h: str = "new"):
+        """One frame enqueued with two C calls (no graph), host one frame ahead; returns the previous frame's output like `step_pipelined`."""
+        m = self.map
+        if self.tiling is not None:
+            raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
+        N = self.intr.height * self.intr.width
+        prune = int(m.args.prune_min_vox_obs)
+        may_add = 7 * (N // (prune + 1)) if prune > 0 else 7 * N
+        out = None
+        with torch.cuda.device(self.device):
+            if m._ws is None or m._xbuf is None or m._cache is None:
+                raise RuntimeError("run at least one eager step before step_direct (buffers are sized there)")
+            if m._n_occ_ub + may_add > m._capacity and self._pending is not None:
+                out = self._finish_frame(self._pending, d2h)     # make the bound exact before deciding to grow
+                self._pending = None
+            m._ensure_capacity(may_add)
+            self._before_frame()
+            if m._gc_wanted:
+                m._cache_gc()
+            self._direct_prepare()
+            k = self._d_seq % self.DIRECT_SLOTS
+            self._d_seq += 1
+            sl, buf = self._d_slots[k], self._d_bufs[k]
+            export = d2h == "new"
+            buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"]) if export else (None, None, None)
+            buf.out_capacity = self.HOST_OUT_TRIANGLES if export else 0
+            sl["frame_np"][:] = self._d_desc[i]
+            lib, w, sp = self._d_lib, self._d_w, _lib.stream_ptr()
+            H, W, fx, fy, cx, cy = self._d_args
+            _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, _lib.ptr(self.xyz),
+                                               _lib.ptr(self.nrm), _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
+            _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std), 0, 1, sp),
+                       "dif_extract")
+            m.mesh_cache.invalidate_host_copy()
+            sl["event"].record()
+            h = dict(event=sl["event"], counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
+                     host_out=(k if export else None), host_slots=self._d_slots)
+        if self._pending is not None:
+            out = self._finish_frame(self._pending, d2h)
+        self._pending = h
         return out
 
     # ---- hipGraph variant: the 19 launches of a frame are captured once and replayed ----------------------------------------

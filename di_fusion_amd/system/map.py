@@ -574,7 +574,7 @@ class DenseIndexedMap:
         """Wait for an enqueued extract and publish its counters (`last_counters`).  Returns the device views of the triangles that
         extract produced (vertices (T,3,3), voxel ids (T,), std (T,3)) — valid until the next-but-one extract overwrites the buffer."""
         handle["event"].synchronize()
-        c = self._publish_counters([int(v) for v in handle["counters"].tolist()], handle["add_total"])
+        c = self._publish_counters(handle["counters"].tolist(), handle["add_total"])
         if c["T"] >= handle["max_n_triangles"]:
             logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {handle['max_n_triangles']}")
         if c["K"] > 0:

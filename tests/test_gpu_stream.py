@@ -80,6 +80,26 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     same(outs["eager"], outs["pipelined"])
     same(outs["eager"], outs["graph"])
 
+    # direct launches through the frame descriptor (two C calls per frame, no graph), with a forced compaction and a tiny staging area
+    st = make_stream(gpu_model)
+    got = []
+    st.step(0, d2h="new")
+    torch.cuda.synchronize()
+    got.append(per_frame[0])
+    for i in range(1, N_FRAMES):
+        if i == 4:
+            st.map._gc_wanted = True
+        o = st.step_direct(i, d2h="new")
+        if o is not None:
+            torch.cuda.synchronize()
+            got.append(tuple(x.clone() for x in o))
+    o = st.flush()
+    got.append(tuple(x.clone() for x in o))
+    assert len(got) == N_FRAMES
+    for a, b in zip(per_frame[1:], got[1:]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    same(outs["eager"], snapshot(st))
+
 
 def test_graph_mode_host_staging_overflow_falls_back(gpu_model):
     """A frame with more new triangles than the pinned staging area of the captured graph holds must still hand back all of them

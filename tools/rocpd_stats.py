@@ -37,6 +37,17 @@ def main():
         rows = [r for r in rows if r[1] >= t0 and (t1 is None or r[1] < t1)]
         nfr = (len([s for s in starts if s >= t0 and (t1 is None or s < t1)]))
         print(f"(restricted to dispatches from dispatch #{nth} of `{marker}` on: the timed region, {nfr} frames)\n")
+    if "--timeline" in sys.argv:            # e.g. --timeline k_prune_mark 150 : every dispatch of two frames, relative times in us
+        i = sys.argv.index("--timeline")
+        marker, nth = sys.argv[i + 1], int(sys.argv[i + 2])
+        all_rows = c.execute("select name, start, end from kernels order by start").fetchall()
+        starts = [s for n, s, e in all_rows if marker in n]
+        t0, t1 = starts[nth], starts[nth + 2]
+        print(f"timeline of two frames from dispatch #{nth} of `{marker}` (us relative to it: start, end, duration)\n")
+        for n, s, e in all_rows:
+            if t0 - 20000 <= s < t1:
+                print(f"{(s - t0) / 1e3:9.2f} {(e - t0) / 1e3:9.2f} {(e - s) / 1e3:7.2f}  {short(n)}")
+        return
     agg = {}
     for n, s, e in rows:
         k = short(n)
