@@ -358,6 +358,8 @@ def main():
     cap = 1 << 16
     p_which, p_ms = (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
     lib.dif_profile_dump(p_which, p_ms, cap, 1)
+    lib.dif_profile_enable(1)               # (fills the library's event pool outside the clock)
+    lib.dif_profile_enable(0)
     a.timed_from = a.warmup
     if not a.direct or stream.tiling is not None:
         lib.dif_profile_enable(1)           # (the direct runner switches it on for the sampled frames only)

@@ -30,7 +30,7 @@ class DifMap(Structure):
                 ("capacity", c_int64),
                 ("indexer", c_void_p), ("latent_vecs", c_void_p), ("latent_vecs_pos", c_void_p),
                 ("voxel_obs_count", c_void_p), ("dirty", c_void_p), ("voxel_optimized", c_void_p), ("counters", c_void_p),
-                ("frame_count", c_void_p), ("grid_bits", c_void_p), ("vbm", c_void_p),
+                ("frame_count", c_void_p), ("grid_bits", c_void_p), ("grid_tot", c_void_p), ("vbm", c_void_p),
                 ("rec_dir", c_void_p), ("upd_list", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
                 ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32)]

@@ -60,6 +60,21 @@ __device__ __forceinline__ void unlinearize(const Geo& g, int lin, int& ix, int&
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ---- grid bitmap whose scan totals are kept up to date by the markers -------------------------------------------------------------
+// The ordered scans over the grid bitmap (allocation candidates, voxels to decode) need the number of set bits per scan block.  A
+// marker knows when it is the first to set a bit (atomicOr returns the old word), so it counts it into the block's total right away and
+// the scan's counting pass — one launch over the whole bitmap per scan — is not needed.  `tot` is idle 0 (zeroed by the kernel that
+// follows the scan); `per_words` = words per scan block, the partition of scan_range() for the same grid.
+struct GridMarks {
+    uint32_t* bits; int* tot; int per_words;
+    __device__ __forceinline__ void set(int v) const {
+        const uint32_t b = 1u << (v & 31);
+        const int w = v >> 5;
+        const uint32_t old = atomicOr(bits + w, b);
+        if (!(old & b)) atomicAdd(tot + w / per_words, 1);
+    }
+};
+
 // ---- wave / block primitives ---------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_incl_scan(int v) {
     int lane = lane_id();
@@ -175,6 +190,23 @@ inline int scan_blocks(int64_t n_upper) {
     if (b < 1) b = 1;
     if (b > 1024) b = 1024;
     return (int)b;
+}
+
+// scan over a bitmap of `n` words whose per-block totals `tot` were maintained by GridMarks: pass 2 only (or the single-workgroup scan)
+inline int counted_scan_blocks(int64_t n) { return n <= 4096 ? 1 : scan_blocks(n); }
+inline int counted_scan_per(int64_t n) {
+    const int nb = counted_scan_blocks(n);
+    int per = (int)((n + nb - 1) / nb);
+    return (per + DIF_BLOCK - 1) / DIF_BLOCK * DIF_BLOCK;        // scan_range()'s partition
+}
+template <class F>
+inline int launch_counted_scan(F f, int n, const int* tot, hipStream_t s) {
+    if (n <= 4096) {
+        hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(1024), 0, s, f, (const int*)nullptr, n);
+    } else {
+        hipLaunchKernelGGL(k_scan_pass2<F>, dim3(scan_blocks(n)), dim3(DIF_BLOCK), 0, s, f, (const int*)nullptr, n, tot);
+    }
+    return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }
 
 template <class F>

@@ -58,6 +58,7 @@ int num_cus() {
 struct ProfRec { hipEvent_t a, b; int which; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;     // events are recycled: creating a pair costs tens of microseconds of host time per launch
 std::mutex g_prof_mu;
 struct ProfScope {
     hipStream_t s; int which; hipEvent_t a = nullptr, b = nullptr;
@@ -68,7 +69,14 @@ struct ProfScope {
         }
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;      // never put events into a captured graph
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        {
+            std::lock_guard<std::mutex> lock(g_prof_mu);
+            if (g_prof_pool.size() >= 2) {
+                a = g_prof_pool.back(); g_prof_pool.pop_back();
+                b = g_prof_pool.back(); g_prof_pool.pop_back();
+            }
+        }
+        if (!a && (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)) { a = b = nullptr; return; }
         (void)hipEventRecord(a, s);
     }
     ~ProfScope() {
@@ -78,6 +86,11 @@ struct ProfScope {
         g_prof.push_back(ProfRec{a, b, which});
     }
 };
+
+inline GridMarks grid_marks_of(const dif_map_t* map) {
+    const int64_t nwords = ((int64_t)map->nx * map->ny * map->nz + 31) / 32;
+    return GridMarks{map->grid_bits, map->grid_tot, counted_scan_per(nwords)};
+}
 
 inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096) {
     int64_t b = (n + per_block - 1) / per_block;
@@ -376,7 +389,7 @@ struct FrameSource {            // integrate straight from a depth frame: the fi
 
 static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
                           void* wsp, int64_t ws_bytes, const FrameSource* src, void* stream_) {
-    if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0) return DIF_EINVAL;
+    if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0 || !map->grid_tot) return DIF_EINVAL;
     if (N == 0) return DIF_OK;
     if (!xyz || !normal || !unq_mask || !wsp) return DIF_EINVAL;
     if (8 * N + 64 >= (int64_t)1 << 31 || map->capacity >= (int64_t)1 << 31) return DIF_EINVAL;      // record ids and slots are int32
@@ -399,16 +412,15 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C, own_lo - map->halo,
                            own_hi + map->halo);
     hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
-                       (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, map->grid_bits, C);
+                       (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, grid_marks_of(map), C);
     DIF_CHECK_LAUNCH();
     {
         AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity};
-        int nwords = (int)((grid + 31) / 32);
-        if (launch_scan(f, nullptr, nwords, nwords, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+        if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // k_prune_mark kept the block totals
     }
     hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
                        (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
-                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0);
+                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, map->grid_tot);
     DIF_CHECK_LAUNCH();
     {
         const size_t lds_bytes = (size_t)ENC_FLOATS * 4;
@@ -689,7 +701,8 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
                         float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
     const int* n_slots = map->counters + DIF_C_N_OCCUPIED;
-    uint32_t* const bits = map->grid_bits;
+    if (!map->grid_tot) return DIF_EINVAL;
+    const GridMarks bits = grid_marks_of(map);
     if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_tri || !buf->cache_id || !buf->cache_std || !buf->cache_alive)
         return DIF_EINVAL;
     if (!map->tri_start || !map->tri_n) return DIF_EINVAL;
@@ -720,9 +733,9 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         }
     }
     {
-        OccFunctor f{bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
-        int nwords = (int)((grid + 31) / 32);
-        if (launch_scan(f, nullptr, nwords, nwords, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
+        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
+        if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // the markers kept the block totals
+
     }
     int rc;
     if (fast && l * l * l <= VD_MAX_L3 && R * R <= VD_MAX_R2) {
@@ -797,6 +810,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (hipMemsetAsync(map->tri_n, 0, sizeof(int32_t) * (size_t)map->capacity, s) != hipSuccess) return DIF_ELAUNCH;
     }
     a.log_counters = C;
+    a.grid_tot = map->grid_tot;
     if (2 * (r + 1) * (r + 1) * (r + 1) <= R3) {         // the refine list is idle from here on: it carries the blended corners between the passes
         a.corner_cache = reinterpret_cast<float*>(buf->refine_list);
         a.corner_stride = R3;
@@ -918,13 +932,13 @@ static int merge_impl(const dif_map_t* map, const int32_t* records, int64_t n, c
     hipStream_t s = (hipStream_t)stream_;
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     if (hipMemsetAsync(map->counters + DIF_C_ALLOC_NEW, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, records, n, n_dev, (const int64_t*)map->indexer, map->grid_bits, grid);
+    if (!map->grid_tot) return DIF_EINVAL;
+    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, records, n, n_dev, (const int64_t*)map->indexer, grid_marks_of(map), grid);
     DIF_CHECK_LAUNCH();
     AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, map->counters, map->capacity};
-    int nwords = (int)((grid + 31) / 32);
-    if (launch_scan(f, nullptr, nwords, nwords, scratch, s) != DIF_OK) return DIF_ELAUNCH;
+    if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, records, n, n_dev, (const int64_t*)map->indexer,
-                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0);
+                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0, map->grid_tot);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -941,6 +955,11 @@ int dif_merge_halo(const dif_map_t* map, const int32_t* message, int64_t max_rec
 int dif_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on = on != 0;
+    while (on && g_prof_pool.size() < 64) {          // a frame's worth of event pairs ready before the first timed launch
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        g_prof_pool.push_back(e);
+    }
     return DIF_OK;
 }
 
@@ -954,7 +973,7 @@ static int prof_collect(std::vector<std::pair<int, float>>& out, bool reset) {
         out.emplace_back(r.which, t);
     }
     if (reset) {
-        for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
         g_prof.clear();
     }
     return DIF_OK;

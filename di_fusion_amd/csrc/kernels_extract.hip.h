@@ -6,7 +6,8 @@
 // =================================================================================================================
 // set the bitmap bits of the confident voxels among `lin` and its 6 allocated neighbours (map.py:628-631)
 __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float ignore_th, const int64_t* __restrict__ indexer,
-                                                    const float* __restrict__ obs, uint32_t* __restrict__ bits) {
+                                                    const float* __restrict__ obs, const GridMarks& marks) {
+    const uint32_t* bits = marks.bits;
     int ix, iy, iz;
     unlinearize(g, lin, ix, iy, iz);
     int cand[7];
@@ -27,11 +28,16 @@ __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float
     uint32_t word[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) word[c] = (w[c] > ignore_th) ? bits[cand[c] >> 5] : 0xFFFFFFFFu;
+    // the seven bitmap updates go out together (one round trip), then the first setters count themselves into their scan blocks
+    uint32_t prev[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
         const uint32_t b = 1u << (cand[c] & 31);
-        if (!(word[c] & b)) atomicOr(bits + (cand[c] >> 5), b);
+        prev[c] = (word[c] & b) ? 0xFFFFFFFFu : atomicOr(marks.bits + (cand[c] >> 5), b);
     }
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+        if (!(prev[c] & (1u << (cand[c] & 31)))) atomicAdd(marks.tot + (cand[c] >> 5) / marks.per_words, 1);
 }
 
 // Spatial tiling: dirty HALO voxels (flag copied from their owner by the halo refresh) are not meshed here, but they pull their
@@ -39,7 +45,7 @@ __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float
 // which neighbours are in the batch, mc_interp_kernel.cu:17-24).
 __global__ void __launch_bounds__(DIF_BLOCK) k_mark_halo_dirty(Geo g, float ignore_th, uint8_t* __restrict__ dirty, const int64_t* __restrict__ pos,
                                                              const int64_t* __restrict__ indexer, const float* __restrict__ obs,
-                                                             uint32_t* __restrict__ bits, const int* __restrict__ n_ptr, int64_t own_lo,
+                                                             GridMarks bits, const int* __restrict__ n_ptr, int64_t own_lo,
                                                              int64_t own_hi) {
     const int n = *n_ptr;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
@@ -65,7 +71,7 @@ struct DirtySet {
     float ignore_th;
     const int64_t* indexer;
     const float* obs;
-    uint32_t* bits;
+    GridMarks bits;
     int64_t own_lin_lo, own_lin_hi;     // only owned voxels are meshed (spatial tiling); the whole grid by default
     bool tiled;
     __device__ __forceinline__ bool owned(int s) const {

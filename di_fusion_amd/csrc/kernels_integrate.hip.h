@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(Geo g, cons
 // voxel has no slot marks that voxel and its 6 clamped neighbours (if empty) in the bitmap (map.py:383-386).
 __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, const int* __restrict__ pt_lin, int64_t N,
                                                         const int* __restrict__ frame_count, const int64_t* __restrict__ indexer,
-                                                        uint8_t* __restrict__ unq_mask, uint32_t* __restrict__ bits,
+                                                        uint8_t* __restrict__ unq_mask, GridMarks marks,
                                                         int* __restrict__ counters) {
+    const uint32_t* bits = marks.bits;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = lane_id();
     int lin = (i < N) ? pt_lin[i] : -2;
@@ -86,13 +87,19 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, 
         cand[4] = linearize(g, ix, clampi(iy + 1, 0, g.ny - 1), iz);
         cand[5] = linearize(g, ix, iy, clampi(iz - 1, 0, g.nz - 1));
         cand[6] = linearize(g, ix, iy, clampi(iz + 1, 0, g.nz - 1));
+        // look-ups, bitmap updates and the first setters' scan-block counts each go out as one batch
+        bool empty[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) empty[c] = indexer[cand[c]] == -1;
+        uint32_t prev[7];
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
-            int v = cand[c];
-            if (indexer[v] != -1) continue;
-            uint32_t b = 1u << (v & 31);
-            if (!(bits[v >> 5] & b)) atomicOr(bits + (v >> 5), b);
+            const uint32_t b = 1u << (cand[c] & 31);
+            prev[c] = (!empty[c] || (bits[cand[c] >> 5] & b)) ? 0xFFFFFFFFu : atomicOr(marks.bits + (cand[c] >> 5), b);
         }
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+            if (!(prev[c] & (1u << (cand[c] & 31)))) atomicAdd(marks.tot + (cand[c] >> 5) / marks.per_words, 1);
     }
 }
 
@@ -137,8 +144,11 @@ __device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restr
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
-                                                          uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w) {
+                                                          uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w,
+                                                          int* __restrict__ grid_tot) {
     __shared__ unsigned tkey[FG_TABLE];
+    if (blockIdx.x == 0)                                     // the allocation scan has consumed the bitmap's block totals: back to idle 0
+        for (int t = (int)threadIdx.x; t < 1024; t += DIF_BLOCK) grid_tot[t] = 0;
     __shared__ int tcnt[FG_TABLE];        // rows per table entry, then (after the scan) the entry's first list position within the workgroup
     __shared__ int smem[8];
     __shared__ int s_loose, s_base;

@@ -22,6 +22,7 @@ struct McArgs {
     // (both idle 0), the emit pass derives a voxel's output offset from < 256 super sums + < 256 chunk sums + < 256 counts and does
     // the log bookkeeping itself — no scan launch between the two passes.
     int32_t* chunk_sum; int32_t* super_sum; int32_t* tri_start; int32_t* tri_n;
+    int* grid_tot;                  // extract path: the grid bitmap's scan totals, returned to idle 0 here (the voxel scan has consumed them)
 };
 
 // batch index of voxel (bx,by,bz) or -1   (query_sdf_raw :13-24)
@@ -112,6 +113,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     V4* vl = reinterpret_cast<V4*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
     const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
     if (!EMIT && a.log_counters && blockIdx.x == 0 && threadIdx.x == 0) a.log_counters[DIF_C_CACHE_KEPT] = a.log_counters[DIF_C_CACHE_T];
+    if (!EMIT && a.grid_tot && blockIdx.x == 0)
+        for (int t = (int)threadIdx.x; t < 1024; t += (int)blockDim.x) a.grid_tot[t] = 0;
     if (EMIT && a.chunk_sum && blockIdx.x == 0 && wid == 0) {        // triangles of this call = sum of all chunk sums (map.py:695 counts them on the host)
         int tot = 0;
         for (int c = lane; c < (int)((K + 65535) >> 16); c += 64) tot += a.super_sum[c];
@@ -439,12 +442,12 @@ struct ExportFunctor {       // ordered compaction over slots: allocated voxels 
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n_static, const int32_t* __restrict__ n_ptr,
-                                                        const int64_t* __restrict__ indexer, uint32_t* __restrict__ bits, int64_t grid) {
+                                                        const int64_t* __restrict__ indexer, GridMarks marks, int64_t grid) {
     const int64_t n = n_ptr ? min((int64_t)*n_ptr, n_static) : n_static;       // a device-side count is bounded by the buffer's capacity
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t lin = rec[i * 32];
         if (lin < 0 || lin >= grid) continue;
-        if (indexer[lin] == -1) atomicOr(bits + (lin >> 5), 1u << (lin & 31));
+        if (indexer[lin] == -1 && !((marks.bits[lin >> 5] >> (lin & 31)) & 1u)) marks.set((int)lin);
     }
 }
 
@@ -452,8 +455,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restr
 __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __restrict__ rec, int64_t n_static, const int32_t* __restrict__ n_ptr,
                                                          const int64_t* __restrict__ indexer, float* __restrict__ latent, float* __restrict__ obs,
                                                          uint8_t* __restrict__ dirty, int* __restrict__ counters, int64_t grid, int64_t capacity,
-                                                         int assign) {
+                                                         int assign, int* __restrict__ grid_tot) {
     const int64_t n = n_ptr ? min((int64_t)*n_ptr, n_static) : n_static;
+    if (blockIdx.x == 0)                                     // the allocation scan has consumed the bitmap's block totals
+        for (int t = (int)threadIdx.x; t < 1024; t += DIF_BLOCK) grid_tot[t] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int no = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (no > capacity) { no = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }

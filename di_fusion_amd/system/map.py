@@ -159,6 +159,7 @@ class DenseIndexedMap:
             self._indexer = torch.full((self._grid,), -1, device=device, dtype=torch.long)
             self._frame_count = torch.zeros((self._grid,), device=device, dtype=torch.int32)
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
+            self._grid_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
         self._capacity = 0
         self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
@@ -217,6 +218,7 @@ class DenseIndexedMap:
         m.counters = _lib.ptr(self._counters)
         m.frame_count = _lib.ptr(self._frame_count)
         m.grid_bits = _lib.ptr(self._grid_bits)
+        m.grid_tot = _lib.ptr(self._grid_tot)
         m.vbm = _lib.ptr(vbm)
         m.rec_dir = _lib.ptr(rec_dir)
         m.upd_list = _lib.ptr(upd_list)

@@ -77,6 +77,7 @@ typedef struct dif_map {
     /* scratch, restored to its idle value by every call that touches it */
     int32_t* frame_count;           /* [nx*ny*nz] idle 0  : points of the current frame per voxel (map.py:374) */
     uint32_t* grid_bits;            /* [ceil(nx*ny*nz/32)] idle 0 : candidate / occupied voxel bitmap          */
+    int32_t* grid_tot;              /* [1024] idle 0 : set bits of grid_bits per scan block, kept by the kernels that set them */
     int32_t* vbm;                   /* [capacity] idle -1 : vec_id_batch_mapping (map.py:633-635)              */
     int32_t* rec_dir;               /* [capacity][16] idle 0 (words 0,1): the slot's encoder run records of the current integrate */
     int32_t* upd_list;              /* [capacity] slots updated by the current integrate (unique_pinds, map.py:437) */

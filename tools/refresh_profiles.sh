@@ -11,6 +11,9 @@ rm -rf $O/trace_g
 timeout 300 python bench.py --graph 1 --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 4 --graph 0 > $O/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 4 --graph 0 > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python bench.py --no-cpu-baseline --no-secondary --steps 200 --warmup 10 --graph 0 > $O/pmc_mfma.log 2>&1
+python tools/pmc_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_mfma_stream.json > $O/pmc_mfma_summary.log 2>&1
+rm -rf $O/pmc_mfma
 python tools/pmc_summary.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_hbm.json > $O/pmc_summary.log 2>&1
 timeout 900 python tools/stress_full_occupancy.py --n 128 --reps 2 > $O/stress_full.json 2> $O/stress_full.err
 timeout 900 python tools/stress_integrate.py > $O/stress_integrate.json 2> $O/stress_integrate.err
