@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the frame's launches from a captured hipGraph (every --sample-every-th frame runs "
                     "eagerly with HIP events around the MFMA kernels); 0 (default): launch them directly, two C calls per frame, HIP events on every "
-                    "--sample-every-th frame — consecutive graph launches start 50-80 us apart on the GPU on this ROCm, direct launches do not")
+                    "--sample-every-th frame — equally fast in steady state (a graph has no kernel boundaries but ~33 us between consecutive launches), and "
+                    "no re-capture when a buffer grows")
     ap.add_argument("--sample-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra run with the mesh left in HBM (keeps profiler traces to one stream)")
@@ -167,20 +168,22 @@ def frame_runner(stream, a, d2h):
 
     def run(i):
         nonlocal lib
-        if a.graph and i >= 2 and (i % a.sample_every) != 0:
+        if stream.tiling is not None or i < 2 or not (a.graph or a.direct):
+            return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
+        sampled = (i % a.sample_every) == 0
+        if a.graph and not sampled:
             return stream.step_graph(i, d2h)
-        if a.direct and i >= 2 and stream.tiling is None:
+        # direct launches (two C calls); on the sampled frames of the timed region with HIP events around the MFMA / marching-cubes kernels
+        timed = sampled and a.timed_from is not None and i >= a.timed_from
+        if timed:
             if lib is None:
                 from di_fusion_amd import _lib
                 lib = _lib.load()
-            sampled = a.timed_from is not None and i >= a.timed_from and (i % a.sample_every) == 0
-            if sampled:
-                lib.dif_profile_enable(1)               # HIP events around this frame's MFMA / marching-cubes kernels (the roofline sample)
-            out = stream.step_direct(i, d2h)
-            if sampled:
-                lib.dif_profile_enable(0)
-            return out
-        return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
+            lib.dif_profile_enable(1)
+        out = stream.step_direct(i, d2h)
+        if timed:
+            lib.dif_profile_enable(0)
+        return out
 
     def drain():
         stream.flush(d2h)
@@ -325,7 +328,7 @@ def main():
     n_frames = a.warmup + a.steps
     if tiled and world > 1:
         a.graph = 0                         # the halo exchange sits between the kernels of a frame: eager, host one frame ahead
-    a.direct = not a.graph and a.pipeline
+    a.direct = bool(a.pipeline)
     a.timed_from = None
 
     def make_stream():
@@ -361,8 +364,8 @@ def main():
     lib.dif_profile_enable(1)               # (fills the library's event pool outside the clock)
     lib.dif_profile_enable(0)
     a.timed_from = a.warmup
-    if not a.direct or stream.tiling is not None:
-        lib.dif_profile_enable(1)           # (the direct runner switches it on for the sampled frames only)
+    if not (a.graph or a.direct) or stream.tiling is not None:
+        lib.dif_profile_enable(1)           # (otherwise the runner switches it on for the sampled frames only)
     gc.collect()
     gc.disable()            # a generation-2 collection in the middle of a 70 ms timed region shows up as a 20 % outlier
     barrier()
@@ -390,7 +393,7 @@ def main():
     if rank == 0:
         st = stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
-        sampled_only = a.graph or (a.direct and stream.tiling is None)
+        sampled_only = (a.graph or a.direct) and stream.tiling is None
         timed_idx = [j for j in range(a.steps) if not (sampled_only and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
         # the event records come in launch order, one k_encode per event-timed frame: cut the list into frames there
         per_frame = []
@@ -401,9 +404,9 @@ def main():
             per_frame[-1].append((name, float(p_ms[k])))
         if len(per_frame) != len(timed_idx):        # (an empty frame launches no encoder) fall back to one group
             per_frame, timed_idx = [[r for f in per_frame for r in f]], timed_idx[:1] if timed_idx else []
-        launch = (f"hipGraph replay, 1 frame in {a.sample_every} eager with HIP events (roofline sample)" if a.graph else
-                  f"direct launches (two C calls per frame), host one frame ahead, HIP events on 1 frame in {a.sample_every} (roofline sample)"
-                  if sampled_only else "eager, host one frame ahead")
+        launch = ("eager, host one frame ahead" if not sampled_only else
+                  f"hipGraph replay; 1 frame in {a.sample_every} launched directly with HIP events (roofline sample)" if a.graph else
+                  f"direct launches (two C calls per frame), host one frame ahead, HIP events on 1 frame in {a.sample_every} (roofline sample)")
         pixels = intr.width * intr.height
         value = (a.steps if tiled else world * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
         out = {"metric": f"frames/s integrate+decode+mesh, {intr.width}x{intr.height} synthetic stream", "value": round(value, 3),

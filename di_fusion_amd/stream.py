@@ -177,9 +177,9 @@ class FusionStream:
     # ---- direct variant: the frame's launches are enqueued by two C calls, the host stays ahead of the GPU ------------------------------
     # The same per-frame protocol as `step_graph` below (frame descriptor in, counters + new triangles out through pinned host memory,
     # written by the frame's first / last kernel; results picked up one frame later), but the ~17 kernels are launched directly:
-    # `dif_integrate_frame` + `dif_extract` enqueue them back to back in ~60 us of host time for ~230 us of GPU time, so the queue never
-    # runs dry.  A replayed hipGraph needs less host time still, but on this ROCm consecutive graph launches on one stream start
-    # 50-80 us apart on the GPU (measured: profiles/README.md), which at 0.23 ms of kernels per frame costs a fifth of the throughput.
+    # `dif_integrate_frame` + `dif_extract` enqueue them back to back in ~60 us of host time for ~250 us of GPU time, so the queue never
+    # runs dry.  A replayed hipGraph has no kernel boundaries inside a frame, but consecutive graph launches on one stream start ~33 us
+    # apart on the GPU (profiles/r02_timeline_graph.txt): the two come out equal, and this path needs no re-capture when a buffer grows.
     DIRECT_SLOTS = 4
 
     def _direct_prepare(self):
