@@ -111,6 +111,7 @@ def load() -> ctypes.CDLL:
     """Load libdifusion.so; loud failure when it has not been built (`python __graft_entry__.py build`)."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  (torch's copy of the HIP runtime must be the one in the process before the library binds to it)
         if not LIB_PATH.exists():
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc, gfx950). di_fusion_amd has no CPU fallback.")
