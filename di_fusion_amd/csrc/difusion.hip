@@ -575,7 +575,7 @@ int dif_decode_rows(const dif_weights_t* w, const float* rows, int64_t n, float*
     return launch_decode(A, w, (n + 31) / 32, (hipStream_t)stream);
 }
 
-// encoder on explicit rows: one work item per 256 rows, partial sums are not what we want here, so a dedicated small kernel
+// encoder on explicit rows (flat op / tests): per-row outputs instead of per-voxel sums, so a dedicated small kernel
 namespace {
 __global__ void __launch_bounds__(512, 2) k_encode_rows(const float* __restrict__ wblob, const float* __restrict__ rows, int64_t n, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

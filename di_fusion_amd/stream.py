@@ -253,7 +253,7 @@ class FusionStream:
         self._pending = h
         return out
 
-    # ---- hipGraph variant: the 19 launches of a frame are captured once and replayed ----------------------------------------
+    # ---- hipGraph variant: the 14 launches of a frame are captured once and replayed ----------------------------------------
     # Everything a frame launches has host-independent shapes (device counters carry the sizes), so a frame is a static graph: write the
     # frame descriptor (input pointers + pose) into pinned host memory, replay, read the counters and the new triangles out of pinned
     # host memory one frame later.  Re-captured only when a buffer is re-allocated (capacity growth).

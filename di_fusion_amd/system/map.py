@@ -101,7 +101,7 @@ class _GetSdfFn(torch.autograd.Function):
 
 
 _OVERFLOW_WHAT = {1: "more voxels than latent rows", 2: "more dirty voxels than extract buffers", 3: "more decoded voxels than extract buffers",
-                  4: "more encoder work items than workspace", 5: "mesh-cache log full", 6: "more records than the export buffer"}
+                  5: "mesh-cache log full", 6: "more records than the export buffer"}
 
 
 def _next_pow2(n: int) -> int:
