@@ -46,6 +46,9 @@ def parse():
                     "--sample-every-th frame — equally fast in steady state (a graph has no kernel boundaries but ~33 us between consecutive launches), and "
                     "no re-capture when a buffer grows")
     ap.add_argument("--sample-every", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=0, help="F > 0: between the sampled frames, F consecutive frames go into ONE captured hipGraph "
+                    "(no kernel boundaries inside, one ~33 us launch gap per F frames); for streams whose poses are known ahead; F = sample-every - 1 "
+                    "fills the space between two sampled frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra run with the mesh left in HBM (keeps profiler traces to one stream)")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed per thread setting by the CPU baseline (after 2 warm-ups)")
@@ -165,12 +168,19 @@ def prime_process(FusionStream, syn, model, intr, dev, d2h):
 def frame_runner(stream, a, d2h):
     """(run(i), drain()) for the chosen way of driving a frame."""
     lib = None
+    skip_until = 0
 
     def run(i):
-        nonlocal lib
+        nonlocal lib, skip_until
+        if i < skip_until:                                  # part of a batch that is already enqueued
+            return None
         if stream.tiling is not None or i < 2 or not (a.graph or a.direct):
             return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
         sampled = (i % a.sample_every) == 0
+        F = a.batch
+        if F > 0 and not sampled and i + F <= a.n_frames and not (i < a.warmup < i + F) and all(((i + j) % a.sample_every) != 0 for j in range(F)):
+            skip_until = i + F
+            return stream.step_batch(i, F, d2h)             # F frames, one graph launch
         if a.graph and not sampled:
             return stream.step_graph(i, d2h)
         # direct launches (two C calls); on the sampled frames of the timed region with HIP events around the MFMA / marching-cubes kernels
@@ -186,15 +196,16 @@ def frame_runner(stream, a, d2h):
         return out
 
     def drain():
-        stream.flush(d2h)
+        stream.flush_all(d2h)
     return run, drain
 
 
-def rate_with_mesh_left_in_hbm(make_stream, a, n_frames):
-    """Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream without the per-frame hand-over of
-    the new triangles to pinned host memory.  The difference is PCIe traffic, not kernels."""
-    s2 = make_stream()
-    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30, "timed_from": None}), "none")
+def secondary_rate(make_stream, a, n_frames, d2h, batch):
+    """Secondary figures (N=1 only, reported next to `value`, never instead of it): the same stream (i) without the per-frame hand-over
+    of the new triangles to pinned host memory — the difference is PCIe traffic, not kernels — and (ii) with 5 frames per captured
+    hipGraph, for callers that know their poses ahead (no kernel boundaries inside a graph, one launch gap per 5 frames)."""
+    s2 = make_stream(batch)
+    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30, "timed_from": None, "batch": batch}), d2h)
     for i in range(a.warmup):
         run2(i)
     drain2()
@@ -330,12 +341,19 @@ def main():
         a.graph = 0                         # the halo exchange sits between the kernels of a frame: eager, host one frame ahead
     a.direct = bool(a.pipeline)
     a.timed_from = None
+    a.n_frames = n_frames
 
-    def make_stream():
+    def make_stream(batch=None):
+        batch = a.batch if batch is None else batch
         if tiled:           # every rank renders the same stream and owns one x-slab of the grid
             return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, noise=bool(a.noise), initial_capacity=1 << 18,
                                 tiling=(rank, world, None))
-        return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))   # own arc of the orbit
+        # (a batch of F frames needs room for the worst-case allocations of two batches in flight: sized up front instead of growing in the clock)
+        cap0 = 1 << 16
+        while batch > 0 and cap0 < (2 * batch + 1) * 7 * (intr.width * intr.height // 17) + (1 << 16):
+            cap0 *= 2
+        return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise),
+                            initial_capacity=cap0)   # own arc of the orbit
 
     stream = make_stream()
     lib = _lib.load()
@@ -384,9 +402,11 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    hbm_resident = None
-    if world == 1 and a.d2h != "none" and not a.no_secondary:
-        hbm_resident = rate_with_mesh_left_in_hbm(make_stream, a, n_frames)
+    hbm_resident = batched = None
+    if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled:
+        hbm_resident = secondary_rate(make_stream, a, n_frames, "none", 0)
+        if a.batch == 0 and (a.graph or a.direct):
+            batched = secondary_rate(make_stream, a, n_frames, a.d2h, 5)
     merge_info = global_map_merge(stream, model, cfg, dev, barrier) if (use_dist and not tiled) else None
 
     out = None
@@ -405,6 +425,8 @@ def main():
         if len(per_frame) != len(timed_idx):        # (an empty frame launches no encoder) fall back to one group
             per_frame, timed_idx = [[r for f in per_frame for r in f]], timed_idx[:1] if timed_idx else []
         launch = ("eager, host one frame ahead" if not sampled_only else
+                  f"{a.batch} frames per captured hipGraph between the sampled frames; 1 frame in {a.sample_every} launched directly with HIP events "
+                  "(roofline sample)" if a.batch > 0 else
                   f"hipGraph replay; 1 frame in {a.sample_every} launched directly with HIP events (roofline sample)" if a.graph else
                   f"direct launches (two C calls per frame), host one frame ahead, HIP events on 1 frame in {a.sample_every} (roofline sample)")
         pixels = intr.width * intr.height
@@ -423,6 +445,7 @@ def main():
                           "avg_per_frame_rank0": {k: round(float(np.mean([s[k] for s in st])), 1)
                                                   for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
+                          "frames_per_s_with_5_frames_per_hipgraph": batched,
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info},
                "roofline": roofline_block(per_frame, [st[j] for j in timed_idx])}

@@ -59,6 +59,9 @@ class FusionStream:
         self._zc = None
         self._d_slots = None
         self._d_sig = None
+        self._b_slots = None
+        self._d2h_mode = "new"
+        self.backlog = []                   # outputs of a pending batch's earlier frames, when a frame-by-frame step had to complete it
 
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
@@ -97,9 +100,11 @@ class FusionStream:
     def _before_frame(self):
         """The D2H of the previous frame's triangles (side stream) reads a region of the mesh-cache LOG that later frames only append
         behind, so the next frame does not wait for it — unless the log is about to be compacted."""
-        if self.map._gc_wanted and self._copy_done is not None:
-            self._copy_done.synchronize()
-            self._copy_done = None
+        if self.map._gc_wanted:
+            self._complete_batch_before_gc(self._d2h_mode)
+            if self._copy_done is not None:
+                self._copy_done.synchronize()
+                self._copy_done = None
 
     # ---- pipelined variant: no host wait inside the frame -----------------------------------------------------------------
     def _enqueue_frame(self, i: int):
@@ -143,7 +148,7 @@ class FusionStream:
         if d2h == "new":
             n = tri.size(0)
             k = handle.get("host_out")
-            if k is not None and n <= self.HOST_OUT_TRIANGLES:
+            if k is not None and n <= handle.get("host_capacity", self.HOST_OUT_TRIANGLES):
                 hp = handle["host_slots"][k]["out"] if "host_slots" in handle else self._zc[2][k]      # already there: written by the frame's last kernel
                 out = (hp[0][:n], hp[1][:n], hp[2][:n])
             else:
@@ -158,21 +163,26 @@ class FusionStream:
         """Same work per frame as `step`, software-pipelined by one frame: frame i is enqueued, then frame i-1 (already finished or
         finishing on the GPU) is completed on the host — counter read-back, D2H of its new triangles on a side stream.  The mesh
         handed back is the previous frame's; call `flush()` after the last frame."""
+        self._d2h_mode = d2h
         h = self._enqueue_frame(i)
         out = None
-        if self._pending is not None:
-            out = self._finish_frame(self._pending, d2h)
+        done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
+        if done:
+            self.backlog += done[:-1]
+            out = done[-1]
         self._pending = h
         return out
 
     def flush(self, d2h: str = "new"):
-        out = None
-        if self._pending is not None:
-            out = self._finish_frame(self._pending, d2h)
-            self._pending = None
+        """Complete what is pending; returns the last frame's output (`flush_all` returns every pending frame's)."""
+        outs = self.flush_all(d2h)
+        return outs[-1] if outs else None
+
+    def flush_all(self, d2h: str = "new"):
+        outs = self._finish_pending(d2h)
         with torch.cuda.device(self.device):
             self._copy_stream.synchronize()
-        return out
+        return outs
 
     # ---- direct variant: the frame's launches are enqueued by two C calls, the host stays ahead of the GPU ------------------------------
     # The same per-frame protocol as `step_graph` below (frame descriptor in, counters + new triangles out through pinned host memory,
@@ -214,6 +224,7 @@ class FusionStream:
     def step_direct(self, i: int, d2h: str = "new"):
         """One frame enqueued with two C calls (no graph), host one frame ahead; returns the previous frame's output like `step_pipelined`."""
         m = self.map
+        self._d2h_mode = d2h
         if self.tiling is not None:
             raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
         N = self.intr.height * self.intr.width
@@ -224,11 +235,13 @@ class FusionStream:
             if m._ws is None or m._xbuf is None or m._cache is None:
                 raise RuntimeError("run at least one eager step before step_direct (buffers are sized there)")
             if m._n_occ_ub + may_add > m._capacity and self._pending is not None:
-                out = self._finish_frame(self._pending, d2h)     # make the bound exact before deciding to grow
-                self._pending = None
+                done = self._finish_pending(d2h)                 # make the bound exact before deciding to grow
+                self.backlog += done[:-1]
+                out = done[-1]
             m._ensure_capacity(may_add)
             self._before_frame()
             if m._gc_wanted:
+                self._complete_batch_before_gc(d2h)
                 m._cache_gc()
             self._direct_prepare()
             k = self._d_seq % self.DIRECT_SLOTS
@@ -248,10 +261,130 @@ class FusionStream:
             sl["event"].record()
             h = dict(event=sl["event"], counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
                      host_out=(k if export else None), host_slots=self._d_slots)
-        if self._pending is not None:
-            out = self._finish_frame(self._pending, d2h)
+        done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
+        if done:
+            self.backlog += done[:-1]
+            out = done[-1]
         self._pending = h
         return out
+
+    # ---- batched variant: F consecutive frames captured into ONE hipGraph -------------------------------------------------------------
+    # Inside a replayed graph the kernels follow each other without the ~2 us boundary of separate launches, but consecutive graph
+    # launches start ~33 us apart on the GPU (profiles/r02_timeline_graph.txt).  For a stream whose poses are known ahead (offline
+    # reconstruction, this benchmark) F frames go into one graph: one such gap per F frames, no boundaries inside.  Every frame still
+    # reads its own descriptor and hands its own counters / new triangles to pinned host memory; the host collects a batch's results
+    # while the next batch runs.  Bit-identical to the frame-by-frame paths (tests/test_gpu_stream.py).
+    BATCH_HOST_OUT_TRIANGLES = 1 << 16
+
+    def _batch_prepare(self, F: int, export: bool):
+        m, dev, intr = self.map, self.device, self.intr
+        H, W = intr.height, intr.width
+        lib = _lib.load()
+        if self._b_slots is None or len(self._b_slots[0]) != F:
+            cap = self.BATCH_HOST_OUT_TRIANGLES
+            self._b_slots = [[dict(frame=torch.zeros((64,), dtype=torch.uint8).pin_memory(),
+                                   counters=torch.zeros((_lib.C_COUNT,), dtype=torch.int32).pin_memory(),
+                                   out=(torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
+                                        torch.empty((cap, 3), dtype=torch.float32).pin_memory())) for _ in range(F)] for _ in range(2)]
+            for g in self._b_slots:
+                for sl in g:
+                    sl["frame_np"], sl["counters_np"] = sl["frame"].numpy(), sl["counters"].numpy()
+            self._b_events = [torch.cuda.Event(), torch.cuda.Event()]
+            self._b_mask = torch.empty((H * W,), dtype=torch.uint8, device=dev)
+            self._b_seq = 0
+            self._b_sig = None
+            if self._d_slots is None:
+                self._d_desc = None
+            self._b_desc = [np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8).copy()
+                            for i, (R, t) in enumerate(self.poses)]
+        sig = (export, F, m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr())
+        if self._b_sig != sig:
+            torch.cuda.synchronize()
+            w = m.model.packed.weights_struct(dev)
+            self._b_graphs = []
+            for g in range(2):
+                bufs = []
+                for sl in self._b_slots[g]:
+                    _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+                    buf.counters_out = _lib.ptr(sl["counters"])
+                    if export:
+                        buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"])
+                        buf.out_capacity = self.BATCH_HOST_OUT_TRIANGLES
+                    bufs.append(buf)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    sp = _lib.stream_ptr()
+                    for sl, buf in zip(self._b_slots[g], bufs):
+                        _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, intr.fx, intr.fy, intr.cx,
+                                                           intr.cy, _lib.ptr(self.xyz), _lib.ptr(self.nrm), _lib.ptr(self._b_mask), _lib.ptr(m._ws),
+                                                           m._ws.numel(), sp), "dif_integrate_frame")
+                        _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1,
+                                                   float(self.max_std), 0, 1, sp), "dif_extract")
+                self._b_graphs.append((graph, bufs))
+            self._b_sig = (export, F, m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr())
+            self.n_captures += 1
+
+    def step_batch(self, i0: int, F: int, d2h: str = "new"):
+        """Frames i0 .. i0+F-1 enqueued as ONE graph launch; returns the list of the outputs of everything that was pending before
+        (the previous batch, or a frame of one of the frame-by-frame paths), oldest first."""
+        m = self.map
+        self._d2h_mode = d2h
+        if self.tiling is not None:
+            raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
+        N = self.intr.height * self.intr.width
+        prune = int(m.args.prune_min_vox_obs)
+        may_add = F * (7 * (N // (prune + 1)) if prune > 0 else 7 * N)
+        outs = []
+        with torch.cuda.device(self.device):
+            if m._ws is None or m._xbuf is None or m._cache is None:
+                raise RuntimeError("run at least one eager step before step_batch (buffers are sized there)")
+            if m._n_occ_ub + may_add > m._capacity:
+                outs += self._finish_pending(d2h)                # make the bound exact before deciding to grow
+            m._ensure_capacity(may_add)
+            self._before_frame()
+            if m._gc_wanted:
+                outs += self._finish_pending(d2h)
+                m._cache_gc()
+            export = d2h == "new"
+            self._batch_prepare(F, export)
+            g = self._b_seq % 2
+            self._b_seq += 1
+            for j, sl in enumerate(self._b_slots[g]):
+                sl["frame_np"][:] = self._b_desc[i0 + j]
+            self._b_graphs[g][0].replay()
+            m.mesh_cache.invalidate_host_copy()
+            ev = self._b_events[g]
+            ev.record()
+            hs = [dict(event=ev, counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
+                       host_out=(j if export else None), host_slots=self._b_slots[g], host_capacity=self.BATCH_HOST_OUT_TRIANGLES)
+                  for j, sl in enumerate(self._b_slots[g])]
+        outs += self._finish_pending(d2h)
+        self._pending = hs
+        return outs
+
+    def _complete_batch_before_gc(self, d2h: str):
+        """A compaction of the mesh-cache log moves entries: with ONE extract pending its triangles are simply the new log's tail, with a
+        batch pending they are not — so a pending batch is completed (into `backlog`) before the log is compacted."""
+        if isinstance(self._pending, list):
+            self.backlog += self._finish_pending(d2h)
+
+    def _finish_pending(self, d2h: str):
+        """Complete whatever is pending (one frame handle or a batch's list of them); returns the outputs, oldest first."""
+        p, self._pending = self._pending, None
+        if p is None:
+            return []
+        if not isinstance(p, list):
+            return [self._finish_frame(p, d2h)]
+        outs = []
+        for h in p:
+            out = self._finish_frame(h, d2h)
+            if self._pin is not None and out[0].numel() and out[0].data_ptr() == self._pin[0].data_ptr():
+                # an update larger than the batch's pinned staging went through the shared fallback buffer: the next frame of the batch
+                # will reuse it, so this one gets a copy of its own
+                self._copy_done.synchronize()
+                out = tuple(x.clone() for x in out)
+            outs.append(out)
+        return outs
 
     # ---- hipGraph variant: the 14 launches of a frame are captured once and replayed ----------------------------------------
     # Everything a frame launches has host-independent shapes (device counters carry the sizes), so a frame is a static graph: write the
@@ -311,6 +444,7 @@ class FusionStream:
         """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: writing a 64-byte frame descriptor
         into pinned memory and one graph launch)."""
         m = self.map
+        self._d2h_mode = d2h
         if self.tiling is not None:
             raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
         N = self.intr.height * self.intr.width
@@ -322,11 +456,13 @@ class FusionStream:
                 raise RuntimeError("run at least one eager step before step_graph (buffers are sized there)")
             if m._n_occ_ub + may_add > m._capacity:
                 if self._pending is not None:                    # make the bound exact before deciding to grow
-                    out = self._finish_frame(self._pending, d2h)
-                    self._pending = None
+                    done = self._finish_pending(d2h)
+                    self.backlog += done[:-1]
+                    out = done[-1]
             m._ensure_capacity(may_add)
             self._before_frame()
             if m._gc_wanted:
+                self._complete_batch_before_gc(d2h)
                 m._cache_gc()
             self._graph_export = (d2h == "new")
             if self._graphs is None or self._graph_sig != self._graph_signature():
@@ -343,7 +479,9 @@ class FusionStream:
             ev.record()
             h = dict(event=ev, counters=pc, epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
                      host_out=(k if self._graph_export else None))
-        if self._pending is not None:
-            out = self._finish_frame(self._pending, d2h)
+        done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
+        if done:
+            self.backlog += done[:-1]
+            out = done[-1]
         self._pending = h
         return out

@@ -101,6 +101,32 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     same(outs["eager"], snapshot(st))
 
 
+def test_batched_graph_matches_frame_by_frame(gpu_model):
+    """F frames captured into one hipGraph (`step_batch`): every frame's mesh update and the final map must equal the eager run bit for
+    bit — with a tiny pinned staging area (fallback export for larger updates), mixed with a direct frame, and across a compaction."""
+    ref = make_stream(gpu_model)
+    want = [tuple(x.clone() for x in ref.step(i, d2h="new")) for i in range(N_FRAMES)]
+    torch.cuda.synchronize()
+    want_state = snapshot(ref)
+    st = make_stream(gpu_model)
+    st.BATCH_HOST_OUT_TRIANGLES = 512
+    got = [tuple(x.clone() for x in st.step(0, d2h="new"))]
+    outs = st.step_batch(1, 2, d2h="new")                       # frames 1, 2
+    outs += st.step_batch(3, 2, d2h="new")                      # frames 3, 4 (completes the first batch)
+    torch.cuda.synchronize()
+    got += [tuple(x.clone() for x in o) for o in outs]
+    st.map._gc_wanted = True
+    o = st.step_direct(5, d2h="new")                            # the compaction completes the pending batch first: its frames are in `backlog`
+    torch.cuda.synchronize()
+    assert o is None and len(st.backlog) == 2
+    got += [tuple(x.clone() for x in b) for b in st.backlog]
+    got += [tuple(x.clone() for x in b) for b in st.flush_all()]
+    assert len(got) == N_FRAMES
+    for a, b in zip(want, got):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    same(want_state, snapshot(st))
+
+
 def test_graph_mode_host_staging_overflow_falls_back(gpu_model):
     """A frame with more new triangles than the pinned staging area of the captured graph holds must still hand back all of them
     (through the side-stream export)."""
