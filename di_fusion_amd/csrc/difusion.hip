@@ -747,18 +747,25 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         const bool fold = w->dec_fold_packed && w->dec_fold_packed_floats == DECF_FLOATS && buf->fold_table;
         V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
         V.low.res = l; V.low.a = (float)sample_a; V.low.vsize = (l > 1) ? (float)((sample_b - sample_a) / (l - 1)) : 0.0f;
-        const size_t lds_bytes = ((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 4 * VD_WAVE_LDS_FLOATS) * 4;       // four pairs of waves
+        const bool x6 = fold && w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES;       // tiles on the bf16 matrix pipe (mlp.hip.h)
+        const size_t lds_bytes = x6 ? (size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4
+                                    : ((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 4 * VD_WAVE_LDS_FLOATS) * 4;       // four pairs of waves
         static bool attr_set[64] = {};
         int dev = 0; (void)hipGetDevice(&dev);
         if (dev < 64 && !attr_set[dev]) {
-            if (hipFuncSetAttribute((const void*)k_decode_voxels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+            const int fp32_bytes = (int)(((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 4 * VD_WAVE_LDS_FLOATS) * 4);
+            const int x6_bytes = (int)((size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4);
+            if (hipFuncSetAttribute((const void*)k_decode_voxels<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fp32_bytes) != hipSuccess) return DIF_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)k_decode_voxels<true>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)k_decode_refine_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
             attr_set[dev] = true;
         }
         int64_t blocks = (buf->max_voxels + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
         {
             ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
-            hipLaunchKernelGGL(k_decode_voxels, dim3((int)blocks), dim3(512), lds_bytes, s, V, w->dec_packed);
+            if (x6) hipLaunchKernelGGL(k_decode_voxels<true>, dim3((int)blocks), dim3(512), lds_bytes, s, V, (const float*)w->dec_x6_packed);
+            else hipLaunchKernelGGL(k_decode_voxels<false>, dim3((int)blocks), dim3(512), lds_bytes, s, V, w->dec_packed);
         }
         DIF_CHECK_LAUNCH();
         DecodeArgs Rf = {};
@@ -766,7 +773,17 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         Rf.lat.res = R; Rf.lat.a = (float)sample_a; Rf.lat.vsize = (float)((sample_b - sample_a) / (R - 1));
         Rf.fold_table = fold ? buf->fold_table : nullptr;
         Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
-        rc = launch_decode(Rf, w, buf->max_voxels * (int64_t)(R3 / 32), s);
+        if (x6) {
+            int64_t rblocks = (buf->max_voxels * (int64_t)(R3 / 32) + 7) / 8;
+            if (rblocks < 1) rblocks = 1;
+            if (rblocks > num_cus()) rblocks = num_cus();
+            ProfScope prof(DIF_PROF_DECODE_POINTS, s);
+            hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed);
+            DIF_CHECK_LAUNCH();
+            rc = DIF_OK;
+        } else {
+            rc = launch_decode(Rf, w, buf->max_voxels * (int64_t)(R3 / 32), s);
+        }
         if (rc != DIF_OK) return rc;
     } else if (fast) {
         // low lattice decode (map.py:644-653)

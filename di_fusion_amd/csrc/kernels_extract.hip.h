@@ -259,6 +259,32 @@ __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(Decod
     }
 }
 
+// Refine rows (mode 1 with the lattice pass's fold table) on the bf16 matrix pipe; wblob = packing.py:pack_decoder_x6.
+__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, X6_LDS_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int res3 = A.lat.res * A.lat.res * A.lat.res, r = A.lat.res;
+    const int64_t n_rows = A.n_ptr ? (int64_t)(*A.n_ptr) : A.n_static;
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+        const int64_t row = tile * 32 + col;
+        const bool live = row < n_rows;
+        const int e = live ? A.list[row] : 0;
+        const int b = e / res3, s = e - b * res3;
+        const float px = A.lat.coord(s / (r * r)), py = A.lat.coord((s / r) % r), pz = A.lat.coord(s % r);
+        float sdf, sd;
+        decoder_tile_folded_x6(lds, wfwd, FoldInitGlobal{A.fold_table + (int64_t)b * 256}, px, py, pz, lane, sdf, sd);
+        if (live) {
+            if (half == 0) A.out_sdf[e] = A.sign * sdf;
+            else A.out_std[e] = sd;
+        }
+    }
+}
+
 // Trilinear x2 upsample (align_corners) of the low lattice + selection of samples to re-decode (map.py:655-667).
 // ATen CPU semantics (see oracle.trilinear_upsample_align_corners): per axis src = scale*j, i0 = int(src),
 // lam1 = src - i0, lam0 = 1 - lam1, two-tap value = fma(t0, lam0, t1*lam1), w innermost then h then d.
@@ -365,15 +391,18 @@ __device__ unsigned long long g_vd_trace[2048 * 8];
 #define VD_STAMP(slot) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
+// X6: the tiles run on the bf16 matrix pipe (decoder_tile_folded_x6; wblob = packing.py:pack_decoder_x6, folding required)
+template <bool X6>
+__global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     VD_STAMP(0);
-    stage_weights(lds, wblob, DEC_LDS_FLOATS);
+    constexpr int LDS_W = X6 ? X6_LDS_BYTES / 4 : ((DEC_LDS_FLOATS + 3) & ~3);
+    stage_weights(lds, wblob, X6 ? X6_LDS_BYTES / 4 : DEC_LDS_FLOATS);
     VD_STAMP(1);
-    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6 ? X6_BYTES / 4 : DEC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
     const int pair = wid >> 1, tsel = wid & 1;                 // wave `tsel` of the pair that owns the voxel
-    float* w_low_sdf = lds + ((DEC_LDS_FLOATS + 3) & ~3) + pair * VD_WAVE_LDS_FLOATS;       // shared by the pair
+    float* w_low_sdf = lds + LDS_W + pair * VD_WAVE_LDS_FLOATS;       // shared by the pair
     float* w_low_std = w_low_sdf + VD_MAX_L3;
     float* w_fold = w_low_std + VD_MAX_L3 + tsel * 256;        // [c0 | c3], see decoder_fold_consts: each wave keeps its own copy (no barrier before the MFMAs)
     const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
@@ -394,19 +423,21 @@ __global__ void __launch_bounds__(512, 2) k_decode_voxels(VoxelDecodeArgs A, con
             const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
             const int s = tsel * 32 + col;
             const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
-            float sdf, sd;
+            float sdf = 0.0f, sd = 0.0f;
             // ---- this wave's tile of the low lattice -> LDS (map.py:644-653) ----
-            if (A.fold_w) {
+            if (X6 || A.fold_w) {
                 // the voxel's latent goes through lin0 / lin3 once (VALU), every sample then only adds its coordinate columns (MFMA)
-                decoder_fold_consts(lds, A.fold_w, lat_row, w_fold, lane);
+                if constexpr (X6) decoder_fold_consts_x6(lds, A.fold_w, lat_row, w_fold, lane);
+                else decoder_fold_consts(lds, A.fold_w, lat_row, w_fold, lane);
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 if (tsel == 0) {
                     float* rec = A.fold_table + (int64_t)b * 256;          // the refine pass picks the constants up from here
                     for (int p = lane; p < 256; p += 64) rec[p] = w_fold[p];
                 }
-                decoder_tile_folded(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
-            } else {
+                if constexpr (X6) decoder_tile_folded_x6(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
+                else decoder_tile_folded(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
+            } else if constexpr (!X6) {
                 f16v xin;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {

@@ -308,6 +308,191 @@ __device__ __forceinline__ void decoder_tile_folded(const float* __restrict__ W 
     stdv = 0.05f + 0.5f * sp;                                              // di_decoder.py:68
 }
 
+// ---- fp32 products on the bf16 matrix pipe ("x6") --------------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the f32-input MFMA.  An fp32 value is the exact sum of three bf16 slices
+// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); the differences are exact), a product of two slices is exact in the
+// fp32 accumulator, and the six slice products of weight >= 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) give the fp32
+// product to ~2^-24 relative: the rounding class of the f32 MFMA (against float64, 128-term dot products: 1.05e-6 vs 1.42e-6 for
+// v_mfma_f32_32x32x2_f32) in 6/16 of its pipe time.  The chaining is the same as above: registers 8s..8s+7 of a D fragment are the
+// eight k values (k = 8*half + j) of k-step s of the next layer, for which packing.py:pack_A_x6 lays out the weight slices.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+struct Tri { u4v q0, q1, q2; };                       // hi / mid / lo slices of 8 values (A: one weight row chunk, B: one point's chunk)
+
+__device__ __forceinline__ f16v mfb(u4v a, u4v b, f16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {        // RNE, lo -> bits 15:0
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// slices of the value pair (a, b) -> dword p of the three fragments
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(sa, sb);
+}
+__device__ __forceinline__ void split_pair_into(const f16v& h, int s, int p, Tri& t) {
+    unsigned p0, p1, p2;
+    split_pair(h[8 * s + 2 * p], h[8 * s + 2 * p + 1], p0, p1, p2);
+    t.q0[p] = p0; t.q1[p] = p1; t.q2[p] = p2;
+}
+
+struct LdsX6 {                  // step t = 3 consecutive 1 KB fragments
+    const u4v* p;
+    __device__ __forceinline__ Tri load(int t, int lane) const { const u4v* q = p + t * 192 + lane; return Tri{q[0], q[64], q[128]}; }
+};
+struct BufX6 {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int base;                   // byte offset of step 0 (wave-uniform)
+    __device__ __forceinline__ Tri load(int t, int lane) const {
+        const int o = base + t * 3072;
+        return Tri{__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o, 0), __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o + 1024, 0),
+                   __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o + 2048, 0)};
+    }
+};
+
+// acc[mo] += W[mo-block][input blocks KB0..KB1) * hin, input blocks outermost (each block is sliced once, while the previous block's
+// MFMAs run: one value pair per step), weight fragments PF steps ahead of their use.  Step order = memory order of the source.
+template <int KB0, int KB1, int NMO, int PF, class SRC>
+__device__ __forceinline__ void layer_x6(const SRC& A, const f16v* hin, f16v* acc, int lane) {
+    constexpr int NS = (KB1 - KB0) * 2 * NMO;
+    Tri ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (i < NS) ring[i] = A.load(i, lane);
+    Tri x[2], xn[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split_pair_into(hin[KB0], i >> 2, i & 3, x[i >> 2]);
+#pragma unroll
+    for (int kb = KB0; kb < KB1; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int mo = 0; mo < NMO; ++mo) {
+                const int u = s * NMO + mo;                      // step within the block, 0 .. 2*NMO-1
+                const int t = (kb - KB0) * 2 * NMO + u;
+                const Tri a = ring[t % PF];
+                if (t + PF < NS) ring[t % PF] = A.load(t + PF, lane);
+                if (kb + 1 < KB1) {                              // next block's slices, spread over this block's steps
+                    constexpr int per = (8 + 2 * NMO - 1) / (2 * NMO);
+#pragma unroll
+                    for (int i = u * per; i < (u + 1) * per && i < 8; ++i) split_pair_into(hin[kb + 1], i >> 2, i & 3, xn[i >> 2]);
+                }
+                f16v c = acc[mo];
+                c = mfb(a.q2, x[s].q0, c);
+                c = mfb(a.q1, x[s].q1, c);
+                c = mfb(a.q0, x[s].q2, c);
+                c = mfb(a.q1, x[s].q0, c);
+                c = mfb(a.q0, x[s].q1, c);
+                c = mfb(a.q0, x[s].q0, c);
+                acc[mo] = c;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (kb + 1 < KB1) { x[0] = xn[0]; x[1] = xn[1]; }
+    }
+}
+
+// blob offsets (packing.py:pack_decoder_x6): fp32 auxiliary part in floats, slices in bytes from the blob start
+#define X6_A0C 0                      // [mb 4][lane 64] float4: k-group 3 of lin0 (the coordinate columns)
+#define X6_B0 1024
+#define X6_B1 1152
+#define X6_B2 1280
+#define X6_B3 1376
+#define X6_HW 1504
+#define X6_HU 1632
+#define X6_HB 1760
+#define X6_A3C 1764                   // [mb 4][lane 64] float4: k-group 15 of lin3
+#define X6_AUX_FLOATS 2788
+#define X6_L1 (X6_AUX_FLOATS * 4)     // [kb 4][s 2][mo 4][slice 3][lane 64][8 bf16]   98,304 B
+#define X6_L2 (X6_L1 + 98304)         // [kb 4][s 2][mo 3]...                           73,728 B; input blocks 0,1 are staged in LDS
+#define X6_LDS_BYTES (X6_L2 + 36864)  // 146,320 B
+#define X6_L3 (X6_L2 + 73728)         // [kb 3][s 2][mo 4]...                           73,728 B
+#define X6_BYTES (X6_L3 + 73728)      // 256,912 B
+
+__device__ __forceinline__ void decoder_fold_consts_x6(const float* __restrict__ aux /* LDS */, const float* __restrict__ fold /* global */,
+                                                       const float* __restrict__ lat_row, float* __restrict__ c, int lane) {
+    float a0 = aux[X6_B0 + lane], a1 = aux[X6_B0 + lane + 64], a2 = aux[X6_B3 + lane], a3 = aux[X6_B3 + lane + 64];
+    const f4v* wk = reinterpret_cast<const f4v*>(fold) + lane;
+#pragma unroll 8
+    for (int k = 0; k < 29; ++k) {
+        const float zk = lat_row[k];
+        const f4v wv = wk[k * 64];
+        a0 = fmaf(wv.x, zk, a0);
+        a1 = fmaf(wv.y, zk, a1);
+        a2 = fmaf(wv.z, zk, a2);
+        a3 = fmaf(wv.w, zk, a3);
+    }
+    c[lane] = a0;
+    c[lane + 64] = a1;
+    c[128 + lane] = a2;
+    c[128 + lane + 64] = a3;
+}
+
+// decoder_tile_folded on the bf16 pipe.  W = LDS copy of blob[0, X6_LDS_BYTES), Wg = buffer resource over the whole blob.
+template <class INIT>
+__device__ __forceinline__ void decoder_tile_folded_x6(const float* __restrict__ W /* LDS */, __amdgpu_buffer_rsrc_t Wg, const INIT& init,
+                                                       float px, float py, float pz, int lane, float& sdf, float& stdv) {
+    const int half = lane >> 5;
+    const float b14 = half ? px : 0.0f;
+    const float b15 = half ? pz : py;
+    const char* Wb = reinterpret_cast<const char*>(W);
+    f16v h0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = init.load(0, mb, half);
+        const f4v a = reinterpret_cast<const f4v*>(W + X6_A0C)[mb * 64 + lane];
+        acc = mfma32(a.z, b14, acc);
+        acc = mfma32(a.w, b15, acc);
+        h0[mb] = relu16(acc);
+    }
+    f16v h1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h1[mb] = load_bias16(W + X6_B1 + mb * 32, half);
+    layer_x6<0, 4, 4, 1>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L1)}, h0, h1, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h1[mb] = relu16(h1[mb]);
+    f16v h2[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) h2[mb] = load_bias16(W + X6_B2 + mb * 32, half);
+    int goff = X6_L2 + 36864;                    // opaque per tile: see decoder_tile (LICM would hoist and spill the loop-invariant loads)
+    asm volatile("" : "+s"(goff) : : "memory");
+    layer_x6<0, 2, 3, 1>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L2)}, h1, h2, lane);
+    layer_x6<2, 4, 3, 3>(BufX6{Wg, goff}, h1, h2, lane);
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) h2[mb] = relu16(h2[mb]);
+    f16v h3[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h3[mb] = init.load(1, mb, half);
+    layer_x6<0, 3, 4, 3>(BufX6{Wg, goff + 36864}, h2, h3, lane);
+    float ps = 0.0f, pu = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f16v acc = h3[mb];
+        const f4v ax = reinterpret_cast<const f4v*>(W + X6_A3C)[mb * 64 + lane];
+        acc = mfma32(ax.z, b14, acc);
+        acc = mfma32(ax.w, b15, acc);
+        acc = relu16(acc);
+        f16v ws = load_bias16(W + X6_HW + mb * 32, half);
+        f16v wu = load_bias16(W + X6_HU + mb * 32, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ps = fmaf(acc[r], ws[r], ps);
+            pu = fmaf(acc[r], wu[r], pu);
+        }
+    }
+    ps += __shfl_xor(ps, 32);
+    pu += __shfl_xor(pu, 32);
+    ps += W[X6_HB + 0];
+    pu += W[X6_HB + 1];
+    sdf = tanhf(ps);
+    float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));
+    stdv = 0.05f + 0.5f * sp;
+}
+
 // ---- decoder with input gradient (get_sdf for the tracker: d sdf / d xyz, reference tracker.py:186-192) -------------------
 // Backward blob (global memory, packing.py:pack_decoder_backward): transposed layers, k order = D-fragment order of the
 // forward layer's OUTPUT blocks, so the masked upstream gradient fragments are again ready-made B operands.

@@ -24,6 +24,10 @@ DEC_LDS_FLOATS = 33508
 DEC_FLOATS = 49892
 DECB_FLOATS = 49152
 DECF_FLOATS = 2 * 29 * 128
+# split-bf16 decoder blob (mlp.hip.h, "x6"): fp32 auxiliary part, then the bf16 slices of lin1 | lin2 | lin3
+X6_AUX_FLOATS = 2788
+X6_L1_BYTES, X6_L2_BYTES, X6_L3_BYTES = 4 * 2 * 4 * 3 * 1024, 4 * 2 * 3 * 3 * 1024, 3 * 2 * 4 * 3 * 1024
+X6_BYTES = X6_AUX_FLOATS * 4 + X6_L1_BYTES + X6_L2_BYTES + X6_L3_BYTES
 
 
 def _frag_feature(r: int, half: int) -> int:
@@ -161,4 +165,76 @@ def pack_decoder_fold(w: Dict[str, np.ndarray]) -> np.ndarray:
     dev = np.stack([out[0, :, :64], out[0, :, 64:], out[1, :, :64], out[1, :, 64:]], axis=-1)     # (29, 64, 4)
     blob = np.ascontiguousarray(dev).reshape(-1).astype(np.float32)
     assert blob.shape[0] == DECF_FLOATS
+    return blob
+
+
+# ---- fp32 products on the bf16 matrix pipe ("x6") ----------------------------------------------------------------------------------
+# gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of the f32-input MFMA.  An fp32 value is the exact sum of three bf16 slices
+# (8 + 8 + 8 mantissa bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), all differences exact in fp32), every slice
+# product is exact in the fp32 accumulator, and the six products whose weight is >= 2^-16 of the leading one
+#   hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi
+# reproduce the fp32 product to ~2^-24 relative — the rounding class of the f32 MFMA itself (measured against float64 on a 128-term
+# dot product: 1.05e-6 with the six-slice scheme, 1.42e-6 with v_mfma_f32_32x32x2_f32) — at 6/16 of its matrix-pipe time.
+
+def bf16_rne(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns (uint16), round to nearest even (finite inputs)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def split_bf16x3(x: np.ndarray):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = bf16_rne(x)
+    r1 = x - bf16_to_f32(hi)
+    mid = bf16_rne(r1)
+    r2 = r1 - bf16_to_f32(mid)
+    lo = bf16_rne(r2)
+    return hi, mid, lo
+
+
+def pack_A_x6(W: np.ndarray, NMO: int, NKB: int) -> np.ndarray:
+    """W (M_out, 32*NKB inputs in D-fragment block order) -> uint16 [kb][s][mo][slice][lane][8]: the A operands of
+    v_mfma_f32_32x32x16_bf16 (lane = (row i = lane & 31, half = lane >> 5), element j <-> k = 8*half + j), where k-step s of input
+    block kb contracts the features held by accumulator registers 8s..8s+7 of the previous layer's out-block kb."""
+    M, K = W.shape
+    sl = split_bf16x3(W)
+    out = np.zeros((NKB, 2, NMO, 3, 64, 8), dtype=np.uint16)
+    for kb in range(NKB):
+        for s in range(2):
+            for mo in range(NMO):
+                for lane in range(64):
+                    m = mo * 32 + (lane & 31)
+                    if m >= M:
+                        continue
+                    for j in range(8):
+                        k = kb * 32 + _frag_feature(8 * s + j, lane >> 5)
+                        if k < K:
+                            for q in range(3):
+                                out[kb, s, mo, q, lane, j] = sl[q][m, k]
+    return out
+
+
+def pack_decoder_x6(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """uint8 blob for the split-bf16 decoder tiles: [aux fp32: A0 coordinate k-group | b0 | b1 | b2 | b3 | sdf head | std head | head
+    biases | A3 coordinate k-group] [lin1 slices] [lin2 slices] [lin3 slices (the 96 h2 columns)]."""
+    Ws, bs, Wu, bu = fold_decoder(w)
+
+    def kmap_l3(t, half):
+        return kmap_dfrag(t, half) if t < 48 else 96 + kmap_natural(t - 48, half)
+
+    a0 = pack_A(Ws[0], 4, 4, kmap_natural)[:, 3]              # (4, 64, 4): features 24..31 of x0, the MFMAs use .z/.w = (28,29),(30,31)
+    a3 = pack_A(Ws[3], 4, 16, kmap_l3)[:, 15]
+    aux = np.concatenate([a0.reshape(-1), pack_vec(bs[0], 4).reshape(-1), pack_vec(bs[1], 4).reshape(-1), pack_vec(bs[2], 3).reshape(-1),
+                          pack_vec(bs[3], 4).reshape(-1), pack_vec(Ws[4][0], 4).reshape(-1), pack_vec(Wu[0], 4).reshape(-1),
+                          np.array([bs[4][0], bu[0], 0.0, 0.0], dtype=np.float32), a3.reshape(-1)]).astype(np.float32)
+    assert aux.shape[0] == X6_AUX_FLOATS, aux.shape
+    l1 = pack_A_x6(Ws[1], 4, 4)
+    l2 = pack_A_x6(Ws[2], 3, 4)
+    l3 = pack_A_x6(Ws[3][:, :96], 4, 3)
+    blob = np.concatenate([aux.view(np.uint8), l1.reshape(-1).view(np.uint8), l2.reshape(-1).view(np.uint8), l3.reshape(-1).view(np.uint8)])
+    assert blob.shape[0] == X6_BYTES, blob.shape
     return blob

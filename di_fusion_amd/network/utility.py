@@ -9,6 +9,7 @@ from __future__ import annotations
 import argparse
 import json
 import math
+import os
 from pathlib import Path
 from typing import Dict, Optional
 
@@ -21,15 +22,22 @@ from . import packing
 DEFAULT_WEIGHTS = Path(__file__).resolve().parent / "weights_default.npz"      # ckpt/default of the reference, as arrays
 
 
+def _x6_default() -> bool:
+    """Extract-path decode tiles on the bf16 matrix pipe (mlp.hip.h "x6")?  DIF_DECODER_PIPE=f32 keeps them on the f32-input MFMA."""
+    return os.environ.get("DIF_DECODER_PIPE", "bf16x6").lower() != "f32"
+
+
 class _PackedNet:
     """Packed weights resident on one GPU."""
 
-    def __init__(self, raw: Dict[str, np.ndarray]):
+    def __init__(self, raw: Dict[str, np.ndarray], x6: Optional[bool] = None):
         self.raw = raw
+        self.x6 = _x6_default() if x6 is None else bool(x6)
         self._enc_blob = packing.pack_encoder(raw)
         self._dec_blob = packing.pack_decoder(raw)
         self._decb_blob = packing.pack_decoder_backward(raw)
         self._decf_blob = packing.pack_decoder_fold(raw)
+        self._x6_blob = packing.pack_decoder_x6(raw) if self.x6 else None
         self._dev = {}
 
     def weights_struct(self, device: torch.device):
@@ -40,8 +48,10 @@ class _PackedNet:
             dec = torch.from_numpy(self._dec_blob).to(device)
             decb = torch.from_numpy(self._decb_blob).to(device)
             decf = torch.from_numpy(self._decf_blob).to(device)
-            w = _lib.DifWeights(_lib.ptr(enc), enc.numel(), _lib.ptr(dec), dec.numel(), _lib.ptr(decb), decb.numel(), _lib.ptr(decf), decf.numel())
-            self._dev[key] = (w, enc, dec, decb, decf)
+            x6 = torch.from_numpy(self._x6_blob).to(device) if self._x6_blob is not None else None
+            w = _lib.DifWeights(_lib.ptr(enc), enc.numel(), _lib.ptr(dec), dec.numel(), _lib.ptr(decb), decb.numel(), _lib.ptr(decf), decf.numel(),
+                                _lib.ptr(x6) if x6 is not None else None, x6.numel() if x6 is not None else 0)
+            self._dev[key] = (w, enc, dec, decb, decf, x6)
         return self._dev[key][0]
 
 

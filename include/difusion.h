@@ -100,6 +100,10 @@ typedef struct dif_weights {
     const float* dec_fold_packed;   /* decoder, latent columns of lin0 / lin3 for the per-voxel constant folding (packing.py:pack_decoder_fold);
                                      * NULL: every sample row carries the latent through the MFMAs */
     int64_t dec_fold_packed_floats;
+    const void* dec_x6_packed;      /* decoder sliced into bf16 triples (packing.py:pack_decoder_x6), or NULL.  When set (together with
+                                     * dec_fold_packed) the extract decode tiles run on the bf16 matrix pipe: every fp32 product as six
+                                     * exact bf16 slice products, fp32 accumulation — same rounding class as the f32 MFMA, 6/16 of its time */
+    int64_t dec_x6_packed_bytes;
 } dif_weights_t;
 
 int dif_version(void);
