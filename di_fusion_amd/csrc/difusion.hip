@@ -423,16 +423,22 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
                        ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, map->grid_tot);
     DIF_CHECK_LAUNCH();
     {
-        const size_t lds_bytes = (size_t)ENC_FLOATS * 4;
+        const bool x6 = w->enc_x6_packed && w->enc_x6_packed_bytes == E6_BYTES;          // tiles on the bf16 matrix pipe (mlp.hip.h)
+        const size_t lds_bytes = x6 ? (size_t)E6_BYTES : (size_t)ENC_FLOATS * 4;
         static bool attr_set[64] = {};
         int dev = 0; (void)hipGetDevice(&dev);
         if (dev < 64 && !attr_set[dev]) {
-            if (hipFuncSetAttribute((const void*)k_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ENC_FLOATS * 4)) != hipSuccess) return DIF_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_BYTES) != hipSuccess) return DIF_ELAUNCH;
             attr_set[dev] = true;
         }
         ProfScope prof(DIF_PROF_ENCODE, s);
-        hipLaunchKernelGGL(k_encode, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint2*)ws.pair_list,
-                           map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C);
+        if (x6)
+            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(512), lds_bytes, s, g, (const float*)w->enc_x6_packed, xyz, normal, N, (const uint2*)ws.pair_list,
+                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C);
+        else
+            hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint2*)ws.pair_list,
+                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C);
         DIF_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.rec, (const int*)ws.rec_next,
@@ -575,51 +581,22 @@ int dif_decode_rows(const dif_weights_t* w, const float* rows, int64_t n, float*
     return launch_decode(A, w, (n + 31) / 32, (hipStream_t)stream);
 }
 
-// encoder on explicit rows (flat op / tests): per-row outputs instead of per-voxel sums, so a dedicated small kernel
-namespace {
-__global__ void __launch_bounds__(512, 2) k_encode_rows(const float* __restrict__ wblob, const float* __restrict__ rows, int64_t n, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_weights(lds, wblob, ENC_FLOATS);
-    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
-    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
-    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
-    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int64_t n_tiles = (n + 31) / 32;
-    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
-        int64_t row = tile * 32 + col;
-        bool live = row < n;
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-        if (live) {
-            const float* p = rows + row * 6;
-            x0 = half ? p[1] : p[0];
-            x1 = half ? p[3] : p[2];
-            x2 = half ? p[5] : p[4];
-        }
-        f16v o = encoder_tile(lds, x0, x1, x2, lane);
-        if (live) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (f < L) out[row * L + f] = o[r];
-            }
-        }
-    }
-}
-}  // namespace
-
 int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float* out, void* stream) {
     if (!w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || n < 0 || (n > 0 && (!rows || !out))) return DIF_EINVAL;
     if (n == 0) return DIF_OK;
-    const size_t lds_bytes = (size_t)ENC_FLOATS * 4;
+    const bool x6 = w->enc_x6_packed && w->enc_x6_packed_bytes == E6_BYTES;
+    const size_t lds_bytes = x6 ? (size_t)E6_BYTES : (size_t)ENC_FLOATS * 4;
     static bool attr_set[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)k_encode_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_encode_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ENC_FLOATS * 4)) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_encode_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_BYTES) != hipSuccess) return DIF_ELAUNCH;
         attr_set[dev] = true;
     }
     int64_t blocks = ((n + 31) / 32 + 7) / 8;
     if (blocks > num_cus()) blocks = num_cus();
-    hipLaunchKernelGGL(k_encode_rows, dim3((int)blocks), dim3(512), lds_bytes, (hipStream_t)stream, w->enc_packed, rows, n, out);
+    if (x6) hipLaunchKernelGGL(k_encode_rows<true>, dim3((int)blocks), dim3(512), lds_bytes, (hipStream_t)stream, (const float*)w->enc_x6_packed, rows, n, out);
+    else hipLaunchKernelGGL(k_encode_rows<false>, dim3((int)blocks), dim3(512), lds_bytes, (hipStream_t)stream, w->enc_packed, rows, n, out);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

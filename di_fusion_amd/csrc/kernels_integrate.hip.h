@@ -269,12 +269,14 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
 #define DIF_DIR_WORDS 16                     /* int32 per slot directory: count | overflow chain head | 14 record ids */
 #define DIF_DIR_IDS (DIF_DIR_WORDS - 2)
 
-__global__ void __launch_bounds__(512, 2)
+// X6: the tile runs on the bf16 matrix pipe (encoder_tile_x6; wblob = packing.py:pack_encoder_x6)
+template <bool X6>
+__global__ void __launch_bounds__(512, X6 ? 1 : 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
          const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
          int* __restrict__ upd_list, int* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_weights(lds, wblob, ENC_FLOATS);
+    stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     // tile t goes to wave (t / #blocks) of block (t % #blocks): a partly filled launch spreads over all CUs and SIMDs first
     const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
@@ -320,7 +322,9 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
         const bool pusher = live && run_tail && half == 0;
         int* dir = rec_dir + (int64_t)key * DIF_DIR_WORDS;
         if (pusher) dir_pos = atomicAdd(dir, 1);
-        f16v out = encoder_tile(lds, x0, x1, x2, lane);
+        f16v out;
+        if constexpr (X6) out = encoder_tile_x6(lds, x0, x1, x2, lane);
+        else out = encoder_tile(lds, x0, x1, x2, lane);
         long long* p = rec + (int64_t)rec_id * DIF_REC_WORDS + half * 16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -338,6 +342,39 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
             if (dir_pos < DIF_DIR_IDS) dir[2 + dir_pos] = rec_id;
             else rec_next[rec_id] = atomicExch(dir + 1, rec_id + 1);                        // a voxel fed by many workgroups: chained
             if (dir_pos == 0) upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;        // first run of this slot in the frame (C of map.py:437)
+        }
+    }
+}
+
+// encoder on explicit rows (flat op / tests): per-row outputs instead of per-voxel sums, so a dedicated small kernel
+template <bool X6>
+__global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __restrict__ wblob, const float* __restrict__ rows, int64_t n, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    // work item w goes to wave (w / #blocks) of block (w % #blocks): a partly filled launch spreads over all CUs and SIMDs first
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int64_t n_tiles = (n + 31) / 32;
+    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+        int64_t row = tile * 32 + col;
+        bool live = row < n;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (live) {
+            const float* p = rows + row * 6;
+            x0 = half ? p[1] : p[0];
+            x1 = half ? p[3] : p[2];
+            x2 = half ? p[5] : p[4];
+        }
+        f16v o;
+        if constexpr (X6) o = encoder_tile_x6(lds, x0, x1, x2, lane);
+        else o = encoder_tile(lds, x0, x1, x2, lane);
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (f < L) out[row * L + f] = o[r];
+            }
         }
     }
 }

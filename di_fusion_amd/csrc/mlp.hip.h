@@ -354,6 +354,17 @@ struct BufX6 {
     }
 };
 
+// the six slice products of one k-step, smallest first
+__device__ __forceinline__ f16v step_x6(const Tri& a, const Tri& x, f16v c) {
+    c = mfb(a.q2, x.q0, c);
+    c = mfb(a.q1, x.q1, c);
+    c = mfb(a.q0, x.q2, c);
+    c = mfb(a.q1, x.q0, c);
+    c = mfb(a.q0, x.q1, c);
+    c = mfb(a.q0, x.q0, c);
+    return c;
+}
+
 // acc[mo] += W[mo-block][input blocks KB0..KB1) * hin, input blocks outermost (each block is sliced once, while the previous block's
 // MFMAs run: one value pair per step), weight fragments PF steps ahead of their use.  Step order = memory order of the source.
 template <int KB0, int KB1, int NMO, int PF, class SRC>
@@ -381,14 +392,7 @@ __device__ __forceinline__ void layer_x6(const SRC& A, const f16v* hin, f16v* ac
 #pragma unroll
                     for (int i = u * per; i < (u + 1) * per && i < 8; ++i) split_pair_into(hin[kb + 1], i >> 2, i & 3, xn[i >> 2]);
                 }
-                f16v c = acc[mo];
-                c = mfb(a.q2, x[s].q0, c);
-                c = mfb(a.q1, x[s].q1, c);
-                c = mfb(a.q0, x[s].q2, c);
-                c = mfb(a.q1, x[s].q0, c);
-                c = mfb(a.q0, x[s].q1, c);
-                c = mfb(a.q0, x[s].q0, c);
-                acc[mo] = c;
+                acc[mo] = step_x6(a, x[s], acc[mo]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -491,6 +495,83 @@ __device__ __forceinline__ void decoder_tile_folded_x6(const float* __restrict__
     sdf = tanhf(ps);
     float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));
     stdv = 0.05f + 0.5f * sp;
+}
+
+// Encoder on the bf16 pipe (blob = packing.py:pack_encoder_x6, all of it staged in LDS).  lin0 (6 -> 32, three k-steps) stays on the f32
+// MFMA.  lin2's out-block mb+1 is computed while out-block mb is being sliced for lin3, so the weight steps are stored in the order
+// they are consumed: lin1 | L2(0) | L2(1) L3(0) | L2(2) L3(1) | ... | L2(7) L3(6) | L3(7)   (L2(mb): 4 steps, L3(mb): 2 steps).
+#define E6_A0 0
+#define E6_B0 256
+#define E6_B1 288
+#define E6_B2 352
+#define E6_B3 608
+#define E6_AUX_FLOATS 640
+#define E6_L1 (E6_AUX_FLOATS * 4)     // [s 2][mo 2][slice 3][lane 64][8 bf16]    12,288 B
+#define E6_L23 (E6_L1 + 12288)        // 48 steps of 3 KB                         147,456 B
+#define E6_BYTES (E6_L23 + 147456)    // 162,304 B
+
+__device__ __forceinline__ f16v encoder_tile_x6(const float* __restrict__ W /* LDS */, float x0, float x1, float x2, int lane) {
+    const int half = lane >> 5;
+    const char* Wb = reinterpret_cast<const char*>(W);
+    f16v h0[1];
+    {
+        f16v acc = load_bias16(W + E6_B0, half);
+        f4v a = reinterpret_cast<const f4v*>(W + E6_A0)[lane];
+        acc = mfma32(a.x, x0, acc);
+        acc = mfma32(a.y, x1, acc);
+        acc = mfma32(a.z, x2, acc);
+        h0[0] = relu16(acc);
+    }
+    f16v h1[2];
+    h1[0] = load_bias16(W + E6_B1, half);
+    h1[1] = load_bias16(W + E6_B1 + 32, half);
+    layer_x6<0, 1, 2, 1>(LdsX6{reinterpret_cast<const u4v*>(Wb + E6_L1)}, h0, h1, lane);
+    h1[0] = relu16(h1[0]);
+    h1[1] = relu16(h1[1]);
+    Tri xs[4];                                  // h1 sliced once: [kb][s]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) split_pair_into(h1[i >> 3], (i >> 2) & 1, i & 3, xs[i >> 2]);
+    const LdsX6 A{reinterpret_cast<const u4v*>(Wb + E6_L23)};
+    int t = 0;
+    Tri a = A.load(0, lane), an;
+    f16v cur = load_bias16(W + E6_B2, half);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {               // L2(0)
+        an = A.load(t + 1, lane);
+        cur = step_x6(a, xs[u], cur);
+        a = an; ++t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f16v out = load_bias16(W + E6_B3, half);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+        const f16v h = relu16(cur);
+        Tri hs[2];
+        if (mb + 1 < 8) {
+            cur = load_bias16(W + E6_B2 + (mb + 1) * 32, half);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {       // L2(mb + 1), with the slicing of h2 block mb spread over its steps
+                an = A.load(t + 1, lane);
+                split_pair_into(h, u >> 1, (2 * u) & 3, hs[u >> 1]);
+                split_pair_into(h, u >> 1, (2 * u + 1) & 3, hs[u >> 1]);
+                cur = step_x6(a, xs[u], cur);
+                a = an; ++t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_pair_into(h, i >> 2, i & 3, hs[i >> 2]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {           // L3(mb)
+            an = a;
+            if (t + 1 < 48) an = A.load(t + 1, lane);
+            out = step_x6(a, hs[s], out);
+            a = an; ++t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return out;
 }
 
 // ---- decoder with input gradient (get_sdf for the tracker: d sdf / d xyz, reference tracker.py:186-192) -------------------

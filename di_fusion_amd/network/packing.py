@@ -28,6 +28,8 @@ DECF_FLOATS = 2 * 29 * 128
 X6_AUX_FLOATS = 2788
 X6_L1_BYTES, X6_L2_BYTES, X6_L3_BYTES = 4 * 2 * 4 * 3 * 1024, 4 * 2 * 3 * 3 * 1024, 3 * 2 * 4 * 3 * 1024
 X6_BYTES = X6_AUX_FLOATS * 4 + X6_L1_BYTES + X6_L2_BYTES + X6_L3_BYTES
+E6_AUX_FLOATS = 640
+E6_BYTES = E6_AUX_FLOATS * 4 + 12288 + 147456
 
 
 def _frag_feature(r: int, half: int) -> int:
@@ -237,4 +239,25 @@ def pack_decoder_x6(w: Dict[str, np.ndarray]) -> np.ndarray:
     l3 = pack_A_x6(Ws[3][:, :96], 4, 3)
     blob = np.concatenate([aux.view(np.uint8), l1.reshape(-1).view(np.uint8), l2.reshape(-1).view(np.uint8), l3.reshape(-1).view(np.uint8)])
     assert blob.shape[0] == X6_BYTES, blob.shape
+    return blob
+
+
+def pack_encoder_x6(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """uint8 blob for `encoder_tile_x6`: [aux fp32: A0 | b0 | b1 | b2 | b3] [lin1 slices] [lin2 / lin3 steps in consumption order:
+    L2(0) | L2(1) L3(0) | ... | L2(7) L3(6) | L3(7)]."""
+    Ws, bs = fold_encoder(w)
+    aux = np.concatenate([pack_A(Ws[0], 1, 1, kmap_natural).reshape(-1), pack_vec(bs[0], 1).reshape(-1), pack_vec(bs[1], 2).reshape(-1),
+                          pack_vec(bs[2], 8).reshape(-1), pack_vec(bs[3], 1).reshape(-1)]).astype(np.float32)
+    assert aux.shape[0] == E6_AUX_FLOATS, aux.shape
+    l1 = pack_A_x6(Ws[1], 2, 1)                                           # (1, 2, 2, 3, 64, 8)
+    l2 = pack_A_x6(Ws[2], 8, 2).transpose(2, 0, 1, 3, 4, 5)               # (mb, kb, s, slice, lane, 8)
+    l3 = pack_A_x6(Ws[3], 1, 8)[:, :, 0]                                  # (mb, s, slice, lane, 8)
+    steps = [l2[0].reshape(-1)]
+    for mb in range(8):
+        if mb + 1 < 8:
+            steps.append(l2[mb + 1].reshape(-1))
+        steps.append(l3[mb].reshape(-1))
+    blob = np.concatenate([aux.view(np.uint8), np.ascontiguousarray(l1).reshape(-1).view(np.uint8)] +
+                          [np.ascontiguousarray(x).view(np.uint8) for x in steps])
+    assert blob.shape[0] == E6_BYTES, blob.shape
     return blob

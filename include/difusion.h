@@ -104,6 +104,9 @@ typedef struct dif_weights {
                                      * dec_fold_packed) the extract decode tiles run on the bf16 matrix pipe: every fp32 product as six
                                      * exact bf16 slice products, fp32 accumulation — same rounding class as the f32 MFMA, 6/16 of its time */
     int64_t dec_x6_packed_bytes;
+    const void* enc_x6_packed;      /* encoder sliced the same way (packing.py:pack_encoder_x6), or NULL: integrate's encoder tiles and
+                                     * dif_encode_rows run on the bf16 matrix pipe when set */
+    int64_t enc_x6_packed_bytes;
 } dif_weights_t;
 
 int dif_version(void);
