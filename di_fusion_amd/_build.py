@@ -12,7 +12,11 @@ LIB = PKG / "libdifusion.so"
 SOURCES = [CSRC / "difusion.hip"]
 HEADERS = sorted(CSRC.glob("*.hip.h")) + [CSRC / "mc_tables.inc", PKG.parent / "include" / "difusion.h"]
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of independent fp32 operations into v_pk_fma_f32 / v_pk_add_f32.  In the bf16-pipe
+# MLP kernels (two 250-register waves per SIMD) those packed operations returned wrong values for one 16-lane quarter of a wave now
+# and then (about one decoder tile in 10^5; tools/determinism_stress.py reproduces it within seconds), and beside MFMAs they are
+# slower than the scalar pair anyway (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-Wno-unused-result", "-DNDEBUG"]
 
 

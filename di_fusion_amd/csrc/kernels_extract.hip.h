@@ -435,6 +435,7 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
                     float* rec = A.fold_table + (int64_t)b * 256;          // the refine pass picks the constants up from here
                     for (int p = lane; p < 256; p += 64) rec[p] = w_fold[p];
                 }
+                VD_STAMP(6);
                 if constexpr (X6) decoder_tile_folded_x6(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
                 else decoder_tile_folded(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
             } else if constexpr (!X6) {

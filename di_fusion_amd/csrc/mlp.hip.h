@@ -32,9 +32,15 @@ __device__ __forceinline__ f16v load_bias16(const float* b, int half) {
     return r;
 }
 
+// max(x, 0) as ONE instruction: fmaxf costs two (IEEE mode makes the compiler canonicalise the MFMA result first, and it turns
+// v_med3 back into that pair).  On the bit pattern a signed-integer max does it: every negative float (and -0) is a negative int32,
+// every non-negative float is returned unchanged.  A NaN keeps its payload if its sign bit is clear (torch's relu propagates NaN too).
+// Not inline asm: the hazard recogniser does not see into asm, and an asm v_max reading an accumulator right behind the MFMA that
+// writes it gets stale registers (measured: encoder rows off by 0.7).
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ f16v relu16(f16v v) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.0f);
+    for (int i = 0; i < 16; ++i) v[i] = relu1(v[i]);
     return v;
 }
 
@@ -321,10 +327,10 @@ struct Tri { u4v q0, q1, q2; };                       // hi / mid / lo slices of
 __device__ __forceinline__ f16v mfb(u4v a, u4v b, f16v c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {        // RNE, lo -> bits 15:0
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {        // v_cvt_pk_bf16_f32: RNE, lo -> bits 15:0
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{lo, hi}, bf2v));
 }
 // slices of the value pair (a, b) -> dword p of the three fragments
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
@@ -401,6 +407,9 @@ __device__ __forceinline__ void layer_x6(const SRC& A, const f16v* hin, f16v* ac
 }
 
 // blob offsets (packing.py:pack_decoder_x6): fp32 auxiliary part in floats, slices in bytes from the blob start
+#ifndef X6_PF_LDS
+#define X6_PF_LDS 2
+#endif
 #define X6_A0C 0                      // [mb 4][lane 64] float4: k-group 3 of lin0 (the coordinate columns)
 #define X6_B0 1024
 #define X6_B1 1152
@@ -456,7 +465,7 @@ __device__ __forceinline__ void decoder_tile_folded_x6(const float* __restrict__
     f16v h1[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) h1[mb] = load_bias16(W + X6_B1 + mb * 32, half);
-    layer_x6<0, 4, 4, 1>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L1)}, h0, h1, lane);
+    layer_x6<0, 4, 4, X6_PF_LDS>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L1)}, h0, h1, lane);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) h1[mb] = relu16(h1[mb]);
     f16v h2[3];
@@ -464,7 +473,7 @@ __device__ __forceinline__ void decoder_tile_folded_x6(const float* __restrict__
     for (int mb = 0; mb < 3; ++mb) h2[mb] = load_bias16(W + X6_B2 + mb * 32, half);
     int goff = X6_L2 + 36864;                    // opaque per tile: see decoder_tile (LICM would hoist and spill the loop-invariant loads)
     asm volatile("" : "+s"(goff) : : "memory");
-    layer_x6<0, 2, 3, 1>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L2)}, h1, h2, lane);
+    layer_x6<0, 2, 3, X6_PF_LDS>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L2)}, h1, h2, lane);
     layer_x6<2, 4, 3, 3>(BufX6{Wg, goff}, h1, h2, lane);
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb) h2[mb] = relu16(h2[mb]);

@@ -115,8 +115,9 @@ class Networks:
         return self
 
 
-def networks_from_arrays(raw: Dict[str, np.ndarray]) -> Networks:
-    packed = _PackedNet({k: np.asarray(v) for k, v in raw.items()})
+def networks_from_arrays(raw: Dict[str, np.ndarray], x6: Optional[bool] = None) -> Networks:
+    """x6: run the MLP tiles on the bf16 matrix pipe (None: the DIF_DECODER_PIPE default, see _x6_default)."""
+    packed = _PackedNet({k: np.asarray(v) for k, v in raw.items()}, x6)
     m = Networks()
     m.packed = packed
     m.decoder = Decoder(packed)

@@ -42,5 +42,13 @@ def oracle_net(raw_weights):
 
 @pytest.fixture(scope="session")
 def gpu_model(raw_weights):
+    """The product default: MLP tiles on the bf16 matrix pipe (six exact slice products per fp32 product, mlp.hip.h "x6")."""
     from di_fusion_amd.network import utility as net_util
     return net_util.networks_from_arrays(raw_weights)
+
+
+@pytest.fixture(scope="session")
+def gpu_model_f32(raw_weights):
+    """Same weights with the tiles on the f32-input MFMA (DIF_DECODER_PIPE=f32)."""
+    from di_fusion_amd.network import utility as net_util
+    return net_util.networks_from_arrays(raw_weights, x6=False)

@@ -130,3 +130,128 @@ def decoder_tile_folded(blob, fold_blob, latent, pts):
     ps = ps + ps[LANES ^ 32] + blob[DEC["HB"]]
     pu = pu + pu[LANES ^ 32] + blob[DEC["HB"] + 1]
     return ps[:32], pu[:32]
+
+
+# ---- the bf16-sliced chain ("x6", mlp.hip.h) ------------------------------------------------------------------------------------
+# v_mfma_f32_32x32x16_bf16: A[i = l & 31][k = 8*(l >> 5) + j], B[k = 8*(l >> 5) + j][n = l & 31], j = 0..7; D as above.
+
+def mfma_bf16(a8, b8, acc):
+    """a8, b8: (64, 8) per-lane operand values (already bf16-representable); acc (64, 16)."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for j in range(8):
+        A[LANES & 31, 8 * (LANES >> 5) + j] = a8[:, j]
+        B[8 * (LANES >> 5) + j, LANES & 31] = b8[:, j]
+    D = A @ B
+    out = acc.copy()
+    for l in range(64):
+        out[l] += D[ROW[l >> 5], l & 31]
+    return out
+
+
+def slices_of(x):
+    """(…) float -> three arrays of the bf16 slice VALUES (hi, mid, lo), as the kernel's split_pair computes them."""
+    return [P.bf16_to_f32(s).astype(np.float64) for s in P.split_bf16x3(np.asarray(x, dtype=np.float32))]
+
+
+def frag_x6(blob_u8, byte_off):
+    """The three weight fragments of one step: (3, 64, 8) slice values."""
+    raw = blob_u8[byte_off: byte_off + 3072].view(np.uint16).reshape(3, 64, 8)
+    return P.bf16_to_f32(raw).astype(np.float64)
+
+
+def step_x6(a, x, acc):
+    """The six slice products the kernel issues (mlp.hip.h:step_x6), smallest first."""
+    for qa, qx in ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)):
+        acc = mfma_bf16(a[qa], x[qx], acc)
+    return acc
+
+
+def layer_x6(blob_u8, byte_off, hin, kb0, kb1, accs):
+    """steps in memory order [kb][s][mo]; hin: list of (64,16) fp32-valued blocks; accs: list of NMO accumulators (updated copies returned)."""
+    accs = [a.copy() for a in accs]
+    nmo = len(accs)
+    t = 0
+    for kb in range(kb0, kb1):
+        h = hin[kb].astype(np.float32)
+        for s in range(2):
+            x = [sl[:, 8 * s: 8 * s + 8] for sl in slices_of(h)]
+            for mo in range(nmo):
+                accs[mo] = step_x6(frag_x6(blob_u8, byte_off + t * 3072), x, accs[mo])
+                t += 1
+    return accs
+
+
+def decoder_tile_folded_x6(x6_blob, fold_blob, latent, pts):
+    """`decoder_fold_consts_x6` + `decoder_tile_folded_x6`: one voxel latent (29,), pts (32,3) -> pre-activation (sdf_lin, std_lin)."""
+    aux = x6_blob[:P.X6_AUX_FLOATS * 4].view(np.float32).astype(np.float64)
+    A0C, B0, B1, B2, B3, HW, HU, HB, A3C = 0, 1024, 1152, 1280, 1376, 1504, 1632, 1760, 1764
+    L1 = P.X6_AUX_FLOATS * 4
+    L2 = L1 + P.X6_L1_BYTES
+    L3 = L2 + P.X6_L2_BYTES
+    half = LANES >> 5
+    col = LANES & 31
+    wk = fold_blob.reshape(29, 64, 4)
+    c = np.zeros((2, 128))
+    c[0] = aux[B0:B0 + 128]; c[1] = aux[B3:B3 + 128]
+    for k in range(29):
+        c[0, :64] += wk[k, :, 0] * latent[k]; c[0, 64:] += wk[k, :, 1] * latent[k]
+        c[1, :64] += wk[k, :, 2] * latent[k]; c[1, 64:] += wk[k, :, 3] * latent[k]
+    b14 = np.where(half == 1, pts[col, 0], 0.0)
+    b15 = np.where(half == 1, pts[col, 2], pts[col, 1])
+    h0 = []
+    for mb in range(4):
+        a4 = aux[A0C + mb * 256: A0C + (mb + 1) * 256].reshape(64, 4)
+        acc = mfma(a4[:, 2], b14, bias16(c[0], mb * 32))
+        acc = mfma(a4[:, 3], b15, acc)
+        h0.append(np.maximum(acc, 0))
+    h1 = [np.maximum(a, 0) for a in layer_x6(x6_blob, L1, h0, 0, 4, [bias16(aux, B1 + mb * 32) for mb in range(4)])]
+    h2 = layer_x6(x6_blob, L2, h1, 0, 4, [bias16(aux, B2 + mb * 32) for mb in range(3)])
+    h2 = [np.maximum(a, 0) for a in h2]
+    h3 = layer_x6(x6_blob, L3, h2, 0, 3, [bias16(c[1], mb * 32) for mb in range(4)])
+    ps = np.zeros(64); pu = np.zeros(64)
+    for mb in range(4):
+        a4 = aux[A3C + mb * 256: A3C + (mb + 1) * 256].reshape(64, 4)
+        acc = mfma(a4[:, 2], b14, h3[mb])
+        acc = np.maximum(mfma(a4[:, 3], b15, acc), 0)
+        ps += (acc * bias16(aux, HW + mb * 32)).sum(1)
+        pu += (acc * bias16(aux, HU + mb * 32)).sum(1)
+    ps = ps + ps[LANES ^ 32] + aux[HB]
+    pu = pu + pu[LANES ^ 32] + aux[HB + 1]
+    return ps[:32], pu[:32]
+
+
+def encoder_tile_x6(e6_blob, pts):
+    """`encoder_tile_x6`: pts (32,6) -> (32,29); weight steps consumed in the blob's own order."""
+    aux = e6_blob[:P.E6_AUX_FLOATS * 4].view(np.float32).astype(np.float64)
+    A0, B0, B1, B2, B3 = 0, 256, 288, 352, 608
+    L1 = P.E6_AUX_FLOATS * 4
+    L23 = L1 + 12288
+    half = LANES >> 5
+    col = LANES & 31
+    xs = [np.where(half == 1, pts[col, 2 * j + 1], pts[col, 2 * j]) for j in range(3)]
+    acc = bias16(aux, B0)
+    a = aux[A0:A0 + 256].reshape(64, 4)
+    for j in range(3):
+        acc = mfma(a[:, j], xs[j], acc)
+    h0 = np.maximum(acc, 0)
+    h1 = [np.maximum(a_, 0) for a_ in layer_x6(e6_blob, L1, [h0], 0, 1, [bias16(aux, B1), bias16(aux, B1 + 32)])]
+    t = [0]
+
+    def l2_block(mb):
+        acc = layer_x6(e6_blob, L23 + t[0] * 3072, h1, 0, 2, [bias16(aux, B2 + mb * 32)])[0]
+        t[0] += 4
+        return acc
+
+    out = bias16(aux, B3)
+    cur = l2_block(0)
+    for mb in range(8):
+        h = np.maximum(cur, 0)
+        if mb + 1 < 8:
+            cur = l2_block(mb + 1)
+        out = layer_x6(e6_blob, L23 + t[0] * 3072, [h], 0, 1, [out])[0]
+        t[0] += 2
+    assert t[0] == 48
+    res = np.zeros((32, 32))
+    for l in range(64):
+        res[l & 31, ROW[l >> 5]] = out[l]
+    return res[:, :29]

@@ -53,11 +53,13 @@ def main():
     out = {"B": int(B), "waves_with_work": int(act.sum()),
            "entry_us": [float(np.percentile(us(t[:, 0][t[:, 0] > 0]), q)) for q in (0, 50, 100)],
            "staged_us": [float(np.percentile(us(t[:, 1][t[:, 1] > 0]), q)) for q in (0, 50, 100)],
+           "last_voxel_folded_us": [float(np.percentile(us(t[act, 6]), q)) for q in (0, 50, 100)],
            "last_voxel_tiles_done_us": [float(np.percentile(us(t[act, 2]), q)) for q in (0, 50, 100)],
            "last_voxel_upsampled_us": [float(np.percentile(us(t[act, 3]), q)) for q in (0, 50, 100)],
            "last_voxel_listed_us": [float(np.percentile(us(t[act, 4]), q)) for q in (0, 50, 100)],
            "exit_us": [float(np.percentile(us(t[:, 5][t[:, 5] > 0]), q)) for q in (0, 50, 100)],
-           "tiles_phase_of_last_voxel_us_median": float(np.median((t[act, 2] - t[act, 1]) / 100.0)),
+           "fold_us_median": float(np.median((t[act, 6] - t[act, 1]) / 100.0)),
+           "tiles_phase_of_last_voxel_us_median": float(np.median((t[act, 2] - t[act, 6]) / 100.0)),
            "upsample_us_median": float(np.median((t[act, 3] - t[act, 2]) / 100.0)),
            "list_us_median": float(np.median((t[act, 4] - t[act, 3]) / 100.0))}
     print(json.dumps(out))
