@@ -27,7 +27,15 @@ sys.path.insert(0, str(ROOT))
 
 ENC_FLOP_PER_ROW = 52096          # encoder FLOP per gathered point
 DEC_FLOP_PER_ROW = 98816          # decoder FLOP per sample row
-PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:41
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:41   (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # /opt/skills/guides/MI355X_MICROARCH.md:42   (v_mfma_f32_32x32x16_bf16, dense)
+# bf16-pipe kernels (mlp.hip.h "x6"): an fp32 product = six exact bf16 slice products, so the matrix-pipe ceiling for the reference's fp32
+# arithmetic is 2,500 / 6 TFLOP/s.  Matrix-pipe cycles one 32-row tile really occupies (per SIMD, 2.4 GHz), for the pipe-busy fraction:
+#   folded decoder tile: 480 bf16 MFMAs x 32 cycles + 16 f32 MFMAs x 64;   encoder tile: 312 x 32 + 3 x 64
+PEAK_X6_FP32_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+TILE_PIPE_CYCLES = {"bf16x6": {"encode": 312 * 32 + 3 * 64, "decode_lattice": 480 * 32 + 16 * 64, "decode_points": 480 * 32 + 16 * 64},
+                    "f32": {"encode": 419 * 64, "decode_lattice": 656 * 64, "decode_points": 656 * 64}}
+SIMDS, SHADER_HZ = 1024, 2.4e9
 
 
 def parse():
@@ -250,14 +258,22 @@ def roofline_of(records, sst):
     return kern
 
 
-def roofline_block(per_frame, sst):
+def roofline_block(per_frame, sst, pipe):
     """`roofline` for the MFMA kernel with the longest average launch.  per_frame: for every event-timed frame the [(kernel, ms)] list
     from the library's HIP events (recorded on the launch stream); sst: the counters of those frames (rows per launch come from there).
     The same figures are also given for the first and the second half of the timed frames: a short run sits in the map-building
-    transient (thousands of voxels decoded per frame), a long one ends in steady state (~900), and the fraction differs."""
+    transient (thousands of voxels decoded per frame), a long one ends in steady state (~900), and the fraction differs.
+    pipe: "bf16x6" (default kernels: every fp32 product as six bf16 slice products on the bf16 matrix pipe) or "f32" (f32-input MFMA).
+    `achieved` is always the reference's ALGORITHMIC fp32 FLOP (98,816 per decoder row, 52,096 per encoder row) per second; `peak` is the
+    matrix-pipe ceiling for that arithmetic on the pipe in use; `pipe_busy_frac` is the share of the launch the matrix pipes really worked."""
     kern = roofline_of([r for f in per_frame for r in f], sst)
     if not kern:
         return None
+    peak = PEAK_X6_FP32_EQUIV_TFLOPS if pipe == "bf16x6" else PEAK_FP32_MFMA_TFLOPS
+
+    def busy(name, v):      # matrix-pipe cycles of the launch's tiles / (SIMDs x launch duration)
+        return v["rows_per_launch"] / 32.0 * TILE_PIPE_CYCLES[pipe][name] / (SIMDS * SHADER_HZ * v["ms_per_launch"] * 1e-3)
+
     dom = max(kern, key=lambda k: kern[k]["ms_per_launch"])
     pmc, pmc_file = {}, None
     try:    # HBM bytes per launch: NOT measured by this run (PMC needs rocprofv3) — the committed summary of separate --pmc passes
@@ -265,26 +281,32 @@ def roofline_block(per_frame, sst):
         pmc = json.loads(pmc_file.read_text())["kernels"]
     except Exception:
         pass
-    kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode<false>"}[dom]
+    kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode_refine_x6" if pipe == "bf16x6" else "k_decode<false>"}[dom]
     half = len(per_frame) // 2
     phases = {}
     if half >= 1:
         for label, lo, hi in (("first_half_of_timed_frames", 0, half), ("second_half_of_timed_frames", half, len(per_frame))):
             k = roofline_of([r for f in per_frame[lo:hi] for r in f], sst[lo:hi])
-            phases[label] = {n: {"frac": round(v["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(v["ms_per_launch"], 4),
+            phases[label] = {n: {"frac": round(v["tflops"] / peak, 4), "pipe_busy_frac": round(busy(n, v), 4), "avg_launch_ms": round(v["ms_per_launch"], 4),
                                  "rows_per_launch": round(v["rows_per_launch"], 1)} for n, v in k.items()}
     other = {}
     for name in ("mc_count", "mc_emit"):
         ts = [ms for f in per_frame for k, ms in f if k == name]
         other[name] = round(sum(ts) / max(1, len(per_frame)), 4)
     return {"bound": "mfma", "kernel": kname,
-            "achieved": round(kern[dom]["tflops"], 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-            "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
+            "pipe": ("v_mfma_f32_32x32x16_bf16: each fp32 product as six exact bf16 slice products, fp32 accumulate" if pipe == "bf16x6"
+                     else "v_mfma_f32_32x32x2_f32"),
+            "achieved": round(kern[dom]["tflops"], 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(kern[dom]["tflops"] / peak, 4),
+            "peak_source": ("2,500 TFLOP/s dense bf16 MFMA / 6 slice products per fp32 product" if pipe == "bf16x6" else "157.3 TFLOP/s f32-input MFMA"),
+            "frac_of_f32_input_mfma_peak": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+            "pipe_busy_frac": round(busy(dom, kern[dom]), 4),
+            "traffic": next((pmc[k]["hbm_bytes_per_launch"] for k in (kname, kname + ("<true>" if pipe == "bf16x6" else "<false>")) if k in pmc), None),
             "traffic_source": (f"static: profiles/{pmc_file.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --graph 0`, "
                                "FETCH_SIZE doubled as the gfx950 guide prescribes); not measured by this run") if pmc_file else None,
             "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
-            "per_kernel": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
+            "per_kernel": {k: dict({kk: round(vv, 4) for kk, vv in v.items()}, frac=round(v["tflops"] / peak, 4), pipe_busy_frac=round(busy(k, v), 4))
+                           for k, v in kern.items()},
             "event_timed_frames": len(sst), "by_phase": phases,
             "other_ms_per_frame": other}
 
@@ -336,6 +358,7 @@ def main():
     scene, cfg = getattr(syn, f"config_{a.config}")()
     intr = syn.Intrinsic().scaled(2.0) if tiled else syn.Intrinsic()          # C5: one 1280x960 stream
     model = net_util.networks_from_arrays(net_util.load_weights_npz())
+    pipe = "bf16x6" if model.packed.x6 else "f32"
     n_frames = a.warmup + a.steps
     if tiled and world > 1:
         a.graph = 0                         # the halo exchange sits between the kernels of a frame: eager, host one frame ahead
@@ -434,10 +457,12 @@ def main():
         out = {"metric": f"frames/s integrate+decode+mesh, {intr.width}x{intr.height} synthetic stream", "value": round(value, 3),
                "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if use_dist else 0, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
+               "dtype": ("f32 (MLP products as six exact bf16 slice products on the bf16 matrix pipe, fp32 accumulate; DIF_DECODER_PIPE=f32 for the f32-input MFMA)"
+                         if pipe == "bf16x6" else "f32"), "data": "synthetic",
                "config": {"workload": WORKLOADS[a.config] + f", {intr.width}x{intr.height} orbit stream 0.5 deg/frame, all {pixels} pixels integrated and meshed "
                                                             "every frame, resolution 4, fast decode, max_std 0.15",
-                          "mode": a.mode, "points_per_frame": pixels,
+                          "mode": a.mode, "points_per_frame": pixels, "mlp_pipe": pipe,
                           "parallelism": (f"one stream, grid cut into {world} x-slabs, halo exchange (RCCL send/recv, 3 boundary layers) after every integrate"
                                           if tiled else f"{world} independent subsequences (one map per GPU)"),
                           "d2h_per_frame": a.d2h,
@@ -448,7 +473,7 @@ def main():
                           "frames_per_s_with_5_frames_per_hipgraph": batched,
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info},
-               "roofline": roofline_block(per_frame, [st[j] for j in timed_idx])}
+               "roofline": roofline_block(per_frame, [st[j] for j in timed_idx], pipe)}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(stream, a.config, scene, cfg, intr, n_frames, a.cpu_frames)
     if use_dist:

@@ -847,6 +847,9 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
 int dif_trace_read(unsigned long long* out, int64_t n) {      // host copy of g_vd_trace (n <= 2048*8)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vd_trace), (size_t)n * 8) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }
+int dif_trace_read_encode(unsigned long long* out, int64_t n) {      // host copy of g_en_trace
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_en_trace), (size_t)n * 8) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+}
 #endif
 
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,

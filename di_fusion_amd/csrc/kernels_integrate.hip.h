@@ -269,6 +269,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
 #define DIF_DIR_WORDS 16                     /* int32 per slot directory: count | overflow chain head | 14 record ids */
 #define DIF_DIR_IDS (DIF_DIR_WORDS - 2)
 
+#ifdef DIF_TRACE            // tools/trace_decode.py --encode: per-wave phase timestamps (100 MHz wall clock) of the last k_encode launch
+__device__ unsigned long long g_en_trace[2048 * 8];
+#define EN_STAMP(slot) do { if (lane_id() == 0) g_en_trace[((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define EN_STAMP(slot) do { } while (0)
+#endif
+
 // X6: the tile runs on the bf16 matrix pipe (encoder_tile_x6; wblob = packing.py:pack_encoder_x6)
 template <bool X6>
 __global__ void __launch_bounds__(512, X6 ? 1 : 2)
@@ -276,7 +283,9 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
          const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
          int* __restrict__ upd_list, int* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    EN_STAMP(0);
     stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
+    EN_STAMP(1);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     // tile t goes to wave (t / #blocks) of block (t % #blocks): a partly filled launch spreads over all CUs and SIMDs first
     const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
@@ -318,6 +327,7 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
         }
         // enter the run in its slot's directory.  Asked after the gathers above have been consumed and before the MFMA chain, answered
         // after it: the round trip hides behind ~11 us of matrix work.
+        EN_STAMP(2);
         int dir_pos = 0;
         const bool pusher = live && run_tail && half == 0;
         int* dir = rec_dir + (int64_t)key * DIF_DIR_WORDS;
@@ -325,6 +335,7 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
         f16v out;
         if constexpr (X6) out = encoder_tile_x6(lds, x0, x1, x2, lane);
         else out = encoder_tile(lds, x0, x1, x2, lane);
+        EN_STAMP(3);
         long long* p = rec + (int64_t)rec_id * DIF_REC_WORDS + half * 16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -343,7 +354,9 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
             else rec_next[rec_id] = atomicExch(dir + 1, rec_id + 1);                        // a voxel fed by many workgroups: chained
             if (dir_pos == 0) upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;        // first run of this slot in the frame (C of map.py:437)
         }
+        EN_STAMP(4);
     }
+    EN_STAMP(5);
 }
 
 // encoder on explicit rows (flat op / tests): per-row outputs instead of per-voxel sums, so a dedicated small kernel

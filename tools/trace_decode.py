@@ -63,6 +63,20 @@ def main():
            "upsample_us_median": float(np.median((t[act, 3] - t[act, 2]) / 100.0)),
            "list_us_median": float(np.median((t[act, 4] - t[act, 3]) / 100.0))}
     print(json.dumps(out))
+    # k_encode: 0 entry, 1 staged, 2 last tile's inputs gathered, 3 its MFMA chain done, 4 its records written, 5 exit
+    assert lib.dif_trace_read_encode(buf, 2048 * 8) == 0
+    e = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8).astype(np.int64)
+    e0 = e[:, 0][e[:, 0] > 0].min()
+    act = (e[:, 2] > e[:, 1]) & (e[:, 1] >= e0)
+    ue = lambda x: (x - e0) / 100.0
+    print(json.dumps({"kernel": "k_encode", "M": int(st.stats[-1]["M"]), "waves_with_work": int(act.sum()),
+                      "staged_us": [float(np.percentile(ue(e[:, 1][e[:, 1] > 0]), q)) for q in (0, 50, 100)],
+                      "last_tile_gathered_us": [float(np.percentile(ue(e[act, 2]), q)) for q in (0, 50, 100)],
+                      "last_tile_mfma_done_us": [float(np.percentile(ue(e[act, 3]), q)) for q in (0, 50, 100)],
+                      "last_tile_written_us": [float(np.percentile(ue(e[act, 4]), q)) for q in (0, 50, 100)],
+                      "exit_us": [float(np.percentile(ue(e[:, 5][e[:, 5] > 0]), q)) for q in (0, 50, 100)],
+                      "chain_us_median": float(np.median((e[act, 3] - e[act, 2]) / 100.0)),
+                      "epilogue_us_median": float(np.median((e[act, 4] - e[act, 3]) / 100.0))}))
 
 
 if __name__ == "__main__":
