@@ -33,7 +33,7 @@ class DifMap(Structure):
                 ("frame_count", c_void_p), ("grid_bits", c_void_p), ("grid_tot", c_void_p), ("vbm", c_void_p),
                 ("rec_dir", c_void_p), ("upd_list", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
-                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32)]
+                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("dirty_tot", c_void_p)]
 
 
 class DifWeights(Structure):

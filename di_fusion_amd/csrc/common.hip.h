@@ -199,6 +199,46 @@ inline int counted_scan_per(int64_t n) {
     int per = (int)((n + nb - 1) / nb);
     return (per + DIF_BLOCK - 1) / DIF_BLOCK * DIF_BLOCK;        // scan_range()'s partition
 }
+// Pass 2 over a FIXED partition (block b owns elements [b*per, (b+1)*per) whatever the live count is) bounded by a device-side count:
+// for per-block totals that were maintained while the flags were set, when the number of live elements is only known on the device.
+template <class F>
+__global__ void __launch_bounds__(DIF_BLOCK) k_scan_pass2_fixed(F f, const int* __restrict__ n_ptr, int per, const int* __restrict__ block_tot) {
+    __shared__ int smem[8];
+    const int n = *n_ptr;
+    const long long l = (long long)blockIdx.x * per;
+    const int lo = l < n ? (int)l : n, hi = (l + per) < n ? (int)(l + per) : n;
+    if (lo >= hi && blockIdx.x != 0) return;
+    int before = 0, all = 0;
+    const int n_blk = blockIdx.x == 0 ? (int)gridDim.x : (int)blockIdx.x;          // block 0 also reports the grand total
+    for (int b = (int)threadIdx.x; b < n_blk; b += DIF_BLOCK) {
+        const int t = block_tot[b];
+        all += t;
+        if (b < (int)blockIdx.x) before += t;
+    }
+    int offset = block_sum(before, smem);
+    const int total = block_sum(all, smem);
+    for (int base = lo; base < hi; base += DIF_BLOCK) {
+        const int i = base + (int)threadIdx.x;
+        const int c = (i < hi) ? f.count(i) : 0;
+        int chunk_total;
+        const int ex = block_excl_scan(c, smem, chunk_total);
+        if (i < hi && c > 0) f.emit(i, offset + ex);
+        offset += chunk_total;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.finish(total);
+}
+
+// `n_upper` elements at most, `*n_ptr` live ones; `tot` follows counted_scan_per(n_upper)
+template <class F>
+inline int launch_counted_scan_bounded(F f, const int* n_ptr, int n_upper, const int* tot, hipStream_t s) {
+    if (n_upper <= 4096) {
+        hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(1024), 0, s, f, n_ptr, 0);
+    } else {
+        hipLaunchKernelGGL(k_scan_pass2_fixed<F>, dim3(scan_blocks(n_upper)), dim3(DIF_BLOCK), 0, s, f, n_ptr, counted_scan_per(n_upper), tot);
+    }
+    return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+}
+
 template <class F>
 inline int launch_counted_scan(F f, int n, const int* tot, hipStream_t s) {
     if (n <= 4096) {

@@ -160,6 +160,7 @@ class DenseIndexedMap:
             self._frame_count = torch.zeros((self._grid,), device=device, dtype=torch.int32)
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._grid_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
+            self._dirty_tot = torch.zeros((1024,), device=device, dtype=torch.int32)       # set dirty flags per block of the slot scan
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
         self._capacity = 0
         self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
@@ -225,7 +226,24 @@ class DenseIndexedMap:
         m.tri_start = _lib.ptr(tri_start)
         m.tri_n = _lib.ptr(tri_n)
         m.own_x_lo, m.own_x_hi, m.halo = getattr(self, "_ownership", (0, self.n_xyz[0], 0))
+        m.dirty_tot = _lib.ptr(self._dirty_tot)
         self._cmap = m
+        self._recount_dirty()
+
+    def _recount_dirty(self):
+        """`dif_map_t.dirty_tot` from the flags themselves: after everything that sets dirty flags other than an integrate (which keeps
+        the totals itself), and after a re-allocation (the scan partition depends on the capacity)."""
+        cap = self._capacity
+        with torch.cuda.device(self.device):
+            self._dirty_tot.zero_()
+            if cap > 4096:                                       # (smaller maps are compacted by one workgroup that counts for itself)
+                nb = min(1024, (cap + 255) // 256)
+                per = (((cap + nb - 1) // nb) + 255) // 256 * 256   # csrc/common.hip.h: counted_scan_per
+                n_blk = (cap + per - 1) // per
+                flags = self._dirty
+                if n_blk * per != cap:
+                    flags = torch.nn.functional.pad(flags, (0, n_blk * per - cap))
+                self._dirty_tot[:n_blk] = flags.view(n_blk, per).sum(dim=1, dtype=torch.int32)
 
     def _publish_counters(self, c, add_total_at_read):
         with self._state_lock:
@@ -335,6 +353,7 @@ class DenseIndexedMap:
         self._counters.zero_()
         self._counters[_lib.C_N_OCCUPIED] = n
         self._n_occ_ub = n
+        self._recount_dirty()
         self.mesh_cache.clear_all()
 
     # ---- integrate --------------------------------------------------------------------------------------------
@@ -390,6 +409,7 @@ class DenseIndexedMap:
         _lib.check(lib.dif_optimize_latents(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), _lib.ptr(nrm), N, _lib.ptr(mask), _lib.ptr(noise),
                                             int(self.args.optim_n_iters), 1.0e-2, lam, _lib.ptr(self.optimize_losses), _lib.ptr(self._opt_ws),
                                             self._opt_ws.numel(), _lib.stream_ptr()), "dif_optimize_latents")
+        self._recount_dirty()                                    # the write-back marks the optimised voxels dirty
 
     def allocate_block(self, idx: torch.Tensor):
         """reference `map.py:310-319`.  Slots are handed out in ASCENDING linear-id order (the only order the reference's
@@ -713,6 +733,7 @@ class DenseIndexedMap:
                 self._halo_scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
             _lib.check(_lib.load().dif_merge_halo(ctypes.byref(self._cmap), _lib.ptr(msg), rows, _lib.ptr(self._halo_scratch), _lib.stream_ptr()),
                        "dif_merge_halo")
+            self._recount_dirty()
             if self._integrate_done is None:
                 self._integrate_done = torch.cuda.Event()
             self._integrate_done.record()
@@ -729,6 +750,7 @@ class DenseIndexedMap:
             scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
             _lib.check(_lib.load().dif_merge_records(ctypes.byref(self._cmap), _lib.ptr(rec), n, 1 if assign else 0, _lib.ptr(scratch),
                                                      _lib.stream_ptr()), "dif_merge_records")
+            self._recount_dirty()
             if self._integrate_done is None:
                 self._integrate_done = torch.cuda.Event()
             self._integrate_done.record()                          # writes latents like an integrate: later extracts wait for it
