@@ -228,13 +228,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_scan_pass2_fixed(F f, const int* 
     if (blockIdx.x == 0 && threadIdx.x == 0) f.finish(total);
 }
 
-// `n_upper` elements at most, `*n_ptr` live ones; `tot` follows counted_scan_per(n_upper)
+// `n_upper` elements at most, `*n_ptr` live ones; tot[b] = count over elements [b*DIF_BLOCK, (b+1)*DIF_BLOCK): one 256-element chunk per
+// workgroup whatever the capacity is (a coarser partition makes a workgroup walk several chunks one after the other, and the emit of
+// a chunk is a chain of dependent look-ups)
 template <class F>
-inline int launch_counted_scan_bounded(F f, const int* n_ptr, int n_upper, const int* tot, hipStream_t s) {
+inline int launch_counted_scan_bounded(F f, const int* n_ptr, int64_t n_upper, const int* tot, hipStream_t s) {
     if (n_upper <= 4096) {
         hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(1024), 0, s, f, n_ptr, 0);
     } else {
-        hipLaunchKernelGGL(k_scan_pass2_fixed<F>, dim3(scan_blocks(n_upper)), dim3(DIF_BLOCK), 0, s, f, n_ptr, counted_scan_per(n_upper), tot);
+        hipLaunchKernelGGL(k_scan_pass2_fixed<F>, dim3((int)((n_upper + DIF_BLOCK - 1) / DIF_BLOCK)), dim3(DIF_BLOCK), 0, s, f, n_ptr, DIF_BLOCK, tot);
     }
     return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }

@@ -442,8 +442,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         DIF_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.rec, (const int*)ws.rec_next,
-                       map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->dirty_tot,
-                       counted_scan_per(map->capacity));
+                       map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->dirty_tot, DIF_BLOCK);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -709,7 +708,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             DirtyFunctor f{ds};
             // every writer of the flags kept the per-block totals (k_fuse; the host recomputes them after anything else): no counting pass
             if (map->dirty_tot && !no_cache && !tiled) {
-                if (launch_counted_scan_bounded(f, n_slots, (int)map->capacity, map->dirty_tot, s) != DIF_OK) return DIF_ELAUNCH;
+                if (launch_counted_scan_bounded(f, n_slots, map->capacity, map->dirty_tot, s) != DIF_OK) return DIF_ELAUNCH;
             } else if (launch_scan(f, n_slots, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
         }
     }
@@ -842,7 +841,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
                        C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
                        (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity},
-                       fused_scan ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot);
+                       fused_scan ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK));
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

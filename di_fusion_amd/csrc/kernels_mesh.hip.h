@@ -320,10 +320,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
                                                             int* __restrict__ counters, int64_t new_limit, int64_t capacity,
                                                             const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                             const float* __restrict__ log_std, ExtractOut out, int32_t* __restrict__ chunk_sum,
-                                                            int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot) {
+                                                            int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot) {
     const int B = counters[DIF_C_B];
-    if (dirty_tot && blockIdx.x == 0)               // every dirty flag has been consumed by this call: the block totals return to idle 0
-        for (int t = (int)threadIdx.x; t < 1024; t += (int)blockDim.x) dirty_tot[t] = 0;
+    if (dirty_tot)                                  // every dirty flag has been consumed by this call: the block totals return to idle 0
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_dirty_tot; t += gridDim.x * blockDim.x) dirty_tot[t] = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
     if (chunk_sum)                                  // back to idle 0 (only the chunks this call's K dirty voxels could have touched)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((counters[DIF_C_K] + 255) >> 8); i += gridDim.x * blockDim.x) {

@@ -354,9 +354,9 @@ struct BufX6 {
     __amdgpu_buffer_rsrc_t rsrc;
     int base;                   // byte offset of step 0 (wave-uniform)
     __device__ __forceinline__ Tri load(int t, int lane) const {
-        const int o = base + t * 3072;
-        return Tri{__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o, 0), __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o + 1024, 0),
-                   __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o + 2048, 0)};
+        const int o = base + t * 3072;              // one scalar offset per step; the three fragments through the instruction's immediate offset
+        return Tri{__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o, 0), __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + 1024, o, 0),
+                   __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + 2048, o, 0)};
     }
 };
 

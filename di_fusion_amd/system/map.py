@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes
+import os
 import functools
 import logging
 import threading
@@ -160,7 +161,6 @@ class DenseIndexedMap:
             self._frame_count = torch.zeros((self._grid,), device=device, dtype=torch.int32)
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._grid_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
-            self._dirty_tot = torch.zeros((1024,), device=device, dtype=torch.int32)       # set dirty flags per block of the slot scan
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
         self._capacity = 0
         self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
@@ -188,6 +188,7 @@ class DenseIndexedMap:
             upd_list = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_n = torch.zeros((capacity,), dtype=torch.int32, device=dev)
+            self._dirty_tot = torch.zeros(((capacity + 255) // 256,), dtype=torch.int32, device=dev)       # set dirty flags per 256 slots
             if self._capacity > 0:
                 c = self._capacity
                 lat[:c] = self._latent
@@ -232,18 +233,14 @@ class DenseIndexedMap:
 
     def _recount_dirty(self):
         """`dif_map_t.dirty_tot` from the flags themselves: after everything that sets dirty flags other than an integrate (which keeps
-        the totals itself), and after a re-allocation (the scan partition depends on the capacity)."""
+        the totals itself), and after a re-allocation."""
         cap = self._capacity
         with torch.cuda.device(self.device):
-            self._dirty_tot.zero_()
-            if cap > 4096:                                       # (smaller maps are compacted by one workgroup that counts for itself)
-                nb = min(1024, (cap + 255) // 256)
-                per = (((cap + nb - 1) // nb) + 255) // 256 * 256   # csrc/common.hip.h: counted_scan_per
-                n_blk = (cap + per - 1) // per
-                flags = self._dirty
-                if n_blk * per != cap:
-                    flags = torch.nn.functional.pad(flags, (0, n_blk * per - cap))
-                self._dirty_tot[:n_blk] = flags.view(n_blk, per).sum(dim=1, dtype=torch.int32)
+            n_blk = (cap + 255) // 256
+            flags = self._dirty
+            if n_blk * 256 != cap:
+                flags = torch.nn.functional.pad(flags, (0, n_blk * 256 - cap))
+            self._dirty_tot.copy_(flags.view(n_blk, 256).sum(dim=1, dtype=torch.int32))
 
     def _publish_counters(self, c, add_total_at_read):
         with self._state_lock:

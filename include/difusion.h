@@ -87,8 +87,7 @@ typedef struct dif_map {
      * voxel lies outside [own_x_lo - halo, own_x_hi + halo) are ignored by integrate, and only owned voxels are meshed.
      * 0, nx, 0 = the whole grid (single-map behaviour). */
     int32_t own_x_lo, own_x_hi, halo;
-    /* Optional int32[1024], idle 0: number of set `dirty` flags per block of the slot scan (block = slot / P, P = the scan partition of
-     * `capacity` slots).  dif_integrate* keeps it while it sets flags and dif_extract then compacts the dirty set with ONE launch (and
+    /* Optional int32[ceil(capacity / 256)], idle 0: number of set `dirty` flags per block of 256 slots.  dif_integrate* keeps it while it sets flags and dif_extract then compacts the dirty set with ONE launch (and
      * zeroes it again).  A caller that sets flags any other way (dif_merge_*, dif_optimize_latents, its own writes) recomputes the array
      * from the flags afterwards — or passes NULL here, and dif_extract counts the flags itself. */
     int32_t* dirty_tot;

@@ -586,3 +586,52 @@ def test_latent_optimisation_vs_reference_and_oracle(gpu_model, oracle_net):
     # without do_optimize nothing changes for the optimiser's bookkeeping, and async is declined
     with pytest.raises(NotImplementedError):
         m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV), do_optimize=True, async_optimize=True)
+
+
+def test_dirty_set_block_totals_match_the_counting_pass(gpu_model):
+    """`dif_map_t.dirty_tot` (per-block totals of the dirty flags, kept by k_fuse) against the two-pass scan that counts the flags itself:
+    two integrates before an extract (a voxel updated twice is counted once), a capacity growth in between (recount on re-allocation),
+    a record merge (recount by the wrapper) and a `no_cache` extract — same valid_blocks, same mesh."""
+    import ctypes
+    from di_fusion_amd.system.map import DenseIndexedMap
+    scene, cfg = syn.config_c2()
+    intr = syn.Intrinsic().scaled(0.5)
+    frames = [tuple(t.to(DEV) for t in syn.frame_points(scene, f, intr, deg_per_frame=2.0)) for f in range(4)]
+
+    def run(use_totals):
+        m = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=8192)
+        outs = []
+
+        def extract(**kw):
+            if not use_totals:
+                m._cmap.dirty_tot = None                    # dif_extract counts the flags itself
+            v = m.extract_mesh_arrays(4, int(4e6), max_std=0.15, to_host=False, **kw)
+            K = m.last_counters["K"]
+            outs.append((m._xbuf[1]["valid_blocks"][:K].clone(), v[0].clone(), v[1].clone(), dict(m.last_counters)))
+
+        def integrate(f):
+            if not use_totals:
+                m._cmap.dirty_tot = None
+            m.integrate_keyframe(*frames[f])
+
+        integrate(0); integrate(1); extract(no_cache=False)          # two integrates, one extract
+        cap0 = m._capacity
+        integrate(2); extract(no_cache=False)
+        integrate(3)
+        m._ensure_capacity(4 * cap0)                                 # grow between the integrate and its extract
+        assert m._capacity > cap0
+        extract(no_cache=False)
+        other = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=8192)
+        other.integrate_keyframe(*frames[0])
+        m.merge_records(other.export_records())                      # dirty flags set by the merge kernel
+        extract(no_cache=False)
+        extract(no_cache=True)                                       # every allocated voxel
+        integrate(1); extract(no_cache=False)                        # and the totals are idle again afterwards
+        return outs, m
+
+    a, ma = run(True)
+    b, mb = run(False)
+    assert ma._cmap.dirty_tot and int(ma._dirty_tot.sum().item()) == 0
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x[3]["K"] == y[3]["K"] > 0 and x[3]["B"] == y[3]["B"] and x[3]["T"] == y[3]["T"], (i, x[3], y[3])
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]), i

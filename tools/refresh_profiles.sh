@@ -25,3 +25,7 @@ timeout 300 python tools/bench_query.py > $O/bench_query.json 2> $O/bench_query.
 rm -rf $O/pmc_fetch $O/pmc_write
 find $O/trace -name "*.db" -size +20M -delete
 ls -la $O
+timeout 300 python bench.py --batch 5 --no-cpu-baseline --no-secondary > $O/bench_batch5.json 2> $O/bench_batch5.err
+DIF_FORCE_DIST=1 timeout 300 python bench.py --no-cpu-baseline --steps 50 --no-secondary > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
+DIF_DECODER_PIPE=f32 timeout 300 python bench.py --no-cpu-baseline --no-secondary > $O/bench_f32pipe.json 2> $O/bench_f32pipe.err
+ls -la $O | wc -l
