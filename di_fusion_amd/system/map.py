@@ -19,7 +19,6 @@ from __future__ import annotations
 
 import argparse
 import ctypes
-import os
 import functools
 import logging
 import threading
