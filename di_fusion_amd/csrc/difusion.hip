@@ -435,14 +435,14 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         ProfScope prof(DIF_PROF_ENCODE, s);
         if (x6)
             hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(512), lds_bytes, s, g, (const float*)w->enc_x6_packed, xyz, normal, N, (const uint2*)ws.pair_list,
-                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C);
+                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, (const uint8_t*)map->dirty, map->dirty_tot);
         else
             hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint2*)ws.pair_list,
-                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C);
+                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, (const uint8_t*)map->dirty, map->dirty_tot);
         DIF_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.rec, (const int*)ws.rec_next,
-                       map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->dirty_tot, DIF_BLOCK);
+                       map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

@@ -281,7 +281,7 @@ template <bool X6>
 __global__ void __launch_bounds__(512, X6 ? 1 : 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
          const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
-         int* __restrict__ upd_list, int* __restrict__ counters) {
+         int* __restrict__ upd_list, int* __restrict__ counters, const uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     EN_STAMP(0);
     stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
@@ -352,7 +352,12 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
         if (pusher) {
             if (dir_pos < DIF_DIR_IDS) dir[2 + dir_pos] = rec_id;
             else rec_next[rec_id] = atomicExch(dir + 1, rec_id + 1);                        // a voxel fed by many workgroups: chained
-            if (dir_pos == 0) upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;        // first run of this slot in the frame (C of map.py:437)
+            if (dir_pos == 0) {                                                             // first run of this slot in the frame (C of map.py:437)
+                upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;
+                // k_fuse will set the slot's dirty flag: if it is not set yet, count it into the total of its 256-slot block here (extract's
+                // ordered compaction of the dirty set then needs no counting pass) — one lane per updated slot and frame, off k_fuse's tail
+                if (dirty_tot && !dirty[key]) atomicAdd(dirty_tot + (key >> 8), 1);
+            }
         }
         EN_STAMP(4);
     }
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 // together, overflow chain walked), fuse, return the directory to its idle state.
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                                   const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
-                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters, int* __restrict__ dirty_tot, int dirty_per) {
+                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters) {
     const int n_upd = counters[DIF_C_C];
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
     const int f = threadIdx.x & 31;
@@ -406,7 +411,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
         const int s = upd_list[u];
         int* dir = rec_dir + (int64_t)s * DIF_DIR_WORDS;
         const int n_rec = dir[0];
-        const bool was_dirty = dirty_tot ? dirty[s] != 0 : true;                 // asked here, used at the end: off the critical path
         const int my_id = (f < DIF_DIR_IDS && f < n_rec) ? dir[2 + f] : -1;       // lane f fetches directory entry f
         long long Si = 0;
         int cnt = 0;
@@ -433,10 +437,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
         __builtin_amdgcn_wave_barrier();
         if (f == 31) {                                       // after every lane of the group has read obs[s]
             obs[s] = obs[s] + (float)cnt;
-            // map.py:452.  The first setter of a flag also counts it into the total of its scan block (extract's ordered compaction of
-            // the dirty set then needs no counting pass); a slot is fused by exactly one group per launch, so the test does not race.
-            if (!was_dirty) atomicAdd(dirty_tot + s / dirty_per, 1);
-            dirty[s] = 1;
+            dirty[s] = 1;                                    // map.py:452
             dir[0] = 0;
             dir[1] = 0;
         }
