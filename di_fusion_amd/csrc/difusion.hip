@@ -814,7 +814,29 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     }
     const bool fused_scan = buf->chunk_sum && buf->max_voxels <= ((int64_t)1 << 24);      // three levels of 256: beyond that the scan kernel
     int32_t* const super_sum = buf->chunk_sum ? buf->chunk_sum + (buf->max_voxels + 255) / 256 : nullptr;
-    if (fused_scan) {
+    const bool onepass = fused_scan && buf->mc_status && r * r * r <= 64;                // count, look-back and emit in one launch
+    if (onepass) {
+        a.tri_start = map->tri_start; a.tri_n = map->tri_n; a.tri_count = buf->tri_count; a.tri_offset = nullptr;
+        size_t lds_bytes; int blocks;
+        rc = mc_setup(a, lds_bytes, blocks, buf->max_voxels);
+        if (rc != DIF_OK) return rc;
+        static bool attr_set1[64] = {};
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (dev < 64 && !attr_set1[dev]) {
+            if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+            attr_set1[dev] = true;
+        }
+        // every workgroup must be resident (a group waits for its predecessors): two per CU (54 KB of LDS each at resolution 4)
+        int64_t need = (buf->max_voxels + 3) / 4;
+        int grid1 = 2 * num_cus();
+        if (lds_bytes * 2 > 150 * 1024) grid1 = num_cus();
+        if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
+        {
+            ProfScope prof(DIF_PROF_MC_COUNT, s);
+            hipLaunchKernelGGL(k_marching_cubes_onepass, dim3(grid1), dim3(DIF_BLOCK), lds_bytes, s, a, buf->mc_status);
+        }
+        DIF_CHECK_LAUNCH();
+    } else if (fused_scan) {
         a.chunk_sum = buf->chunk_sum; a.super_sum = super_sum; a.tri_start = map->tri_start; a.tri_n = map->tri_n;
         a.tri_count = buf->tri_count; a.tri_offset = nullptr;
         size_t lds_bytes; int blocks;
@@ -841,7 +863,8 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
                        C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
                        (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity},
-                       fused_scan ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK));
+                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
+                       onepass ? buf->mc_status : nullptr);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

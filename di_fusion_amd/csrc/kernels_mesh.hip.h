@@ -258,6 +258,185 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     }
 }
 
+// ---- one-pass variant for the stream (mesh-cache path, r^3 <= 64 cells per voxel) ---------------------------------------------------
+// count -> offsets -> emit inside ONE launch: after its cells are counted a wave still holds everything the emit needs (edge
+// vertices in LDS, the case row and the per-cell count in registers), so the second pass's reload + recomputation and one kernel
+// boundary go away.  What the waves need from each other is the canonical output offset = number of triangles of all earlier dirty
+// voxels: a decoupled look-back over groups of 4 voxels (one workgroup per group and iteration).  status[g] packs a 2-bit state and
+// a 30-bit value in one word, so there is no payload to order against the flag; it is published and polled with device-scope atomic
+// read-modify-writes only (the same coherence every other counter in this library relies on).  The grid is sized to be co-resident
+// (2 workgroups per CU), and work is handed out in index order, so a group only ever waits for groups that are already running.
+// A poll that does not succeed within MC_SPIN_LIMIT rounds gives up with DIF_C_OVERFLOW = 7 instead of hanging the queue.
+#define MC_ST_AGG 0x40000000u
+#define MC_ST_PREFIX 0x80000000u
+#define MC_ST_VALUE 0x3FFFFFFFu
+#define MC_SPIN_LIMIT (1 << 22)
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_cnt[DIF_BLOCK / 64];
+    __shared__ int s_excl;
+    const int r = a.R / 2, r1 = r + 1, nc = r1 * r1 * r1, r3 = r * r * r;
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    float* c_sdf = lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc);
+    float* c_std = c_sdf + nc;
+    int* nb = reinterpret_cast<int*>(c_std + nc);
+    V4* vl = reinterpret_cast<V4*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
+    const int K = *a.K_ptr;
+    const int n_groups = (K + 3) >> 2;
+    const int64_t log_n = a.log_counters[DIF_C_CACHE_T];                 // log length before this call (k_extract_finish advances it)
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            a.log_counters[DIF_C_CACHE_KEPT] = (int)log_n;
+            if (K == 0) a.log_counters[DIF_C_T] = 0;
+        }
+        if (a.grid_tot)
+            for (int t = (int)threadIdx.x; t < 1024; t += (int)blockDim.x) a.grid_tot[t] = 0;
+    }
+    const float sbs = 1.0f / (float)r;
+    for (int g = (int)blockIdx.x; g < n_groups; g += (int)gridDim.x) {
+        const int k = g * 4 + wid;
+        const bool active = k < K;
+        int ntri = 0, voxel_total = 0;
+        unsigned long long tri_row = ~0ull;
+        int64_t vb = 0;
+        int bx = 0, by = 0, bz = 0;
+        if (active) {
+            vb = a.valid_blocks[k];
+            bx = (int)((vb / ((int64_t)a.ny * a.nz)) % a.nx); by = (int)((vb / a.nz) % a.ny); bz = (int)(vb % a.nz);
+            if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            bool any_neg = false, any_pos = false;
+            for (int c = lane; c < nc; c += 64) {
+                float sv, dv;
+                const bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, sv, dv);
+                c_sdf[c] = ok ? sv : __builtin_nanf("");
+                c_std[c] = ok ? dv : 0.0f;
+                any_neg |= ok && sv < 0.0f;
+                any_pos |= ok && !(sv < 0.0f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const bool crossing = __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
+            if (crossing && lane < r3) {
+                const int rx = lane / (r * r), ry = (lane / r) % r, rz = lane % r;
+                float val[8], sdv[8], pts[8][3];
+                bool dropped = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int dx = (q == 1 || q == 2 || q == 5 || q == 6), dy = (q == 2 || q == 3 || q == 6 || q == 7), dz = (q >= 4);
+                    const int ci = ((rx + dx) * r1 + (ry + dy)) * r1 + (rz + dz);
+                    val[q] = c_sdf[ci]; sdv[q] = c_std[ci];
+                    dropped |= !(val[q] == val[q]);
+                    pts[q][0] = (float)bx + (float)(rx + dx) * sbs;
+                    pts[q][1] = (float)by + (float)(ry + dy) * sbs;
+                    pts[q][2] = (float)bz + (float)(rz + dz) * sbs;
+                }
+                if (!dropped) {
+                    int cube_type = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) cube_type |= (val[q] < 0.0f) ? (1 << q) : 0;
+                    const int edge_config = c_mc_edge_table[cube_type];
+                    if (edge_config) {
+                        const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+#pragma unroll
+                        for (int e = 0; e < 12; ++e)
+                            if (edge_config & (1 << e)) vl[e * 64] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
+                        tri_row = c_mc_tri_packed[cube_type];
+                        for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
+                            const float w0 = vl[(int)(t3 & 0xF) * 64].w, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].w, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].w;
+                            if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
+                            ++ntri;
+                        }
+                    }
+                }
+            }
+        }
+        const int incl = wave_incl_scan(ntri);
+        voxel_total = __shfl(incl, 63);
+        if (lane == 0) {
+            s_cnt[wid] = voxel_total;
+            if (active) a.tri_count[k] = voxel_total;
+        }
+        __syncthreads();
+        if (wid == 0) {
+            const int agg = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            int excl = 0;
+            if (g > 0) {
+                if (lane == 0) atomicExch(status + g, MC_ST_AGG | (unsigned)agg);
+                int idx = g - 1;
+                while (idx >= 0) {
+                    const int i = idx - lane;
+                    unsigned st = (i >= 0) ? 0u : MC_ST_PREFIX;
+                    int spins = 0;
+                    while (true) {
+                        if ((st & ~MC_ST_VALUE) == 0u) st = atomicOr(status + i, 0u);
+                        if (__ballot((st & ~MC_ST_VALUE) == 0u) == 0ull) break;
+                        if (++spins > MC_SPIN_LIMIT) { if (lane == 0) a.log_counters[DIF_C_OVERFLOW] = 7; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    const unsigned long long pre = __ballot((st & MC_ST_PREFIX) != 0u);
+                    const int p = pre ? (__ffsll((long long)pre) - 1) : 64;               // nearest predecessor that knows its inclusive prefix
+                    int v = (lane <= p) ? (int)(st & MC_ST_VALUE) : 0;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                    excl += v;
+                    if (pre) break;
+                    idx -= 64;
+                }
+            }
+            if (lane == 0) {
+                atomicExch(status + g, MC_ST_PREFIX | ((unsigned)(excl + agg) & MC_ST_VALUE));
+                s_excl = excl;
+                if (g == n_groups - 1) a.log_counters[DIF_C_T] = excl + agg;            // triangles of this call (map.py:695 counts them on the host)
+            }
+        }
+        __syncthreads();
+        if (active && voxel_total > 0) {
+            int voxel_offset = s_excl;
+            for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[w];
+            // mesh-cache log: this voxel's previous batch dies, the voxel points at its new one (map.py:708-709)
+            const int64_t slot = a.indexer[vb];
+            const int old_n = a.tri_n[slot], old_s = a.tri_start[slot];
+            for (int j = lane; j < old_n; j += 64) a.tri_alive[old_s + j] = 0;
+            int64_t n_new = voxel_total;
+            if (voxel_offset + n_new > a.new_limit) n_new = a.new_limit > voxel_offset ? a.new_limit - voxel_offset : 0;      // truncated by max_n_triangles
+            if (log_n + voxel_offset + n_new > a.max_triangles) n_new = a.max_triangles > log_n + voxel_offset ? a.max_triangles - (log_n + voxel_offset) : 0;
+            __builtin_amdgcn_wave_barrier();             // every lane has read tri_n / tri_start
+            if (lane == 0) {
+                a.tri_start[slot] = (int)(log_n + voxel_offset);
+                a.tri_n[slot] = (int)n_new;
+                if (old_n) atomicAdd(a.log_counters + DIF_C_CACHE_DEAD, old_n);
+            }
+            if (ntri > 0) {
+                int64_t tl = (int64_t)voxel_offset + (incl - ntri);                     // index among this call's triangles
+                int64_t t = tl + log_n;
+                for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
+                    const V4 v0 = vl[(int)(t3 & 0xF) * 64], v1 = vl[(int)((t3 >> 4) & 0xF) * 64], v2 = vl[(int)((t3 >> 8) & 0xF) * 64];
+                    if (v0.w > a.max_std || v1.w > a.max_std || v2.w > a.max_std) continue;
+                    if (tl < a.new_limit && t < a.max_triangles) {
+                        const V4 vv[3] = {v0, v1, v2};
+#pragma unroll
+                        for (int vi = 0; vi < 3; ++vi) {
+                            float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
+                            if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }   // map.py:698
+                            a.triangles[(t * 3 + vi) * 3 + 0] = x;
+                            a.triangles[(t * 3 + vi) * 3 + 1] = y;
+                            a.triangles[(t * 3 + vi) * 3 + 2] = z;
+                            a.tri_std[t * 3 + vi] = vv[vi].w;
+                        }
+                        a.tri_id[t] = vb;
+                        a.tri_alive[t] = 1;
+                    }
+                    ++t; ++tl;
+                }
+            }
+        }
+        __syncthreads();                                 // s_cnt / s_excl are rewritten by the next group
+    }
+}
+
 // ---- a16 : device-resident mesh cache as an append-only log (map.py:703-714) -----------------------------------------
 // A voxel that produced >= 1 new triangle replaces its previous batch (the reference drops cached triangles whose voxel id
 // occurs among the new ones, map.py:708-709): TriScanFunctor::emit marks the old batch dead and points the voxel at its new one.
@@ -320,8 +499,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
                                                             int* __restrict__ counters, int64_t new_limit, int64_t capacity,
                                                             const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                             const float* __restrict__ log_std, ExtractOut out, int32_t* __restrict__ chunk_sum,
-                                                            int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot) {
+                                                            int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status) {
     const int B = counters[DIF_C_B];
+    if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((counters[DIF_C_K] + 3) >> 2); i += gridDim.x * blockDim.x) mc_status[i] = 0u;
     if (dirty_tot)                                  // every dirty flag has been consumed by this call: the block totals return to idle 0
         for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_dirty_tot; t += gridDim.x * blockDim.x) dirty_tot[t] = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;

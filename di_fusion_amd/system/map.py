@@ -101,7 +101,8 @@ class _GetSdfFn(torch.autograd.Function):
 
 
 _OVERFLOW_WHAT = {1: "more voxels than latent rows", 2: "more dirty voxels than extract buffers", 3: "more decoded voxels than extract buffers",
-                  5: "mesh-cache log full", 6: "more records than the export buffer"}
+                  5: "mesh-cache log full", 6: "more records than the export buffer",
+                  7: "marching cubes gave up waiting for an earlier workgroup (the GPU was shared with another kernel for seconds)"}
 
 
 def _next_pow2(n: int) -> int:
@@ -547,6 +548,7 @@ class DenseIndexedMap:
                      tri_offset=torch.empty((max_vox,), dtype=torch.int32, device=dev),
                      block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev),
                      chunk_sum=torch.zeros(((max_vox + 255) // 256 + (max_vox + 65535) // 65536,), dtype=torch.int32, device=dev),
+                     mc_status=torch.zeros(((max_vox + 3) // 4,), dtype=torch.int32, device=dev),
                      fold_table=torch.empty((max_vox, 256), dtype=torch.float32, device=dev))
             self._xbuf = (key, t)
         t = self._xbuf[1]

@@ -36,7 +36,7 @@ extern "C" {
 /* Device-resident counters (one per map).  int32 each; indices into the `counters` array. */
 enum {
     DIF_C_N_OCCUPIED = 0,   /* map.py:200  n_occupied                                                   */
-    DIF_C_OVERFLOW = 1,     /* set !=0 when a device-side buffer was too small (checked by the façade)    */
+    DIF_C_OVERFLOW = 1,     /* set !=0 when a device-side buffer was too small (checked by the façade); 7 = the one-pass marching cubes gave up a look-back */
     DIF_C_ALLOC_NEW = 2,    /* voxels allocated by the last integrate                                     */
     DIF_C_M = 3,            /* gathered (point, offset) rows of the last integrate  (map.py:434-435)      */
     DIF_C_C = 4,            /* voxels updated by the encoder in the last integrate  (map.py:437)          */
@@ -253,6 +253,9 @@ typedef struct dif_extract_buffers {
                                      * instead of count, scan, emit */
     float* fold_table;              /* optional [max_voxels][256]: per-voxel decoder constants handed from the lattice decode to the refine
                                      * decode (used when dif_weights_t.dec_fold_packed is set) */
+    uint32_t* mc_status;            /* optional [(max_voxels + 3) / 4], idle 0: with it (and chunk_sum, resolution <= 4) marching cubes is ONE launch:
+                                     * a wave counts its voxel's triangles, learns its output offset by a decoupled look-back over groups of
+                                     * four voxels and emits straight away (same canonical order) */
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
