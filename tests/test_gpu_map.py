@@ -635,3 +635,46 @@ def test_dirty_set_block_totals_match_the_counting_pass(gpu_model):
     for i, (x, y) in enumerate(zip(a, b)):
         assert x[3]["K"] == y[3]["K"] > 0 and x[3]["B"] == y[3]["B"] and x[3]["T"] == y[3]["T"], (i, x[3], y[3])
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]), i
+
+
+def test_one_pass_marching_cubes_equals_count_and_emit_passes(gpu_model):
+    """The stream path's single-launch marching cubes (count, decoupled look-back, emit) against the count pass + emit pass it replaces:
+    12.8 k dirty voxels (3,200 look-back groups over 512 resident workgroups, i.e. several groups per workgroup), then a second frame
+    that replaces batches in the log — the same log, bit for bit, and the same bookkeeping."""
+    from di_fusion_amd.system.map import DenseIndexedMap
+    scene, cfg = syn.config_c3()
+    intr = syn.Intrinsic()
+    frames = [tuple(t.to(DEV) for t in syn.frame_points(scene, f, intr, deg_per_frame=0.5)) for f in range(2)]
+
+    def run(one_pass):
+        m = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=32768)
+        outs = []
+        for f in range(2):
+            m.integrate_keyframe(*frames[f])
+            h = m.extract_mesh_enqueue(4, int(4e6), max_std=0.15)
+            assert m._xbuf[1]["mc_status"].numel() > 0
+            outs.append(h)
+            m.extract_mesh_finish(h)
+            t = m.mesh_cache_tensors()
+            outs[-1] = (tuple(x.clone() for x in t), dict(m.last_counters), m._tri_start.clone(), m._tri_n.clone())
+        return outs
+
+    import di_fusion_amd.system.map as M
+    a = run(True)
+    orig = M.DenseIndexedMap._extract_buffers
+
+    def without_status(self, *args, **kw):
+        t, b = orig(self, *args, **kw)
+        b.mc_status = None                                   # dif_extract falls back to the count pass + emit pass
+        return t, b
+
+    M.DenseIndexedMap._extract_buffers = without_status
+    try:
+        b = run(False)
+    finally:
+        M.DenseIndexedMap._extract_buffers = orig
+    for f, (x, y) in enumerate(zip(a, b)):
+        assert x[1] == y[1] and x[1]["T"] > 100000 and x[1]["K"] > 10000, (f, x[1], y[1])
+        for u, v in zip(x[0], y[0]):
+            assert torch.equal(u, v), f
+        assert torch.equal(x[2], y[2]) and torch.equal(x[3], y[3]), f

@@ -14,7 +14,7 @@ def short(name: str) -> str:
     if "k_scan_pass" in name:
         f = re.search(r"<(?:.*::)?(\w+Functor)", name)
         base = base + "<" + (f.group(1) if f else "?") + ">"
-    elif "k_marching_cubes" in name:
+    elif base.endswith("k_marching_cubes"):
         base += "<emit>" if "true" in name else "<count>"
     elif base.startswith("rocprim"):
         base = "rocprim::" + (re.search(r"(\w+kernel\w*|\w+_kernel)", name).group(1) if re.search(r"(\w+kernel\w*|\w+_kernel)", name) else base)
