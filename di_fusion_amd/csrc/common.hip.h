@@ -76,6 +76,28 @@ struct GridMarks {
 };
 
 // ---- wave / block primitives ---------------------------------------------------------------------------------
+// 64-bit value of another lane through DPP (VALU data path; __shfl_up goes through the LDS crossbar: two ds_bpermute per 64-bit value)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_mov64(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// Inclusive SEGMENTED scan along the 32 columns of each half-wave: lane (col) adds up its run [my_head .. col].  Four row-local
+// steps (row_shr 1, 2, 4, 8 inside the 16-lane DPP rows) and one cross-row step (row_bcast15: lane 15 of the first row to the lanes
+// of the second row whose run began in the first).
+__device__ __forceinline__ long long seg_incl_scan32(long long v, int col, int my_head) {
+    const int head_r = max(my_head, col & 16);                  // where the run starts inside this lane's row
+    long long u;
+    u = dpp_mov64<0x111, 0xF>(v); if (col - 1 >= head_r) v += u;
+    u = dpp_mov64<0x112, 0xF>(v); if (col - 2 >= head_r) v += u;
+    u = dpp_mov64<0x114, 0xF>(v); if (col - 4 >= head_r) v += u;
+    u = dpp_mov64<0x118, 0xF>(v); if (col - 8 >= head_r) v += u;
+    u = dpp_mov64<0x142, 0xA>(v); if (col >= 16 && my_head < 16) v += u;
+    return v;
+}
+
 __device__ __forceinline__ int wave_incl_scan(int v) {
     int lane = lane_id();
 #pragma unroll

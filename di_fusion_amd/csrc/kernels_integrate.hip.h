@@ -341,12 +341,7 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
         for (int r = 0; r < 16; ++r) {
             long long v = live ? __float2ll_rn(out[r] * DIF_FIX_SCALE) : 0ll;
             if (half == 1 && r == 13) v = live ? 1ll : 0ll;          // feature 29 (a zero row): carries the run length instead
-            // segmented inclusive scan along the 32 columns: a lane adds the value `d` columns below if that column is still in its run
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const long long u = __shfl_up(v, d, 32);
-                if (col - d >= my_head) v += u;
-            }
+            v = seg_incl_scan32(v, col, my_head);            // sum of the lane's run up to its column
             if (live && run_tail) p[r] = v;
         }
         if (pusher) {
