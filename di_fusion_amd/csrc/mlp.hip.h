@@ -430,7 +430,7 @@ __device__ __forceinline__ void decoder_fold_consts_x6(const float* __restrict__
                                                        const float* __restrict__ lat_row, float* __restrict__ c, int lane) {
     float a0 = aux[X6_B0 + lane], a1 = aux[X6_B0 + lane + 64], a2 = aux[X6_B3 + lane], a3 = aux[X6_B3 + lane + 64];
     const f4v* wk = reinterpret_cast<const f4v*>(fold) + lane;
-#pragma unroll 8
+#pragma unroll 15                                    // two batches of loads in flight (fully unrolled the kernel spills: 256 VGPRs + scratch)
     for (int k = 0; k < 29; ++k) {
         const float zk = lat_row[k];
         const f4v wv = wk[k * 64];
