@@ -826,14 +826,14 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
             attr_set1[dev] = true;
         }
-        // every workgroup must be resident (a group waits for its predecessors): two per CU (54 KB of LDS each at resolution 4)
+        // two workgroups per CU (54 KB of LDS each at resolution 4); groups of four voxels are claimed through a ticket counter
         int64_t need = (buf->max_voxels + 3) / 4;
         int grid1 = 2 * num_cus();
         if (lds_bytes * 2 > 150 * 1024) grid1 = num_cus();
         if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
         {
             ProfScope prof(DIF_PROF_MC_COUNT, s);
-            hipLaunchKernelGGL(k_marching_cubes_onepass, dim3(grid1), dim3(DIF_BLOCK), lds_bytes, s, a, buf->mc_status);
+            hipLaunchKernelGGL(k_marching_cubes_onepass, dim3(grid1), dim3(DIF_BLOCK), lds_bytes, s, a, buf->mc_status, buf->mc_status + (buf->max_voxels + 3) / 4);
         }
         DIF_CHECK_LAUNCH();
     } else if (fused_scan) {
@@ -864,7 +864,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
                        C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
                        (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity},
                        (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
-                       onepass ? buf->mc_status : nullptr);
+                       onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

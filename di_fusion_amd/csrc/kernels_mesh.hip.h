@@ -264,15 +264,16 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 // boundary go away.  What the waves need from each other is the canonical output offset = number of triangles of all earlier dirty
 // voxels: a decoupled look-back over groups of 4 voxels (one workgroup per group and iteration).  status[g] packs a 2-bit state and
 // a 30-bit value in one word, so there is no payload to order against the flag; it is published and polled with device-scope atomic
-// read-modify-writes only (the same coherence every other counter in this library relies on).  The grid is sized to be co-resident
-// (2 workgroups per CU), and work is handed out in index order, so a group only ever waits for groups that are already running.
+// read-modify-writes only (the same coherence every other counter in this library relies on).  Groups are claimed through a ticket
+// counter in index order, so a group only ever waits for groups that some running (or finished) workgroup has already claimed —
+// no assumption about how many workgroups of the grid are resident, or about what else shares the GPU.
 // A poll that does not succeed within MC_SPIN_LIMIT rounds gives up with DIF_C_OVERFLOW = 7 instead of hanging the queue.
 #define MC_ST_AGG 0x40000000u
 #define MC_ST_PREFIX 0x80000000u
 #define MC_ST_VALUE 0x3FFFFFFFu
 #define MC_SPIN_LIMIT (1 << 22)
 
-__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status) {
+__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_cnt[DIF_BLOCK / 64];
     __shared__ int s_excl;
@@ -294,7 +295,19 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, 
             for (int t = (int)threadIdx.x; t < 1024; t += (int)blockDim.x) a.grid_tot[t] = 0;
     }
     const float sbs = 1.0f / (float)r;
-    for (int g = (int)blockIdx.x; g < n_groups; g += (int)gridDim.x) {
+    __shared__ int s_g;
+    // Which group a workgroup takes: with at most one group per workgroup (a stream frame: ~150 groups) simply its own index —
+    // workgroups are dispatched in index order, so every predecessor is running or done.  Otherwise groups are handed out by a ticket
+    // counter, lowest first: whatever the residency of the grid, a group's predecessors have all been claimed by workgroups that are
+    // running (or done), and the look-back below cannot wait for work nobody has started.
+    const bool use_ticket = n_groups > (int)gridDim.x;
+    for (int round = 0;; ++round) {
+        if (use_ticket) {
+            if (threadIdx.x == 0) s_g = (int)atomicAdd(ticket, 1u);
+            __syncthreads();
+        }
+        const int g = use_ticket ? s_g : (int)blockIdx.x;
+        if (g >= n_groups || (!use_ticket && round > 0)) break;
         const int k = g * 4 + wid;
         const bool active = k < K;
         int ntri = 0, voxel_total = 0;
@@ -499,10 +512,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
                                                             int* __restrict__ counters, int64_t new_limit, int64_t capacity,
                                                             const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                             const float* __restrict__ log_std, ExtractOut out, int32_t* __restrict__ chunk_sum,
-                                                            int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status) {
+                                                            int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket) {
     const int B = counters[DIF_C_B];
     if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
+    {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((counters[DIF_C_K] + 3) >> 2); i += gridDim.x * blockDim.x) mc_status[i] = 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *mc_ticket = 0u;
+    }
     if (dirty_tot)                                  // every dirty flag has been consumed by this call: the block totals return to idle 0
         for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_dirty_tot; t += gridDim.x * blockDim.x) dirty_tot[t] = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;

@@ -253,7 +253,7 @@ typedef struct dif_extract_buffers {
                                      * instead of count, scan, emit */
     float* fold_table;              /* optional [max_voxels][256]: per-voxel decoder constants handed from the lattice decode to the refine
                                      * decode (used when dif_weights_t.dec_fold_packed is set) */
-    uint32_t* mc_status;            /* optional [(max_voxels + 3) / 4], idle 0: with it (and chunk_sum, resolution <= 4) marching cubes is ONE launch:
+    uint32_t* mc_status;            /* optional [(max_voxels + 3) / 4 + 1], idle 0: with it (and chunk_sum, resolution <= 4) marching cubes is ONE launch:
                                      * a wave counts its voxel's triangles, learns its output offset by a decoupled look-back over groups of
                                      * four voxels and emits straight away (same canonical order) */
 } dif_extract_buffers_t;
