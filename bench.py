@@ -426,7 +426,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     hbm_resident = batched = None
-    if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled:
+    # (secondary figures need a run long enough to amortise their own one-time costs — a fresh stream's buffer growth, graph captures)
+    if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled and a.steps >= 100:
         hbm_resident = secondary_rate(make_stream, a, n_frames, "none", 0)
         if a.batch == 0 and (a.graph or a.direct):
             batched = secondary_rate(make_stream, a, n_frames, a.d2h, 5)
