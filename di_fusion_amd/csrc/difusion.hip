@@ -559,6 +559,16 @@ static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t ti
     if (blocks < 1) blocks = 1;
     if (blocks > num_cus()) blocks = num_cus();
     ProfScope prof(A.mode == 0 ? DIF_PROF_DECODE_LATTICE : DIF_PROF_DECODE_POINTS, s);
+    if (!grad && A.mode != 1 && w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES && w->dec_x6u_packed && w->dec_x6u_packed_bytes == X6U_BYTES) {
+        static bool attr_set6[64] = {};                      // forward-only rows on the bf16 matrix pipe
+        if (dev < 64 && !attr_set6[dev]) {
+            if (hipFuncSetAttribute((const void*)k_decode_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+            attr_set6[dev] = true;
+        }
+        hipLaunchKernelGGL(k_decode_x6, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed, (const float*)w->dec_x6u_packed);
+        DIF_CHECK_LAUNCH();
+        return DIF_OK;
+    }
     if (grad) {
         DecodeArgs B = A;
         B.wbwd = w->dec_bwd_packed;

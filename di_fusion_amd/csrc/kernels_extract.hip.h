@@ -259,6 +259,79 @@ __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(Decod
     }
 }
 
+// Modes 0 (lattice, every sample), 2 (explicit rows) and 3 (map point query, values only) on the bf16 matrix pipe: the row set-up of
+// k_decode, the tile of decoder_tile_x6.  wblob = packing.py:pack_decoder_x6, wu = pack_decoder_x6u.
+__global__ void __launch_bounds__(512, 1) k_decode_x6(DecodeArgs A, const float* __restrict__ wblob, const float* __restrict__ wu) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, X6_LDS_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t wun = make_rsrc(wu, X6U_BYTES / 4);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int res3 = A.lat.res * A.lat.res * A.lat.res;
+    const int tiles_per_voxel = (res3 + 31) / 32;
+    int64_t n_rows, n_tiles;
+    if (A.mode == 0) {
+        n_rows = (int64_t)(*A.n_ptr) * res3;
+        n_tiles = (int64_t)(*A.n_ptr) * tiles_per_voxel;
+    } else {
+        n_rows = A.n_ptr ? (int64_t)(*A.n_ptr) : A.n_static;
+        n_tiles = (n_rows + 31) / 32;
+    }
+    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+        bool live;
+        int64_t out_idx = 0;
+        const float* lat_row = nullptr;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        const float* row32 = nullptr;
+        if (A.mode == 0) {
+            const int64_t b = tile / tiles_per_voxel;
+            const int s = (int)(tile - b * tiles_per_voxel) * 32 + col;
+            live = s < res3;
+            if (live) {
+                const int r = A.lat.res;
+                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
+                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+                out_idx = b * res3 + s;
+            }
+        } else if (A.mode == 2) {
+            const int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) { row32 = A.rows + row * 32; out_idx = row; }
+        } else {
+            const int64_t row = tile * 32 + col;
+            live = row < n_rows;
+            if (live) {
+                const int64_t p = A.list[row];
+                float xn, yn, zn; int ix, iy, iz;
+                voxel_of(A.geo, A.xyz[p * 3 + 0], A.xyz[p * 3 + 1], A.xyz[p * 3 + 2], xn, yn, zn, ix, iy, iz);
+                px = (xn - (float)ix) - 0.5f; py = (yn - (float)iy) - 0.5f; pz = (zn - (float)iz) - 0.5f;      // map.py:575
+                lat_row = A.latent + A.indexer[linearize(A.geo, ix, iy, iz)] * L;
+                out_idx = row;
+            }
+        }
+        f16v xin;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int k = 2 * t + half;
+            float v = 0.0f;
+            if (live) {
+                if (row32) v = row32[k];
+                else if (k < L) v = lat_row[k];
+                else v = (k == L) ? px : ((k == L + 1) ? py : pz);
+            }
+            xin[t] = v;
+        }
+        float sdf, sd;
+        decoder_tile_x6(lds, wfwd, wun, xin, lane, sdf, sd);
+        if (live) {
+            if (half == 0) A.out_sdf[out_idx] = A.sign * sdf;
+            else A.out_std[out_idx] = sd;
+        }
+    }
+}
+
 // Refine rows (mode 1 with the lattice pass's fold table) on the bf16 matrix pipe; wblob = packing.py:pack_decoder_x6.
 __global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

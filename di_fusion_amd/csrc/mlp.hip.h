@@ -506,6 +506,65 @@ __device__ __forceinline__ void decoder_tile_folded_x6(const float* __restrict__
     stdv = 0.05f + 0.5f * sp;
 }
 
+// The unfolded decoder tile on the bf16 pipe (explicit 32-column rows: dif_decode_rows, get_sdf values, the non-fast lattice): lin0 and
+// the skip block of lin3 take the input fragment `xin` (natural k order) through slices of their own (Wu = packing.py:pack_decoder_x6u,
+// streamed from L2); everything else as decoder_tile_folded_x6.
+#define X6U_L0 0
+#define X6U_L3X 24576
+#define X6U_BYTES 49152
+__device__ __forceinline__ void decoder_tile_x6(const float* __restrict__ W /* LDS */, __amdgpu_buffer_rsrc_t Wg, __amdgpu_buffer_rsrc_t Wu,
+                                                const f16v& xin, int lane, float& sdf, float& stdv) {
+    const int half = lane >> 5;
+    const char* Wb = reinterpret_cast<const char*>(W);
+    int uoff = X6U_L0, goff = X6_L2 + 36864;     // opaque per tile (see decoder_tile)
+    asm volatile("" : "+s"(uoff), "+s"(goff) : : "memory");
+    f16v hx[1];
+    hx[0] = xin;
+    f16v h0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h0[mb] = load_bias16(W + X6_B0 + mb * 32, half);
+    layer_x6<0, 1, 4, 3>(BufX6{Wu, uoff}, hx, h0, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h0[mb] = relu16(h0[mb]);
+    f16v h1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h1[mb] = load_bias16(W + X6_B1 + mb * 32, half);
+    layer_x6<0, 4, 4, X6_PF_LDS>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L1)}, h0, h1, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h1[mb] = relu16(h1[mb]);
+    f16v h2[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) h2[mb] = load_bias16(W + X6_B2 + mb * 32, half);
+    layer_x6<0, 2, 3, X6_PF_LDS>(LdsX6{reinterpret_cast<const u4v*>(Wb + X6_L2)}, h1, h2, lane);
+    layer_x6<2, 4, 3, 3>(BufX6{Wg, goff}, h1, h2, lane);
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) h2[mb] = relu16(h2[mb]);
+    f16v h3[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h3[mb] = load_bias16(W + X6_B3 + mb * 32, half);
+    layer_x6<0, 3, 4, 3>(BufX6{Wg, goff + 36864}, h2, h3, lane);
+    layer_x6<0, 1, 4, 3>(BufX6{Wu, uoff + X6U_L3X}, hx, h3, lane);
+    float ps = 0.0f, pu = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const f16v acc = relu16(h3[mb]);
+        f16v ws = load_bias16(W + X6_HW + mb * 32, half);
+        f16v wu = load_bias16(W + X6_HU + mb * 32, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ps = fmaf(acc[r], ws[r], ps);
+            pu = fmaf(acc[r], wu[r], pu);
+        }
+    }
+    ps += __shfl_xor(ps, 32);
+    pu += __shfl_xor(pu, 32);
+    ps += W[X6_HB + 0];
+    pu += W[X6_HB + 1];
+    sdf = tanhf(ps);
+    float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));
+    stdv = 0.05f + 0.5f * sp;
+}
+
 // Encoder on the bf16 pipe (blob = packing.py:pack_encoder_x6, all of it staged in LDS).  lin0 (6 -> 32, three k-steps) stays on the f32
 // MFMA.  lin2's out-block mb+1 is computed while out-block mb is being sliced for lin3, so the weight steps are stored in the order
 // they are consumed: lin1 | L2(0) | L2(1) L3(0) | L2(2) L3(1) | ... | L2(7) L3(6) | L3(7)   (L2(mb): 4 steps, L3(mb): 2 steps).

@@ -28,6 +28,7 @@ DECF_FLOATS = 2 * 29 * 128
 X6_AUX_FLOATS = 2788
 X6_L1_BYTES, X6_L2_BYTES, X6_L3_BYTES = 4 * 2 * 4 * 3 * 1024, 4 * 2 * 3 * 3 * 1024, 3 * 2 * 4 * 3 * 1024
 X6_BYTES = X6_AUX_FLOATS * 4 + X6_L1_BYTES + X6_L2_BYTES + X6_L3_BYTES
+X6U_BYTES = 2 * 2 * 4 * 3 * 1024       # lin0 | lin3's skip block, natural input order (the unfolded tile: explicit rows, get_sdf)
 E6_AUX_FLOATS = 640
 E6_BYTES = E6_AUX_FLOATS * 4 + 12288 + 147456
 
@@ -260,4 +261,32 @@ def pack_encoder_x6(w: Dict[str, np.ndarray]) -> np.ndarray:
     blob = np.concatenate([aux.view(np.uint8), np.ascontiguousarray(l1).reshape(-1).view(np.uint8)] +
                           [np.ascontiguousarray(x).view(np.uint8) for x in steps])
     assert blob.shape[0] == E6_BYTES, blob.shape
+    return blob
+
+
+def pack_A_x6_nat(W: np.ndarray, NMO: int) -> np.ndarray:
+    """As pack_A_x6 for ONE 32-feature input block that arrives in natural order (B-operand register t of half h holds feature 2t + h:
+    the rows of `dif_decode_rows` / the [latent | xyz] input): element j of k-step s <-> feature 2*(8s + j) + half."""
+    M, K = W.shape
+    assert K == 32
+    sl = split_bf16x3(W)
+    out = np.zeros((1, 2, NMO, 3, 64, 8), dtype=np.uint16)
+    for s in range(2):
+        for mo in range(NMO):
+            for lane in range(64):
+                m = mo * 32 + (lane & 31)
+                if m >= M:
+                    continue
+                for j in range(8):
+                    k = 2 * (8 * s + j) + (lane >> 5)
+                    for q in range(3):
+                        out[0, s, mo, q, lane, j] = sl[q][m, k]
+    return out
+
+
+def pack_decoder_x6u(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """The two input blocks the folded tiles do not need: lin0 (all 32 inputs) and the skip block of lin3 (columns 96..127 = x0)."""
+    Ws, bs, Wu, bu = fold_decoder(w)
+    blob = np.concatenate([pack_A_x6_nat(Ws[0], 4).reshape(-1).view(np.uint8), pack_A_x6_nat(Ws[3][:, 96:128], 4).reshape(-1).view(np.uint8)])
+    assert blob.shape[0] == X6U_BYTES, blob.shape
     return blob

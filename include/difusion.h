@@ -111,6 +111,9 @@ typedef struct dif_weights {
     const void* enc_x6_packed;      /* encoder sliced the same way (packing.py:pack_encoder_x6), or NULL: integrate's encoder tiles and
                                      * dif_encode_rows run on the bf16 matrix pipe when set */
     int64_t enc_x6_packed_bytes;
+    const void* dec_x6u_packed;     /* with dec_x6_packed: slices of lin0 and of lin3's skip block (packing.py:pack_decoder_x6u) for the tiles that
+                                     * carry the whole 32-column input (dif_decode_rows, dif_query_sdf without gradient, non-fast extract) */
+    int64_t dec_x6u_packed_bytes;
 } dif_weights_t;
 
 int dif_version(void);

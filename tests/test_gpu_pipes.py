@@ -80,3 +80,27 @@ def test_repeated_frames_are_bit_identical():
     import determinism_stress
     bad, counters = determinism_stress.run(25, verbose=True)
     assert counters["B"] > 10000 and bad == 0
+
+
+def test_decoder_rows_and_point_queries_both_pipes(gpu_model, gpu_model_f32):
+    """Explicit (N,32) rows and `get_sdf` values (no gradient) run the unfolded tile: bf16 pipe (`k_decode_x6`) and f32-input MFMA
+    (`k_decode`) against the reference golden rows, and against each other on a map's point query."""
+    from di_fusion_amd.system.map import DenseIndexedMap
+    g = np.load(GOLDEN / "networks.npz")
+    x = torch.from_numpy(g["dec_x"]).to(DEV)
+    for model in (gpu_model, gpu_model_f32):
+        for n in (384, 33, 1):
+            sdf, std = model.decoder(x[:n].contiguous())
+            assert np.abs(sdf.cpu().numpy() - g["dec_sdf"][:n]).max() < 1e-5 and np.abs(std.cpu().numpy() - g["dec_std"][:n]).max() < 1e-5
+    scene, cfg = syn.config_c2()
+    xyz, nrm = (t.to(DEV) for t in syn.frame_points(scene, 0, syn.Intrinsic().scaled(0.5), deg_per_frame=0.5))
+    out = []
+    for model in (gpu_model, gpu_model_f32):
+        m = DenseIndexedMap(model, cfg.namespace(), 29, DEV, initial_capacity=16384)
+        m.integrate_keyframe(xyz, nrm)
+        sdf, std, mask = m.get_sdf(xyz[::7].contiguous())
+        out.append((sdf.cpu().numpy(), std.cpu().numpy(), mask.cpu().numpy()))
+    assert np.array_equal(out[0][2], out[1][2]) and out[0][2].sum() > 1000
+    d = max(np.abs(out[0][0] - out[1][0]).max(), np.abs(out[0][1] - out[1][1]).max())
+    print(f"get_sdf values, bf16 pipe vs f32 pipe: max diff {d:.2e} over {int(out[0][2].sum())} points")
+    assert d < 2e-5
