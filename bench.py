@@ -459,11 +459,13 @@ def main():
                "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if use_dist else 0, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
-               "dtype": ("f32 (MLP products as six exact bf16 slice products on the bf16 matrix pipe, fp32 accumulate; DIF_DECODER_PIPE=f32 for the f32-input MFMA)"
-                         if pipe == "bf16x6" else "f32"), "data": "synthetic",
+               "dtype": "f32", "data": "synthetic",
                "config": {"workload": WORKLOADS[a.config] + f", {intr.width}x{intr.height} orbit stream 0.5 deg/frame, all {pixels} pixels integrated and meshed "
                                                             "every frame, resolution 4, fast decode, max_std 0.15",
-                          "mode": a.mode, "points_per_frame": pixels, "mlp_pipe": pipe,
+                          "mode": a.mode, "points_per_frame": pixels,
+                          "mlp_pipe": ("bf16x6: every fp32 product of the MLP tiles as six exact bf16 slice products on v_mfma_f32_32x32x16_bf16, fp32 accumulate "
+                                       "(fp32-equivalent: same parity bars as the f32-input MFMA kernels, which DIF_DECODER_PIPE=f32 selects)" if pipe == "bf16x6"
+                                       else "f32: v_mfma_f32_32x32x2_f32"),
                           "parallelism": (f"one stream, grid cut into {world} x-slabs, halo exchange (RCCL send/recv, 3 boundary layers) after every integrate"
                                           if tiled else f"{world} independent subsequences (one map per GPU)"),
                           "d2h_per_frame": a.d2h,
