@@ -91,6 +91,36 @@ __device__ __forceinline__ f16v block_mm_src(const ASRC& A, const f16v (&hin)[NB
     return acc;
 }
 
+// All NMB out-blocks of a layer whose A operand is STREAMED from global memory (L2), as one software pipeline: the float4 of k-group
+// u + PF is requested before the 4 MFMAs of k-group u.  One k-group is 256 cycles of matrix-pipe time (~0.1 us) against ~0.6 us of L2
+// latency, so a kernel with a single wave per SIMD (the gradient kernels: nothing else on the SIMD hides the wait) needs PF ~ 8; the
+// stream runs across the out-blocks (they are consecutive in the blob), so only the first k-groups of a layer see the full latency.
+template <int NMB, int NB, int PF>
+__device__ __forceinline__ void stream_mm(const BufA& A, const f16v (&hin)[NB], f16v (&acc)[NMB], int lane) {
+    constexpr int NU = NMB * NB * 4;
+    f4v ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (i < NU) ring[i] = A.load(i, lane);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u = (mb * NB + kb) * 4 + g;
+                const f4v a = ring[u % PF];
+                if (u + PF < NU) ring[u % PF] = A.load(u + PF, lane);
+                acc[mb] = mfma32(a.x, hin[kb][4 * g + 0], acc[mb]);
+                acc[mb] = mfma32(a.y, hin[kb][4 * g + 1], acc[mb]);
+                acc[mb] = mfma32(a.z, hin[kb][4 * g + 2], acc[mb]);
+                acc[mb] = mfma32(a.w, hin[kb][4 * g + 3], acc[mb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 template <int NB>
 __device__ __forceinline__ f16v block_mm(const f4v* __restrict__ A, const f16v (&hin)[NB], f16v acc, int lane) {
     return block_mm_src<NB>(LdsA{A}, hin, acc, lane);
@@ -675,6 +705,7 @@ __device__ __forceinline__ f16v zero16() {
     return z;
 }
 
+#define GRAD_PF 8
 // Forward as decoder_tile (recording the ReLU masks, 16 bits per out-block), then the reverse chain
 //   g3 = w4 (.) mask3 ; [g2 | gx_skip] = W3^T g3 ; g1 = W2^T (g2 (.) mask2) ; g0 = W1^T (g1 (.) mask1) ; gx = W0^T (g0 (.) mask0)
 // d sdf / d x0[29..31] = (1 - sdf^2) * (gx + gx_skip)[29..31]   (tanh').  Features 29,30,31 of a natural-order block sit in
@@ -712,11 +743,13 @@ __device__ __forceinline__ void decoder_tile_grad(const float* __restrict__ W /*
     asm volatile("" : "+s"(off3), "+s"(offb) : : "memory");
     float ps = 0.0f, pu = 0.0f;
     f16v g3[4];
+    f16v h3[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h3[mb] = load_bias16(W + DEC_B3 + mb * 32, half);
+    stream_mm<4, 4, GRAD_PF>(BufA{Wg, off3}, h2x, h3, lane);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-        f16v acc = load_bias16(W + DEC_B3 + mb * 32, half);
-        acc = block_mm_src<4>(BufA{Wg, off3 + mb * 16 * 1024}, h2x, acc, lane);
-        acc = relu16_mask(acc, m3[mb]);
+        f16v acc = relu16_mask(h3[mb], m3[mb]);
         f16v ws = load_bias16(W + DEC_HW + mb * 32, half);
         f16v wu = load_bias16(W + DEC_HU + mb * 32, half);
 #pragma unroll
@@ -734,20 +767,29 @@ __device__ __forceinline__ void decoder_tile_grad(const float* __restrict__ W /*
     float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));
     stdv = 0.05f + 0.5f * sp;
     // ---- reverse chain ----
+    f16v t3[4];                         // W3^T g3: rows h2 (3 blocks) | x0 (the skip block)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) t3[mb] = zero16();
+    stream_mm<4, 4, GRAD_PF>(BufA{Wb, offb + DECB_T3 * 4}, g3, t3, lane);
     f16v g2[3];
 #pragma unroll
-    for (int mb = 0; mb < 3; ++mb)
-        g2[mb] = apply_mask16(block_mm_src<4>(BufA{Wb, offb + DECB_T3 * 4 + mb * 16 * 1024}, g3, zero16(), lane), m2[mb]);
-    f16v gskip = block_mm_src<4>(BufA{Wb, offb + DECB_T3 * 4 + 3 * 16 * 1024}, g3, zero16(), lane);
+    for (int mb = 0; mb < 3; ++mb) g2[mb] = apply_mask16(t3[mb], m2[mb]);
     f16v g1[4];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-        g1[mb] = apply_mask16(block_mm_src<3>(BufA{Wb, offb + DECB_T2 * 4 + mb * 12 * 1024}, g2, zero16(), lane), m1[mb]);
+    for (int mb = 0; mb < 4; ++mb) g1[mb] = zero16();
+    stream_mm<4, 3, GRAD_PF>(BufA{Wb, offb + DECB_T2 * 4}, g2, g1, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) g1[mb] = apply_mask16(g1[mb], m1[mb]);
     f16v g0[4];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-        g0[mb] = apply_mask16(block_mm_src<4>(BufA{Wb, offb + DECB_T1 * 4 + mb * 16 * 1024}, g1, zero16(), lane), m0[mb]);
-    f16v gxv = block_mm_src<4>(BufA{Wb, offb + DECB_T0 * 4}, g0, gskip, lane);
+    for (int mb = 0; mb < 4; ++mb) g0[mb] = zero16();
+    stream_mm<4, 4, GRAD_PF>(BufA{Wb, offb + DECB_T1 * 4}, g1, g0, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) g0[mb] = apply_mask16(g0[mb], m0[mb]);
+    f16v gx1[1];
+    gx1[0] = t3[3];
+    stream_mm<1, 4, GRAD_PF>(BufA{Wb, offb + DECB_T0 * 4}, g0, gx1, lane);
+    const f16v gxv = gx1[0];
     const float dt = 1.0f - sdf * sdf;
     gx = dt * gxv[13];
     gy = dt * gxv[14];
