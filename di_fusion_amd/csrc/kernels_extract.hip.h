@@ -162,6 +162,64 @@ struct DecodeArgs {
     const float* fold_table;        // mode 1, optional: [batch voxel][256] constants written by k_decode_voxels (decoder_tile_folded)
 };
 
+// Row of a decode tile: which sample lane `col` of tile `tile` works on, where its result goes, and its input fragment
+// xin[t] = x0[2t + half] with x0 = [latent 29 | xyz 3] (the natural k order of layer 0 and of the skip input).
+struct DecodeRow { bool live; int64_t out_idx; float px, py, pz; };
+__device__ __forceinline__ DecodeRow decode_row_input(const DecodeArgs& A, int64_t tile, int col, int half, int res3, int tiles_per_voxel, int64_t n_rows,
+                                                      f16v& xin) {
+    DecodeRow R{false, 0, 0.f, 0.f, 0.f};
+    const float* lat_row = nullptr;
+    const float* row32 = nullptr;
+    if (A.mode == 0) {
+        const int64_t b = tile / tiles_per_voxel;
+        const int s = (int)(tile - b * tiles_per_voxel) * 32 + col;
+        R.live = s < res3;
+        if (R.live) {
+            const int r = A.lat.res;
+            R.px = A.lat.coord(s / (r * r)); R.py = A.lat.coord((s / r) % r); R.pz = A.lat.coord(s % r);
+            lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+            R.out_idx = b * res3 + s;
+        }
+    } else if (A.mode == 1) {
+        const int64_t row = tile * 32 + col;
+        R.live = row < n_rows;
+        if (R.live) {
+            const int e = A.list[row];
+            const int b = e / res3, s = e - b * res3, r = A.lat.res;
+            R.px = A.lat.coord(s / (r * r)); R.py = A.lat.coord((s / r) % r); R.pz = A.lat.coord(s % r);
+            lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
+            R.out_idx = e;
+        }
+    } else if (A.mode == 2) {
+        const int64_t row = tile * 32 + col;
+        R.live = row < n_rows;
+        if (R.live) { row32 = A.rows + row * 32; R.out_idx = row; }
+    } else {
+        const int64_t row = tile * 32 + col;
+        R.live = row < n_rows;
+        if (R.live) {
+            const int64_t p = A.list[row];
+            float xn, yn, zn; int ix, iy, iz;
+            voxel_of(A.geo, A.xyz[p * 3 + 0], A.xyz[p * 3 + 1], A.xyz[p * 3 + 2], xn, yn, zn, ix, iy, iz);
+            R.px = (xn - (float)ix) - 0.5f; R.py = (yn - (float)iy) - 0.5f; R.pz = (zn - (float)iz) - 0.5f;      // map.py:575
+            lat_row = A.latent + A.indexer[linearize(A.geo, ix, iy, iz)] * L;
+            R.out_idx = row;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int k = 2 * t + half;
+        float v = 0.0f;
+        if (R.live) {
+            if (row32) v = row32[k];
+            else if (k < L) v = lat_row[k];
+            else v = (k == L) ? R.px : ((k == L + 1) ? R.py : R.pz);
+        }
+        xin[t] = v;
+    }
+    return R;
+}
+
 // GRAD: 256 threads = one wave per SIMD with the full 512-register budget (forward + reverse chain keep ~300 values live)
 template <bool GRAD>
 __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(DecodeArgs A, const float* __restrict__ wblob) {
@@ -184,59 +242,11 @@ __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(Decod
         n_tiles = (n_rows + 31) / 32;
     }
     for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
-        bool live;
-        int64_t out_idx = 0;
-        const float* lat_row = nullptr;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        const float* row32 = nullptr;
-        if (A.mode == 0) {
-            int64_t b = tile / tiles_per_voxel;
-            int s = (int)(tile - b * tiles_per_voxel) * 32 + col;
-            live = s < res3;
-            if (live) {
-                int r = A.lat.res;
-                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
-                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
-                out_idx = b * res3 + s;
-            }
-        } else if (A.mode == 1) {
-            int64_t row = tile * 32 + col;
-            live = row < n_rows;
-            if (live) {
-                int e = A.list[row];
-                int b = e / res3, s = e - b * res3, r = A.lat.res;
-                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
-                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
-                out_idx = e;
-            }
-        } else if (A.mode == 2) {
-            int64_t row = tile * 32 + col;
-            live = row < n_rows;
-            if (live) { row32 = A.rows + row * 32; out_idx = row; }
-        } else {
-            int64_t row = tile * 32 + col;
-            live = row < n_rows;
-            if (live) {
-                int64_t p = A.list[row];
-                float xn, yn, zn; int ix, iy, iz;
-                voxel_of(A.geo, A.xyz[p * 3 + 0], A.xyz[p * 3 + 1], A.xyz[p * 3 + 2], xn, yn, zn, ix, iy, iz);
-                px = (xn - (float)ix) - 0.5f; py = (yn - (float)iy) - 0.5f; pz = (zn - (float)iz) - 0.5f;      // map.py:575
-                lat_row = A.latent + A.indexer[linearize(A.geo, ix, iy, iz)] * L;
-                out_idx = row;
-            }
-        }
         f16v xin;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int k = 2 * t + half;                     // natural k order of layer 0 (and of the skip input)
-            float v = 0.0f;
-            if (live) {
-                if (row32) v = row32[k];
-                else if (k < L) v = lat_row[k];
-                else v = (k == L) ? px : ((k == L + 1) ? py : pz);
-            }
-            xin[t] = v;
-        }
+        const DecodeRow R = decode_row_input(A, tile, col, half, res3, tiles_per_voxel, n_rows, xin);
+        const bool live = R.live;
+        const int64_t out_idx = R.out_idx;
+        const float px = R.px, py = R.py, pz = R.pz;
         float sdf, sd;
         if (!GRAD && A.mode == 1 && A.fold_table) {          // refine rows: the voxel's latent terms come ready-made from the lattice pass
             const int b = live ? A.list[tile * 32 + col] / res3 : 0;
@@ -280,49 +290,10 @@ __global__ void __launch_bounds__(512, 1) k_decode_x6(DecodeArgs A, const float*
         n_tiles = (n_rows + 31) / 32;
     }
     for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
-        bool live;
-        int64_t out_idx = 0;
-        const float* lat_row = nullptr;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        const float* row32 = nullptr;
-        if (A.mode == 0) {
-            const int64_t b = tile / tiles_per_voxel;
-            const int s = (int)(tile - b * tiles_per_voxel) * 32 + col;
-            live = s < res3;
-            if (live) {
-                const int r = A.lat.res;
-                px = A.lat.coord(s / (r * r)); py = A.lat.coord((s / r) % r); pz = A.lat.coord(s % r);
-                lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
-                out_idx = b * res3 + s;
-            }
-        } else if (A.mode == 2) {
-            const int64_t row = tile * 32 + col;
-            live = row < n_rows;
-            if (live) { row32 = A.rows + row * 32; out_idx = row; }
-        } else {
-            const int64_t row = tile * 32 + col;
-            live = row < n_rows;
-            if (live) {
-                const int64_t p = A.list[row];
-                float xn, yn, zn; int ix, iy, iz;
-                voxel_of(A.geo, A.xyz[p * 3 + 0], A.xyz[p * 3 + 1], A.xyz[p * 3 + 2], xn, yn, zn, ix, iy, iz);
-                px = (xn - (float)ix) - 0.5f; py = (yn - (float)iy) - 0.5f; pz = (zn - (float)iz) - 0.5f;      // map.py:575
-                lat_row = A.latent + A.indexer[linearize(A.geo, ix, iy, iz)] * L;
-                out_idx = row;
-            }
-        }
         f16v xin;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int k = 2 * t + half;
-            float v = 0.0f;
-            if (live) {
-                if (row32) v = row32[k];
-                else if (k < L) v = lat_row[k];
-                else v = (k == L) ? px : ((k == L + 1) ? py : pz);
-            }
-            xin[t] = v;
-        }
+        const DecodeRow R = decode_row_input(A, tile, col, half, res3, tiles_per_voxel, n_rows, xin);
+        const bool live = R.live;
+        const int64_t out_idx = R.out_idx;
         float sdf, sd;
         decoder_tile_x6(lds, wfwd, wun, xin, lane, sdf, sd);
         if (live) {

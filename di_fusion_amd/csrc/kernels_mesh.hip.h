@@ -92,6 +92,46 @@ __device__ __forceinline__ V4 mc_interp(const float* p1, const float* p2, float 
     return V4{p1[0] * w1 + p2[0] * w2, p1[1] * w1 + p2[1] * w2, p1[2] * w1 + p2[2] * w2, s1 * w1 + s2 * w2};
 }
 
+// One cell of a voxel (lane = cell): reads its 8 blended corners from LDS, writes the cell's edge vertices to vl[edge * 64] and returns
+// the number of triangles that survive max_std (mc_interp_kernel.cu:202-320); tri_row = the packed triangle-table row (~0 if none).
+__device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __restrict__ c_sdf, const float* __restrict__ c_std, V4* __restrict__ vl,
+                                            int r, int cell, int bx, int by, int bz, unsigned long long& tri_row) {
+    const int r1 = r + 1;
+    const float sbs = 1.0f / (float)r;
+    const int rx = cell / (r * r), ry = (cell / r) % r, rz = cell % r;
+    float val[8], sdv[8], pts[8][3];
+    bool dropped = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int dx = (q == 1 || q == 2 || q == 5 || q == 6), dy = (q == 2 || q == 3 || q == 6 || q == 7), dz = (q >= 4);
+        const int ci = ((rx + dx) * r1 + (ry + dy)) * r1 + (rz + dz);
+        val[q] = c_sdf[ci]; sdv[q] = c_std[ci];
+        dropped |= !(val[q] == val[q]);
+        pts[q][0] = (float)bx + (float)(rx + dx) * sbs;
+        pts[q][1] = (float)by + (float)(ry + dy) * sbs;
+        pts[q][2] = (float)bz + (float)(rz + dz) * sbs;
+    }
+    tri_row = ~0ull;
+    if (dropped) return 0;
+    int cube_type = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cube_type |= (val[q] < 0.0f) ? (1 << q) : 0;
+    const int edge_config = c_mc_edge_table[cube_type];
+    if (!edge_config) return 0;
+    const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+#pragma unroll
+    for (int e = 0; e < 12; ++e)
+        if (edge_config & (1 << e)) vl[e * 64] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
+    tri_row = c_mc_tri_packed[cube_type];
+    int ntri = 0;
+    for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
+        const float w0 = vl[(int)(t3 & 0xF) * 64].w, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].w, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].w;
+        if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
+        ++ntri;
+    }
+    return ntri;
+}
+
 // One wave per dirty voxel.  Phase 1: the (r+1)^3 blended corner values are computed ONCE into LDS (the reference
 // recomputes each corner for up to 8 cells).  Phase 2: lane = cell; EMIT=false counts the triangles that survive
 // max_std, EMIT=true writes them at tri_offset[k] + wave-prefix (canonical order: voxel, cell, table order).
@@ -122,7 +162,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
         for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
         if (lane == 0) a.log_counters[DIF_C_T] = tot;
     }
-    const float sbs = 1.0f / (float)r;
     for (int64_t k = (int64_t)blockIdx.x * wpb + wid; k < K; k += (int64_t)gridDim.x * wpb) {
         if (EMIT && a.tri_count[k] == 0) continue;          // nothing to write for this voxel: the count pass has already said so
         const int64_t vb = a.valid_blocks[k];
@@ -184,45 +223,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
         }
         for (int s0 = 0; crossing && s0 < r3; s0 += 64) {
             const int s = s0 + lane;
-            int ntri = 0;
-            int cube_type = 0;
             unsigned long long tri_row = ~0ull;
-            if (s < r3) {
-                const int rx = s / (r * r), ry = (s / r) % r, rz = s % r;
-                float val[8], sdv[8], pts[8][3];
-                bool dropped = false;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int dx = (q == 1 || q == 2 || q == 5 || q == 6), dy = (q == 2 || q == 3 || q == 6 || q == 7), dz = (q >= 4);
-                    const int ci = ((rx + dx) * r1 + (ry + dy)) * r1 + (rz + dz);
-                    val[q] = c_sdf[ci]; sdv[q] = c_std[ci];
-                    dropped |= !(val[q] == val[q]);
-                    pts[q][0] = (float)bx + (float)(rx + dx) * sbs;
-                    pts[q][1] = (float)by + (float)(ry + dy) * sbs;
-                    pts[q][2] = (float)bz + (float)(rz + dz) * sbs;
-                }
-                if (!dropped) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) cube_type |= (val[q] < 0.0f) ? (1 << q) : 0;
-                    const int edge_config = c_mc_edge_table[cube_type];
-                    if (edge_config) {
-                        const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
-#pragma unroll
-                        for (int e = 0; e < 12; ++e)
-                            if (edge_config & (1 << e)) vl[e * 64] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
-                        tri_row = c_mc_tri_packed[cube_type];
-                        for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
-                            float w0 = vl[(int)(t3 & 0xF) * 64].w, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].w, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].w;
-                            if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
-                            ++ntri;
-                        }
-                    } else {
-                        cube_type = 0;
-                    }
-                } else {
-                    cube_type = 0;
-                }
-            }
+            const int ntri = (s < r3) ? mc_eval_cell(a, c_sdf, c_std, vl, r, s, bx, by, bz, tri_row) : 0;
             const int incl = wave_incl_scan(ntri);
             const int chunk_total = __shfl(incl, 63);
             if (EMIT && ntri > 0) {
@@ -294,7 +296,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, 
         if (a.grid_tot)
             for (int t = (int)threadIdx.x; t < 1024; t += (int)blockDim.x) a.grid_tot[t] = 0;
     }
-    const float sbs = 1.0f / (float)r;
     __shared__ int s_g;
     // Which group a workgroup takes: with at most one group per workgroup (a stream frame: ~150 groups) simply its own index —
     // workgroups are dispatched in index order, so every predecessor is running or done.  Otherwise groups are handed out by a ticket
@@ -332,39 +333,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const bool crossing = __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
-            if (crossing && lane < r3) {
-                const int rx = lane / (r * r), ry = (lane / r) % r, rz = lane % r;
-                float val[8], sdv[8], pts[8][3];
-                bool dropped = false;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int dx = (q == 1 || q == 2 || q == 5 || q == 6), dy = (q == 2 || q == 3 || q == 6 || q == 7), dz = (q >= 4);
-                    const int ci = ((rx + dx) * r1 + (ry + dy)) * r1 + (rz + dz);
-                    val[q] = c_sdf[ci]; sdv[q] = c_std[ci];
-                    dropped |= !(val[q] == val[q]);
-                    pts[q][0] = (float)bx + (float)(rx + dx) * sbs;
-                    pts[q][1] = (float)by + (float)(ry + dy) * sbs;
-                    pts[q][2] = (float)bz + (float)(rz + dz) * sbs;
-                }
-                if (!dropped) {
-                    int cube_type = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) cube_type |= (val[q] < 0.0f) ? (1 << q) : 0;
-                    const int edge_config = c_mc_edge_table[cube_type];
-                    if (edge_config) {
-                        const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
-#pragma unroll
-                        for (int e = 0; e < 12; ++e)
-                            if (edge_config & (1 << e)) vl[e * 64] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
-                        tri_row = c_mc_tri_packed[cube_type];
-                        for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
-                            const float w0 = vl[(int)(t3 & 0xF) * 64].w, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].w, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].w;
-                            if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
-                            ++ntri;
-                        }
-                    }
-                }
-            }
+            if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, bx, by, bz, tri_row);
         }
         const int incl = wave_incl_scan(ntri);
         voxel_total = __shfl(incl, 63);

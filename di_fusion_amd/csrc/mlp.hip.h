@@ -253,12 +253,15 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W /* LDS 
 // terms first), so results agree to rounding (~1e-7 relative), not bit for bit.
 #define DECF_FLOATS (2 * 29 * 128)
 
-// c (256 floats, wave-private LDS): [c0 | c3] in accumulator-fragment order.  lat_row is the same for the whole wave.
-__device__ __forceinline__ void decoder_fold_consts(const float* __restrict__ W /* LDS */, const float* __restrict__ fold /* global */,
-                                                    const float* __restrict__ lat_row, float* __restrict__ c, int lane) {
-    float a0 = W[DEC_B0 + lane], a1 = W[DEC_B0 + lane + 64], a2 = W[DEC_B3 + lane], a3 = W[DEC_B3 + lane + 64];
+// c (256 floats, wave-private LDS): [c0 | c3] in accumulator-fragment order.  lat_row is the same for the whole wave.  B0 / B3: where
+// the two biases sit in the LDS image (the f32 blob and the bf16-pipe blob differ); UNROLL loads are in flight together (fully
+// unrolled they get hoisted en masse and spill).
+template <int B0, int B3, int UNROLL>
+__device__ __forceinline__ void decoder_fold_consts_at(const float* __restrict__ W /* LDS */, const float* __restrict__ fold /* global */,
+                                                       const float* __restrict__ lat_row, float* __restrict__ c, int lane) {
+    float a0 = W[B0 + lane], a1 = W[B0 + lane + 64], a2 = W[B3 + lane], a3 = W[B3 + lane + 64];
     const f4v* wk = reinterpret_cast<const f4v*>(fold) + lane;       // [k][lane] -> (lin0: p = lane, lane + 64; lin3: p = lane, lane + 64)
-#pragma unroll 8                                      // a batch of loads in flight; fully unrolled they get hoisted en masse and spill
+#pragma unroll UNROLL
     for (int k = 0; k < 29; ++k) {
         const float zk = lat_row[k];
         const f4v wv = wk[k * 64];
@@ -271,6 +274,10 @@ __device__ __forceinline__ void decoder_fold_consts(const float* __restrict__ W 
     c[lane + 64] = a1;
     c[128 + lane] = a2;
     c[128 + lane + 64] = a3;
+}
+__device__ __forceinline__ void decoder_fold_consts(const float* __restrict__ W, const float* __restrict__ fold, const float* __restrict__ lat_row,
+                                                    float* __restrict__ c, int lane) {
+    decoder_fold_consts_at<DEC_B0, DEC_B3, 8>(W, fold, lat_row, c, lane);
 }
 
 // acc init for (layer, out-block mb): from the wave's LDS record, or from a per-lane record in global memory (rows of different voxels)
@@ -458,21 +465,7 @@ __device__ __forceinline__ void layer_x6(const SRC& A, const f16v* hin, f16v* ac
 
 __device__ __forceinline__ void decoder_fold_consts_x6(const float* __restrict__ aux /* LDS */, const float* __restrict__ fold /* global */,
                                                        const float* __restrict__ lat_row, float* __restrict__ c, int lane) {
-    float a0 = aux[X6_B0 + lane], a1 = aux[X6_B0 + lane + 64], a2 = aux[X6_B3 + lane], a3 = aux[X6_B3 + lane + 64];
-    const f4v* wk = reinterpret_cast<const f4v*>(fold) + lane;
-#pragma unroll 15                                    // two batches of loads in flight (fully unrolled the kernel spills: 256 VGPRs + scratch)
-    for (int k = 0; k < 29; ++k) {
-        const float zk = lat_row[k];
-        const f4v wv = wk[k * 64];
-        a0 = fmaf(wv.x, zk, a0);
-        a1 = fmaf(wv.y, zk, a1);
-        a2 = fmaf(wv.z, zk, a2);
-        a3 = fmaf(wv.w, zk, a3);
-    }
-    c[lane] = a0;
-    c[lane + 64] = a1;
-    c[128 + lane] = a2;
-    c[128 + lane + 64] = a3;
+    decoder_fold_consts_at<X6_B0, X6_B3, 15>(aux, fold, lat_row, c, lane);       // two batches of loads (fully unrolled the kernel spills)
 }
 
 // decoder_tile_folded on the bf16 pipe.  W = LDS copy of blob[0, X6_LDS_BYTES), Wg = buffer resource over the whole blob.
