@@ -54,6 +54,9 @@ def parse():
                     "--sample-every-th frame — equally fast in steady state (a graph has no kernel boundaries but ~33 us between consecutive launches), and "
                     "no re-capture when a buffer grows")
     ap.add_argument("--sample-every", type=int, default=8)
+    ap.add_argument("--mlp-pipe", choices=["bf16x6", "f32"], default=None,
+                    help="matrix pipe of the MLP tiles: bf16x6 (default; fp32 products as six exact bf16 slice products) or f32 (f32-input MFMA); "
+                         "same as the DIF_DECODER_PIPE environment variable")
     ap.add_argument("--batch", type=int, default=0, help="F > 0: between the sampled frames, F consecutive frames go into ONE captured hipGraph "
                     "(no kernel boundaries inside, one ~33 us launch gap per F frames); for streams whose poses are known ahead; F = sample-every - 1 "
                     "fills the space between two sampled frames")
@@ -363,7 +366,7 @@ def main():
     tiled = a.mode == "tiled"
     scene, cfg = getattr(syn, f"config_{a.config}")()
     intr = syn.Intrinsic().scaled(2.0) if tiled else syn.Intrinsic()          # C5: one 1280x960 stream
-    model = net_util.networks_from_arrays(net_util.load_weights_npz())
+    model = net_util.networks_from_arrays(net_util.load_weights_npz(), x6=(None if a.mlp_pipe is None else a.mlp_pipe == "bf16x6"))
     pipe = "bf16x6" if model.packed.x6 else "f32"
     n_frames = a.warmup + a.steps
     if tiled and world > 1:
