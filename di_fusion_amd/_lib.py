@@ -43,7 +43,8 @@ class DifWeights(Structure):
                 ("dec_fold_packed", c_void_p), ("dec_fold_packed_floats", c_int64),
                 ("dec_x6_packed", c_void_p), ("dec_x6_packed_bytes", c_int64),
                 ("enc_x6_packed", c_void_p), ("enc_x6_packed_bytes", c_int64),
-                ("dec_x6u_packed", c_void_p), ("dec_x6u_packed_bytes", c_int64)]
+                ("dec_x6u_packed", c_void_p), ("dec_x6u_packed_bytes", c_int64),
+                ("dec_x6b_packed", c_void_p), ("dec_x6b_packed_bytes", c_int64)]
 
 
 class DifExtractBuffers(Structure):

@@ -543,6 +543,9 @@ int dif_optimize_latents(const dif_map_t* map, const dif_weights_t* w, const flo
 }
 
 // ---- decoder launches ------------------------------------------------------------------------------------------
+#ifndef GRAD_X6_PF
+#define GRAD_X6_PF 3          /* weight steps (3 KB each) a wave keeps in flight in the gradient kernel (3, 6 and 10 measured the same) */
+#endif
 static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t tiles_upper, hipStream_t s) {
     if (!w || !w->dec_packed || w->dec_packed_floats != DEC_FLOATS) return DIF_EINVAL;
     const bool grad = A.out_grad != nullptr;
@@ -566,6 +569,21 @@ static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t ti
             attr_set6[dev] = true;
         }
         hipLaunchKernelGGL(k_decode_x6, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed, (const float*)w->dec_x6u_packed);
+        DIF_CHECK_LAUNCH();
+        return DIF_OK;
+    }
+    if (grad && A.mode >= 2 && w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES && w->dec_x6u_packed && w->dec_x6u_packed_bytes == X6U_BYTES &&
+        w->dec_x6b_packed && w->dec_x6b_packed_bytes == X6B_BYTES) {
+        static bool attr_set7[64] = {};                      // values + input gradient on the bf16 matrix pipe
+        if (dev < 64 && !attr_set7[dev]) {
+            if (hipFuncSetAttribute((const void*)k_decode_grad_x6<GRAD_X6_PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+            attr_set7[dev] = true;
+        }
+        blocks = (tiles_upper + GRAD_X6_THREADS / 64 - 1) / (GRAD_X6_THREADS / 64);
+        if (blocks < 1) blocks = 1;
+        if (blocks > num_cus()) blocks = num_cus();
+        hipLaunchKernelGGL(k_decode_grad_x6<GRAD_X6_PF>, dim3((int)blocks), dim3(GRAD_X6_THREADS), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed,
+                           (const float*)w->dec_x6u_packed, (const float*)w->dec_x6b_packed);
         DIF_CHECK_LAUNCH();
         return DIF_OK;
     }

@@ -303,6 +303,42 @@ __global__ void __launch_bounds__(512, 1) k_decode_x6(DecodeArgs A, const float*
     }
 }
 
+#ifndef GRAD_X6_THREADS
+#define GRAD_X6_THREADS 256
+#endif
+// Values AND d sdf / d xyz (modes 2, 3) on the bf16 matrix pipe: decoder_tile_grad_x6.  One wave per SIMD with the 512-register budget,
+// like k_decode<true>; wb = packing.py:pack_decoder_x6_backward.
+template <int PF>
+__global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArgs A, const float* __restrict__ wblob, const float* __restrict__ wu,
+                                                          const float* __restrict__ wb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_weights(lds, wblob, X6_LDS_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t wun = make_rsrc(wu, X6U_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t wbw = make_rsrc(wb, X6B_BYTES / 4);
+    const int lane = lane_id(), half = lane >> 5, col = lane & 31;
+    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int res3 = A.lat.res * A.lat.res * A.lat.res;
+    const int64_t n_rows = A.n_ptr ? (int64_t)(*A.n_ptr) : A.n_static;
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+        f16v xin;
+        const DecodeRow R = decode_row_input(A, tile, col, half, res3, 1, n_rows, xin);
+        float sdf, sd, gx, gy, gz;
+        decoder_tile_grad_x6<PF>(lds, wfwd, wun, wbw, xin, lane, sdf, sd, gx, gy, gz);
+        if (R.live) {
+            if (half == 0) A.out_sdf[R.out_idx] = A.sign * sdf;
+            else {
+                A.out_std[R.out_idx] = sd;
+                A.out_grad[R.out_idx * 3 + 0] = gx * A.grad_scale;      // d rel / d xyz = 1 / voxel_size (map.py:565,575)
+                A.out_grad[R.out_idx * 3 + 1] = gy * A.grad_scale;
+                A.out_grad[R.out_idx * 3 + 2] = gz * A.grad_scale;
+            }
+        }
+    }
+}
+
 // Refine rows (mode 1 with the lattice pass's fold table) on the bf16 matrix pipe; wblob = packing.py:pack_decoder_x6.
 __global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

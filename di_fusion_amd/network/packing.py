@@ -29,6 +29,7 @@ X6_AUX_FLOATS = 2788
 X6_L1_BYTES, X6_L2_BYTES, X6_L3_BYTES = 4 * 2 * 4 * 3 * 1024, 4 * 2 * 3 * 3 * 1024, 3 * 2 * 4 * 3 * 1024
 X6_BYTES = X6_AUX_FLOATS * 4 + X6_L1_BYTES + X6_L2_BYTES + X6_L3_BYTES
 X6U_BYTES = 2 * 2 * 4 * 3 * 1024       # lin0 | lin3's skip block, natural input order (the unfolded tile: explicit rows, get_sdf)
+X6B_BYTES = (4 * 2 * 4 + 3 * 2 * 4 + 4 * 2 * 4 + 4 * 2 * 1) * 3 * 1024      # transposed layers for the input-gradient chain on the bf16 pipe
 E6_AUX_FLOATS = 640
 E6_BYTES = E6_AUX_FLOATS * 4 + 12288 + 147456
 
@@ -289,4 +290,18 @@ def pack_decoder_x6u(w: Dict[str, np.ndarray]) -> np.ndarray:
     Ws, bs, Wu, bu = fold_decoder(w)
     blob = np.concatenate([pack_A_x6_nat(Ws[0], 4).reshape(-1).view(np.uint8), pack_A_x6_nat(Ws[3][:, 96:128], 4).reshape(-1).view(np.uint8)])
     assert blob.shape[0] == X6U_BYTES, blob.shape
+    return blob
+
+
+def pack_decoder_x6_backward(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """bf16 slices of the transposed decoder layers for `decoder_tile_grad_x6` (mlp.hip.h): W3^T | W2^T | W1^T | W0^T, each packed like a
+    forward layer — rows (MFMA M) = the layer's INPUT features, k = its OUTPUT features in D-fragment order (the masked upstream
+    gradient blocks are the B operands).  Same matrices as pack_decoder_backward."""
+    Ws, bs, Wu, bu = fold_decoder(w)
+    parts = [pack_A_x6(np.ascontiguousarray(Ws[3].T), 4, 4),      # (128 in: h2 96 | x0 32) x (128 out)
+             pack_A_x6(np.ascontiguousarray(Ws[2].T), 4, 3),      # (128 in) x (96 out)
+             pack_A_x6(np.ascontiguousarray(Ws[1].T), 4, 4),      # (128) x (128)
+             pack_A_x6(np.ascontiguousarray(Ws[0].T), 1, 4)]      # (32 in: latent 29 | xyz 3) x (128 out)
+    blob = np.concatenate([p.reshape(-1).view(np.uint8) for p in parts])
+    assert blob.shape[0] == X6B_BYTES, blob.shape
     return blob

@@ -40,6 +40,7 @@ class _PackedNet:
         self._x6_blob = packing.pack_decoder_x6(raw) if self.x6 else None
         self._e6_blob = packing.pack_encoder_x6(raw) if self.x6 else None
         self._x6u_blob = packing.pack_decoder_x6u(raw) if self.x6 else None
+        self._x6b_blob = packing.pack_decoder_x6_backward(raw) if self.x6 else None
         self._dev = {}
 
     def weights_struct(self, device: torch.device):
@@ -53,11 +54,13 @@ class _PackedNet:
             x6 = torch.from_numpy(self._x6_blob).to(device) if self._x6_blob is not None else None
             e6 = torch.from_numpy(self._e6_blob).to(device) if self._e6_blob is not None else None
             x6u = torch.from_numpy(self._x6u_blob).to(device) if self._x6u_blob is not None else None
+            x6b = torch.from_numpy(self._x6b_blob).to(device) if self._x6b_blob is not None else None
             w = _lib.DifWeights(_lib.ptr(enc), enc.numel(), _lib.ptr(dec), dec.numel(), _lib.ptr(decb), decb.numel(), _lib.ptr(decf), decf.numel(),
                                 _lib.ptr(x6) if x6 is not None else None, x6.numel() if x6 is not None else 0,
                                 _lib.ptr(e6) if e6 is not None else None, e6.numel() if e6 is not None else 0,
-                                _lib.ptr(x6u) if x6u is not None else None, x6u.numel() if x6u is not None else 0)
-            self._dev[key] = (w, enc, dec, decb, decf, x6, e6, x6u)
+                                _lib.ptr(x6u) if x6u is not None else None, x6u.numel() if x6u is not None else 0,
+                                _lib.ptr(x6b) if x6b is not None else None, x6b.numel() if x6b is not None else 0)
+            self._dev[key] = (w, enc, dec, decb, decf, x6, e6, x6u, x6b)
         return self._dev[key][0]
 
 

@@ -114,6 +114,9 @@ typedef struct dif_weights {
     const void* dec_x6u_packed;     /* with dec_x6_packed: slices of lin0 and of lin3's skip block (packing.py:pack_decoder_x6u) for the tiles that
                                      * carry the whole 32-column input (dif_decode_rows, dif_query_sdf without gradient, non-fast extract) */
     int64_t dec_x6u_packed_bytes;
+    const void* dec_x6b_packed;     /* with the two above: slices of the transposed layers (packing.py:pack_decoder_x6_backward): dif_query_sdf with
+                                     * gradient on the bf16 matrix pipe */
+    int64_t dec_x6b_packed_bytes;
 } dif_weights_t;
 
 int dif_version(void);

@@ -104,3 +104,26 @@ def test_decoder_rows_and_point_queries_both_pipes(gpu_model, gpu_model_f32):
     d = max(np.abs(out[0][0] - out[1][0]).max(), np.abs(out[0][1] - out[1][1]).max())
     print(f"get_sdf values, bf16 pipe vs f32 pipe: max diff {d:.2e} over {int(out[0][2].sum())} points")
     assert d < 2e-5
+
+
+def test_point_query_gradient_both_pipes(gpu_model, gpu_model_f32):
+    """`get_sdf` with `xyz.requires_grad` (the tracker's call): values and the analytic d sdf / d xyz from the bf16-pipe kernel
+    (`k_decode_grad_x6`) against the f32-input MFMA kernel (`k_decode<GRAD>`); tests/test_gpu_map.py checks the default pipe against
+    float64 autograd and finite differences."""
+    from di_fusion_amd.system.map import DenseIndexedMap
+    scene, cfg = syn.config_c2()
+    xyz, nrm = (t.to(DEV) for t in syn.frame_points(scene, 0, syn.Intrinsic().scaled(0.5), deg_per_frame=0.5))
+    out = []
+    for model in (gpu_model, gpu_model_f32):
+        m = DenseIndexedMap(model, cfg.namespace(), 29, DEV, initial_capacity=16384)
+        m.integrate_keyframe(xyz, nrm)
+        q = (xyz[::5] + 0.01).contiguous().requires_grad_(True)
+        sdf, std, mask = m.get_sdf(q)
+        (g,) = torch.autograd.grad((sdf / std.detach()).sum(), q)
+        out.append((sdf.detach().cpu().numpy(), std.cpu().numpy(), mask.cpu().numpy(), g.cpu().numpy()))
+    assert np.array_equal(out[0][2], out[1][2]) and out[0][2].sum() > 1000
+    dv = max(np.abs(out[0][0] - out[1][0]).max(), np.abs(out[0][1] - out[1][1]).max())
+    gs = np.abs(out[1][3]).max()
+    dg = np.abs(out[0][3] - out[1][3]).max()
+    print(f"values max diff {dv:.2e}; gradient max diff {dg:.2e} (max |g| {gs:.2e})")
+    assert dv < 2e-5 and dg < 2e-5 * max(1.0, gs)
