@@ -126,11 +126,7 @@ __global__ void __launch_bounds__(256, 1) k_optim_grad(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             long long q = live ? __float2ll_rn(gx[r] * DIF_OPT_FIX_SCALE) : 0ll;
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const long long up = __shfl_up(q, d, 32);
-                if (col - d >= my_head) q += up;
-            }
+            q = seg_incl_scan32(q, col, my_head);
             const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
             if (live && run_tail && f < L) (void)__hip_atomic_fetch_add(grad + (int64_t)u * 32 + f, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
