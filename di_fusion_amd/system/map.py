@@ -532,6 +532,11 @@ class DenseIndexedMap:
         R = 2 * resolution
         if max_vox is None:
             max_vox = _next_pow2(max(self._n_occ_ub, 1024))
+            # sized for the map's capacity while that stays under 8 GB (HBM is plentiful; re-allocating ~8 KB per voxel every time the
+            # occupancy crosses a power of two costs tens of milliseconds in the middle of a stream), for the occupancy beyond that
+            per_voxel = (R ** 3) * 12 + (resolution ** 3) * 8 + 1024 + 64
+            if self._capacity * per_voxel <= (8 << 30):
+                max_vox = max(max_vox, self._capacity)
             if self._xbuf is not None and self._xbuf[0][0] == resolution and self._xbuf[0][1] >= max_vox:
                 max_vox = self._xbuf[0][1]                      # never shrink: keeps pointers stable
         key = (resolution, max_vox)
