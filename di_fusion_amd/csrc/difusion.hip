@@ -845,6 +845,9 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     const bool onepass = fused_scan && buf->mc_status && r * r * r <= 64;                // count, look-back and emit in one launch
     if (onepass) {
         a.tri_start = map->tri_start; a.tri_n = map->tri_n; a.tri_count = buf->tri_count; a.tri_offset = nullptr;
+        if (buf->out_tri && buf->out_id && buf->out_std) {      // the emitting waves also write the caller's copy (PCIe overlaps the launch)
+            a.out_tri = buf->out_tri; a.out_id = buf->out_id; a.out_std = buf->out_std; a.out_capacity = buf->out_capacity;
+        }
         size_t lds_bytes; int blocks;
         rc = mc_setup(a, lds_bytes, blocks, buf->max_voxels);
         if (rc != DIF_OK) return rc;
@@ -890,7 +893,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     }
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
                        C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
-                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity},
+                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity, (onepass && a.out_tri) ? 1 : 0},
                        (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
                        onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr);
     DIF_CHECK_LAUNCH();

@@ -23,6 +23,9 @@ struct McArgs {
     // the log bookkeeping itself — no scan launch between the two passes.
     int32_t* chunk_sum; int32_t* super_sum; int32_t* tri_start; int32_t* tri_n;
     int* grid_tot;                  // extract path: the grid bitmap's scan totals, returned to idle 0 here (the voxel scan has consumed them)
+    // one-pass kernel only: the caller's copy of this call's new triangles (dif_extract_buffers_t.out_*; pinned host memory allowed),
+    // written by the wave that emits them, so the transfer runs while the rest of the launch is still counting and emitting
+    float* out_tri; int64_t* out_id; float* out_std; int64_t out_capacity;
 };
 
 // batch index of voxel (bx,by,bz) or -1   (query_sdf_raw :13-24)
@@ -410,6 +413,18 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, 
                         }
                         a.tri_id[t] = vb;
                         a.tri_alive[t] = 1;
+                        if (a.out_tri && tl < a.out_capacity) {
+#pragma unroll
+                            for (int vi = 0; vi < 3; ++vi) {
+                                float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
+                                if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }
+                                a.out_tri[(tl * 3 + vi) * 3 + 0] = x;
+                                a.out_tri[(tl * 3 + vi) * 3 + 1] = y;
+                                a.out_tri[(tl * 3 + vi) * 3 + 2] = z;
+                                a.out_std[tl * 3 + vi] = vv[vi].w;
+                            }
+                            a.out_id[tl] = vb;
+                        }
                     }
                     ++t; ++tl;
                 }
@@ -475,6 +490,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cache_reindex(const int64_t* __re
 struct ExtractOut {
     int32_t* counters_out;          // [DIF_C_COUNT] or NULL
     float* tri; int64_t* id; float* sd; int64_t capacity;      // this call's new triangles (first `capacity` of them) or NULL
+    int already_exported;           // the one-pass marching cubes wrote them while it emitted
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
@@ -502,7 +518,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
     int64_t tot = kept + n_new;
     const bool over = tot > capacity;
     if (over) { tot = capacity; n_new = capacity - kept; }
-    if (out.tri) {                                  // destinations may be device-mapped pinned host memory: coalesced, one pass
+    if (out.tri && !out.already_exported) {          // destinations may be device-mapped pinned host memory: coalesced, one pass
         const int64_t n = n_new < out.capacity ? n_new : out.capacity;
         const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         for (int64_t j = t0; j < n * 9; j += stride) out.tri[j] = log_tri[kept * 9 + j];
