@@ -438,7 +438,7 @@ def main():
     # (secondary figures need a run long enough to amortise their own one-time costs — a fresh stream's buffer growth, graph captures)
     if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled and a.steps >= 100:
         hbm_resident = secondary_rate(make_stream, a, n_frames, "none", 0)
-        if a.batch == 0 and (a.graph or a.direct):
+        if a.batch == 0 and a.direct and not a.graph:        # (a per-frame-graph run would mix two sets of captured graphs on one stream)
             batched = secondary_rate(make_stream, a, n_frames, a.d2h, 5)
     merge_info = global_map_merge(stream, model, cfg, dev, barrier) if (use_dist and not tiled) else None
 
