@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"])
     ap.add_argument("--mode", default="c4", choices=["c4", "tiled"], help="c4: independent subsequences per GPU; tiled: one 1280x960 stream "
                     "spatially tiled across the GPUs (BASELINE config C5)")
+    ap.add_argument("--loopback", type=int, default=0, help="--mode tiled on ONE GPU: this process plays the middle slab of S and exchanges halos with "
+                    "itself (device copies of the size that would go over xGMI): export / merge kernels and message sizes land in the timed region")
+    ap.add_argument("--halo", default="delta", choices=["delta", "full"], help="--mode tiled: bounded delta halo messages (default) or whole boundary layers")
     ap.add_argument("--noise", type=int, default=0)
     ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
@@ -255,6 +258,22 @@ def global_map_merge(stream, model, cfg, dev, barrier):
         return {"error": repr(e)[:200]}
 
 
+def halo_summary(stream, a):
+    """--mode tiled: what the per-frame halo refresh moved (bytes per direction and frame, message kinds) over the last frames of the run."""
+    hist = getattr(stream, "_halo_buffers", {}).get("hist") if stream.tiling is not None else None
+    if not hist:
+        return None
+    frames = sorted(hist)
+    kinds = [k for f in frames for d in hist[f]["kinds"] for k in d.values()]
+    recs = [int(hist[f]["out"][4 * k]) for f in frames for k in (0, 1)]
+    return {"mode": a.halo, "loopback_slabs": a.loopback or None, "frames_summarised": len(frames),
+            "bytes_sent_per_frame": round(float(np.mean([hist[f]["bytes_out"] for f in frames])), 1),
+            "bytes_received_per_frame": round(float(np.mean([hist[f]["bytes_in"] for f in frames])), 1),
+            "delta_messages_share": round(kinds.count("delta") / max(1, len(kinds)), 3),
+            "records_per_message_avg": round(float(np.mean(recs)), 1), "records_per_message_max": int(max(recs)),
+            "whole_layer_message_bytes": (1 + stream.map.halo_message_rows(3)) * 128}
+
+
 def roofline_of(records, sst):
     """records: [(kernel name, ms)] of the event-timed launches of the frames whose counters are `sst`."""
     rows = {"encode": (sum(s["M"] for s in sst), ENC_FLOP_PER_ROW), "decode_lattice": (sum(s["B"] * 64 for s in sst), DEC_FLOP_PER_ROW),
@@ -364,6 +383,8 @@ def main():
     from di_fusion_amd.stream import FusionStream
 
     tiled = a.mode == "tiled"
+    if a.loopback > 1 and (not tiled or world != 1):
+        raise SystemExit("bench.py --loopback S needs --mode tiled on one GPU")
     scene, cfg = getattr(syn, f"config_{a.config}")()
     intr = syn.Intrinsic().scaled(2.0) if tiled else syn.Intrinsic()          # C5: one 1280x960 stream
     model = net_util.networks_from_arrays(net_util.load_weights_npz(), x6=(None if a.mlp_pipe is None else a.mlp_pipe == "bf16x6"))
@@ -378,8 +399,9 @@ def main():
     def make_stream(batch=None):
         batch = a.batch if batch is None else batch
         if tiled:           # every rank renders the same stream and owns one x-slab of the grid
+            tiling = (a.loopback // 2, a.loopback, None) if a.loopback > 1 else (rank, world, None)
             return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, noise=bool(a.noise), initial_capacity=1 << 18,
-                                tiling=(rank, world, None))
+                                tiling=tiling, halo_mode=a.halo, halo_loopback=a.loopback > 1)
         # (a batch of F frames needs room for the worst-case allocations of two batches in flight: sized up front instead of growing in the clock)
         cap0 = 1 << 16
         while batch > 0 and cap0 < (2 * batch + 1) * 7 * (intr.width * intr.height // 17) + (1 << 16):
@@ -475,7 +497,9 @@ def main():
                           "mlp_pipe": ("bf16x6: every fp32 product of the MLP tiles as six exact bf16 slice products on v_mfma_f32_32x32x16_bf16, fp32 accumulate "
                                        "(fp32-equivalent: same parity bars as the f32-input MFMA kernels, which DIF_DECODER_PIPE=f32 selects)" if pipe == "bf16x6"
                                        else "f32: v_mfma_f32_32x32x2_f32"),
-                          "parallelism": (f"one stream, grid cut into {world} x-slabs, halo exchange (RCCL send/recv, 3 boundary layers) after every integrate"
+                          "parallelism": (f"slab {a.loopback // 2} of {a.loopback} x-slabs of one stream on ONE GPU, halo exchange with itself (loopback) after every integrate"
+                                          if a.loopback > 1 else
+                                          f"one stream, grid cut into {world} x-slabs, halo exchange (RCCL send/recv, 3 boundary layers) after every integrate"
                                           if tiled else f"{world} independent subsequences (one map per GPU)"),
                           "d2h_per_frame": a.d2h,
                           "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1, "launch": launch,
@@ -484,7 +508,8 @@ def main():
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
                           "frames_per_s_with_5_frames_per_hipgraph": batched,
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
-                          "global_map_merge_after_the_clock": merge_info},
+                          "global_map_merge_after_the_clock": merge_info,
+                          "halo_exchange": halo_summary(stream, a)},
                "roofline": roofline_block(per_frame, [st[j] for j in timed_idx], pipe)}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(stream, a.config, scene, cfg, intr, n_frames, a.cpu_frames)

@@ -1,7 +1,9 @@
 """Build libdifusion.so (HIP, gfx950) in-tree.  Called by `__graft_entry__.build()`; hipcc cross-compiles without a GPU."""
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 from pathlib import Path
@@ -27,20 +29,39 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: libdifusion.so cannot be built")
 
 
+def source_hash() -> str:
+    """Hash of everything the library is compiled from (sources, headers, tables, the C ABI header, the compiler flags)."""
+    h = hashlib.sha256()
+    for p in sorted(SOURCES + HEADERS, key=lambda q: q.name):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def lib_build_id(lib: Path = None):
+    """The hash the library carries (`dif_build_id()`), read from the file without loading it; None if absent."""
+    lib = LIB if lib is None else lib
+    if not lib.exists():
+        return None
+    m = re.search(rb"DIF_BUILD_ID=([0-9a-f]{16})", lib.read_bytes())
+    return m.group(1).decode() if m else None
+
+
 def needs_build() -> bool:
-    if not LIB.exists():
-        return True
-    t = LIB.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+    """The shipped library is used only if it was built from exactly this tree (file times say nothing after a checkout or rsync)."""
+    return lib_build_id() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + [str(s) for s in SOURCES] + ["-o", str(LIB)]
+    cmd = [hipcc()] + HIPCC_FLAGS + [f'-DDIF_BUILD_ID="{source_hash()}"'] + [str(s) for s in SOURCES] + ["-o", str(LIB)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if lib_build_id() != source_hash():
+        raise RuntimeError("libdifusion.so was built but does not carry the hash of this tree")
     return LIB
 
 

@@ -14,9 +14,9 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "libdifusion.so"    # DIF_LIB: instrumented builds (tools/)
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS = range(20)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS, C_HALO_L, C_HALO_R, C_HALO_TICKET = range(23)
 C_COUNT = 32
-PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit"]
+PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge"]
 PROF_COUNT = 8
 LATENT_DIM = 29
 
@@ -33,7 +33,8 @@ class DifMap(Structure):
                 ("frame_count", c_void_p), ("grid_bits", c_void_p), ("grid_tot", c_void_p), ("vbm", c_void_p),
                 ("rec_dir", c_void_p), ("upd_list", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
-                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("dirty_tot", c_void_p)]
+                ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("dirty_tot", c_void_p),
+                ("halo_list", c_void_p), ("halo_list_cap", c_int32)]
 
 
 class DifWeights(Structure):
@@ -60,6 +61,7 @@ class DifExtractBuffers(Structure):
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)
 SIGNATURES = {
     "dif_version": (c_int32, []),
+    "dif_build_id": (ctypes.c_char_p, []),
     "dif_unproject": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p]),
     "dif_unproject_transform": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
                                           c_float, c_float, POINTER(c_float), POINTER(c_float), c_void_p]),
@@ -102,6 +104,9 @@ SIGNATURES = {
     "dif_merge_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "dif_export_halo": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "dif_merge_halo": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_export_halo_delta": (c_int32, [POINTER(DifMap), c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_halo_lists_reset": (c_int32, [POINTER(DifMap), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dif_merge_halo2": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "dif_profile_enable": (c_int32, [c_int32]),
     "dif_profile_read": (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
     "dif_profile_dump": (c_int64, [POINTER(c_int32), POINTER(c_float), c_int64, c_int32]),
@@ -119,6 +124,16 @@ def load() -> ctypes.CDLL:
         if not LIB_PATH.exists():
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc, gfx950). di_fusion_amd has no CPU fallback.")
+        if not os.environ.get("DIF_LIB"):
+            # provenance: the library carries a hash of the sources it was built from; a library from another tree (stale after a checkout,
+            # an rsync, an edit without a rebuild) is rebuilt here rather than silently used
+            from . import _build
+            have, want = _build.lib_build_id(), _build.source_hash()
+            if have != want:
+                try:
+                    _build.build(force=True, verbose=False)
+                except Exception as e:
+                    raise RuntimeError(f"{LIB_PATH} was built from other sources (build id {have}, tree {want}) and rebuilding it failed: {e!r}")
         lib = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

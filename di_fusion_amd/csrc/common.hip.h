@@ -75,6 +75,31 @@ struct GridMarks {
     }
 };
 
+// ---- boundary change lists of a spatially tiled map (dif_map_t.halo_list) ----------------------------------------------------------
+// Whoever allocates or fuses an OWNED voxel of the left / right boundary layers appends its slot; dif_export_halo_delta turns the lists
+// into the frame's halo messages.  list == nullptr: off (single map, or a caller that only uses whole-layer messages).
+struct HaloLists {
+    int32_t* list; int cap; int* counters;
+    int64_t l_lo, l_hi, r_lo, r_hi;         // linear-id ranges of the two boundary layer sets (empty: no neighbour on that side)
+    __device__ __forceinline__ void note(int slot, int64_t lin) const {
+        if (!list) return;
+        if (lin >= l_lo && lin < l_hi) { const int k = atomicAdd(counters + DIF_C_HALO_L, 1); if (k < cap) list[k] = slot; }
+        if (lin >= r_lo && lin < r_hi) { const int k = atomicAdd(counters + DIF_C_HALO_R, 1); if (k < cap) list[cap + k] = slot; }
+    }
+};
+
+__host__ inline bool map_is_tiled(const dif_map_t* m) { return m->own_x_hi > m->own_x_lo && (m->own_x_lo > 0 || m->own_x_hi < m->nx); }
+
+__host__ inline HaloLists halo_lists_of(const dif_map_t* m) {
+    HaloLists h = {};
+    if (!m->halo_list || m->halo_list_cap <= 0 || !map_is_tiled(m) || m->halo <= 0) return h;
+    const int64_t plane = (int64_t)m->ny * m->nz;
+    h.list = m->halo_list; h.cap = m->halo_list_cap; h.counters = m->counters;
+    if (m->own_x_lo > 0) { h.l_lo = m->own_x_lo * plane; h.l_hi = (int64_t)(m->own_x_lo + m->halo < m->own_x_hi ? m->own_x_lo + m->halo : m->own_x_hi) * plane; }
+    if (m->own_x_hi < m->nx) { h.r_hi = m->own_x_hi * plane; h.r_lo = (int64_t)(m->own_x_hi - m->halo > m->own_x_lo ? m->own_x_hi - m->halo : m->own_x_lo) * plane; }
+    return h;
+}
+
 // ---- wave / block primitives ---------------------------------------------------------------------------------
 // 64-bit value of another lane through DPP (VALU data path; __shfl_up goes through the LDS crossbar: two ds_bpermute per 64-bit value)
 template <int CTRL, int ROW_MASK>

@@ -115,6 +115,12 @@ extern "C" {
 
 int dif_version(void) { return DIF_VERSION; }
 
+#ifndef DIF_BUILD_ID
+#define DIF_BUILD_ID "unknown"
+#endif
+static const char k_build_id[] = "DIF_BUILD_ID=" DIF_BUILD_ID;      // (findable in the file without loading it: di_fusion_amd/_build.py)
+const char* dif_build_id(void) { return k_build_id + 13; }
+
 int dif_unproject(const float* depth, float* pc, int32_t H, int32_t W, float fx, float fy, float cx, float cy, void* stream) {
     if (!depth || !pc || H <= 0 || W <= 0) return DIF_EINVAL;
     hipLaunchKernelGGL(k_unproject, dim3(grid_for((int64_t)H * W)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, depth, pc, H, W, fx, fy, cx, cy);
@@ -415,12 +421,12 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
                        (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, grid_marks_of(map), C);
     DIF_CHECK_LAUNCH();
     {
-        AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity};
+        AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
         if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // k_prune_mark kept the block totals
     }
     hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
                        (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
-                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, map->grid_tot);
+                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, map->grid_tot, own_lo, own_hi);
     DIF_CHECK_LAUNCH();
     {
         const bool x6 = w->enc_x6_packed && w->enc_x6_packed_bytes == E6_BYTES;          // tiles on the bf16 matrix pipe (mlp.hip.h)
@@ -442,7 +448,8 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         DIF_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.rec, (const int*)ws.rec_next,
-                       map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C);
+                       map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, (const int64_t*)map->latent_vecs_pos,
+                       halo_lists_of(map));
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -976,34 +983,69 @@ int dif_export_records(const dif_map_t* map, int32_t* records, int64_t max_recor
 
 int dif_export_halo(const dif_map_t* map, int32_t* message, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t* scratch, void* stream) {
     if (!message) return DIF_EINVAL;
+    ProfScope prof(DIF_PROF_HALO_EXPORT, (hipStream_t)stream);
     return export_impl(map, message + 32, max_records, x_lo, x_hi, 1, message, scratch, stream);      // row 0 = header, word 0 = record count
 }
 
-static int merge_impl(const dif_map_t* map, const int32_t* records, int64_t n, const int32_t* n_dev, int32_t assign, int32_t* scratch, void* stream_) {
-    if (!map || n < 0) return DIF_EINVAL;
+static int merge_impl(const dif_map_t* map, const MergeSrc& src, int32_t assign, int32_t* scratch, int32_t* note, void* stream_) {
+    if (!map) return DIF_EINVAL;
+    const int64_t n = (src.rec[0] ? src.n_static[0] : 0) + (src.rec[1] ? src.n_static[1] : 0);      // upper bound: the device may know less
     if (n == 0) return DIF_OK;
-    if (!records || !scratch) return DIF_EINVAL;
+    if (!scratch) return DIF_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     if (hipMemsetAsync(map->counters + DIF_C_ALLOC_NEW, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
     if (!map->grid_tot) return DIF_EINVAL;
-    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, records, n, n_dev, (const int64_t*)map->indexer, grid_marks_of(map), grid);
+    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, src, (const int64_t*)map->indexer, grid_marks_of(map), grid);
     DIF_CHECK_LAUNCH();
-    AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, map->counters, map->capacity};
+    // (voxels allocated by a merge are not noted in the boundary change lists: a map that merges foreign records into its own slab
+    // refreshes its neighbours with whole-layer messages afterwards — the façade does)
+    AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, map->counters, map->capacity, HaloLists{}};
     if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, records, n, n_dev, (const int64_t*)map->indexer,
-                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0, map->grid_tot);
+    hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, src, (const int64_t*)map->indexer,
+                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0, map->grid_tot, note);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
 
 int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, int32_t assign, int32_t* scratch, void* stream_) {
-    return merge_impl(map, records, n, nullptr, assign, scratch, stream_);
+    if (n < 0 || (n > 0 && !records)) return DIF_EINVAL;
+    MergeSrc src = {{records, nullptr}, {n, 0}, {nullptr, nullptr}};
+    return merge_impl(map, src, assign, scratch, nullptr, stream_);
 }
 
 int dif_merge_halo(const dif_map_t* map, const int32_t* message, int64_t max_records, int32_t* scratch, void* stream_) {
     if (!message || max_records <= 0) return DIF_EINVAL;
-    return merge_impl(map, message + 32, max_records, message, 1, scratch, stream_);
+    MergeSrc src = {{message + 32, nullptr}, {max_records, 0}, {message, nullptr}};
+    ProfScope prof(DIF_PROF_HALO_MERGE, (hipStream_t)stream_);
+    return merge_impl(map, src, 1, scratch, nullptr, stream_);
+}
+
+int dif_merge_halo2(const dif_map_t* map, const int32_t* msg_a, int64_t max_a, const int32_t* msg_b, int64_t max_b, int32_t* scratch, int32_t* note,
+                    void* stream_) {
+    if ((msg_a && max_a <= 0) || (msg_b && max_b <= 0)) return DIF_EINVAL;
+    MergeSrc src = {{msg_a ? msg_a + 32 : nullptr, msg_b ? msg_b + 32 : nullptr}, {msg_a ? max_a : 0, msg_b ? max_b : 0}, {msg_a, msg_b}};
+    ProfScope prof(DIF_PROF_HALO_MERGE, (hipStream_t)stream_);
+    return merge_impl(map, src, 1, scratch, note, stream_);
+}
+
+int dif_export_halo_delta(const dif_map_t* map, int32_t* msg_left, int32_t* msg_right, int64_t max_records, int32_t* note, void* stream) {
+    if (!map || max_records <= 0 || !map->halo_list || map->halo_list_cap <= 0 || !map_is_tiled(map)) return DIF_EINVAL;
+    HaloLists hl = halo_lists_of(map);
+    if (!hl.list) return DIF_EINVAL;
+    ProfScope prof(DIF_PROF_HALO_EXPORT, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_export_halo_delta, dim3(64), dim3(DIF_BLOCK), 0, (hipStream_t)stream, hl, (const int64_t*)map->latent_vecs_pos,
+                       (const float*)map->voxel_obs_count, (const float*)map->latent_vecs, (const uint8_t*)map->dirty, msg_left, msg_right, max_records,
+                       map->counters, note);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_halo_lists_reset(const dif_map_t* map, int32_t* header_left, int32_t* header_right, int32_t* note, void* stream) {
+    if (!map) return DIF_EINVAL;
+    hipLaunchKernelGGL(k_halo_lists_reset, dim3(1), dim3(64), 0, (hipStream_t)stream, map->counters, header_left, header_right, note);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
 }
 
 int dif_profile_enable(int32_t on) {

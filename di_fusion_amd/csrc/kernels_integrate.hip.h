@@ -111,6 +111,7 @@ struct AllocFunctor {
     int64_t* pos;
     int* counters;
     int64_t capacity;
+    HaloLists hl;           // spatial tiling: a new owned boundary voxel goes into the frame's halo delta
     __device__ int count(int w) const { return __popc(bits[w]); }
     __device__ void emit(int w, int offset) const {
         uint32_t word = bits[w];
@@ -123,6 +124,7 @@ struct AllocFunctor {
             if (base < capacity) {
                 indexer[lin] = base;
                 pos[base] = lin;
+                hl.note(base, lin);
             }
             ++base;
         }
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
                                                           uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w,
-                                                          int* __restrict__ grid_tot) {
+                                                          int* __restrict__ grid_tot, int own_lo, int own_hi) {
     __shared__ unsigned tkey[FG_TABLE];
     if (blockIdx.x == 0)                                     // the allocation scan has consumed the bitmap's block totals: back to idle 0
         for (int t = (int)threadIdx.x; t < 1024; t += DIF_BLOCK) grid_tot[t] = 0;
@@ -210,7 +212,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
             int gx = clampi((int)(ceilf(xn + ox) - 1.0f), 0, g.nx - 1);                                   // map.py:422-424
             int gy = clampi((int)(ceilf(yn + oy) - 1.0f), 0, g.ny - 1);
             int gz = clampi((int)(ceilf(zn + oz) - 1.0f), 0, g.nz - 1);
-            slot[o] = indexer[linearize(g, gx, gy, gz)];
+            // spatial tiling: a voxel is only ever written by its owner (the others receive it with the halo refresh), so pairs that
+            // target a voxel outside the own slab are dropped here — no encoder rows are spent on them
+            slot[o] = (gx >= own_lo && gx < own_hi) ? indexer[linearize(g, gx, gy, gz)] : -1;
         }
         float w[8];
 #pragma unroll
@@ -396,8 +400,9 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 // together, overflow chain walked), fuse, return the directory to its idle state.
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                                   const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
-                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters) {
+                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, HaloLists hl) {
     const int n_upd = counters[DIF_C_C];
+    const int first_new = counters[DIF_C_N_OCCUPIED] - counters[DIF_C_ALLOC_NEW];      // this frame's new slots are already in the halo delta
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
     const int f = threadIdx.x & 31;
     // where feature f sits in a record: the accumulator-fragment order of the tile's two halves (mlp.hip.h)
@@ -435,6 +440,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
             dirty[s] = 1;                                    // map.py:452
             dir[0] = 0;
             dir[1] = 0;
+            if (hl.list && s < first_new) hl.note(s, slot_lin[s]);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_ITEMS] = (counters[DIF_C_M] + 31) >> 5;   // encoder tiles of this frame

@@ -532,7 +532,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
         if (lane == DIF_C_OVERFLOW && over) v = 5;
         if (out.counters_out && lane < DIF_C_COUNT) out.counters_out[lane] = v;
         if (lane == 0) {
-            if (over) counters[DIF_C_OVERFLOW] = 5;
+            // a flag that has just been handed to the caller with this snapshot is reported: cleared here, in stream order, so that the next
+            // call's snapshot neither repeats it nor loses a flag raised in between
+            if (out.counters_out) counters[DIF_C_OVERFLOW] = 0;
+            else if (over) counters[DIF_C_OVERFLOW] = 5;
             counters[DIF_C_CACHE_T] = (int)tot;
         }
     }
@@ -625,22 +628,93 @@ struct ExportFunctor {       // ordered compaction over slots: allocated voxels 
     }
 };
 
-__global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(const int32_t* __restrict__ rec, int64_t n_static, const int32_t* __restrict__ n_ptr,
-                                                        const int64_t* __restrict__ indexer, GridMarks marks, int64_t grid) {
-    const int64_t n = n_ptr ? min((int64_t)*n_ptr, n_static) : n_static;       // a device-side count is bounded by the buffer's capacity
+// Delta halo messages (dif_export_halo_delta): one 32-lane group per entry of the boundary change lists writes the voxel's raw record
+// (lin | flags | w | z[29]) — both neighbours' messages in one launch.  The workgroup that takes the last ticket has seen every other
+// workgroup read the list lengths (a workgroup takes its ticket after its loops, whose bounds are those lengths), so it can empty the
+// lists and write the headers without a second launch.
+__global__ void __launch_bounds__(DIF_BLOCK) k_export_halo_delta(HaloLists hl, const int64_t* __restrict__ pos, const float* __restrict__ obs,
+                                                               const float* __restrict__ latent, const uint8_t* __restrict__ dirty,
+                                                               int32_t* __restrict__ msg_l, int32_t* __restrict__ msg_r, int64_t max_records,
+                                                               int* __restrict__ counters, int32_t* __restrict__ note) {
+    const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);
+    const int f = threadIdx.x & 31;
+    int pending[2], n[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        int32_t* msg = side ? msg_r : msg_l;
+        pending[side] = counters[DIF_C_HALO_L + side];
+        int64_t m = pending[side];
+        if (m > hl.cap) m = hl.cap;
+        if (m > max_records) m = max_records;
+        n[side] = msg ? (int)m : 0;
+        for (int e = grp; e < n[side]; e += ngrp) {
+            const int s = hl.list[side * hl.cap + e];
+            int32_t word;
+            if (f == 0) word = (int32_t)pos[s];
+            else if (f == 1) word = dirty[s] ? 1 : 0;
+            else if (f == 2) word = __float_as_int(obs[s]);
+            else word = __float_as_int(latent[(int64_t)s * L + (f - 3)]);
+            msg[(int64_t)(1 + e) * 32 + f] = word;
+        }
+    }
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(counters + DIF_C_HALO_TICKET, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    counters[DIF_C_HALO_TICKET] = 0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        int32_t* msg = side ? msg_r : msg_l;
+        if (!msg) continue;                              // a side without a message keeps its list (a whole-layer export may follow)
+        counters[DIF_C_HALO_L + side] = 0;
+        msg[0] = n[side]; msg[1] = pending[side]; msg[2] = 1;
+        if (note) { note[4 * side] = n[side]; note[4 * side + 1] = pending[side]; note[4 * side + 2] = 1; }
+        if (pending[side] > n[side]) counters[DIF_C_OVERFLOW] = 8;
+    }
+}
+
+__global__ void k_halo_lists_reset(int* __restrict__ counters, int32_t* __restrict__ hdr_l, int32_t* __restrict__ hdr_r, int32_t* __restrict__ note) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        int32_t* hdr = side ? hdr_r : hdr_l;
+        if (!hdr) continue;
+        const int pending = counters[DIF_C_HALO_L + side];
+        hdr[1] = pending; hdr[2] = 0;
+        if (note) { note[4 * side] = hdr[0]; note[4 * side + 1] = pending; note[4 * side + 2] = 0; }
+        counters[DIF_C_HALO_L + side] = 0;
+    }
+}
+
+// Up to two record sources per merge (the halo messages of both neighbours in one pass); record ids are distinct across both.
+struct MergeSrc {
+    const int32_t* rec[2]; int64_t n_static[2]; const int32_t* n_ptr[2];
+    __device__ __forceinline__ int64_t count(int k) const {       // a device-side count is bounded by the buffer's capacity
+        if (!rec[k]) return 0;
+        return n_ptr[k] ? min((int64_t)max(*n_ptr[k], 0), n_static[k]) : n_static[k];
+    }
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_mark(MergeSrc src, const int64_t* __restrict__ indexer, GridMarks marks, int64_t grid) {
+    const int64_t n0 = src.count(0), n = n0 + src.count(1);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t lin = rec[i * 32];
+        const int32_t* rec = i < n0 ? src.rec[0] + i * 32 : src.rec[1] + (i - n0) * 32;
+        int64_t lin = rec[0];
         if (lin < 0 || lin >= grid) continue;
         if (indexer[lin] == -1 && !((marks.bits[lin >> 5] >> (lin & 31)) & 1u)) marks.set((int)lin);
     }
 }
 
 // records of one call carry distinct lin ids => plain read-modify-write, deterministic
-__global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __restrict__ rec, int64_t n_static, const int32_t* __restrict__ n_ptr,
-                                                         const int64_t* __restrict__ indexer, float* __restrict__ latent, float* __restrict__ obs,
-                                                         uint8_t* __restrict__ dirty, int* __restrict__ counters, int64_t grid, int64_t capacity,
-                                                         int assign, int* __restrict__ grid_tot) {
-    const int64_t n = n_ptr ? min((int64_t)*n_ptr, n_static) : n_static;
+__global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(MergeSrc src, const int64_t* __restrict__ indexer, float* __restrict__ latent,
+                                                         float* __restrict__ obs, uint8_t* __restrict__ dirty, int* __restrict__ counters, int64_t grid,
+                                                         int64_t capacity, int assign, int* __restrict__ grid_tot, int32_t* __restrict__ note) {
+    const int64_t n0 = src.count(0), n = n0 + src.count(1);
+    if (note && blockIdx.x == 0 && threadIdx.x < 8) {        // the received headers, for the host's bookkeeping (may be pinned host memory)
+        const int k = (int)threadIdx.x >> 2;
+        note[threadIdx.x] = src.n_ptr[k] ? src.n_ptr[k][threadIdx.x & 3] : 0;
+    }
     if (blockIdx.x == 0)                                     // the allocation scan has consumed the bitmap's block totals
         for (int t = (int)threadIdx.x; t < 1024; t += DIF_BLOCK) grid_tot[t] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -653,15 +727,16 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __rest
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t i = e >> 5;
         int f = (int)(e & 31);
-        int64_t lin = rec[i * 32];
+        const int32_t* rec = i < n0 ? src.rec[0] + i * 32 : src.rec[1] + (i - n0) * 32;
+        int64_t lin = rec[0];
         if (lin < 0 || lin >= grid) continue;
         int64_t s = indexer[lin];
         if (s < 0) continue;
-        float w_r = __int_as_float(rec[i * 32 + 2]);
+        float w_r = __int_as_float(rec[2]);
         float w_old = obs[s];
         float w_new = assign ? w_r : w_old + w_r;
         if (f < L) {
-            float pay = __int_as_float(rec[i * 32 + 3 + f]);
+            float pay = __int_as_float(rec[3 + f]);
             float z = latent[s * L + f];
             if (assign) latent[s * L + f] = pay;
             else if (w_r > 0.0f) latent[s * L + f] = (z * w_old + pay) / w_new;      // a weight-0 record only allocates (allocate_block): no re-rounding of z
@@ -669,9 +744,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_merge_apply(const int32_t* __rest
         __builtin_amdgcn_wave_barrier();
         if (f == 31) {
             obs[s] = w_new;
-            if (assign) dirty[s] = (uint8_t)(rec[i * 32 + 1] & 1);
+            if (assign) dirty[s] = (uint8_t)(rec[1] & 1);
             else if (w_r > 0.0f) dirty[s] = 1;
         }
     }
 }
-

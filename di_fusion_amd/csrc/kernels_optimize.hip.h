@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_optim_adam(float* __restrict__ z,
             float nn = f < L ? zf * zf : 0.0f;
 #pragma unroll
             for (int d = 16; d >= 1; d >>= 1) nn += __shfl_xor(nn, d, 32);
-            g += reg_lambda * zf / sqrtf(nn) * inv_n;
+            if (nn > 0.0f) g += reg_lambda * zf / sqrtf(nn) * inv_n;          // torch.norm's backward: subgradient 0 at z = 0 (a merged / loaded all-zero latent)
         }
         if (f < L) {
             const float mf = b1 * m[e] + (1.0f - b1) * g;
@@ -175,6 +175,6 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_optim_writeback(const int* __rest
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         const int u = e >> 5, f = e & 31, s = uniq_slot[u];
         if (f < L) latent[(int64_t)s * L + f] = z[e];
-        if (f == 31) { optimized[s] = 1; dirty[s] = 1; slot_flag[s] = 0; }
+        if (f == 31) { optimized[s] = 1; dirty[s] = 1; slot_flag[s] = 0; }      // (a tiled map's façade refreshes its neighbours with whole-layer halo messages after this)
     }
 }

@@ -21,16 +21,19 @@ class FusionStream:
     def __init__(self, model, scene: syn.Scene, cfg: syn.MapConfig, intr: syn.Intrinsic, device: torch.device,
                  n_frames: int, deg_per_frame: float = 0.5, phase_deg: float = 0.0, orbit_radius: float = 0.3,
                  noise: bool = False, resolution: int = 4, max_n_triangles: int = int(4e6), max_std: float = 0.15,
-                 initial_capacity: int = 1 << 16, tiling=None):
+                 initial_capacity: int = 1 << 16, tiling=None, halo_mode: str = "delta", halo_loopback: bool = False):
         """tiling = (rank, world, group): BASELINE config C5 — the grid is cut into `world` x-slabs, this stream's map owns slab `rank`,
         every rank is offered the whole frame and the 3 boundary layers are refreshed from the ring neighbours after every integrate
-        (`parallel.exchange_halo`: one send + one receive per neighbour over RCCL / xGMI).  Eager / pipelined stepping only."""
+        (`parallel.exchange_halo`: one send + one receive per neighbour over RCCL / xGMI; halo_mode "delta": bounded messages with the
+        frame's changes, "full": whole layers).  halo_loopback: this process plays slab `rank` of `world` alone and exchanges with
+        itself (bench.py --loopback).  Eager / pipelined stepping only."""
         self.device = device
         self.intr = intr
         self.resolution, self.max_n_triangles, self.max_std = resolution, max_n_triangles, max_std
         self.map = DenseIndexedMap(model, cfg.namespace(), 29, device, initial_capacity=initial_capacity)
         self.tiling = tiling if (tiling is not None and tiling[1] > 1) else None
         self._halo_buffers = {}
+        self.halo_mode, self.halo_loopback = halo_mode, bool(halo_loopback)
         if self.tiling is not None:
             from . import parallel
             rank, world, _ = self.tiling
@@ -95,7 +98,7 @@ class FusionStream:
             from . import parallel
             rank, world, group = self.tiling
             with torch.cuda.device(self.device):
-                parallel.exchange_halo(self.map, rank, world, group, self._halo_buffers)
+                parallel.exchange_halo(self.map, rank, world, group, self._halo_buffers, mode=self.halo_mode, loopback=self.halo_loopback)
 
     def _before_frame(self):
         """The D2H of the previous frame's triangles (side stream) reads a region of the mesh-cache LOG that later frames only append
@@ -224,6 +227,7 @@ class FusionStream:
     def step_direct(self, i: int, d2h: str = "new"):
         """One frame enqueued with two C calls (no graph), host one frame ahead; returns the previous frame's output like `step_pipelined`."""
         m = self.map
+        self._no_async_meshing()
         self._d2h_mode = d2h
         if self.tiling is not None:
             raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
@@ -324,10 +328,17 @@ class FusionStream:
             self._b_sig = (export, F, m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr())
             self.n_captures += 1
 
+    def _no_async_meshing(self):
+        """The direct / graph / batch paths enqueue integrate and extract on ONE stream without the map's lock, its `_integrate_done` event
+        or a wait on `meshing_stream`: they are exclusive with `extract_mesh(extract_async=True)` on the same map."""
+        if self.map.meshing_thread is not None and self.map.meshing_thread.is_alive():
+            raise RuntimeError("step_direct / step_graph / step_batch cannot be mixed with an asynchronous extract_mesh on the same map")
+
     def step_batch(self, i0: int, F: int, d2h: str = "new"):
         """Frames i0 .. i0+F-1 enqueued as ONE graph launch; returns the list of the outputs of everything that was pending before
-        (the previous batch, or a frame of one of the frame-by-frame paths), oldest first."""
+        (the previous batch, a frame of one of the frame-by-frame paths, and anything an earlier call left in `backlog`), oldest first."""
         m = self.map
+        self._no_async_meshing()
         self._d2h_mode = d2h
         if self.tiling is not None:
             raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
@@ -360,6 +371,8 @@ class FusionStream:
                   for j, sl in enumerate(self._b_slots[g])]
         outs += self._finish_pending(d2h)
         self._pending = hs
+        # whatever a log compaction above had to complete early went to `backlog`: it is older than everything in `outs`
+        outs, self.backlog = self.backlog + outs, []
         return outs
 
     def _complete_batch_before_gc(self, d2h: str):
@@ -444,6 +457,7 @@ class FusionStream:
         """`step_pipelined` with the frame's launches replayed from a captured hipGraph (host cost: writing a 64-byte frame descriptor
         into pinned memory and one graph launch)."""
         m = self.map
+        self._no_async_meshing()
         self._d2h_mode = d2h
         if self.tiling is not None:
             raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")

@@ -100,7 +100,9 @@ class _GetSdfFn(torch.autograd.Function):
         return out, None
 
 
-_OVERFLOW_WHAT = {1: "more voxels than latent rows", 2: "more dirty voxels than extract buffers", 3: "more decoded voxels than extract buffers",
+_OVERFLOW_WHAT = {8: "a delta halo message overflowed: the neighbours' halo copies are stale from that frame on (use whole-layer messages, "
+                     "parallel.exchange_halo(mode='full'), for streams that change this much per frame)",
+                  1: "more voxels than latent rows", 2: "more dirty voxels than extract buffers", 3: "more decoded voxels than extract buffers",
                   5: "mesh-cache log full", 6: "more records than the export buffer",
                   7: "marching cubes gave up waiting for an earlier workgroup (the GPU was shared with another kernel for seconds)"}
 
@@ -152,6 +154,9 @@ class DenseIndexedMap:
         self.optimize_noise = None          # optional (k,) tensor of N(0,1) samples for the optimiser's perturbations (default: torch.randn)
         self.optimize_losses = None         # device float[64]: likelihood loss before each Adam step of the last optimisation
         self._cache_call_limit = 0          # max_n_triangles of the latest extract (what one more call may append to the log)
+        self.extract_buffer_bytes = 8 << 30 # upper bound for the per-voxel extract buffers sized ahead of the occupancy (see _extract_buffers)
+        self._halo_list = None              # spatial tiling: boundary change lists (dif_map_t.halo_list)
+        self._halo_lists_stale = True       # the lists do not cover every change since the last halo export: whole-layer messages next
 
         self._grid = int(np.prod(self.n_xyz))
         if self._grid >= 2 ** 31:
@@ -228,6 +233,9 @@ class DenseIndexedMap:
         m.tri_n = _lib.ptr(tri_n)
         m.own_x_lo, m.own_x_hi, m.halo = getattr(self, "_ownership", (0, self.n_xyz[0], 0))
         m.dirty_tot = _lib.ptr(self._dirty_tot)
+        hl = getattr(self, "_halo_list", None)
+        m.halo_list = _lib.ptr(hl)
+        m.halo_list_cap = 0 if hl is None else hl.size(1)
         self._cmap = m
         self._recount_dirty()
 
@@ -246,11 +254,14 @@ class DenseIndexedMap:
         with self._state_lock:
             return self._publish_counters_locked(c, add_total_at_read)
 
-    def _publish_counters_locked(self, c, add_total_at_read):
+    def _publish_counters_locked(self, c, add_total_at_read, clear_flag=False):
         if c[_lib.C_OVERFLOW] != 0:
-            # reported once: the device flag is cleared so that the session can go on (e.g. with a no_cache re-extraction)
-            with torch.cuda.device(self.device):
-                self._counters[_lib.C_OVERFLOW:_lib.C_OVERFLOW + 1].zero_()
+            # Reported once, so that the session can go on (e.g. with a no_cache re-extraction).  A snapshot taken by an extract has
+            # already cleared the device flag in stream order, right behind the copy (`k_extract_finish` / `extract_mesh_enqueue`): the
+            # next frame's snapshot neither repeats this overflow nor loses one raised in between.  Only a blocking read clears it here.
+            if clear_flag:
+                with torch.cuda.device(self.device):
+                    self._counters[_lib.C_OVERFLOW:_lib.C_OVERFLOW + 1].zero_()
             raise RuntimeError(f"libdifusion: device buffer overflow (code {c[_lib.C_OVERFLOW]}: "
                                f"{_OVERFLOW_WHAT.get(c[_lib.C_OVERFLOW], '?')}); the result of that call is incomplete")
         # exact n_occupied at the time the counters were read + whatever later calls may have allocated since
@@ -270,7 +281,7 @@ class DenseIndexedMap:
             if self.meshing_thread is not None or threading.current_thread() is not threading.main_thread():
                 torch.cuda.synchronize(self.device)
             _lib.check(_lib.load().dif_read_counters(ctypes.byref(self._cmap), self._host_counters, _lib.stream_ptr()), "dif_read_counters")
-            return self._publish_counters_locked(list(self._host_counters), self._add_total)
+            return self._publish_counters_locked(list(self._host_counters), self._add_total, clear_flag=True)
 
     def _ensure_capacity(self, may_add: int):
         """Called with `_state_lock` held by whoever is about to enqueue work that may allocate up to `may_add` voxels."""
@@ -350,6 +361,7 @@ class DenseIndexedMap:
         self._counters.zero_()
         self._counters[_lib.C_N_OCCUPIED] = n
         self._n_occ_ub = n
+        self._halo_lists_stale = True
         self._recount_dirty()
         self.mesh_cache.clear_all()
 
@@ -406,6 +418,7 @@ class DenseIndexedMap:
         _lib.check(lib.dif_optimize_latents(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), _lib.ptr(nrm), N, _lib.ptr(mask), _lib.ptr(noise),
                                             int(self.args.optim_n_iters), 1.0e-2, lam, _lib.ptr(self.optimize_losses), _lib.ptr(self._opt_ws),
                                             self._opt_ws.numel(), _lib.stream_ptr()), "dif_optimize_latents")
+        self._halo_lists_stale = True                            # changed voxels that are not in the boundary change lists
         self._recount_dirty()                                    # the write-back marks the optimised voxels dirty
 
     def allocate_block(self, idx: torch.Tensor):
@@ -413,10 +426,11 @@ class DenseIndexedMap:
         own caller ever passes, `map.py:383-387`); ids that are already allocated are left untouched (weight-0 records)."""
         if idx.ndimension() == 2 and idx.size(1) == 3:
             idx = idx[:, 2] + self.n_xyz[-1] * idx[:, 1] + (self.n_xyz[-1] * self.n_xyz[-2]) * idx[:, 0]
-        idx = idx.to(self.device).long().contiguous()
-        if idx.numel() > 1 and not bool((idx[1:] > idx[:-1]).all()):
-            raise NotImplementedError("allocate_block: pass sorted, unique linear ids (slots are numbered in ascending id order; the "
-                                      "reference numbers them in the caller's order, map.py:317-319, and its only caller passes torch.unique output)")
+        # slots are numbered in ascending id order, whatever order the caller passes (the reference numbers them in the caller's order,
+        # map.py:317-319, and its only caller passes torch.unique output, i.e. sorted unique ids: same numbering there)
+        idx = torch.unique(idx.to(self.device).long().flatten())
+        if idx.numel() == 0:
+            return
         rec = torch.zeros((idx.size(0), 32), dtype=torch.int32, device=self.device)
         rec[:, 0] = idx.to(torch.int32)          # grid < 2^31 (checked in __init__), high word stays 0
         self.merge_records(rec)
@@ -532,11 +546,13 @@ class DenseIndexedMap:
         R = 2 * resolution
         if max_vox is None:
             max_vox = _next_pow2(max(self._n_occ_ub, 1024))
-            # sized for the map's capacity while that stays under 8 GB (HBM is plentiful; re-allocating ~8 KB per voxel every time the
-            # occupancy crosses a power of two costs tens of milliseconds in the middle of a stream), for the occupancy beyond that
+            # Room to grow: four times the occupancy bound, at most the map's capacity and at most `extract_buffer_bytes` (8 GB unless the
+            # caller sets it) — re-allocating ~8 KB per voxel every time the occupancy crosses a power of two costs tens of milliseconds in
+            # the middle of a stream, while sizing for the capacity of a nearly empty map would tie up gigabytes for nothing.
             per_voxel = (R ** 3) * 12 + (resolution ** 3) * 8 + 1024 + 64
-            if self._capacity * per_voxel <= (8 << 30):
-                max_vox = max(max_vox, self._capacity)
+            roomy = min(self._capacity, 4 * max_vox)
+            if roomy * per_voxel <= self.extract_buffer_bytes:
+                max_vox = max(max_vox, roomy)
             if self._xbuf is not None and self._xbuf[0][0] == resolution and self._xbuf[0][1] >= max_vox:
                 max_vox = self._xbuf[0][1]                      # never shrink: keeps pointers stable
         key = (resolution, max_vox)
@@ -591,6 +607,7 @@ class DenseIndexedMap:
             pc = self._pinned_counters[self._pending_seq % 4]
             self._pending_seq += 1
             pc.copy_(self._counters, non_blocking=True)
+            self._counters[_lib.C_OVERFLOW:_lib.C_OVERFLOW + 1].zero_()        # handed over with this snapshot (see _publish_counters_locked)
             ev = torch.cuda.Event()
             ev.record()
             return dict(event=ev, counters=pc, epoch=self._gc_epoch, add_total=self._add_total, max_n_triangles=max_n_triangles)
@@ -685,13 +702,31 @@ class DenseIndexedMap:
         return self._make_mesh_from_cache()
 
     # ---- multi-GPU (no reference counterpart) ---------------------------------------------
+    HALO_LIST_CAP = 4096                    # entries per boundary change list = records of a delta halo message (512 KB)
+
     def set_ownership(self, x_lo: int, x_hi: int, halo: int = 3):
         """Spatial tiling (SURVEY.md section 8e "C5"): this map owns the voxels with x index in [x_lo, x_hi).  Integrate ignores points
-        whose own voxel is farther than `halo` voxels from the slab, and only owned voxels are meshed.  With the boundary layers
-        refreshed after every integrate (`parallel.exchange_halo`), halo = 3 makes every owned voxel bit-identical to the
-        single-map result (see the derivation in parallel.py)."""
+        whose own voxel is farther than `halo` voxels from the slab and never writes a voxel it does not own; only owned voxels are meshed.
+        With the boundary layers refreshed after every integrate (`parallel.exchange_halo`), halo = 3 makes every owned voxel
+        bit-identical to the single-map result (see the derivation in parallel.py)."""
         self._ownership = (int(x_lo), int(x_hi), int(halo))
         self._cmap.own_x_lo, self._cmap.own_x_hi, self._cmap.halo = self._ownership
+        tiled = x_hi > x_lo and (x_lo > 0 or x_hi < self.n_xyz[0])
+        if tiled and self._halo_list is None:
+            with torch.cuda.device(self.device):
+                self._halo_list = torch.zeros((2, self.HALO_LIST_CAP), dtype=torch.int32, device=self.device)
+        self._cmap.halo_list = _lib.ptr(self._halo_list if tiled else None)
+        self._cmap.halo_list_cap = self.HALO_LIST_CAP if tiled else 0
+        self._halo_lists_stale = True
+        with torch.cuda.device(self.device):
+            self._counters[_lib.C_HALO_L:_lib.C_HALO_TICKET + 1].zero_()
+        if not tiled:
+            self._recount_dirty()           # (a tiled map's extract counts the dirty flags itself; the totals are kept only for the whole grid)
+
+    @property
+    def _tiled(self) -> bool:
+        lo, hi, _ = getattr(self, "_ownership", (0, self.n_xyz[0], 0))
+        return hi > lo and (lo > 0 or hi < self.n_xyz[0])
 
     def export_records(self, x_lo: int = None, x_hi: int = None, raw: bool = False) -> torch.Tensor:
         """(n, 32) int32 records of the allocated voxels with x index in [x_lo, x_hi) (default: all), slot order:
@@ -725,18 +760,47 @@ class DenseIndexedMap:
                                                    _lib.ptr(self._halo_scratch), _lib.stream_ptr()), "dif_export_halo")
         return out
 
-    def merge_halo(self, msg: torch.Tensor):
+    def export_halo_delta(self, out_left: Optional[torch.Tensor], out_right: Optional[torch.Tensor], note: Optional[torch.Tensor] = None):
+        """Bounded delta messages for both neighbours in ONE launch: the owned boundary voxels this map allocated or fused since the
+        last halo export (`dif_export_halo_delta`).  out_left / out_right: (1 + rows, 32) int32 device buffers (None: no neighbour on that
+        side, whose change list is left alone); header word 0 = records, word 1 = records that were pending (> word 0: overflow), word 2 = 1.
+        note: optional int32[8] (pinned host memory is fine) receiving both headers."""
+        rows = min(t.size(0) - 1 for t in (out_left, out_right) if t is not None)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().dif_export_halo_delta(ctypes.byref(self._cmap), _lib.ptr(out_left), _lib.ptr(out_right), min(rows, self.HALO_LIST_CAP),
+                                                         _lib.ptr(note), _lib.stream_ptr()), "dif_export_halo_delta")
+
+    def halo_lists_reset(self, hdr_left: Optional[torch.Tensor], hdr_right: Optional[torch.Tensor], note: Optional[torch.Tensor] = None):
+        """After whole-layer messages (which supersede the change lists): complete their headers (word 1 = what a delta would have carried,
+        word 2 = 0) and empty the lists."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().dif_halo_lists_reset(ctypes.byref(self._cmap), _lib.ptr(hdr_left), _lib.ptr(hdr_right), _lib.ptr(note), _lib.stream_ptr()),
+                       "dif_halo_lists_reset")
+
+    def merge_halo(self, msg: torch.Tensor, rows: int = None):
         """Overwrite (w, z, dirty) of the voxels named in a halo message (allocating the unseen ones, ascending id); the record count is
-        read on the device."""
-        _lib.require_cuda(msg)
-        rows = msg.size(0) - 1
+        read on the device.  `rows`: records the message can hold (default: its whole length)."""
+        self.merge_halo2(msg, None, rows, None)
+
+    def merge_halo2(self, msg_a: Optional[torch.Tensor], msg_b: Optional[torch.Tensor], rows_a: int = None, rows_b: int = None,
+                    note: Optional[torch.Tensor] = None):
+        """`merge_halo` for the messages of both neighbours in one pass (`dif_merge_halo2`); note: optional int32[8] receiving the two
+        headers as received."""
+        rows = []
+        for m, r in ((msg_a, rows_a), (msg_b, rows_b)):
+            if m is not None:
+                _lib.require_cuda(m)
+            rows.append(0 if m is None else (m.size(0) - 1 if r is None else min(int(r), m.size(0) - 1)))
+        if rows[0] + rows[1] == 0:
+            return
         with self.modifying_lock, self._state_lock, torch.cuda.device(self.device):
-            self._ensure_capacity(rows)
+            self._ensure_capacity(rows[0] + rows[1])
             if self._halo_scratch is None:
                 self._halo_scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
-            _lib.check(_lib.load().dif_merge_halo(ctypes.byref(self._cmap), _lib.ptr(msg), rows, _lib.ptr(self._halo_scratch), _lib.stream_ptr()),
-                       "dif_merge_halo")
-            self._recount_dirty()
+            _lib.check(_lib.load().dif_merge_halo2(ctypes.byref(self._cmap), _lib.ptr(msg_a), rows[0], _lib.ptr(msg_b), rows[1],
+                                                   _lib.ptr(self._halo_scratch), _lib.ptr(note), _lib.stream_ptr()), "dif_merge_halo2")
+            if not self._tiled:
+                self._recount_dirty()       # (a tiled map's extract counts the dirty flags itself)
             if self._integrate_done is None:
                 self._integrate_done = torch.cuda.Event()
             self._integrate_done.record()
@@ -753,6 +817,7 @@ class DenseIndexedMap:
             scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
             _lib.check(_lib.load().dif_merge_records(ctypes.byref(self._cmap), _lib.ptr(rec), n, 1 if assign else 0, _lib.ptr(scratch),
                                                      _lib.stream_ptr()), "dif_merge_records")
+            self._halo_lists_stale = True
             self._recount_dirty()
             if self._integrate_done is None:
                 self._integrate_done = torch.cuda.Event()

@@ -36,7 +36,8 @@ extern "C" {
 /* Device-resident counters (one per map).  int32 each; indices into the `counters` array. */
 enum {
     DIF_C_N_OCCUPIED = 0,   /* map.py:200  n_occupied                                                   */
-    DIF_C_OVERFLOW = 1,     /* set !=0 when a device-side buffer was too small (checked by the façade); 7 = the one-pass marching cubes gave up a look-back */
+    DIF_C_OVERFLOW = 1,     /* set !=0 when a device-side buffer was too small (checked by the façade); 7 = the one-pass marching cubes gave up a look-back;
+                             * 8 = a delta halo message / boundary change list overflowed */
     DIF_C_ALLOC_NEW = 2,    /* voxels allocated by the last integrate                                     */
     DIF_C_M = 3,            /* gathered (point, offset) rows of the last integrate  (map.py:434-435)      */
     DIF_C_C = 4,            /* voxels updated by the encoder in the last integrate  (map.py:437)          */
@@ -55,6 +56,9 @@ enum {
     DIF_C_CACHE_LIVE = 17,  /* triangles written by the last dif_mesh_cache_compact                        */
     DIF_C_OPT_ROWS = 18,    /* samples gathered by the last dif_optimize_latents (n_samples, map.py:85)      */
     DIF_C_OPT_VOXELS = 19,  /* voxels optimised by it (latent_id_subset_uniques, map.py:496)                  */
+    DIF_C_HALO_L = 20,      /* entries appended to the LEFT / RIGHT boundary change list (dif_map_t.halo_list) since the last    */
+    DIF_C_HALO_R = 21,      /* halo export; may exceed halo_list_cap (then the list is incomplete and the delta export says so)   */
+    DIF_C_HALO_TICKET = 22, /* idle 0: workgroups of dif_export_halo_delta that are done                                          */
     DIF_C_COUNT = 32
 };
 
@@ -91,6 +95,12 @@ typedef struct dif_map {
      * zeroes it again).  A caller that sets flags any other way (dif_merge_*, dif_optimize_latents, its own writes) recomputes the array
      * from the flags afterwards — or passes NULL here, and dif_extract counts the flags itself. */
     int32_t* dirty_tot;
+    /* Optional (spatial tiling): int32[2][halo_list_cap], the slots of OWNED voxels in the left boundary layers [own_x_lo, own_x_lo + halo)
+     * (row 0) and in the right ones [own_x_hi - halo, own_x_hi) (row 1) that dif_integrate* allocated or fused since the last halo export, in
+     * arrival order (a slot may appear more than once); counts in counters[DIF_C_HALO_L / DIF_C_HALO_R].  dif_export_halo_delta turns them into
+     * bounded halo messages; NULL: only the whole-layer export (dif_export_halo) is available. */
+    int32_t* halo_list;
+    int32_t halo_list_cap;
 } dif_map_t;
 
 /* Network weights packed for the MFMA kernels by di_fusion_amd/network/packing.py (layout documented there). */
@@ -120,6 +130,9 @@ typedef struct dif_weights {
 } dif_weights_t;
 
 int dif_version(void);
+/* Hash of the sources this library was built from (everything under csrc/ and this header; di_fusion_amd/_build.py computes it and passes it as
+ * -DDIF_BUILD_ID): the loader compares it with the tree and rebuilds on a mismatch instead of trusting file times. */
+const char* dif_build_id(void);
 
 /* ---- a1/a2: depth -> points (ext/imgproc/imgproc.cu:5-44, utils/motion_util.py:322-327) -------------------- */
 /* pc[v][u] = ((u-cx)/fx*d, (v-cy)/fy*d, d); NaN depth -> (NaN,NaN,NaN).  depth (H,W) f32 -> pc (H,W,3) f32.     */
@@ -322,10 +335,27 @@ int dif_merge_records(const dif_map_t* map, const int32_t* records, int64_t n, i
  * device (clamped to max_records).  scratch: int32 [4096]. */
 int dif_export_halo(const dif_map_t* map, int32_t* message, int64_t max_records, int32_t x_lo, int32_t x_hi, int32_t* scratch, void* stream);
 int dif_merge_halo(const dif_map_t* map, const int32_t* message, int64_t max_records, int32_t* scratch, void* stream);
+/* Bounded DELTA messages: only the boundary voxels that dif_integrate* allocated or fused since the last halo export (map->halo_list), for
+ * both neighbours in ONE launch.  A receiver whose halo copy was exact before the frame is exact again after merging the delta, because
+ * integrate never writes a voxel it does not own (its gather drops those targets).  msg_left / msg_right (NULL: no delta message for that
+ * side — its change list is left alone): int32 [1 + max_records][32]; header word 0 = records that follow, word 1 = records that were
+ * pending (> word 0: the message or the change list overflowed, counters[DIF_C_OVERFLOW] = 8 and the receiver's halo is stale from here on),
+ * word 2 = 1.  The change list of every side that got a message is emptied.
+ * dif_export_halo writes header word 0 only; dif_halo_lists_reset completes the headers of such whole-layer messages (word 1 = entries
+ * that were pending in that side's list, i.e. the size a delta message would have had — what the host's choice between the two message
+ * kinds looks at —, word 2 = 0; NULL: side not touched) and empties those sides' lists, which the whole-layer export supersedes.
+ * note (optional, all three calls; may be device-mapped pinned HOST memory): int32[8] = header words 0..3 of the left / first message, then
+ * of the right / second one, as written (exports) or as received (merge): the host reads them a frame or two later, without a copy. */
+int dif_export_halo_delta(const dif_map_t* map, int32_t* msg_left, int32_t* msg_right, int64_t max_records, int32_t* note, void* stream);
+int dif_halo_lists_reset(const dif_map_t* map, int32_t* header_left, int32_t* header_right, int32_t* note, void* stream);
+/* dif_merge_halo for the messages of both neighbours in one pass (three launches instead of six); either may be NULL. */
+int dif_merge_halo2(const dif_map_t* map, const int32_t* msg_a, int64_t max_a, const int32_t* msg_b, int64_t max_b, int32_t* scratch,
+                    int32_t* note, void* stream);
 
 /* ---- per-kernel timing for bench.py's roofline leg ---------------------------------------------------------- */
 /* When enabled, a hipEvent pair is recorded around each launch of the named kernels ON THE STREAM THEY RUN ON. */
 enum { DIF_PROF_ENCODE = 0, DIF_PROF_DECODE_LATTICE = 1, DIF_PROF_DECODE_POINTS = 2, DIF_PROF_MC_COUNT = 3, DIF_PROF_MC_EMIT = 4,
+       DIF_PROF_HALO_EXPORT = 5 /* the launches of one dif_export_halo* call */, DIF_PROF_HALO_MERGE = 6 /* of one dif_merge_halo* call */,
        DIF_PROF_COUNT = 8 };
 int dif_profile_enable(int32_t on);
 /* Sum of elapsed milliseconds and number of launches per kernel since the last reset; synchronises on the events. */

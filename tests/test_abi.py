@@ -8,7 +8,7 @@ from tests.conftest import ROOT
 def header_symbols():
     src = (ROOT / "include" / "difusion.h").read_text()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(dif_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\*)\s+(dif_\w+)\s*\(", src)))
 
 
 def test_header_library_and_binding_agree():
@@ -21,6 +21,28 @@ def test_header_library_and_binding_agree():
         assert hasattr(h, s), f"{s} declared in difusion.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms
     assert h.dif_version() == 100
+
+
+def test_library_carries_the_hash_of_the_tree():
+    """Build provenance: `dif_build_id()` = hash of csrc/* + include/difusion.h + flags; a library built from other sources is rebuilt,
+    whatever the file times say."""
+    import os
+    from di_fusion_amd import _build
+    lib_path = _build.build()
+    assert _build.lib_build_id() == _build.source_hash()
+    h = ctypes.CDLL(str(lib_path))
+    h.dif_build_id.restype = ctypes.c_char_p
+    assert h.dif_build_id().decode() == _build.source_hash()
+    assert not _build.needs_build()
+    # a newer file time alone does not trigger a rebuild; a stale id does
+    hdr = _build.HEADERS[0]
+    st = hdr.stat()
+    try:
+        os.utime(hdr, (st.st_atime, lib_path.stat().st_mtime + 100))
+        assert not _build.needs_build()
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+    assert _build.lib_build_id(_build.PKG / "does_not_exist.so") is None
 
 
 def test_counter_enum_matches_binding():

@@ -12,19 +12,20 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, str(ROOT / "tools"))
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+# 120 / 200 / 120 cases per fuzzer and suite run (four seeds each)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_fuzz_integrate_extract_query(seed):
     import fuzz_integrate
-    fuzz_integrate.run(cases=10, seed=seed)
+    fuzz_integrate.run(cases=30, seed=seed)
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_fuzz_marching_cubes(seed):
     import fuzz_mc
-    fuzz_mc.run(cases=40, seed=seed)
+    fuzz_mc.run(cases=50, seed=seed)
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_fuzz_cloud_ops(seed):
     import fuzz_cloud
-    fuzz_cloud.run(cases=25, seed=seed)
+    fuzz_cloud.run(cases=30, seed=seed)

@@ -13,7 +13,6 @@ DEV = torch.device("cuda:0")
 
 LATENT_TOL = 2e-5        # |z_gpu - z_ref| : fp32 sums of ~10^3 encoder outputs in a different order
 SDF_TOL = 5e-5           # cube values away from the 0.05 refinement threshold
-VERT_TOL = 2e-4          # voxel units, away from the 1e-5 epsilon branches of sdf_interp
 
 CASES = {
     "seq_small": (syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6,) * 3, (1.6,) * 3, 0.4), syn.Intrinsic().scaled(0.125)),
@@ -348,6 +347,36 @@ def test_get_sdf_gradient_matches_autograd_and_finite_differences(gpu_model, raw
     assert rel_err < 0.05, rel_err
 
 
+@pytest.mark.parametrize("pipe", ["bf16x6", "f32"])
+@pytest.mark.parametrize("name", ["seq_small", "seq_c2"])
+def test_get_sdf_gradient_vs_reference_autograd(name, pipe, gpu_model, gpu_model_f32):
+    """SURVEY 8f-1 pinned on the reference itself: `probe_grad` is what the reference's tracker differentiates
+    (`get_sdf(xyz.requires_grad_())`, residual sdf / std.detach(), `autograd.grad`; tracker.py:184-192, map.py:559-579), recorded on CPU by
+    tests/golden/make_golden.py on the map the golden frames build.  The analytic gradient of the reverse MFMA chain, on both matrix
+    pipes, must agree to 1e-4 of the gradient scale."""
+    scene, cfg, intr = CASES[name]
+    g = np.load(GOLDEN / f"{name}.npz")
+    m = make_map(gpu_model if pipe == "bf16x6" else gpu_model_f32, cfg)
+    for f in range(int(g["n_frames"])):
+        xyz, nrm = frame_inputs(g, name, f)
+        m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+        m.extract_mesh_arrays(4, int(4e6), max_std=0.15, to_host=False)
+    q = torch.from_numpy(g["probe_xyz"]).to(DEV).requires_grad_(True)
+    sdf, std, mask = m.get_sdf(q)
+    res = sdf / std.detach()
+    (gq,) = torch.autograd.grad(res, [q], grad_outputs=torch.ones_like(res))
+    assert np.array_equal(mask.cpu().numpy(), g["probe_mask"])
+    got, want = gq[mask].cpu().numpy(), g["probe_grad"]
+    assert got.shape == want.shape and want.shape[0] > 400
+    scale = np.abs(want).max()
+    d = np.abs(got - want)
+    # a probe within rounding of a ReLU kink may take the other branch on another arithmetic: counted, must stay rare
+    bad = (d > 1e-4 * scale).any(axis=1)
+    print(f"  {name}/{pipe}: grad vs reference autograd: max |diff| {d[~bad].max():.3e} of scale {scale:.3e} ({int(bad.sum())} of {len(bad)} probes on a kink)")
+    assert bad.sum() <= 2
+    assert torch.all(gq[~mask] == 0)
+
+
 @pytest.mark.parametrize("resolution,fast", [(4, False), (2, True), (8, True), (3, True)])
 def test_other_resolutions_and_exact_decode(resolution, fast, gpu_model, oracle_net):
     """extract_mesh(voxel_resolution, fast) away from the shipped default (4, True): same pipeline, checked against the oracle."""
@@ -538,8 +567,14 @@ def test_allocate_block(gpu_model):
     assert torch.equal(m.indexer[taken], idx0[taken])
     assert torch.equal(m.latent_vecs[:n0], z0) and torch.equal(m.voxel_obs_count[:n0], w0)      # bit for bit
     assert float(m.voxel_obs_count[n0:n0 + 5].abs().sum()) == 0.0
-    with pytest.raises(NotImplementedError):
-        m.allocate_block(torch.flip(ids, [0]))
+    # any order, duplicates included (the reference accepts whatever its caller passes, map.py:310-319): slots still go out in ascending id
+    more = torch.nonzero(m.indexer == -1).flatten()[:4]
+    m.allocate_block(torch.cat([torch.flip(more, [0]), more[:2], taken]))
+    assert m.n_occupied == n0 + 9
+    assert torch.equal(m.indexer[more].cpu(), torch.arange(n0 + 5, n0 + 9))
+    assert torch.equal(m.latent_vecs[:n0], z0) and torch.equal(m.voxel_obs_count[:n0], w0)
+    m.allocate_block(torch.zeros((0,), dtype=torch.long))
+    assert m.n_occupied == n0 + 9
 
 
 def test_latent_optimisation_vs_reference_and_oracle(gpu_model, oracle_net):
@@ -578,8 +613,14 @@ def test_latent_optimisation_vs_reference_and_oracle(gpu_model, oracle_net):
         assert d_or.max() < 1e-3 and d_or[opt_now].mean() < 5e-5
         assert d_ref[~opt_now].max() < LATENT_TOL                               # voxels the optimiser did not touch: the ordinary fusion bar
         if m.last_counters["opt_rows"]:
-            assert losses[-1] < losses[0]
-            assert abs(losses[0] - om.last_stats["optim_losses"][0] + args.code_reg_lambda * 0) < 0.2 * abs(losses[0]) + 0.05
+            # the likelihood loss before EVERY Adam step against what the reference's own run evaluated (recorded from its
+            # CombinedChunkLoss, tests/golden/make_golden.py), to 1e-3 relative; and the oracle's
+            want = g[f"f{f}_loss_ll"]
+            assert want.shape[0] == args.optim_n_iters
+            rel = np.abs(losses - want) / np.abs(want)
+            rel_or = np.abs(np.asarray(om.last_stats["optim_losses"])[:args.optim_n_iters] - want) / np.abs(want)
+            print(f"           loss vs reference: rel {rel.max():.2e} (oracle {rel_or.max():.2e})")
+            assert rel.max() < 1e-3 and rel_or.max() < 1e-3
         m.extract_mesh_arrays(4, int(4e6), max_std=0.15)                        # the golden sequence meshes (clears the dirty set) every frame
         om.extract_prepare(4)
     assert int(m.voxel_optimized.sum()) > 50

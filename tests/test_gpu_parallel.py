@@ -49,29 +49,36 @@ def test_export_merge_records_vs_oracle(gpu_model, oracle_net):
 
 TILING_CASES = {
     # 16^3 grid, quarter-resolution frames, large yaw: allocation, the 600-count gate and re-meshing all happen across the cut
-    "room16_2slabs": (syn.default_room(), syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4), 0.25, 2, 4, 15.0),
-    # BASELINE config C5: ONE 1280x960 stream (1.23 M points per frame) on the C3 grid (128^3, 0.05 m), cut into 2 and into 8 x-slabs
-    "c5_1280x960_2slabs": (*syn.config_c3(), 2.0, 2, 2, 0.5),
-    "c5_1280x960_8slabs": (*syn.config_c3(), 2.0, 8, 2, 0.5),
+    "room16_2slabs": (syn.default_room(), syn.MapConfig((-3.2,) * 3, (3.2,) * 3, 0.4), 0.25, 2, 4, 15.0, "full"),
+    # BASELINE config C5: ONE 1280x960 stream (1.23 M points per frame) on the C3 grid (128^3, 0.05 m), cut into 2 and into 8 x-slabs:
+    # whole-layer messages every frame ...
+    "c5_1280x960_2slabs": (*syn.config_c3(), 2.0, 2, 2, 0.5, "full"),
+    "c5_1280x960_8slabs": (*syn.config_c3(), 2.0, 8, 2, 0.5, "full"),
+    # ... and the bounded delta protocol (frames 0-1 whole layers, then only what changed, at most 4,096 records per message)
+    "c5_1280x960_2slabs_delta": (*syn.config_c3(), 2.0, 2, 6, 0.5, "delta"),
+    "c5_1280x960_8slabs_delta": (*syn.config_c3(), 2.0, 8, 6, 0.5, "delta"),
 }
 
 
 @pytest.mark.parametrize("case", list(TILING_CASES))
 def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
-    """C5: x-slabs with halo exchange (emulated in one process, same kernels and record path as the RCCL version) reproduce
-    the single-map state of every owned voxel BIT FOR BIT, and the union of the slab meshes equals the single-map mesh."""
+    """C5: x-slabs with halo exchange (emulated in one process: `parallel.HaloExchange` phase by phase over all slabs, the same kernels,
+    message kinds and record path as the RCCL version, messages handed over by device copies) reproduce the single-map state of every
+    owned voxel BIT FOR BIT, and the union of the slab meshes equals the single-map mesh."""
     from di_fusion_amd import parallel
     from di_fusion_amd.system.map import DenseIndexedMap
-    scene, cfg, scale, world, n_frames, deg = TILING_CASES[case]
+    scene, cfg, scale, world, n_frames, deg, mode = TILING_CASES[case]
     intr = syn.Intrinsic().scaled(scale)
     full = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=2048)
     nx = full.n_xyz[0]
-    slabs = []
+    slabs, states = [], []
     for r in range(world):
         m = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=2048)
         m.set_ownership(*parallel.slab_range(nx, r, world), halo=parallel.HALO)
         slabs.append(m)
+        states.append({})
     plane = full.n_xyz[1] * full.n_xyz[2]
+    delta_messages = delta_bytes = full_bytes = 0
     for f in range(n_frames):
         xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg)
         xyz, nrm = xyz.to(DEV), nrm.to(DEV)
@@ -79,15 +86,22 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
         full.integrate_keyframe(xyz, nrm)
         for m in slabs:
             m.integrate_keyframe(xyz, nrm)
-        # halo exchange (what parallel.exchange_halo does over RCCL)
-        # the same fixed-size messages with a device-side record count, only handed over inside the process
-        lefts = [m.export_halo(m._ownership[0], m._ownership[0] + parallel.HALO) for m in slabs]
-        rights = [m.export_halo(m._ownership[1] - parallel.HALO, m._ownership[1]) for m in slabs]
-        for r, m in enumerate(slabs):
-            if r > 0:
-                m.merge_halo(rights[r - 1])
-            if r < world - 1:
-                m.merge_halo(lefts[r + 1])
+        # halo exchange: every rank exports, the messages change hands (what RCCL send/recv does), every rank merges
+        xs = [parallel.HaloExchange(m, r, world, states[r], mode) for r, m in enumerate(slabs)]
+        for x in xs:
+            x.export()
+        for r, x in enumerate(xs):
+            for name, peer, _, _ in x.sides:
+                other = "right" if name == "left" else "left"
+                assert x.n_in[name] == xs[peer].n_out[other]          # both ends chose the same message kind without talking
+                x.inp[name][:x.n_in[name]].copy_(xs[peer].out[other][:x.n_in[name]])
+                if x.kind_in[name] == "delta":
+                    delta_messages += 1
+                    delta_bytes += x.n_in[name] * 128
+                else:
+                    full_bytes += x.n_in[name] * 128
+        for x in xs:
+            x.merge()
         # ---- state of owned voxels ----
         nF = full.n_occupied
         posF = full.latent_vecs_pos[:nF].cpu().numpy()
@@ -106,6 +120,15 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
             posS = m.latent_vecs_pos[:nS].cpu().numpy()
             assert ((posS >= lo) & (posS < hi)).sum() == own.sum()
             covered += own.sum()
+            # the halo layers mirror their owners exactly: same voxels, same (w, z) bits
+            for side, nb in (("left", r - 1), ("right", r + 1)):
+                if not 0 <= nb < world:
+                    continue
+                h_lo, h_hi = (m._ownership[0] - parallel.HALO, m._ownership[0]) if side == "left" else (m._ownership[1], m._ownership[1] + parallel.HALO)
+                inh = (posF >= h_lo * plane) & (posF < h_hi * plane)
+                hidx = m.indexer.cpu().numpy()[posF[inh]]
+                assert (hidx >= 0).all(), f"frame {f} rank {r}: halo voxel missing"
+                assert np.array_equal(m._obs.cpu().numpy()[hidx], wF[inh]) and np.array_equal(m._latent.cpu().numpy()[hidx], zF[inh])
         assert covered == nF
         # ---- meshes ----
         vF, idF, _ = full.extract_mesh_arrays(4, int(4e6), max_std=0.15)
@@ -123,6 +146,34 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
         kF = np.lexsort(tuple(tF.reshape(len(tF), -1).T[::-1]) + (iF,))
         assert np.array_equal(iS[kS], iF[kF])
         assert np.array_equal(tS[kS], tF[kF])                  # bit-identical vertices
+    if mode == "delta":
+        assert delta_messages > 0, "the stream never reached the bounded delta messages"
+        print(f"{case}: {delta_messages} delta messages ({delta_bytes} B), whole-layer messages {full_bytes} B")
+
+
+def test_delta_halo_overflow_is_reported(gpu_model):
+    """A delta message that cannot hold the frame's changes is reported, not silently truncated: the device flags it (DIF_C_OVERFLOW = 8,
+    raised by the next counter read) and the header carries pending > records."""
+    from di_fusion_amd import parallel
+    from di_fusion_amd.system.map import DenseIndexedMap
+    scene, cfg = syn.config_c3()
+    m = DenseIndexedMap(gpu_model, cfg.namespace(), 29, DEV, initial_capacity=1 << 16)
+    m.set_ownership(*parallel.slab_range(m.n_xyz[0], 3, 8), halo=parallel.HALO)
+    xyz, nrm = syn.frame_points(scene, 0, syn.Intrinsic(), deg_per_frame=0.5)
+    m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV))               # the first frame of a stream: thousands of new boundary voxels
+    rows = 64                                                     # a message far too small for them
+    left = torch.zeros((1 + rows, 32), dtype=torch.int32, device=DEV)
+    right = torch.zeros((1 + rows, 32), dtype=torch.int32, device=DEV)
+    note = torch.zeros((8,), dtype=torch.int32).pin_memory()
+    m.export_halo_delta(left, right, note)
+    torch.cuda.synchronize()
+    hl, hr = left[0, :3].cpu().numpy(), right[0, :3].cpu().numpy()
+    assert np.array_equal(note.numpy()[:3], hl) and np.array_equal(note.numpy()[4:7], hr)
+    assert hl[2] == 1 and hr[2] == 1 and hl[0] <= rows and hr[0] <= rows
+    assert max(hl[1], hr[1]) > rows, (hl, hr)
+    with pytest.raises(RuntimeError, match="delta halo message"):
+        m.n_occupied
+    m.n_occupied                                                  # reported once
 
 
 def _tiled_worker(rank, world, port, q):
