@@ -188,7 +188,7 @@ def frame_runner(stream, a, d2h):
         nonlocal lib, skip_until
         if i < skip_until:                                  # part of a batch that is already enqueued
             return None
-        if stream.tiling is not None or i < 2 or not (a.graph or a.direct):
+        if i < 2 or not (a.graph or a.direct) or (stream.tiling is not None and not a.direct):
             return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
         sampled = (i % a.sample_every) == 0
         F = a.batch
@@ -390,8 +390,8 @@ def main():
     model = net_util.networks_from_arrays(net_util.load_weights_npz(), x6=(None if a.mlp_pipe is None else a.mlp_pipe == "bf16x6"))
     pipe = "bf16x6" if model.packed.x6 else "f32"
     n_frames = a.warmup + a.steps
-    if tiled and world > 1:
-        a.graph = 0                         # the halo exchange sits between the kernels of a frame: eager, host one frame ahead
+    if tiled:
+        a.graph = a.batch = 0               # the halo exchange sits between the kernels of a frame: direct launches, host one frame ahead
     a.direct = bool(a.pipeline)
     a.timed_from = None
     a.n_frames = n_frames
@@ -436,7 +436,7 @@ def main():
     lib.dif_profile_enable(1)               # (fills the library's event pool outside the clock)
     lib.dif_profile_enable(0)
     a.timed_from = a.warmup
-    if not (a.graph or a.direct) or stream.tiling is not None:
+    if not (a.graph or a.direct):
         lib.dif_profile_enable(1)           # (otherwise the runner switches it on for the sampled frames only)
     gc.collect()
     gc.disable()            # a generation-2 collection in the middle of a 70 ms timed region shows up as a 20 % outlier
@@ -468,7 +468,7 @@ def main():
     if rank == 0:
         st = stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
-        sampled_only = (a.graph or a.direct) and stream.tiling is None
+        sampled_only = bool(a.graph or a.direct)
         timed_idx = [j for j in range(a.steps) if not (sampled_only and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
         # the event records come in launch order, one k_encode per event-timed frame: cut the list into frames there
         per_frame = []

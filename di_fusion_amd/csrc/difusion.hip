@@ -99,6 +99,9 @@ inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096)
     return (int)b;
 }
 
+#ifndef GRAD_X6_PF
+#define GRAD_X6_PF 3          /* weight steps (3 KB each) a wave keeps in flight in the gradient kernels (3, 6 and 10 measured the same) */
+#endif
 #include "kernels_points.hip.h"
 #include "kernels_integrate.hip.h"
 #include "kernels_extract.hip.h"
@@ -528,17 +531,27 @@ int dif_optimize_latents(const dif_map_t* map, const dif_weights_t* w, const flo
     const int small = grid_for(map->capacity * 32, DIF_BLOCK, 512);
     hipLaunchKernelGGL(k_optim_init, dim3(small), dim3(DIF_BLOCK), 0, s, (const int*)ws.uniq_slot, (const float*)map->latent_vecs, ws.z, ws.m, ws.v, ws.grad, (const int*)C);
     DIF_CHECK_LAUNCH();
-    const size_t lds_bytes = (size_t)DEC_LDS_FLOATS * 4;
+    // the MLP tiles on the bf16 matrix pipe when the sliced blobs are there (as every other decoder launch), else on the f32-input MFMA
+    const bool x6 = w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES && w->dec_x6u_packed && w->dec_x6u_packed_bytes == X6U_BYTES &&
+                    w->dec_x6b_packed && w->dec_x6b_packed_bytes == X6B_BYTES;
+    const size_t lds_bytes = x6 ? (size_t)X6_LDS_BYTES : (size_t)DEC_LDS_FLOATS * 4;
     static bool attr_set[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)k_optim_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_optim_grad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)DEC_LDS_FLOATS * 4)) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_optim_grad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
         attr_set[dev] = true;
     }
     for (int it = 1; it <= n_iters; ++it) {
-        hipLaunchKernelGGL(k_optim_grad, dim3(num_cus()), dim3(256), lds_bytes, s, w->dec_packed, w->dec_bwd_packed, (const int*)ws.row_slot,
-                           (const float*)ws.row_xyz, (const float*)ws.row_sdf, (const int*)ws.slot_u, (const float*)ws.z, (unsigned long long*)ws.grad,
-                           loss_out ? ws.loss + (it - 1 < 64 ? it - 1 : 63) : nullptr, (const int*)C);
+        float* const loss_it = loss_out ? ws.loss + (it - 1 < 64 ? it - 1 : 63) : nullptr;
+        if (x6)
+            hipLaunchKernelGGL(k_optim_grad<true>, dim3(num_cus()), dim3(256), lds_bytes, s, (const float*)w->dec_x6_packed, (const float*)w->dec_x6b_packed,
+                               (const float*)w->dec_x6u_packed, (const int*)ws.row_slot, (const float*)ws.row_xyz, (const float*)ws.row_sdf, (const int*)ws.slot_u,
+                               (const float*)ws.z, (unsigned long long*)ws.grad, loss_it, (const int*)C);
+        else
+            hipLaunchKernelGGL(k_optim_grad<false>, dim3(num_cus()), dim3(256), lds_bytes, s, w->dec_packed, w->dec_bwd_packed, (const float*)nullptr,
+                               (const int*)ws.row_slot, (const float*)ws.row_xyz, (const float*)ws.row_sdf, (const int*)ws.slot_u, (const float*)ws.z,
+                               (unsigned long long*)ws.grad, loss_it, (const int*)C);
         hipLaunchKernelGGL(k_optim_adam, dim3(small), dim3(DIF_BLOCK), 0, s, ws.z, ws.m, ws.v, ws.grad, (const int*)C, it, lr, code_reg_lambda);
         DIF_CHECK_LAUNCH();
     }
@@ -550,9 +563,6 @@ int dif_optimize_latents(const dif_map_t* map, const dif_weights_t* w, const flo
 }
 
 // ---- decoder launches ------------------------------------------------------------------------------------------
-#ifndef GRAD_X6_PF
-#define GRAD_X6_PF 3          /* weight steps (3 KB each) a wave keeps in flight in the gradient kernel (3, 6 and 10 measured the same) */
-#endif
 static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t tiles_upper, hipStream_t s) {
     if (!w || !w->dec_packed || w->dec_packed_floats != DEC_FLOATS) return DIF_EINVAL;
     const bool grad = A.out_grad != nullptr;
@@ -948,20 +958,46 @@ int dif_mesh_cache_reindex(const dif_map_t* map, const dif_extract_buffers_t* bu
 }
 
 // ---- get_sdf ---------------------------------------------------------------------------------------------------
+int dif_query_select(const dif_map_t* map, const float* xyz, int64_t N, uint8_t* mask, int32_t* sel, int32_t* scratch, int32_t* count_out,
+                     int32_t seq, void* stream_) {
+    if (!map || N < 0 || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    if (N == 0) {
+        if (count_out) return DIF_EINVAL;            // (nothing would ever write the sequence number)
+        return hipMemsetAsync(map->counters + DIF_C_QUERY_M, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+    }
+    if (!xyz || !mask || !sel || !scratch) return DIF_EINVAL;
+    QueryFunctor f{geo_of(map), map->ignore_count_th, xyz, map->indexer, map->voxel_obs_count, mask, sel, map->counters, count_out, seq};
+    return launch_scan(f, nullptr, (int)N, N, scratch, s);
+}
+
+int dif_query_decode(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, const int32_t* sel, float* sdf, float* std_out,
+                     float* grad, void* stream_) {
+    if (!map || !w || N < 0 || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    if (N == 0) return DIF_OK;
+    if (!xyz || !sel || !sdf || !std_out) return DIF_EINVAL;
+    DecodeArgs A = {};
+    A.mode = 3; A.n_ptr = map->counters + DIF_C_QUERY_M; A.latent = map->latent_vecs; A.list = sel; A.xyz = xyz; A.indexer = map->indexer;
+    A.geo = geo_of(map); A.out_sdf = sdf; A.out_std = std_out; A.sign = 1.0f; A.lat.res = 1;
+    A.out_grad = grad; A.grad_scale = 1.0f / map->voxel_size;
+    return launch_decode(A, w, (N + 31) / 32, (hipStream_t)stream_);
+}
+
 int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, uint8_t* mask, int32_t* sel, float* sdf,
                   float* std_out, float* grad, int32_t* scratch, void* stream_) {
     if (!map || !w || N < 0 || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
-    hipStream_t s = (hipStream_t)stream_;
-    if (N == 0) return hipMemsetAsync(map->counters + DIF_C_QUERY_M, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
-    if (!xyz || !mask || !sel || !sdf || !std_out || !scratch) return DIF_EINVAL;
-    Geo g = geo_of(map);
-    QueryFunctor f{g, map->ignore_count_th, xyz, map->indexer, map->voxel_obs_count, mask, sel, map->counters};
-    if (launch_scan(f, nullptr, (int)N, N, scratch, s) != DIF_OK) return DIF_ELAUNCH;
-    DecodeArgs A = {};
-    A.mode = 3; A.n_ptr = map->counters + DIF_C_QUERY_M; A.latent = map->latent_vecs; A.list = sel; A.xyz = xyz; A.indexer = map->indexer;
-    A.geo = g; A.out_sdf = sdf; A.out_std = std_out; A.sign = 1.0f; A.lat.res = 1;
-    A.out_grad = grad; A.grad_scale = 1.0f / map->voxel_size;
-    return launch_decode(A, w, (N + 31) / 32, s);
+    if (N > 0 && (!sdf || !std_out)) return DIF_EINVAL;
+    int rc = dif_query_select(map, xyz, N, mask, sel, scratch, nullptr, 0, stream_);
+    if (rc != DIF_OK || N == 0) return rc;
+    return dif_query_decode(map, w, xyz, N, sel, sdf, std_out, grad, stream_);
+}
+
+int dif_query_grad_scatter(const float* grad, const float* g_sdf, const int32_t* sel, int64_t M, float* out, void* stream) {
+    if (M < 0 || (M > 0 && (!grad || !g_sdf || !sel || !out))) return DIF_EINVAL;
+    if (M == 0) return DIF_OK;
+    hipLaunchKernelGGL(k_query_grad_scatter, dim3(grid_for(M * 3, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, grad, g_sdf, sel, M, out);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
 }
 
 // ---- multi-GPU merge -------------------------------------------------------------------------------------------

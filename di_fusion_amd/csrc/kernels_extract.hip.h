@@ -342,18 +342,22 @@ __global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArg
 // Refine rows (mode 1 with the lattice pass's fold table) on the bf16 matrix pipe; wblob = packing.py:pack_decoder_x6.
 __global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_weights(lds, wblob, X6_LDS_BYTES / 4);
-    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     const int res3 = A.lat.res * A.lat.res * A.lat.res, r = A.lat.res;
     const int64_t n_rows = A.n_ptr ? (int64_t)(*A.n_ptr) : A.n_static;
     const int64_t n_tiles = (n_rows + 31) / 32;
+    // the first tile's list entries are requested before the weights are staged (one dependent hop off the critical path)
+    int e_next = ((int64_t)wave * 32 + col < n_rows) ? A.list[(int64_t)wave * 32 + col] : 0;
+    __builtin_amdgcn_sched_barrier(0);
+    stage_weights(lds, wblob, X6_LDS_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
     for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
         const int64_t row = tile * 32 + col;
         const bool live = row < n_rows;
-        const int e = live ? A.list[row] : 0;
+        const int e = e_next;
+        e_next = (row + (int64_t)nwaves * 32 < n_rows) ? A.list[row + (int64_t)nwaves * 32] : 0;
         const int b = e / res3, s = e - b * res3;
         const float px = A.lat.coord(s / (r * r)), py = A.lat.coord((s / r) % r), pz = A.lat.coord(s % r);
         float sdf, sd;

@@ -288,30 +288,24 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
          int* __restrict__ upd_list, int* __restrict__ counters, const uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     EN_STAMP(0);
-    stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
-    EN_STAMP(1);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     // tile t goes to wave (t / #blocks) of block (t % #blocks): a partly filled launch spreads over all CUs and SIMDs first
     const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     const int M = counters[DIF_C_M];
     const int n_tiles = (M + 31) >> 5;
-    for (int tile = wave; tile < n_tiles; tile += nwaves) {
+    // a tile's inputs: its 32 list entries and, through them, the points' coordinates and normals (two dependent gathers).  They are
+    // requested one tile ahead: the first tile's before the weights are staged into LDS, the next tile's before the current tile's MFMA
+    // chain — neither wait is on the critical path any more
+    struct TileIn { uint2 e; float x0, x1, x2; };
+    auto gather = [&](int tile) __attribute__((always_inline)) {
+        TileIn t;
+        t.e = make_uint2(DIF_INVALID_KEY, 0u);
+        t.x0 = t.x1 = t.x2 = 0.f;
         const int row = tile * 32 + col;
-        const bool live = row < M;
-        uint2 e = make_uint2(DIF_INVALID_KEY, 0u);
-        if (live) e = pair_list[row];
-        const uint32_t key = e.x;
-        // runs of equal slots (both halves of the wave hold the same 32 rows and compute the same run structure)
-        const uint32_t key_prev = (uint32_t)__shfl_up((int)key, 1), key_next = (uint32_t)__shfl_down((int)key, 1);
-        const bool run_head = (col == 0) || (key_prev != key);
-        const bool run_tail = (col == 31) || (key_next != key);
-        const uint32_t heads32 = (uint32_t)(__ballot(run_head) >> (half * 32));
-        const int my_head = 31 - __clz((int)(heads32 & ((2u << col) - 1u)));      // column where this lane's run starts
-        const int rec_id = tile * 32 + __popc(heads32 & ((2u << col) - 1u)) - 1;  // record of this lane's run
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-        if (live) {
-            const uint32_t v = e.y;
+        if (tile < n_tiles && row < M) {
+            t.e = pair_list[row];
+            const uint32_t v = t.e.y;
             int o = 0;
 #pragma unroll
             for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
@@ -325,10 +319,31 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
             float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
             float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
             float nxv = normal[i * 3 + 0], nyv = normal[i * 3 + 1], nzv = normal[i * 3 + 2];
-            x0 = half ? ry : rx;
-            x1 = half ? nxv : rz;
-            x2 = half ? nzv : nyv;
+            t.x0 = half ? ry : rx;
+            t.x1 = half ? nxv : rz;
+            t.x2 = half ? nzv : nyv;
         }
+        return t;
+    };
+    TileIn nxt = gather(wave);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
+    EN_STAMP(1);
+    for (int tile = wave; tile < n_tiles; tile += nwaves) {
+        const TileIn cur = nxt;
+        nxt = gather(tile + nwaves);
+        const int row = tile * 32 + col;
+        const bool live = row < M;
+        const uint2 e = cur.e;
+        const uint32_t key = e.x;
+        // runs of equal slots (both halves of the wave hold the same 32 rows and compute the same run structure)
+        const uint32_t key_prev = (uint32_t)__shfl_up((int)key, 1), key_next = (uint32_t)__shfl_down((int)key, 1);
+        const bool run_head = (col == 0) || (key_prev != key);
+        const bool run_tail = (col == 31) || (key_next != key);
+        const uint32_t heads32 = (uint32_t)(__ballot(run_head) >> (half * 32));
+        const int my_head = 31 - __clz((int)(heads32 & ((2u << col) - 1u)));      // column where this lane's run starts
+        const int rec_id = tile * 32 + __popc(heads32 & ((2u << col) - 1u)) - 1;  // record of this lane's run
+        const float x0 = cur.x0, x1 = cur.x1, x2 = cur.x2;
         // enter the run in its slot's directory.  Asked after the gathers above have been consumed and before the MFMA chain, answered
         // after it: the round trip hides behind ~11 us of matrix work.
         EN_STAMP(2);

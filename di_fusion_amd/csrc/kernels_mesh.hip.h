@@ -583,6 +583,8 @@ struct QueryFunctor {
     uint8_t* mask;
     int32_t* sel;
     int* counters;
+    int32_t* count_out;          // optional (pinned host memory allowed): [0] = M, [1] = the caller's sequence number — the host slices its outputs
+    int32_t seq;                 //   as soon as THIS kernel is done, while the decode of the M rows is still running
     __device__ int count(int i) const {
         float xn, yn, zn; int ix, iy, iz;
         bool ok = voxel_of(g, xyz[(int64_t)i * 3 + 0], xyz[(int64_t)i * 3 + 1], xyz[(int64_t)i * 3 + 2], xn, yn, zn, ix, iy, iz);
@@ -594,8 +596,20 @@ struct QueryFunctor {
         return ok ? 1 : 0;
     }
     __device__ void emit(int i, int offset) const { sel[offset] = i; }
-    __device__ void finish(int total) const { counters[DIF_C_QUERY_M] = total; }
+    __device__ void finish(int total) const {
+        counters[DIF_C_QUERY_M] = total;
+        if (count_out) { count_out[0] = total; count_out[1] = seq; }
+    }
 };
+
+// d loss / d xyz of get_sdf for the caller's autograd: out[sel[m]] = grad[m] * g_sdf[m] (out zeroed by the caller; rows of invalid points stay 0)
+__global__ void __launch_bounds__(DIF_BLOCK) k_query_grad_scatter(const float* __restrict__ grad, const float* __restrict__ g_sdf, const int32_t* __restrict__ sel,
+                                                                int64_t M, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M * 3; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / 3;
+        out[(int64_t)sel[m] * 3 + (e - m * 3)] = grad[e] * g_sdf[m];
+    }
+}
 
 // =================================================================================================================
 // multi-GPU merge helpers

@@ -89,13 +89,17 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_optim_init(const int* __restrict_
 
 // One Adam iteration, part 1: rows through the decoder forward + reverse chain; d loss / d latent summed per voxel.
 // 256 threads = one wave per SIMD with the full register budget (as k_decode<GRAD>).
-__global__ void __launch_bounds__(256, 1) k_optim_grad(const float* __restrict__ wblob, const float* __restrict__ wbwd_blob, const int* __restrict__ row_slot,
+// X6: the tile runs on the bf16 matrix pipe (decoder_tile_nll_grad_x6: wblob = pack_decoder_x6, wbwd_blob = pack_decoder_x6_backward, wu_blob =
+// pack_decoder_x6u); otherwise on the f32-input MFMA (wblob = pack_decoder, wbwd_blob = pack_decoder_backward).
+template <bool X6>
+__global__ void __launch_bounds__(256, 1) k_optim_grad(const float* __restrict__ wblob, const float* __restrict__ wbwd_blob, const float* __restrict__ wu_blob, const int* __restrict__ row_slot,
                                                      const float* __restrict__ row_xyz, const float* __restrict__ row_sdf, const int* __restrict__ slot_u,
                                                      const float* __restrict__ z, unsigned long long* __restrict__ grad, float* __restrict__ loss_sum,
                                                      const int* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_weights(lds, wblob, DEC_LDS_FLOATS);
-    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS), wbwd = make_rsrc(wbwd_blob, DECB_FLOATS);
+    stage_weights(lds, wblob, X6 ? X6_LDS_BYTES / 4 : DEC_LDS_FLOATS);
+    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6 ? X6_BYTES / 4 : DEC_FLOATS), wbwd = make_rsrc(wbwd_blob, X6 ? X6B_BYTES / 4 : DECB_FLOATS);
+    const __amdgpu_buffer_rsrc_t wun = make_rsrc(X6 ? wu_blob : wblob, X6 ? X6U_BYTES / 4 : 4);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     const int n_rows = counters[DIF_C_OPT_ROWS];
@@ -116,7 +120,8 @@ __global__ void __launch_bounds__(256, 1) k_optim_grad(const float* __restrict__
         }
         float sdf, sd, loss;
         f16v gx;
-        decoder_tile_nll_grad(lds, wfwd, wbwd, xin, lane, live ? row_sdf[row] : 0.0f, inv_n, sdf, sd, loss, gx);
+        if constexpr (X6) decoder_tile_nll_grad_x6<GRAD_X6_PF>(lds, wfwd, wun, wbwd, xin, lane, live ? row_sdf[row] : 0.0f, inv_n, sdf, sd, loss, gx);
+        else decoder_tile_nll_grad(lds, wfwd, wbwd, xin, lane, live ? row_sdf[row] : 0.0f, inv_n, sdf, sd, loss, gx);
         // per-voxel sums: segmented scan over runs of equal voxels, the last lane of a run adds the run's sum (exact fixed point, so the
         // result does not depend on the order the atomics land in)
         const int u_prev = __shfl_up(u, 1), u_next = __shfl_down(u, 1);

@@ -882,6 +882,106 @@ __device__ __forceinline__ void decoder_tile_grad_x6(const float* __restrict__ W
     gz = dt * gx1[0][15];
 }
 
+// The optimiser's tile (decoder_tile_nll_grad below) on the bf16 matrix pipe: forward and reverse chain as decoder_tile_grad_x6, the
+// upstream gradient a * w_sdf + b * w_std formed after both heads are known.  Returns d loss / d x0 as a D fragment.
+template <int PF>
+__device__ __forceinline__ void decoder_tile_nll_grad_x6(const float* __restrict__ W /* LDS */, __amdgpu_buffer_rsrc_t Wg, __amdgpu_buffer_rsrc_t Wu,
+                                                         __amdgpu_buffer_rsrc_t Wb, const f16v& xin, int lane, float gt, float inv_n,
+                                                         float& sdf, float& stdv, float& loss, f16v& gx) {
+    const int half = lane >> 5;
+    const char* Wc = reinterpret_cast<const char*>(W);
+    int uoff = X6U_L0, goff = X6_L2 + 36864, boff = 0;       // opaque per tile (see decoder_tile)
+    asm volatile("" : "+s"(uoff), "+s"(goff), "+s"(boff) : : "memory");
+    unsigned m0[4], m1[4], m2[3], m3[4];
+    f16v hx[1];
+    hx[0] = xin;
+    f16v h0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h0[mb] = load_bias16(W + X6_B0 + mb * 32, half);
+    layer_x6<0, 1, 4, PF>(BufX6{Wu, uoff}, hx, h0, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h0[mb] = relu16_mask(h0[mb], m0[mb]);
+    f16v h1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h1[mb] = load_bias16(W + X6_B1 + mb * 32, half);
+    layer_x6<0, 4, 4, X6_PF_LDS>(LdsX6{reinterpret_cast<const u4v*>(Wc + X6_L1)}, h0, h1, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h1[mb] = relu16_mask(h1[mb], m1[mb]);
+    f16v h2[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) h2[mb] = load_bias16(W + X6_B2 + mb * 32, half);
+    layer_x6<0, 2, 3, X6_PF_LDS>(LdsX6{reinterpret_cast<const u4v*>(Wc + X6_L2)}, h1, h2, lane);
+    layer_x6<2, 4, 3, PF>(BufX6{Wg, goff}, h1, h2, lane);
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) h2[mb] = relu16_mask(h2[mb], m2[mb]);
+    f16v h3[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) h3[mb] = load_bias16(W + X6_B3 + mb * 32, half);
+    layer_x6<0, 3, 4, PF>(BufX6{Wg, goff + 36864}, h2, h3, lane);
+    layer_x6<0, 1, 4, PF>(BufX6{Wu, uoff + X6U_L3X}, hx, h3, lane);
+    float ps = 0.0f, pu = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const f16v acc = relu16_mask(h3[mb], m3[mb]);
+        const f16v ws = load_bias16(W + X6_HW + mb * 32, half);
+        const f16v wu = load_bias16(W + X6_HU + mb * 32, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ps = fmaf(acc[r], ws[r], ps);
+            pu = fmaf(acc[r], wu[r], pu);
+        }
+    }
+    ps += __shfl_xor(ps, 32);
+    pu += __shfl_xor(pu, 32);
+    ps += W[X6_HB + 0];
+    pu += W[X6_HB + 1];
+    sdf = tanhf(ps);
+    const float sp = (pu > 20.0f) ? pu : log1pf(expf(pu));
+    stdv = 0.05f + 0.5f * sp;
+    // ---- loss and its derivative w.r.t. the two pre-activations (as decoder_tile_nll_grad) ----
+    const float g = fminf(fmaxf(gt, -0.2f), 0.2f), mu = fminf(fmaxf(sdf, -0.2f), 0.2f);
+    const float diff = g - mu, var = stdv * stdv;
+    loss = (logf(stdv) + 0.918938533204672742f + diff * diff / (2.0f * var)) * inv_n;          // 0.5 * log(2 pi)
+    const float d_mu = (sdf >= -0.2f && sdf <= 0.2f) ? -diff / var : 0.0f;
+    const float d_sigma = 1.0f / stdv - diff * diff / (var * stdv);
+    const float a = inv_n * d_mu * (1.0f - sdf * sdf);
+    const float b = inv_n * d_sigma * 0.5f * ((pu > 20.0f) ? 1.0f : 1.0f / (1.0f + expf(-pu)));
+    // ---- reverse chain ----
+    f16v g3[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const f16v ws = load_bias16(W + X6_HW + mb * 32, half);
+        const f16v wu = load_bias16(W + X6_HU + mb * 32, half);
+        f16v t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = a * ws[r] + b * wu[r];
+        g3[mb] = apply_mask16(t, m3[mb]);
+    }
+    f16v t3[4];                         // W3^T g3: rows h2 (3 blocks) | x0 (the skip block)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) t3[mb] = zero16();
+    layer_x6<0, 4, 4, PF>(BufX6{Wb, boff + X6B_T3}, g3, t3, lane);
+    f16v g2[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) g2[mb] = apply_mask16(t3[mb], m2[mb]);
+    f16v g1[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) g1[mb] = zero16();
+    layer_x6<0, 3, 4, PF>(BufX6{Wb, boff + X6B_T2}, g2, g1, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) g1[mb] = apply_mask16(g1[mb], m1[mb]);
+    f16v g0[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) g0[mb] = zero16();
+    layer_x6<0, 4, 4, PF>(BufX6{Wb, boff + X6B_T1}, g1, g0, lane);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) g0[mb] = apply_mask16(g0[mb], m0[mb]);
+    f16v gx1[1];
+    gx1[0] = t3[3];
+    layer_x6<0, 4, 1, PF>(BufX6{Wb, boff + X6B_T0}, g0, gx1, lane);
+    gx = gx1[0];
+}
+
 // ---- decoder with the gradient of the optimiser's loss w.r.t. ALL 32 inputs (latent optimisation, reference map.py:80-113) -------------
 // Loss per row (map.py:87-96): -log N(clamp(gt, +-0.2); clamp(sdf, +-0.2), std) * inv_n.  Forward as decoder_tile_grad; the upstream
 // gradient entering lin3's output is  a * w_sdf + b * w_std  with  a = dL/d(sdf pre-activation), b = dL/d(std pre-activation), both

@@ -136,6 +136,11 @@ class HaloExchange:
         self.on_gpu = dev is not None and torch.device(dev).type == "cuda"
         self.dev = dev if self.on_gpu else "cpu"
         self.rows = {"full": self.rows_full, "delta": DELTA_ROWS}
+        self.reserved = False               # the caller has made room in the map for the voxels the incoming messages may allocate
+
+    def max_new_voxels(self) -> int:
+        """Upper bound of the voxels one exchange can allocate in this map (what `reserved` stands for)."""
+        return len(self.sides) * self.rows_full
 
     def export(self):
         """Decide the kind of every message of this frame and enqueue the export kernels.  Afterwards: `out[name]` / `inp[name]` are the
@@ -220,7 +225,7 @@ class HaloExchange:
         if self.sides and self.on_gpu:
             inp, rows = self.inp, self.rows
             m.merge_halo2(inp.get("left"), inp.get("right"), rows[self.kind_in["left"]] if "left" in inp else None,
-                          rows[self.kind_in["right"]] if "right" in inp else None, self.note_in)
+                          rows[self.kind_in["right"]] if "right" in inp else None, self.note_in, reserved=self.reserved)
             ev = torch.cuda.Event()
             ev.record()
             st["hist"][f] = dict(event=ev, out=self.note_out.numpy(), **{"in": self.note_in.numpy()}, kinds=(dict(self.kind_out), dict(self.kind_in)),
@@ -232,7 +237,8 @@ class HaloExchange:
         st["frame"] = f + 1
 
 
-def exchange_halo(m, rank: int, world: int, group=None, buffers: Optional[dict] = None, mode: str = "delta", loopback: bool = False):
+def exchange_halo(m, rank: int, world: int, group=None, buffers: Optional[dict] = None, mode: str = "delta", loopback: bool = False,
+                  reserved: bool = False):
     """Refresh the halo layers of `m` (a map with `set_ownership`) from the neighbouring slabs' owners: one send and one receive per
     neighbour (`ncclSend` / `ncclRecv` grouped by `batch_isend_irecv`; ring neighbours are directly xGMI-linked), nothing else.  Message
     sizes are known to the host (see above) and the record counts travel in the messages, so export, transfers and merge are all enqueued
@@ -245,6 +251,7 @@ def exchange_halo(m, rank: int, world: int, group=None, buffers: Optional[dict] 
     peer access); that path waits for the frame's integrate."""
     buffers = {} if buffers is None else buffers
     x = HaloExchange(m, rank, world, buffers, mode)
+    x.reserved = reserved
     x.export()
     if loopback:
         x.transfer_loopback()

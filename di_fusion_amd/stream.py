@@ -93,12 +93,13 @@ class FusionStream:
         self.stats.append(dict(self.map.last_counters))
         return out
 
-    def _exchange_halo(self):
+    def _exchange_halo(self, reserved: bool = False):
         if self.tiling is not None:
             from . import parallel
             rank, world, group = self.tiling
             with torch.cuda.device(self.device):
-                parallel.exchange_halo(self.map, rank, world, group, self._halo_buffers, mode=self.halo_mode, loopback=self.halo_loopback)
+                parallel.exchange_halo(self.map, rank, world, group, self._halo_buffers, mode=self.halo_mode, loopback=self.halo_loopback,
+                                       reserved=reserved)
 
     def _before_frame(self):
         """The D2H of the previous frame's triangles (side stream) reads a region of the mesh-cache LOG that later frames only append
@@ -229,11 +230,11 @@ class FusionStream:
         m = self.map
         self._no_async_meshing()
         self._d2h_mode = d2h
-        if self.tiling is not None:
-            raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
         N = self.intr.height * self.intr.width
         prune = int(m.args.prune_min_vox_obs)
         may_add = 7 * (N // (prune + 1)) if prune > 0 else 7 * N
+        if self.tiling is not None:         # the halo refresh between integrate and extract may allocate too: room for it is made up front, so that
+            may_add += 2 * m.halo_message_rows(3)   # no buffer moves between the two C calls whose descriptors are prepared below
         out = None
         with torch.cuda.device(self.device):
             if m._ws is None or m._xbuf is None or m._cache is None:
@@ -259,6 +260,8 @@ class FusionStream:
             H, W, fx, fy, cx, cy = self._d_args
             _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, _lib.ptr(self.xyz),
                                                _lib.ptr(self.nrm), _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
+            if self.tiling is not None:
+                self._exchange_halo(reserved=True)              # export -> send/recv -> merge, all on this stream, no host wait
             _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std), 0, 1, sp),
                        "dif_extract")
             m.mesh_cache.invalidate_host_copy()

@@ -96,7 +96,12 @@ class _GetSdfFn(torch.autograd.Function):
     def backward(ctx, g_sdf, g_std, g_mask):
         sel, grad = ctx.saved_tensors
         out = torch.zeros((ctx.n, 3), dtype=torch.float32, device=grad.device)
-        out[sel.long()] = grad * g_sdf.unsqueeze(1)
+        M = grad.size(0)
+        if M:
+            g = g_sdf.contiguous().float()
+            with torch.cuda.device(grad.device):      # one launch: out[sel[m]] = grad[m] * g_sdf[m]
+                _lib.check(_lib.load().dif_query_grad_scatter(_lib.ptr(grad), _lib.ptr(g), _lib.ptr(sel), M, _lib.ptr(out), _lib.stream_ptr()),
+                           "dif_query_grad_scatter")
         return out, None
 
 
@@ -155,6 +160,7 @@ class DenseIndexedMap:
         self.optimize_losses = None         # device float[64]: likelihood loss before each Adam step of the last optimisation
         self._cache_call_limit = 0          # max_n_triangles of the latest extract (what one more call may append to the log)
         self.extract_buffer_bytes = 8 << 30 # upper bound for the per-voxel extract buffers sized ahead of the occupancy (see _extract_buffers)
+        self._query_ws = None               # get_sdf: scan scratch + pinned count slots
         self._halo_list = None              # spatial tiling: boundary change lists (dif_map_t.halo_list)
         self._halo_lists_stale = True       # the lists do not cover every change since the last halo export: whole-layer messages next
 
@@ -437,21 +443,47 @@ class DenseIndexedMap:
 
     # ---- get_sdf ----------------------------------------------------------------------------------------------
     def _query(self, xyz: torch.Tensor, want_grad: bool):
+        """`dif_query_select` (mask + ordered compaction of the valid points), then `dif_query_decode` over the M selected rows.  The host
+        needs M to hand back M-row tensors (the reference's return shapes): the compaction's last workgroup writes it into pinned host
+        memory and the host waits for THAT small kernel only — the decoder is still running when this returns (the tracker calls
+        get_sdf once per Gauss-Newton iteration, reference tracker.py:184: no GPU idle gap between iterations)."""
         xyz = xyz.detach().contiguous().float()
         _lib.require_cuda(xyz)
         N = xyz.size(0)
         dev = self.device
+        lib = _lib.load()
         with torch.cuda.device(dev):
             mask = torch.empty((N,), dtype=torch.uint8, device=dev)
             sel = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
             sdf = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
             std = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
             grad = torch.empty((max(N, 1), 3), dtype=torch.float32, device=dev) if want_grad else None
-            scratch = torch.empty((N + 4096,), dtype=torch.int32, device=dev)
+            if N == 0:
+                return sdf[:0], std[:0], mask.view(torch.bool), sel[:0], (grad[:0] if want_grad else None)
+            q = self._query_ws
+            if q is None or q["scratch"].numel() < N + 4096:
+                # (per-map, grow-only: scan scratch and the pinned slots the count comes back through)
+                q = self._query_ws = dict(scratch=torch.empty((N + 4096,), dtype=torch.int32, device=dev),
+                                          notes=[torch.zeros((2,), dtype=torch.int32).pin_memory() for _ in range(4)],
+                                          events=[torch.cuda.Event() for _ in range(4)], seq=0)
+                for t in q["notes"]:
+                    t.numpy()[1] = -1
+                q["notes_np"] = [t.numpy() for t in q["notes"]]
+            q["seq"] = seq = (q["seq"] + 1) & 0x3FFFFFFF
+            k = seq & 3
+            note, ev = q["notes"][k], q["events"][k]
+            sp = _lib.stream_ptr()
+            _lib.check(lib.dif_query_select(ctypes.byref(self._cmap), _lib.ptr(xyz), N, _lib.ptr(mask), _lib.ptr(sel), _lib.ptr(q["scratch"]),
+                                            _lib.ptr(note), seq, sp), "dif_query_select")
+            ev.record()
             w = self.model.packed.weights_struct(dev)
-            _lib.check(_lib.load().dif_query_sdf(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), N, _lib.ptr(mask), _lib.ptr(sel),
-                                                 _lib.ptr(sdf), _lib.ptr(std), _lib.ptr(grad), _lib.ptr(scratch), _lib.stream_ptr()), "dif_query_sdf")
-        M = self._read_counters()["query_M"]
+            _lib.check(lib.dif_query_decode(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), N, _lib.ptr(sel), _lib.ptr(sdf), _lib.ptr(std),
+                                            _lib.ptr(grad), sp), "dif_query_decode")
+            ev.synchronize()                                    # the compaction only; the decoder keeps running
+            got = q["notes_np"][k]
+            if int(got[1]) != seq:
+                raise RuntimeError("libdifusion: get_sdf lost its row count (pinned slot overwritten)")
+            M = int(got[0])
         return sdf[:M], std[:M], mask.view(torch.bool), sel[:M], (grad[:M] if want_grad else None)
 
     def get_sdf(self, xyz: torch.Tensor):
@@ -464,6 +496,15 @@ class DenseIndexedMap:
             return sdf, std, mask
         sdf, std, mask, _, _ = self._query(xyz, False)
         return sdf, std, mask
+
+    def get_sdf_with_gradient(self, xyz: torch.Tensor):
+        """`get_sdf` plus the analytic d sdf / d xyz of the valid points, (M, 3), straight from the decoder's reverse chain — for callers
+        that build their Jacobian themselves.  The reference's tracker obtains the same numbers through
+        `autograd.grad(sdf / std.detach(), xyz)` (tracker.py:186-192), which works here too (`get_sdf` on a tensor that requires grad), but
+        torch's autograd engine adds ~0.2 ms of host time per call to a 0.1 ms kernel; dividing this gradient by `std` gives that result.
+        :return: sdf (M,), std (M,), valid_mask (N,) bool, d sdf / d xyz (M, 3)"""
+        sdf, std, mask, _, grad = self._query(xyz, True)
+        return sdf, std, mask, grad
 
     # ---- extract ----------------------------------------------------------------------------------------------
     def _new_cache_set(self, capacity: int):
@@ -783,9 +824,9 @@ class DenseIndexedMap:
         self.merge_halo2(msg, None, rows, None)
 
     def merge_halo2(self, msg_a: Optional[torch.Tensor], msg_b: Optional[torch.Tensor], rows_a: int = None, rows_b: int = None,
-                    note: Optional[torch.Tensor] = None):
+                    note: Optional[torch.Tensor] = None, reserved: bool = False):
         """`merge_halo` for the messages of both neighbours in one pass (`dif_merge_halo2`); note: optional int32[8] receiving the two
-        headers as received."""
+        headers as received.  reserved: the caller has already made room for the voxels the messages may allocate (`_ensure_capacity`)."""
         rows = []
         for m, r in ((msg_a, rows_a), (msg_b, rows_b)):
             if m is not None:
@@ -794,7 +835,8 @@ class DenseIndexedMap:
         if rows[0] + rows[1] == 0:
             return
         with self.modifying_lock, self._state_lock, torch.cuda.device(self.device):
-            self._ensure_capacity(rows[0] + rows[1])
+            if not reserved:
+                self._ensure_capacity(rows[0] + rows[1])
             if self._halo_scratch is None:
                 self._halo_scratch = torch.empty((4096,), dtype=torch.int32, device=self.device)
             _lib.check(_lib.load().dif_merge_halo2(ctypes.byref(self._cmap), _lib.ptr(msg_a), rows[0], _lib.ptr(msg_b), rows[1],

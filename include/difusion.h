@@ -314,6 +314,17 @@ int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float*
  * scratch: int32 [N + 4096]. */
 int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, uint8_t* mask,
                   int32_t* sel, float* sdf, float* std_out, float* grad, int32_t* scratch, void* stream);
+/* The same in two steps, for a caller that has to hand back M-row tensors (map.py:559-579 does) without waiting for the decoder:
+ * dif_query_select = validity mask + ordered compaction (mask, sel, M -> counters[DIF_C_QUERY_M]); count_out (optional, device-mapped pinned
+ * HOST memory allowed): [0] = M, [1] = seq, written by the compaction's last workgroup — the host can slice its outputs as soon as that
+ * small kernel is done.  dif_query_decode = the decoder over those M rows (grad may be NULL), reading M on the device. */
+int dif_query_select(const dif_map_t* map, const float* xyz, int64_t N, uint8_t* mask, int32_t* sel, int32_t* scratch, int32_t* count_out,
+                     int32_t seq, void* stream);
+int dif_query_decode(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, const int32_t* sel, float* sdf,
+                     float* std_out, float* grad, void* stream);
+/* Backward of get_sdf for the caller's autograd (the reference differentiates through the decoder, tracker.py:186-192):
+ * out[sel[m]][:] = grad[m][:] * g_sdf[m] for m < M; out (N,3) is zeroed by the caller. */
+int dif_query_grad_scatter(const float* grad, const float* g_sdf, const int32_t* sel, int64_t M, float* out, void* stream);
 
 /* ---- multi-GPU map merge (no reference counterpart) ----------------------------------- */
 /* Pack the allocated voxels whose x index lies in [x_lo, x_hi) as 32-word records, in slot order:

@@ -375,6 +375,10 @@ def test_get_sdf_gradient_vs_reference_autograd(name, pipe, gpu_model, gpu_model
     print(f"  {name}/{pipe}: grad vs reference autograd: max |diff| {d[~bad].max():.3e} of scale {scale:.3e} ({int(bad.sum())} of {len(bad)} probes on a kink)")
     assert bad.sum() <= 2
     assert torch.all(gq[~mask] == 0)
+    # the explicit entry point hands out the same Jacobian without torch's autograd engine
+    s2, d2, m2, g2 = m.get_sdf_with_gradient(q.detach())
+    assert torch.equal(m2, mask) and torch.equal(s2, sdf.detach()) and torch.equal(d2, std)
+    assert torch.allclose(g2 / d2.unsqueeze(1), gq[mask], rtol=1e-6, atol=1e-6 * scale)
 
 
 @pytest.mark.parametrize("resolution,fast", [(4, False), (2, True), (8, True), (3, True)])
@@ -577,8 +581,10 @@ def test_allocate_block(gpu_model):
     assert m.n_occupied == n0 + 9
 
 
-def test_latent_optimisation_vs_reference_and_oracle(gpu_model, oracle_net):
-    """8f-4, `integrate_keyframe(do_optimize=True)` (map.py:459-513, :80-113, :321-335): which voxels are optimised, how many samples are
+@pytest.mark.parametrize("pipe", ["bf16x6", "f32"])
+def test_latent_optimisation_vs_reference_and_oracle(pipe, gpu_model, gpu_model_f32, oracle_net):
+    """8f-4, `integrate_keyframe(do_optimize=True)` (map.py:459-513, :80-113, :321-335), on both matrix pipes (`k_optim_grad<true>`: the
+    optimiser's forward + reverse chain as six-slice bf16 products, `<false>`: f32-input MFMA): which voxels are optimised, how many samples are
     gathered for them, the dirty set and the observation counts must equal the reference's run bit for bit; the optimised latents agree
     to what five Adam steps in fp32 allow — the same algorithm evaluated in float64 instead of float32 moves them by up to 2e-4 (mean
     6e-6), the reference's own fp32 result sits 3e-4 (mean 9e-6) from the float64 one (Adam's g / sqrt(v) amplifies rounding where a
@@ -589,7 +595,7 @@ def test_latent_optimisation_vs_reference_and_oracle(gpu_model, oracle_net):
     args = cfg.namespace()
     args.optim_n_iters, args.code_regularization, args.code_reg_lambda = int(g["optim_n_iters"]), True, float(g["code_reg_lambda"])
     from di_fusion_amd.system.map import DenseIndexedMap
-    m = DenseIndexedMap(gpu_model, args, 29, DEV, initial_capacity=1024)
+    m = DenseIndexedMap(gpu_model if pipe == "bf16x6" else gpu_model_f32, args, 29, DEV, initial_capacity=1024)
     om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
     om.optim_n_iters, om.code_regularization, om.code_reg_lambda = args.optim_n_iters, True, args.code_reg_lambda
     for f in range(int(g["n_frames"])):

@@ -78,7 +78,7 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
         slabs.append(m)
         states.append({})
     plane = full.n_xyz[1] * full.n_xyz[2]
-    delta_messages = delta_bytes = full_bytes = 0
+    delta_messages = delta_bytes = full_bytes = delta_records = 0
     for f in range(n_frames):
         xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg)
         xyz, nrm = xyz.to(DEV), nrm.to(DEV)
@@ -102,6 +102,13 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
                     full_bytes += x.n_in[name] * 128
         for x in xs:
             x.merge()
+        torch.cuda.synchronize()
+        for x in xs:
+            for name, _, k, _ in x.sides:
+                if x.kind_out[name] == "delta":
+                    n_rec, pending = int(x.note_out[4 * k]), int(x.note_out[4 * k + 1])
+                    assert n_rec == pending <= parallel.DELTA_ROWS      # nothing was cut off
+                    delta_records += n_rec
         # ---- state of owned voxels ----
         nF = full.n_occupied
         posF = full.latent_vecs_pos[:nF].cpu().numpy()
@@ -147,8 +154,45 @@ def test_spatial_tiling_matches_single_map_bit_for_bit(case, gpu_model):
         assert np.array_equal(iS[kS], iF[kF])
         assert np.array_equal(tS[kS], tF[kF])                  # bit-identical vertices
     if mode == "delta":
-        assert delta_messages > 0, "the stream never reached the bounded delta messages"
-        print(f"{case}: {delta_messages} delta messages ({delta_bytes} B), whole-layer messages {full_bytes} B")
+        assert delta_messages > 0 and delta_records > 0, "the stream never reached the bounded delta messages"
+        print(f"{case}: {delta_messages} delta messages ({delta_bytes} B, {delta_records} records), whole-layer messages {full_bytes} B")
+
+
+def test_tiled_direct_launches_match_eager_steps(gpu_model):
+    """The spatially tiled stream driven like the headline stream (`step_direct`: two C calls per frame with the halo refresh enqueued
+    between them, host one frame ahead) against eager `step`s, in the loopback arrangement `bench.py --mode tiled --loopback 8` times
+    (slab 4 of 8 exchanging with itself): same map, bit for bit, same mesh updates."""
+    from di_fusion_amd.stream import FusionStream
+    scene, cfg = syn.config_c3()
+    outs, maps = {}, {}
+    for how in ("eager", "direct"):
+        st = FusionStream(gpu_model, scene, cfg, syn.Intrinsic(), DEV, 8, deg_per_frame=0.5, tiling=(4, 8, None), halo_loopback=True,
+                          initial_capacity=1 << 16)
+        res = []
+        for i in range(8):
+            if how == "eager" or i < 2:
+                o = st.step(i, "new")
+                torch.cuda.synchronize()
+                res.append(None if o is None else tuple(x.numpy().copy() for x in o))
+            else:
+                o = st.step_direct(i, "new")
+                if o is not None or i > 2:
+                    res.append(None if o is None else tuple(x.numpy().copy() for x in o))
+        o = st.flush("new")
+        if how == "direct":
+            res.append(None if o is None else tuple(x.numpy().copy() for x in o))
+        n = st.map.n_occupied
+        maps[how] = (st.map.latent_vecs_pos[:n].cpu().numpy(), st.map.voxel_obs_count[:n].cpu().numpy(), st.map.latent_vecs[:n].cpu().numpy())
+        outs[how] = res
+        kinds = [st._halo_buffers["hist"][f]["kinds"][0] for f in sorted(st._halo_buffers["hist"])]
+        assert any("delta" in k.values() for k in kinds)
+    for a, b in zip(maps["eager"], maps["direct"]):
+        assert np.array_equal(a, b)
+    assert len(outs["eager"]) == len(outs["direct"]) == 8
+    for a, b in zip(outs["eager"], outs["direct"]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
 def test_delta_halo_overflow_is_reported(gpu_model):
