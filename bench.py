@@ -286,7 +286,7 @@ def roofline_of(records, sst):
     return kern
 
 
-def roofline_block(per_frame, sst, pipe):
+def roofline_block(per_frame, sst, pipe, short_run=False):
     """`roofline` for the MFMA kernel with the longest average launch.  per_frame: for every event-timed frame the [(kernel, ms)] list
     from the library's HIP events (recorded on the launch stream); sst: the counters of those frames (rows per launch come from there).
     The same figures are also given for the first and the second half of the timed frames: a short run sits in the map-building
@@ -303,10 +303,18 @@ def roofline_block(per_frame, sst, pipe):
         return v["rows_per_launch"] / 32.0 * TILE_PIPE_CYCLES[pipe][name] / (SIMDS * SHADER_HZ * v["ms_per_launch"] * 1e-3)
 
     dom = max(kern, key=lambda k: kern[k]["ms_per_launch"])
-    pmc, pmc_file = {}, None
-    try:    # HBM bytes per launch: NOT measured by this run (PMC needs rocprofv3) — the committed summary of separate --pmc passes
-        pmc_file = sorted((ROOT / "profiles").glob("r*_pmc_hbm.json"))[-1]
+    # HBM bytes per launch and matrix-pipe busy cycles are NOT measured by this run (PMC needs rocprofv3): they come from the committed
+    # summaries of separate --pmc passes OF THE SAME INVOCATION — `--steps 20 --warmup 5` (what the driver runs: map-building transient)
+    # has its own set (profiles/rNN_pmc_*_k20.json), every longer run uses the 200-step set
+    pmc, pmc_file, busy_pmc, busy_file = {}, None, {}, None
+    try:
+        pmc_file = sorted((ROOT / "profiles").glob("r*_pmc_hbm_k20.json" if short_run else "r*_pmc_hbm.json"))[-1]
         pmc = json.loads(pmc_file.read_text())["kernels"]
+    except Exception:
+        pass
+    try:
+        busy_file = sorted((ROOT / "profiles").glob("r*_pmc_mfma_k20.json" if short_run else "r*_pmc_mfma_stream.json"))[-1]
+        busy_pmc = json.loads(busy_file.read_text())["kernels"]
     except Exception:
         pass
     kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode_refine_x6" if pipe == "bf16x6" else "k_decode<false>"}[dom]
@@ -328,9 +336,14 @@ def roofline_block(per_frame, sst, pipe):
             "frac": round(kern[dom]["tflops"] / peak, 4),
             "peak_source": ("2,500 TFLOP/s dense bf16 MFMA / 6 slice products per fp32 product" if pipe == "bf16x6" else "157.3 TFLOP/s f32-input MFMA"),
             "frac_of_f32_input_mfma_peak": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frac_executed": round(busy(dom, kern[dom]), 4),
+            "frac_executed_is": "matrix-pipe cycles of the launch's tiles (MFMAs x cycles each) / (1,024 SIMDs x launch time): the share of the launch the pipes worked",
             "pipe_busy_frac": round(busy(dom, kern[dom]), 4),
+            "pmc_mfma_busy_frac": next((busy_pmc[k]["mfma_util"] for k in (kname, kname + ("<true>" if pipe == "bf16x6" else "<false>")) if k in busy_pmc), None),
+            "pmc_mfma_busy_source": (f"static: profiles/{busy_file.name} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of the same invocation)"
+                                     if busy_file else None),
             "traffic": next((pmc[k]["hbm_bytes_per_launch"] for k in (kname, kname + ("<true>" if pipe == "bf16x6" else "<false>")) if k in pmc), None),
-            "traffic_source": (f"static: profiles/{pmc_file.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --graph 0`, "
+            "traffic_source": (f"static: profiles/{pmc_file.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same invocation, "
                                "FETCH_SIZE doubled as the gfx950 guide prescribes); not measured by this run") if pmc_file else None,
             "avg_launch_ms": round(kern[dom]["ms_per_launch"], 4), "rows_per_launch": round(kern[dom]["rows_per_launch"], 1),
             "per_kernel": {k: dict({kk: round(vv, 4) for kk, vv in v.items()}, frac=round(v["tflops"] / peak, 4), pipe_busy_frac=round(busy(k, v), 4))
@@ -510,7 +523,7 @@ def main():
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info,
                           "halo_exchange": halo_summary(stream, a)},
-               "roofline": roofline_block(per_frame, [st[j] for j in timed_idx], pipe)}
+               "roofline": roofline_block(per_frame, [st[j] for j in timed_idx], pipe, short_run=(a.steps <= 30))}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(stream, a.config, scene, cfg, intr, n_frames, a.cpu_frames)
     if use_dist:

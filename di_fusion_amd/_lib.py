@@ -159,8 +159,12 @@ def ptr(t) -> c_void_p:
 
 
 def stream_ptr() -> c_void_p:
+    """The current HIP stream of the current device as a raw pointer (what every entry point takes)."""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:        # ~1 us; `torch.cuda.current_stream().cuda_stream` builds a Stream object and costs ~8 us — six of them per frame add up
+        return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def require_cuda(*tensors):

@@ -114,7 +114,9 @@ def _message_kind(st: dict, f: int, which: str, side: int, rows_full: int, mode:
     if mode == "full" or rows_full <= DELTA_ROWS or f < 2:
         return "full"
     h = st["hist"][f - 2]
-    h["event"].synchronize()                                 # two frames back: long done
+    if not h.get("done"):
+        h["event"].synchronize()                             # two frames back: long done
+        h["done"] = True
     n, pending, was_delta = (int(v) for v in h[which][4 * side:4 * side + 3])
     if was_delta and pending > n:
         raise RuntimeError(f"halo exchange: the delta message of frame {f - 2} overflowed ({pending} changed boundary voxels, room for {n}): "
@@ -150,12 +152,15 @@ class HaloExchange:
         hist = st.setdefault("hist", {})
         self.note_out = self.note_in = None
         if self.on_gpu and self.sides:
-            ring = st.setdefault("notes", [(torch.zeros((8,), dtype=torch.int32).pin_memory(), torch.zeros((8,), dtype=torch.int32).pin_memory())
-                                           for _ in range(4)])
-            self.note_out, self.note_in = ring[f % 4]
+            if "notes" not in st:           # four rotating slots of pinned header notes + the events that say when a slot's frame is done
+                st["notes"] = [(torch.zeros((8,), dtype=torch.int32).pin_memory(), torch.zeros((8,), dtype=torch.int32).pin_memory()) for _ in range(4)]
+                st["notes_np"] = [(a.numpy(), b.numpy()) for a, b in st["notes"]]
+                st["events"] = [torch.cuda.Event() for _ in range(4)]
+            self.note_out, self.note_in = st["notes"][f % 4]
             if f >= 4:
                 hist[f - 4]["event"].synchronize()           # the slot's previous user
-            self.note_out.zero_(); self.note_in.zero_()
+            for a in st["notes_np"][f % 4]:
+                a[:] = 0
         kind = lambda which, k: _message_kind(st, f, which, k, self.rows_full, self.mode) if self.on_gpu else "full"
         self.kind_out = {name: kind("out", k) for name, _, k, _ in self.sides}
         self.kind_in = {name: kind("in", k) for name, _, k, _ in self.sides}
@@ -226,9 +231,10 @@ class HaloExchange:
             inp, rows = self.inp, self.rows
             m.merge_halo2(inp.get("left"), inp.get("right"), rows[self.kind_in["left"]] if "left" in inp else None,
                           rows[self.kind_in["right"]] if "right" in inp else None, self.note_in, reserved=self.reserved)
-            ev = torch.cuda.Event()
+            ev = st["events"][f % 4]
             ev.record()
-            st["hist"][f] = dict(event=ev, out=self.note_out.numpy(), **{"in": self.note_in.numpy()}, kinds=(dict(self.kind_out), dict(self.kind_in)),
+            no, ni = st["notes_np"][f % 4]
+            st["hist"][f] = dict(event=ev, out=no, **{"in": ni}, kinds=(self.kind_out, self.kind_in),
                                  bytes_out=sum(self.n_out.values()) * 128, bytes_in=sum(self.n_in.values()) * 128)
             st["hist"].pop(f - 8, None)
         else:

@@ -1,10 +1,12 @@
 # usage: bash tools/install_profiles.sh <gpurun_out tag> <profiles prefix>     copies the summaries of tools/refresh_profiles.sh into profiles/
 set -e
 S=gpurun_out/$1; P=profiles/$2
-for f in bench_n1 bench_graph bench_k20 bench_c1 bench_c2 bench_tiled_n1 bench_cloud bench_query pmc_hbm pmc_mfma_stream bench_batch5 bench_rccl_1rank; do
+for f in bench_n1 bench_graph bench_k20 bench_c1 bench_c2 bench_tiled_n1 bench_tiled_loopback8_delta bench_tiled_loopback8_full bench_tiled_loopback2_delta \
+         bench_cloud bench_query pmc_hbm pmc_hbm_k20 pmc_mfma_stream pmc_mfma_k20 bench_batch5 bench_rccl_1rank; do
   [ -s $S/$f.json ] && cp $S/$f.json ${P}_$f.json
 done
 [ -s $S/stress_full.json ] && cp $S/stress_full.json ${P}_stress_full_occupancy.json
 [ -s $S/stress_integrate.json ] && cp $S/stress_integrate.json ${P}_stress_integrate.json
-for f in kernel_stats.md timeline_direct.txt timeline_graph.txt; do [ -s $S/$f ] && cp $S/$f ${P}_$f; done
+[ -s $S/sweep_decode.jsonl ] && cp $S/sweep_decode.jsonl ${P}_sweep_decode.jsonl
+for f in kernel_stats.md kernel_stats_steady.md kernel_stats_k20.md kernel_stats_tiled_loopback8.md kernel_stats_tiled_n1.md timeline_direct.txt; do [ -s $S/$f ] && cp $S/$f ${P}_$f; done
 ls -la profiles | grep "$2" | wc -l

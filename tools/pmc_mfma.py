@@ -3,7 +3,7 @@
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / XCDs * CUs * 4 SIMDs).
 On gfx950 GRBM_GUI_ACTIVE comes back summed over the 8 XCDs, and SQ_VALU_MFMA_BUSY_CYCLES is exactly 64 x the number of
 v_mfma_f32_32x32x2_f32 issued (checked against the known MFMA count of the full-occupancy decode).
-Usage: python tools/pmc_mfma.py <counter_collection.csv> <out.json> [--cus 256] [--xcds 8]"""
+Usage: python tools/pmc_mfma.py <counter_collection.csv> <out.json> [--cus 256] [--xcds 8] [--last N]"""
 import collections
 import csv
 import json
@@ -26,8 +26,9 @@ def main():
     for k, c in per.items():
         if not (k.startswith("k_") or k.startswith("dif::")) or "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
             continue
-        b = c["SQ_VALU_MFMA_BUSY_CYCLES"][len(c["SQ_VALU_MFMA_BUSY_CYCLES"]) // 2:]
-        g = c["GRBM_GUI_ACTIVE"][len(c["GRBM_GUI_ACTIVE"]) // 2:]
+        last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else None      # the timed frames of a short run
+        b = c["SQ_VALU_MFMA_BUSY_CYCLES"][-last:] if last else c["SQ_VALU_MFMA_BUSY_CYCLES"][len(c["SQ_VALU_MFMA_BUSY_CYCLES"]) // 2:]
+        g = c["GRBM_GUI_ACTIVE"][-last:] if last else c["GRBM_GUI_ACTIVE"][len(c["GRBM_GUI_ACTIVE"]) // 2:]
         busy, act = sum(b) / len(b), sum(g) / len(g)
         if busy > 0:
             out["kernels"][k] = {"mfma_busy_cycles": round(busy), "gpu_active_cycles_per_xcd": round(act / xcds), "mfma_util": round(busy / (act / xcds * cus * 4), 4)}

@@ -1,31 +1,52 @@
+# usage (GPU box, via gpurun): bash tools/refresh_profiles.sh <tag>      -> gpurun_out/<tag>/ ; tools/install_profiles.sh copies the summaries to profiles/
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-final1}; mkdir -p $O
-timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python bench.py --no-cpu-baseline --no-secondary > $O/trace_bench.log 2>&1
+B="python bench.py"
+# ---- the default invocation (200 steps) ----
+timeout 600 $B > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- $B --no-cpu-baseline --no-secondary > $O/trace_bench.log 2>&1
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 200 > $O/kernel_stats.md 2>&1
+python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --after-nth k_prune_mark 160 --frames 50 > $O/kernel_stats_steady.md 2>&1
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --timeline k_prune_mark 150 > $O/timeline_direct.txt 2>&1
-timeout 400 rocprofv3 --kernel-trace -d $O/trace_g -o bench -- python bench.py --graph 1 --no-cpu-baseline --no-secondary --steps 100 > $O/trace_graph.log 2>&1
-python tools/rocpd_stats.py $(find $O/trace_g -name "*.db" | head -1) --timeline k_prune_mark 90 > $O/timeline_graph.txt 2>&1
-rm -rf $O/trace_g
-timeout 300 python bench.py --graph 1 --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 4 --graph 0 > $O/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 4 --graph 0 > $O/pmc_write.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python bench.py --no-cpu-baseline --no-secondary --steps 200 --warmup 10 --graph 0 > $O/pmc_mfma.log 2>&1
-python tools/pmc_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_mfma_stream.json > $O/pmc_mfma_summary.log 2>&1
-rm -rf $O/pmc_mfma
+rm -rf $O/trace
+# ---- the DRIVER's invocation: --steps 20 --warmup 5 (map-building transient) ----
+K20="--steps 20 --warmup 5 --no-cpu-baseline"
+timeout 300 $B $K20 > $O/bench_k20.json 2> $O/bench_k20.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace20 -o bench -- $B $K20 > $O/trace20.log 2>&1
+python tools/rocpd_stats.py $(find $O/trace20 -name "*.db" | head -1) --after-nth k_prune_mark 9 --frames 20 > $O/kernel_stats_k20.md 2>&1
+rm -rf $O/trace20
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma20 -o m -- $B $K20 > $O/pmc_mfma20.log 2>&1
+python tools/pmc_mfma.py $(find $O/pmc_mfma20 -name "*counter_collection.csv" | head -1) $O/pmc_mfma_k20.json --last 20 > $O/pmc_mfma20_summary.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch20 -o f -- $B $K20 > $O/pmc_fetch20.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write20 -o w -- $B $K20 > $O/pmc_write20.log 2>&1
+python tools/pmc_summary.py $(find $O/pmc_fetch20 -name "*counter_collection.csv" | head -1) $(find $O/pmc_write20 -name "*counter_collection.csv" | head -1) $O/pmc_hbm_k20.json --last 20 > $O/pmc_summary20.log 2>&1
+rm -rf $O/pmc_mfma20 $O/pmc_fetch20 $O/pmc_write20
+# ---- PMC passes of the 200-step stream ----
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- $B --no-cpu-baseline --no-secondary --steps 40 --warmup 4 > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- $B --no-cpu-baseline --no-secondary --steps 40 --warmup 4 > $O/pmc_write.log 2>&1
 python tools/pmc_summary.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_hbm.json > $O/pmc_summary.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- $B --no-cpu-baseline --no-secondary > $O/pmc_mfma.log 2>&1
+python tools/pmc_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_mfma_stream.json > $O/pmc_mfma_summary.log 2>&1
+rm -rf $O/pmc_mfma $O/pmc_fetch $O/pmc_write
+# ---- C5: the 1280x960 stream on one GPU, and slab 4 of 8 exchanging halos with itself ----
+timeout 600 $B --mode tiled --no-cpu-baseline --steps 100 > $O/bench_tiled_n1.json 2> $O/bench_tiled_n1.err
+timeout 600 $B --mode tiled --loopback 8 --no-cpu-baseline --steps 100 > $O/bench_tiled_loopback8_delta.json 2> $O/bench_tiled_loopback8_delta.err
+timeout 600 $B --mode tiled --loopback 8 --halo full --no-cpu-baseline --steps 100 > $O/bench_tiled_loopback8_full.json 2> $O/bench_tiled_loopback8_full.err
+timeout 600 $B --mode tiled --loopback 2 --no-cpu-baseline --steps 100 > $O/bench_tiled_loopback2_delta.json 2> $O/bench_tiled_loopback2_delta.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_lb8 -o bench -- $B --mode tiled --loopback 8 --no-cpu-baseline --steps 100 > $O/trace_lb8.log 2>&1
+python tools/rocpd_stats.py $(find $O/trace_lb8 -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 100 > $O/kernel_stats_tiled_loopback8.md 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_t1 -o bench -- $B --mode tiled --no-cpu-baseline --steps 100 > $O/trace_t1.log 2>&1
+python tools/rocpd_stats.py $(find $O/trace_t1 -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 100 > $O/kernel_stats_tiled_n1.md 2>&1
+rm -rf $O/trace_lb8 $O/trace_t1
+# ---- the rest ----
+timeout 300 $B --graph 1 --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
+timeout 300 $B --batch 5 --no-cpu-baseline --no-secondary > $O/bench_batch5.json 2> $O/bench_batch5.err
+for c in c1 c2; do timeout 300 $B --config $c --no-cpu-baseline --steps 50 > $O/bench_$c.json 2> $O/bench_$c.err; done
+DIF_FORCE_DIST=1 timeout 300 $B --no-cpu-baseline --steps 50 --no-secondary > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
 timeout 900 python tools/stress_full_occupancy.py --n 128 --reps 2 > $O/stress_full.json 2> $O/stress_full.err
 timeout 900 python tools/stress_integrate.py > $O/stress_integrate.json 2> $O/stress_integrate.err
 timeout 300 python tools/bench_cloud.py --cpu-sample 20000 > $O/bench_cloud.json 2> $O/bench_cloud.err
-for c in c1 c2; do timeout 300 python bench.py --config $c --no-cpu-baseline --steps 50 > $O/bench_$c.json 2> $O/bench_$c.err; done
-timeout 600 python bench.py --mode tiled --no-cpu-baseline --steps 100 > $O/bench_tiled_n1.json 2> $O/bench_tiled_n1.err
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_k20.json 2> $O/bench_k20.err
 timeout 300 python tools/bench_query.py > $O/bench_query.json 2> $O/bench_query.err
-rm -rf $O/pmc_fetch $O/pmc_write
-find $O/trace -name "*.db" -size +20M -delete
-ls -la $O
-timeout 300 python bench.py --batch 5 --no-cpu-baseline --no-secondary > $O/bench_batch5.json 2> $O/bench_batch5.err
-DIF_FORCE_DIST=1 timeout 300 python bench.py --no-cpu-baseline --steps 50 --no-secondary > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
-DIF_DECODER_PIPE=f32 timeout 300 python bench.py --no-cpu-baseline --no-secondary > $O/bench_f32pipe.json 2> $O/bench_f32pipe.err
+timeout 300 python tools/sweep_decode.py > $O/sweep_decode.jsonl 2> $O/sweep_decode.err
 ls -la $O | wc -l
