@@ -413,12 +413,15 @@ def main():
         batch = a.batch if batch is None else batch
         if tiled:           # every rank renders the same stream and owns one x-slab of the grid
             tiling = (a.loopback // 2, a.loopback, None) if a.loopback > 1 else (rank, world, None)
-            return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, noise=bool(a.noise), initial_capacity=1 << 18,
+            return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, noise=bool(a.noise),
                                 tiling=tiling, halo_mode=a.halo, halo_loopback=a.loopback > 1)
-        # (a batch of F frames needs room for the worst-case allocations of two batches in flight: sized up front instead of growing in the clock)
-        cap0 = 1 << 16
-        while batch > 0 and cap0 < (2 * batch + 1) * 7 * (intr.width * intr.height // 17) + (1 << 16):
-            cap0 *= 2
+        # (a batch of F frames needs room for the worst-case allocations of two batches in flight: sized up front instead of growing in the clock;
+        # frame-by-frame streams size themselves: FusionStream's default)
+        cap0 = None
+        if batch > 0:
+            cap0 = 1 << 16
+            while cap0 < (2 * batch + 1) * 7 * (intr.width * intr.height // 17) + (1 << 16):
+                cap0 *= 2
         return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise),
                             initial_capacity=cap0)   # own arc of the orbit
 

@@ -34,7 +34,7 @@ class DifMap(Structure):
                 ("rec_dir", c_void_p), ("upd_list", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
                 ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("dirty_tot", c_void_p),
-                ("halo_list", c_void_p), ("halo_list_cap", c_int32)]
+                ("halo_list", c_void_p), ("halo_list_cap", c_int32), ("pending_export", c_void_p)]
 
 
 class DifWeights(Structure):
@@ -55,7 +55,7 @@ class DifExtractBuffers(Structure):
                 ("max_triangles", c_int64), ("cache_capacity", c_int64),
                 ("cache_tri", c_void_p), ("cache_id", c_void_p), ("cache_std", c_void_p), ("cache_alive", c_void_p),
                 ("counters_out", c_void_p), ("out_tri", c_void_p), ("out_id", c_void_p), ("out_std", c_void_p), ("out_capacity", c_int64),
-                ("chunk_sum", c_void_p), ("fold_table", c_void_p), ("mc_status", c_void_p)]
+                ("chunk_sum", c_void_p), ("fold_table", c_void_p), ("mc_status", c_void_p), ("defer_export", c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)
@@ -90,6 +90,7 @@ SIGNATURES = {
                                        c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
                               c_int32, c_int32, c_void_p]),
+    "dif_export_pending": (c_int32, [POINTER(DifMap), c_void_p]),
     "dif_mesh_cache_export": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dif_mesh_cache_compact": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "dif_mesh_cache_reindex": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_int64, c_void_p]),

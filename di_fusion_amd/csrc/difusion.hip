@@ -414,22 +414,27 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
 
     // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
     const int own_lo = map->own_x_hi > map->own_x_lo ? map->own_x_lo : 0, own_hi = map->own_x_hi > map->own_x_lo ? map->own_x_hi : map->nx;
+    // a deferred triangle export of the previous extract rides with the three point passes of a streaming frame: nb_x leading workgroups each
+    dif_pending_export_t* const pending = src ? (dif_pending_export_t*)map->pending_export : nullptr;
+    const int nb_x = pending ? DIF_EXPORT_WGS : 0;
     if (src)
-        hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, src->frame, src->H, src->W, src->fx, src->fy, src->cx, src->cy,
-                           const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C, own_lo - map->halo, own_hi + map->halo);
+        hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, g, src->frame, src->H, src->W,
+                           src->fx, src->fy, src->cx, src->cy, const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C,
+                           own_lo - map->halo, own_hi + map->halo, (const dif_pending_export_t*)pending, nb_x);
     else
         hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C, own_lo - map->halo,
                            own_hi + map->halo);
-    hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
-                       (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, grid_marks_of(map), C);
+    hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
+                       (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, grid_marks_of(map), C, (const dif_pending_export_t*)pending, nb_x);
     DIF_CHECK_LAUNCH();
     {
         AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
         if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // k_prune_mark kept the block totals
     }
-    hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
+    hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
                        (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
-                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, map->grid_tot, own_lo, own_hi);
+                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, map->grid_tot, own_lo, own_hi,
+                       (const dif_pending_export_t*)pending, nb_x);
     DIF_CHECK_LAUNCH();
     {
         const bool x6 = w->enc_x6_packed && w->enc_x6_packed_bytes == E6_BYTES;          // tiles on the bf16 matrix pipe (mlp.hip.h)
@@ -452,7 +457,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.rec, (const int*)ws.rec_next,
                        map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, (const int64_t*)map->latent_vecs_pos,
-                       halo_lists_of(map));
+                       halo_lists_of(map), pending);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -857,12 +862,14 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         a.corner_cache = reinterpret_cast<float*>(buf->refine_list);
         a.corner_stride = R3;
     }
+    // deferred export: the copy of the new triangles to the caller's arrays is left to the next frame's first kernel (dif_map_t.pending_export)
+    const bool defer = buf->defer_export && map->pending_export && buf->out_tri && buf->out_id && buf->out_std;
     const bool fused_scan = buf->chunk_sum && buf->max_voxels <= ((int64_t)1 << 24);      // three levels of 256: beyond that the scan kernel
     int32_t* const super_sum = buf->chunk_sum ? buf->chunk_sum + (buf->max_voxels + 255) / 256 : nullptr;
     const bool onepass = fused_scan && buf->mc_status && r * r * r <= 64;                // count, look-back and emit in one launch
     if (onepass) {
         a.tri_start = map->tri_start; a.tri_n = map->tri_n; a.tri_count = buf->tri_count; a.tri_offset = nullptr;
-        if (buf->out_tri && buf->out_id && buf->out_std) {      // the emitting waves also write the caller's copy (PCIe overlaps the launch)
+        if (!defer && buf->out_tri && buf->out_id && buf->out_std) {      // the emitting waves also write the caller's copy (PCIe overlaps the launch)
             a.out_tri = buf->out_tri; a.out_id = buf->out_id; a.out_std = buf->out_std; a.out_capacity = buf->out_capacity;
         }
         size_t lds_bytes; int blocks;
@@ -910,7 +917,8 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     }
     hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
                        C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
-                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity, (onepass && a.out_tri) ? 1 : 0},
+                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity, ((onepass && a.out_tri) || defer) ? 1 : 0,
+                                  defer ? (dif_pending_export_t*)map->pending_export : nullptr},
                        (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
                        onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr);
     DIF_CHECK_LAUNCH();
@@ -929,6 +937,16 @@ int dif_trace_read_encode(unsigned long long* out, int64_t n) {      // host cop
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                 float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, stream_);
+}
+
+int dif_export_pending(const dif_map_t* map, void* stream) {
+    if (!map) return DIF_EINVAL;
+    if (!map->pending_export) return DIF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_export_pending, dim3(DIF_EXPORT_WGS), dim3(DIF_BLOCK), 0, s, (dif_pending_export_t*)map->pending_export);
+    DIF_CHECK_LAUNCH();
+    if (hipMemsetAsync(map->pending_export, 0, sizeof(int32_t), s) != hipSuccess) return DIF_ELAUNCH;      // .pending = 0
+    return DIF_OK;
 }
 
 int dif_mesh_cache_export(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std, void* stream) {

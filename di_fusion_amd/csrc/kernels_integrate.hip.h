@@ -41,9 +41,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* _
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(Geo g, const dif_frame_t* __restrict__ frame, int H, int W, float fx, float fy,
                                                                    float cx, float cy, float* __restrict__ xyz, float* __restrict__ nrm,
                                                                    int* __restrict__ pt_lin, int* __restrict__ frame_count, int* __restrict__ counters,
-                                                                   int px_lo, int px_hi) {
+                                                                   int px_lo, int px_hi, const dif_pending_export_t* __restrict__ pending, int nb_x) {
+    // The first nb_x workgroups (dispatched first, so that the copy runs beside the whole point pass and not at its tail) carry out a third of
+    // the previous extract's deferred triangle export; the other two thirds ride with the next two kernels.
+    if ((int)blockIdx.x < nb_x) {
+        export_pending_rows(pending, (int)blockIdx.x, 3 * nb_x);
+        return;
+    }
     const int64_t N = (int64_t)H * W;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)((int)blockIdx.x - nb_x) * blockDim.x + threadIdx.x;
     const bool in = i < N;
     float p[3] = {0.f, 0.f, 0.f}, nv[3];
     if (in) {
@@ -64,9 +70,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(Geo g, cons
 __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, const int* __restrict__ pt_lin, int64_t N,
                                                         const int* __restrict__ frame_count, const int64_t* __restrict__ indexer,
                                                         uint8_t* __restrict__ unq_mask, GridMarks marks,
-                                                        int* __restrict__ counters) {
+                                                        int* __restrict__ counters, const dif_pending_export_t* __restrict__ pending, int nb_x) {
+    if ((int)blockIdx.x < nb_x) {           // leading workgroups: the second third of a deferred triangle export
+        export_pending_rows(pending, nb_x + (int)blockIdx.x, 3 * nb_x);
+        return;
+    }
     const uint32_t* bits = marks.bits;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t)((int)blockIdx.x - nb_x) * blockDim.x + threadIdx.x;
     int lane = lane_id();
     int lin = (i < N) ? pt_lin[i] : -2;
     bool keep = false;
@@ -147,9 +157,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
                                                           const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                           const int64_t* __restrict__ indexer, const float* __restrict__ obs,
                                                           uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w,
-                                                          int* __restrict__ grid_tot, int own_lo, int own_hi) {
+                                                          int* __restrict__ grid_tot, int own_lo, int own_hi,
+                                                          const dif_pending_export_t* __restrict__ pending, int nb_x) {
+    if ((int)blockIdx.x < nb_x) {           // leading workgroups: the last third of a deferred triangle export
+        export_pending_rows(pending, 2 * nb_x + (int)blockIdx.x, 3 * nb_x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - nb_x;
     __shared__ unsigned tkey[FG_TABLE];
-    if (blockIdx.x == 0)                                     // the allocation scan has consumed the bitmap's block totals: back to idle 0
+    if (bid == 0)                                            // the allocation scan has consumed the bitmap's block totals: back to idle 0
         for (int t = (int)threadIdx.x; t < 1024; t += DIF_BLOCK) grid_tot[t] = 0;
     __shared__ int tcnt[FG_TABLE];        // rows per table entry, then (after the scan) the entry's first list position within the workgroup
     __shared__ int smem[8];
@@ -159,10 +175,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
     if (threadIdx.x == 0) s_loose = 0;
     // Points of a frame (img_w > 0, N = H * img_w with both multiples of 16) are walked in 16 x 16 pixel tiles: a workgroup then
     // touches 10-30 voxels instead of the ~90 that a 256-pixel piece of an image row does.
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole workgroups
+    int64_t i = (int64_t)bid * blockDim.x + threadIdx.x;      // grid covers N rounded up to whole workgroups
     if (img_w > 0) {
         const int tiles_x = img_w >> 4;
-        const int ty = (int)(blockIdx.x / tiles_x), tx = (int)(blockIdx.x % tiles_x);
+        const int ty = bid / tiles_x, tx = bid % tiles_x;
         i = (int64_t)(ty * 16 + (int)(threadIdx.x >> 4)) * img_w + tx * 16 + (int)(threadIdx.x & 15);
     }
     if (i == 0) {
@@ -415,7 +431,9 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 // together, overflow chain walked), fuse, return the directory to its idle state.
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                                   const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
-                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, HaloLists hl) {
+                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, HaloLists hl,
+                                                  dif_pending_export_t* __restrict__ pending) {
+    if (pending && blockIdx.x == 0 && threadIdx.x == 0) pending->pending = 0;      // the point kernels' extra workgroups have done the copy
     const int n_upd = counters[DIF_C_C];
     const int first_new = counters[DIF_C_N_OCCUPIED] - counters[DIF_C_ALLOC_NEW];      // this frame's new slots are already in the halo delta
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);

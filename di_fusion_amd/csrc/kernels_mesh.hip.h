@@ -490,7 +490,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cache_reindex(const int64_t* __re
 struct ExtractOut {
     int32_t* counters_out;          // [DIF_C_COUNT] or NULL
     float* tri; int64_t* id; float* sd; int64_t capacity;      // this call's new triangles (first `capacity` of them) or NULL
-    int already_exported;           // the one-pass marching cubes wrote them while it emitted
+    int already_exported;           // the one-pass marching cubes wrote them while it emitted (or the copy is deferred)
+    dif_pending_export_t* defer;    // deferred export: leave the copy to the next frame's first kernel (dif_map_t.pending_export)
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
@@ -531,6 +532,14 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
         if (lane == DIF_C_CACHE_T) v = (int)tot;
         if (lane == DIF_C_OVERFLOW && over) v = 5;
         if (out.counters_out && lane < DIF_C_COUNT) out.counters_out[lane] = v;
+        if (lane == 0 && out.defer) {
+            const int64_t n = n_new < out.capacity ? n_new : out.capacity;
+            dif_pending_export_t d;
+            d.pending = n > 0 ? 1 : 0; d.kept = (int)kept; d.n = (int)n; d.reserved = 0;
+            d.log_tri = log_tri; d.log_id = log_id; d.log_std = log_std;
+            d.out_tri = out.tri; d.out_id = out.id; d.out_std = out.sd;
+            *out.defer = d;
+        }
         if (lane == 0) {
             // a flag that has just been handed to the caller with this snapshot is reported: cleared here, in stream order, so that the next
             // call's snapshot neither repeats it nor loses a flag raised in between

@@ -49,6 +49,33 @@ __device__ __forceinline__ void unproject_point(const float* __restrict__ depth,
     }
 }
 
+// Deferred export (dif_map_t.pending_export): workgroup `part` of `nparts` copies its share of the previous extract's new triangles to the
+// caller's arrays (pinned host memory: PCIe-bound, ~0.5 MB per frame) — run by a few extra workgroups of the next frame's first kernel.
+__device__ __forceinline__ void copy_dwords_strided(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t n, int64_t t0, int64_t stride) {
+    int64_t j = t0;
+    for (; j + 3 * stride < n; j += 4 * stride) {           // four loads in flight per thread, then four stores: the copy is latency-bound
+        const uint32_t a = src[j], b = src[j + stride], c = src[j + 2 * stride], d = src[j + 3 * stride];
+        dst[j] = a; dst[j + stride] = b; dst[j + 2 * stride] = c; dst[j + 3 * stride] = d;
+    }
+    for (; j < n; j += stride) dst[j] = src[j];
+}
+
+__device__ __forceinline__ void export_pending_rows(const dif_pending_export_t* __restrict__ d, int part, int nparts) {
+    if (!d->pending) return;
+    const int64_t kept = d->kept, n = d->n;
+    const int64_t stride = (int64_t)nparts * blockDim.x, t0 = (int64_t)part * blockDim.x + threadIdx.x;
+    // consecutive lanes write consecutive dwords: 256 contiguous bytes per wave and store instruction (whole PCIe write bursts)
+    copy_dwords_strided(reinterpret_cast<const uint32_t*>(d->log_tri + kept * 9), reinterpret_cast<uint32_t*>(d->out_tri), n * 9, t0, stride);
+    copy_dwords_strided(reinterpret_cast<const uint32_t*>(d->log_std + kept * 3), reinterpret_cast<uint32_t*>(d->out_std), n * 3, t0, stride);
+    copy_dwords_strided(reinterpret_cast<const uint32_t*>(d->log_id + kept), reinterpret_cast<uint32_t*>(d->out_id), n * 2, t0, stride);
+}
+
+#define DIF_EXPORT_WGS 64
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_export_pending(dif_pending_export_t* __restrict__ d) {
+    export_pending_rows(d, (int)blockIdx.x, (int)gridDim.x);
+}
+
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_transform(const float* __restrict__ depth, const float* __restrict__ ncam,
                                                                  float* __restrict__ xyz, float* __restrict__ nrm, int H, int W,
                                                                  float fx, float fy, float cx, float cy, Pose P, const float* __restrict__ pose_dev,

@@ -21,7 +21,7 @@ class FusionStream:
     def __init__(self, model, scene: syn.Scene, cfg: syn.MapConfig, intr: syn.Intrinsic, device: torch.device,
                  n_frames: int, deg_per_frame: float = 0.5, phase_deg: float = 0.0, orbit_radius: float = 0.3,
                  noise: bool = False, resolution: int = 4, max_n_triangles: int = int(4e6), max_std: float = 0.15,
-                 initial_capacity: int = 1 << 16, tiling=None, halo_mode: str = "delta", halo_loopback: bool = False):
+                 initial_capacity: Optional[int] = None, tiling=None, halo_mode: str = "delta", halo_loopback: bool = False):
         """tiling = (rank, world, group): BASELINE config C5 — the grid is cut into `world` x-slabs, this stream's map owns slab `rank`,
         every rank is offered the whole frame and the 3 boundary layers are refreshed from the ring neighbours after every integrate
         (`parallel.exchange_halo`: one send + one receive per neighbour over RCCL / xGMI; halo_mode "delta": bounded messages with the
@@ -30,6 +30,19 @@ class FusionStream:
         self.device = device
         self.intr = intr
         self.resolution, self.max_n_triangles, self.max_std = resolution, max_n_triangles, max_std
+        if initial_capacity is None:
+            # Room for the worst-case allocations of the frames the host keeps in flight.  A frame may allocate up to 7 voxels per
+            # (prune_min_vox_obs + 1) points (a bound nothing comes near: a steady-state frame allocates tens), and the host's bound of
+            # n_occupied lags the device by two frames; with less room than that, every frame would first have to wait for the previous
+            # one to finish just to learn that there is space (`_ensure_capacity`), and the GPU would idle while the host enqueues.
+            n_pts = intr.height * intr.width
+            prune = int(cfg.namespace().prune_min_vox_obs)
+            per_frame = 7 * (n_pts // (prune + 1)) if prune > 0 else 7 * n_pts
+            if tiling is not None and tiling[1] > 1:
+                per_frame += 2 * 3 * int(np.ceil((cfg.bound_max[1] - cfg.bound_min[1]) / cfg.voxel_size)) * int(np.ceil((cfg.bound_max[2] - cfg.bound_min[2]) / cfg.voxel_size))
+            initial_capacity = 1 << 16
+            while initial_capacity < 3 * per_frame + (1 << 16):
+                initial_capacity *= 2
         self.map = DenseIndexedMap(model, cfg.namespace(), 29, device, initial_capacity=initial_capacity)
         self.tiling = tiling if (tiling is not None and tiling[1] > 1) else None
         self._halo_buffers = {}
@@ -64,6 +77,7 @@ class FusionStream:
         self._d_sig = None
         self._b_slots = None
         self._d2h_mode = "new"
+        self.defer_export = True            # step_direct: a frame's new triangles travel to the host beside the NEXT frame's first kernel
         self.backlog = []                   # outputs of a pending batch's earlier frames, when a frame-by-frame step had to complete it
 
     def step(self, i: int, d2h: str = "new"):
@@ -146,8 +160,21 @@ class FusionStream:
                 self._copy_done.record()
         return (self._pin[0][:n], self._pin[1][:n], self._pin[2][:n])
 
+    def _export_deferred_now(self, handle):
+        """A frame whose triangle export was deferred and that no later frame's first kernel has carried out yet: do the copy now
+        (stream-ordered; `dif_export_pending`)."""
+        if isinstance(handle, dict) and handle.get("deferred") and "export_event" not in handle:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().dif_export_pending(ctypes.byref(self.map._cmap), _lib.stream_ptr()), "dif_export_pending")
+                ev = handle["host_slots"][handle["host_out"]]["export_event"]
+                ev.record()
+                handle["export_event"] = ev
+
     def _finish_frame(self, handle, d2h: str):
+        self._export_deferred_now(handle)
         tri, tid, tstd = self.map.extract_mesh_finish(handle)
+        if handle.get("deferred"):
+            handle["export_event"].synchronize()
         out = (tri, tid, tstd)
         if d2h == "new":
             n = tri.size(0)
@@ -205,7 +232,7 @@ class FusionStream:
                                   counters=torch.zeros((_lib.C_COUNT,), dtype=torch.int32).pin_memory(),
                                   out=(torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
                                        torch.empty((cap, 3), dtype=torch.float32).pin_memory()),
-                                  event=torch.cuda.Event()) for _ in range(self.DIRECT_SLOTS)]
+                                  event=torch.cuda.Event(), export_event=torch.cuda.Event()) for _ in range(self.DIRECT_SLOTS)]
             for sl in self._d_slots:
                 sl["frame_np"] = sl["frame"].numpy()
                 sl["counters_np"] = sl["counters"].numpy()
@@ -247,6 +274,7 @@ class FusionStream:
             self._before_frame()
             if m._gc_wanted:
                 self._complete_batch_before_gc(d2h)
+                self._export_deferred_now(self._pending)      # (the pending copy reads log positions that the compaction moves)
                 m._cache_gc()
             self._direct_prepare()
             k = self._d_seq % self.DIRECT_SLOTS
@@ -255,11 +283,20 @@ class FusionStream:
             export = d2h == "new"
             buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"]) if export else (None, None, None)
             buf.out_capacity = self.HOST_OUT_TRIANGLES if export else 0
+            # Deferred export: this frame's extract leaves the copy of its new triangles (~0.5 MB over PCIe) to the FIRST kernel of the next
+            # frame, where it overlaps the point pass instead of lengthening marching cubes; the host picks a frame's triangles up behind
+            # that kernel (`export_event`), still before it enqueues the frame after.
+            buf.defer_export = 1 if (export and self.defer_export) else 0
             sl["frame_np"][:] = self._d_desc[i]
             lib, w, sp = self._d_lib, self._d_w, _lib.stream_ptr()
             H, W, fx, fy, cx, cy = self._d_args
             _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, _lib.ptr(self.xyz),
                                                _lib.ptr(self.nrm), _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
+            p = self._pending
+            if isinstance(p, dict) and p.get("deferred") and "export_event" not in p:
+                ev = p["host_slots"][p["host_out"]]["export_event"]      # the pending frame's triangles have just been copied by this frame's first kernel
+                ev.record()
+                p["export_event"] = ev
             if self.tiling is not None:
                 self._exchange_halo(reserved=True)              # export -> send/recv -> merge, all on this stream, no host wait
             _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std), 0, 1, sp),
@@ -267,7 +304,7 @@ class FusionStream:
             m.mesh_cache.invalidate_host_copy()
             sl["event"].record()
             h = dict(event=sl["event"], counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
-                     host_out=(k if export else None), host_slots=self._d_slots)
+                     host_out=(k if export else None), host_slots=self._d_slots, deferred=bool(buf.defer_export))
         done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
         if done:
             self.backlog += done[:-1]

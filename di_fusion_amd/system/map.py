@@ -173,6 +173,7 @@ class DenseIndexedMap:
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._grid_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
+            self._pending_export = torch.zeros((16,), device=device, dtype=torch.int32)        # dif_pending_export_t, idle all-zero
         self._capacity = 0
         self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
         self._n_occ_ub = 0                  # host-side upper bound of n_occupied (exact after a counter read)
@@ -239,6 +240,7 @@ class DenseIndexedMap:
         m.tri_n = _lib.ptr(tri_n)
         m.own_x_lo, m.own_x_hi, m.halo = getattr(self, "_ownership", (0, self.n_xyz[0], 0))
         m.dirty_tot = _lib.ptr(self._dirty_tot)
+        m.pending_export = _lib.ptr(self._pending_export)
         hl = getattr(self, "_halo_list", None)
         m.halo_list = _lib.ptr(hl)
         m.halo_list_cap = 0 if hl is None else hl.size(1)

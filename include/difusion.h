@@ -101,7 +101,19 @@ typedef struct dif_map {
      * bounded halo messages; NULL: only the whole-layer export (dif_export_halo) is available. */
     int32_t* halo_list;
     int32_t halo_list_cap;
+    /* Optional: one dif_pending_export_t in device memory, all-zero when idle.  With it (and dif_extract_buffers_t.defer_export) a
+     * streaming caller's copy of an extract's new triangles is not written by that extract but by the FIRST kernel of the next
+     * dif_integrate_frame on this map (a few extra workgroups beside the point pass): the PCIe transfer overlaps the next frame
+     * instead of lengthening this one.  dif_export_pending does the same copy on its own (last frame of a stream, before a log compaction). */
+    void* pending_export;
 } dif_map_t;
+
+/* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
+typedef struct dif_pending_export {
+    int32_t pending, kept, n, reserved;
+    const float* log_tri; const int64_t* log_id; const float* log_std;
+    float* out_tri; int64_t* out_id; float* out_std;
+} dif_pending_export_t;
 
 /* Network weights packed for the MFMA kernels by di_fusion_amd/network/packing.py (layout documented there). */
 typedef struct dif_weights {
@@ -275,6 +287,8 @@ typedef struct dif_extract_buffers {
     uint32_t* mc_status;            /* optional [(max_voxels + 3) / 4 + 1], idle 0: with it (and chunk_sum, resolution <= 4) marching cubes is ONE launch:
                                      * a wave counts its voxel's triangles, learns its output offset by a decoupled look-back over groups of
                                      * four voxels and emits straight away (same canonical order) */
+    int32_t defer_export;           /* != 0 (with out_* and dif_map_t.pending_export): do not copy the new triangles to out_* now, leave a
+                                     * dif_pending_export_t for the next dif_integrate_frame / dif_export_pending */
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
@@ -283,6 +297,9 @@ typedef struct dif_extract_buffers {
  * (map.py:698) instead of voxel units.  Triangles come out in canonical order (dirty voxel, cell, table order). */
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution,
                 int32_t fast, float max_std, int32_t no_cache, int32_t scale_vertices, void* stream);
+
+/* Perform the copy a deferred export left pending (dif_map_t.pending_export), if any, and mark it done. */
+int dif_export_pending(const dif_map_t* map, void* stream);
 
 /* Log entries [lo, lo+n) -> (out_tri, out_id, out_std) in one launch.  The destinations may be device-mapped pinned HOST memory: a
  * streaming caller ships each call's new triangles (lo = DIF_C_CACHE_KEPT, n = DIF_C_CACHE_T - lo) without copy-engine transfers. */
