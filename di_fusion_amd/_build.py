@@ -22,6 +22,22 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wno-unused-result", "-DNDEBUG"]
 
 
+# The compiler this tree was validated with (parity suite + tools/determinism_stress.py soak).  The bf16-pipe MLP kernels once showed a
+# schedule-dependent wrong tile with the SLP vectoriser on (see above): a different compiler means a different schedule, so its version is
+# part of the build id, and a build with another one says so loudly (DIF_ALLOW_OTHER_HIPCC=1 silences the warning once the GPU suite and
+# the soak have passed with it).
+VALIDATED_HIPCC = "7.2.26015"
+
+
+def hipcc_version() -> str:
+    try:
+        out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+        m = re.search(r"HIP version:\s*([0-9.]+)", out)
+        return m.group(1) if m else "unknown"
+    except Exception:
+        return "unknown"
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and Path(c).exists():
@@ -48,6 +64,15 @@ def lib_build_id(lib: Path = None):
     return m.group(1).decode() if m else None
 
 
+def lib_hipcc_version(lib: Path = None):
+    """The compiler version the library says it was built with (`dif_build_id()` = "<source hash>:<hipcc version>")."""
+    lib = LIB if lib is None else lib
+    if not lib.exists():
+        return None
+    m = re.search(rb"DIF_BUILD_ID=[0-9a-f]{16}:([0-9A-Za-z.\-]+)", lib.read_bytes())
+    return m.group(1).decode() if m else None
+
+
 def needs_build() -> bool:
     """The shipped library is used only if it was built from exactly this tree (file times say nothing after a checkout or rsync)."""
     return lib_build_id() != source_hash()
@@ -56,7 +81,11 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + [f'-DDIF_BUILD_ID="{source_hash()}"'] + [str(s) for s in SOURCES] + ["-o", str(LIB)]
+    ver = hipcc_version()
+    if not ver.startswith(VALIDATED_HIPCC) and os.environ.get("DIF_ALLOW_OTHER_HIPCC") != "1":
+        print(f"WARNING: libdifusion is being built with hipcc {ver}; the tree was validated with {VALIDATED_HIPCC}. Run `pytest -m gpu` and "
+              "`python tools/determinism_stress.py 400` on the GPU before trusting the MLP kernels of this build.", flush=True)
+    cmd = [hipcc()] + HIPCC_FLAGS + [f'-DDIF_BUILD_ID="{source_hash()}:{ver}"'] + [str(s) for s in SOURCES] + ["-o", str(LIB)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

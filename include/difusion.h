@@ -142,8 +142,9 @@ typedef struct dif_weights {
 } dif_weights_t;
 
 int dif_version(void);
-/* Hash of the sources this library was built from (everything under csrc/ and this header; di_fusion_amd/_build.py computes it and passes it as
- * -DDIF_BUILD_ID): the loader compares it with the tree and rebuilds on a mismatch instead of trusting file times. */
+/* "<hash>:<hipcc version>": hash of the sources this library was built from (everything under csrc/, this header, the compiler flags;
+ * di_fusion_amd/_build.py computes it and passes it as -DDIF_BUILD_ID) — the loader compares it with the tree and rebuilds on a mismatch
+ * instead of trusting file times — and the version of the compiler that built it. */
 const char* dif_build_id(void);
 
 /* ---- a1/a2: depth -> points (ext/imgproc/imgproc.cu:5-44, utils/motion_util.py:322-327) -------------------- */

@@ -32,7 +32,8 @@ def test_library_carries_the_hash_of_the_tree():
     assert _build.lib_build_id() == _build.source_hash()
     h = ctypes.CDLL(str(lib_path))
     h.dif_build_id.restype = ctypes.c_char_p
-    assert h.dif_build_id().decode() == _build.source_hash()
+    assert h.dif_build_id().decode().split(":")[0] == _build.source_hash()
+    assert _build.lib_hipcc_version() == h.dif_build_id().decode().split(":")[1] != ""
     assert not _build.needs_build()
     # a newer file time alone does not trigger a rebuild; a stale id does
     hdr = _build.HEADERS[0]
