@@ -481,8 +481,14 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     VD_STAMP(0);
     constexpr int LDS_W = X6 ? X6_LDS_BYTES / 4 : ((DEC_LDS_FLOATS + 3) & ~3);
+#if defined(DIF_VD_CUT) && DIF_VD_CUT == 0
+    return;                                      // (measurement builds only, tools/sweep_decode.py: what an empty launch of this shape costs)
+#endif
     stage_weights(lds, wblob, X6 ? X6_LDS_BYTES / 4 : DEC_LDS_FLOATS);
     VD_STAMP(1);
+#if defined(DIF_VD_CUT) && DIF_VD_CUT == 1
+    return;                                      // ... + the weight staging
+#endif
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6 ? X6_BYTES / 4 : DEC_FLOATS);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
     const int pair = wid >> 1, tsel = wid & 1;                 // wave `tsel` of the pair that owns the voxel
@@ -520,8 +526,12 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
                     for (int p = lane; p < 256; p += 64) rec[p] = w_fold[p];
                 }
                 VD_STAMP(6);
+#if defined(DIF_VD_CUT) && DIF_VD_CUT == 2
+                sdf = w_fold[lane]; sd = w_fold[lane + 64];      // ... + the fold constants, no MLP tile (the rest of the round runs on garbage)
+#else
                 if constexpr (X6) decoder_tile_folded_x6(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
                 else decoder_tile_folded(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
+#endif
             } else if constexpr (!X6) {
                 f16v xin;
 #pragma unroll
