@@ -368,8 +368,12 @@ def spawn_ranks(a):
 def main():
     import gc
     a = parse()
+    # DIF_BENCH_REHEARSAL=1: every rank on cuda:0, gloo instead of RCCL (which refuses two ranks on one device; the library stages the
+    # messages through pinned host memory) — the multi-rank code paths of this file and of di_fusion_amd.parallel with live processes on
+    # a ONE-GPU box (tests/test_gpu_multiproc.py).  The numbers of such a run mean nothing.
+    rehearsal = os.environ.get("DIF_BENCH_REHEARSAL") == "1"
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        if torch.cuda.device_count() < a.gpus:
+        if torch.cuda.device_count() < a.gpus and not rehearsal:
             raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
         spawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -380,6 +384,8 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("DIF_FORCE_DIST") == "1"      # DIF_FORCE_DIST: exercise the RCCL path with one rank
@@ -387,7 +393,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()                      # first collective: RCCL builds its communicator (and prints its version banner) here,
         torch.cuda.synchronize()            # not inside the timed region
         flush_c_stdio()                     # the banner sits in C stdio's buffer: push it out before any JSON is printed
@@ -469,7 +478,7 @@ def main():
     if n_rec < 0:
         raise SystemExit("dif_profile_dump failed")
     if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=("cpu" if rehearsal else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     hbm_resident = batched = None
@@ -503,7 +512,8 @@ def main():
         pixels = intr.width * intr.height
         value = (a.steps if tiled else world * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
         out = {"metric": f"frames/s integrate+decode+mesh, {intr.width}x{intr.height} synthetic stream", "value": round(value, 3),
-               "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if use_dist else 0, "steps": a.steps, "warmup": a.warmup,
+               "unit": "frames/s", "n_gpus": world, "rccl_ranks": (0 if rehearsal else world) if use_dist else 0,
+               **({"rehearsal": "all ranks on one GPU over gloo: a functional run of the multi-rank paths, not a measurement"} if rehearsal else {}), "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",

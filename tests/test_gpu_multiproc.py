@@ -197,3 +197,34 @@ def test_merge_of_eight_c3_maps_vs_oracle(gpu_model, oracle_net):
     assert n < sum(sizes)
     v = g.extract_mesh_arrays(4, int(8e6), max_std=0.15, to_host=False)
     assert v is not None and v[0].shape[0] > 10_000
+
+
+@pytest.mark.parametrize("mode", ["c4", "tiled"])
+def test_bench_multi_rank_paths_rehearsal(mode):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), both ranks on this box's one
+    GPU over gloo (`DIF_BENCH_REHEARSAL=1`): barrier, max-over-ranks timing, the JSON contract, and — c4 — the all-gather merge of the
+    two maps with the global mesh / — tiled — one 1280x960 stream over two slabs with the per-frame halo exchange.  Numbers mean nothing
+    here; a crash or a hang in these paths would first show up on the 8-GPU node otherwise."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, DIF_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline",
+           "--mode", mode]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    line = [l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3 and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["scaling"] == ("weak" if mode == "c4" else "strong") and "rehearsal" in d
+    if mode == "c4":
+        m = d["config"]["global_map_merge_after_the_clock"]
+        assert "error" not in m, m
+        assert m["global_voxels"] > m["local_voxels_rank0"] > 0 and m["global_mesh_triangles"] > 0
+    else:
+        h = d["config"]["halo_exchange"]
+        assert h["mode"] == "delta" and h["bytes_sent_per_frame"] > 0
