@@ -217,10 +217,12 @@ class FusionStream:
 
     # ---- direct variant: the frame's launches are enqueued by two C calls, the host stays ahead of the GPU ------------------------------
     # The same per-frame protocol as `step_graph` below (frame descriptor in, counters + new triangles out through pinned host memory,
-    # written by the frame's first / last kernel; results picked up one frame later), but the ~17 kernels are launched directly:
-    # `dif_integrate_frame` + `dif_extract` enqueue them back to back in ~60 us of host time for ~250 us of GPU time, so the queue never
-    # runs dry.  A replayed hipGraph has no kernel boundaries inside a frame, but consecutive graph launches on one stream start ~33 us
-    # apart on the GPU (profiles/r02_timeline_graph.txt): the two come out equal, and this path needs no re-capture when a buffer grows.
+    # written by the frame's first / last kernel; results picked up one frame later), but the 12 kernels are launched directly:
+    # `dif_integrate_frame` + `dif_extract` enqueue them back to back in ~60 us of host time for ~190 us of GPU time, so the queue never
+    # runs dry — provided the map has room for the worst-case allocations of the frames in flight (see __init__: otherwise every frame
+    # first waits for its predecessor).  A replayed hipGraph has no kernel boundaries inside a frame, but consecutive graph launches on one
+    # stream start ~33 us apart on the GPU (profiles/r02_timeline_graph.txt); this path is the faster one and needs no re-capture when a
+    # buffer grows.  A frame's new triangles are copied to the host beside the NEXT frame's point kernels (`defer_export`).
     DIRECT_SLOTS = 4
 
     def _direct_prepare(self):
@@ -242,6 +244,8 @@ class FusionStream:
                             for i, (R, t) in enumerate(self.poses)]
         sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES)
         if self._d_sig != sig:                       # (re)build the per-slot buffer descriptors after a re-allocation
+            # (a pending deferred export points into the mesh log: carry it out before anything below may re-allocate that log)
+            self._export_deferred_now(self._pending)
             self._d_bufs = []
             for sl in self._d_slots:
                 _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
