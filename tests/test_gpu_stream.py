@@ -11,11 +11,11 @@ DEV = torch.device("cuda:0")
 N_FRAMES = 6
 
 
-def make_stream(gpu_model):
+def make_stream(gpu_model, initial_capacity=1 << 13):
     from di_fusion_amd.stream import FusionStream
     cfg = S.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)          # 32^3 grid
     intr = S.Intrinsic().scaled(0.25)
-    return FusionStream(gpu_model, S.default_room(), cfg, intr, DEV, N_FRAMES, deg_per_frame=6.0, initial_capacity=1 << 13)
+    return FusionStream(gpu_model, S.default_room(), cfg, intr, DEV, N_FRAMES, deg_per_frame=6.0, initial_capacity=initial_capacity)
 
 
 def snapshot(st):
@@ -99,6 +99,49 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     for a, b in zip(per_frame[1:], got[1:]):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
     same(outs["eager"], snapshot(st))
+
+
+@pytest.mark.parametrize("mix", ["direct", "direct+graph"])
+def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
+    """`step_direct` with the stream's own capacity (room for the frames in flight, so the host never completes a frame early): a frame's new
+    triangles are copied to the pinned slot by the leading workgroups of the NEXT frame's point kernels (`dif_map_t.pending_export`), or —
+    mixed with `step_graph` frames — by a captured graph's first kernels; the last frame's by `dif_export_pending` at flush.  Every frame's
+    triangles and the final map equal the eager stream's, bit for bit; no frame was exported by the fallback path in mid-stream."""
+    st = make_stream(gpu_model)
+    per_frame = []
+    for i in range(N_FRAMES):
+        o = st.step(i, d2h="new")
+        torch.cuda.synchronize()
+        per_frame.append(tuple(x.clone() for x in o))
+    want = snapshot(st)
+    st = make_stream(gpu_model, initial_capacity=None)
+    assert st.map._capacity >= 3 * 7 * (19200 // 17)
+    got, early = [], 0
+    orig = st._export_deferred_now
+
+    def counting(handle):
+        nonlocal early
+        if isinstance(handle, dict) and handle.get("deferred") and "export_event" not in handle:
+            early += 1
+        return orig(handle)
+    st._export_deferred_now = counting
+    st.step(0, d2h="new")
+    torch.cuda.synchronize()
+    got.append(per_frame[0])
+    for i in range(1, N_FRAMES):
+        o = st.step_graph(i, d2h="new") if (mix == "direct+graph" and i % 2 == 0) else st.step_direct(i, d2h="new")
+        if o is not None:
+            torch.cuda.synchronize()
+            got.append(tuple(x.clone() for x in o))
+    in_stream = early
+    o = st.flush()
+    got.append(tuple(x.clone() for x in o))
+    assert len(got) == N_FRAMES
+    for f, (a, b) in enumerate(zip(per_frame[1:], got[1:])):
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), f"frame {f + 1}"
+    same(want, snapshot(st))
+    if mix == "direct":
+        assert in_stream == 0 and early <= 1               # only the last frame (at flush) needed the stand-alone copy
 
 
 def test_batched_graph_matches_frame_by_frame(gpu_model):
