@@ -318,10 +318,16 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, 
         unsigned long long tri_row = ~0ull;
         int64_t vb = 0;
         int bx = 0, by = 0, bz = 0;
+        int64_t slot = 0;
+        int old_n = 0, old_s = 0;
         if (active) {
             vb = a.valid_blocks[k];
             bx = (int)((vb / ((int64_t)a.ny * a.nz)) % a.nx); by = (int)((vb / a.nz) % a.ny); bz = (int)(vb % a.nz);
             if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
+            // the voxel's previous triangle batch (needed only by the emit phase, two dependent look-ups): requested here, beside the
+            // neighbour look-ups, instead of behind the look-back
+            slot = a.indexer[vb];
+            old_n = a.tri_n[slot]; old_s = a.tri_start[slot];
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
             bool any_neg = false, any_pos = false;
@@ -382,13 +388,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, 
             int voxel_offset = s_excl;
             for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[w];
             // mesh-cache log: this voxel's previous batch dies, the voxel points at its new one (map.py:708-709)
-            const int64_t slot = a.indexer[vb];
-            const int old_n = a.tri_n[slot], old_s = a.tri_start[slot];
             for (int j = lane; j < old_n; j += 64) a.tri_alive[old_s + j] = 0;
             int64_t n_new = voxel_total;
             if (voxel_offset + n_new > a.new_limit) n_new = a.new_limit > voxel_offset ? a.new_limit - voxel_offset : 0;      // truncated by max_n_triangles
             if (log_n + voxel_offset + n_new > a.max_triangles) n_new = a.max_triangles > log_n + voxel_offset ? a.max_triangles - (log_n + voxel_offset) : 0;
-            __builtin_amdgcn_wave_barrier();             // every lane has read tri_n / tri_start
             if (lane == 0) {
                 a.tri_start[slot] = (int)(log_n + voxel_offset);
                 a.tri_n[slot] = (int)n_new;
