@@ -757,7 +757,10 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         {
             DirtyFunctor f{ds};
             // every writer of the flags kept the per-block totals (k_fuse; the host recomputes them after anything else): no counting pass
-            if (map->dirty_tot && !no_cache && !tiled) {
+            if (map->dirty_tot && !no_cache && !tiled && map->capacity > 4096 && map->capacity % DIF_BLOCK == 0) {
+                hipLaunchKernelGGL(k_dirty_scan, dim3((int)(map->capacity / DIF_BLOCK)), dim3(DIF_BLOCK), 0, s, ds, n_slots, (const int*)map->dirty_tot);
+                DIF_CHECK_LAUNCH();
+            } else if (map->dirty_tot && !no_cache && !tiled) {
                 if (launch_counted_scan_bounded(f, n_slots, map->capacity, map->dirty_tot, s) != DIF_OK) return DIF_ELAUNCH;
             } else if (launch_scan(f, n_slots, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
         }

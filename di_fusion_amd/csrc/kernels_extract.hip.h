@@ -101,6 +101,76 @@ struct DirtyFunctor {
     }
 };
 
+// The stream's dirty-set compaction (DirtyFunctor through k_scan_pass2_fixed: block b owns slots [256 b, 256 b + 256), the per-block totals
+// were kept by whoever set the flags) with its memory chain started EARLY: a thread reads its flag without waiting for n_occupied (flags
+// beyond it are never set), and a dirty slot's position -> 7 neighbour look-ups -> 7 observation counts -> 7 bitmap words are requested
+// before the two block-wide sums of the prefix, not after them — nine dependent hops become six.
+__global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan(DirtySet a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot) {
+    __shared__ int smem[8];
+    const int s = (int)blockIdx.x * DIF_BLOCK + (int)threadIdx.x;           // grid covers the capacity (a multiple of DIF_BLOCK)
+    const bool flag = a.dirty[s] != 0;
+    if (!__syncthreads_or((int)flag) && blockIdx.x != 0) return;            // nothing dirty among this block's 256 slots (most blocks of a frame)
+    int before = 0, all = 0;
+    const int n_blk = blockIdx.x == 0 ? (int)gridDim.x : (int)blockIdx.x;  // block 0 also reports the grand total
+    for (int b = (int)threadIdx.x; b < n_blk; b += DIF_BLOCK) {
+        const int t = block_tot[b];
+        all += t;
+        if (b < (int)blockIdx.x) before += t;
+    }
+    // ---- the dirty voxel's confident neighbourhood: loads now, bitmap updates after the offsets are known (mark_confident_nbhd) ----
+    const GridMarks& marks = a.bits;
+    int lin = 0, cand[7];
+    uint32_t word[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { cand[c] = 0; word[c] = 0xFFFFFFFFu; }
+    if (flag) {
+        lin = (int)a.pos[s];
+        int ix, iy, iz;
+        unlinearize(a.g, lin, ix, iy, iz);
+        cand[0] = lin;
+        cand[1] = linearize(a.g, clampi(ix - 1, 0, a.g.nx - 1), iy, iz);
+        cand[2] = linearize(a.g, clampi(ix + 1, 0, a.g.nx - 1), iy, iz);
+        cand[3] = linearize(a.g, ix, clampi(iy - 1, 0, a.g.ny - 1), iz);
+        cand[4] = linearize(a.g, ix, clampi(iy + 1, 0, a.g.ny - 1), iz);
+        cand[5] = linearize(a.g, ix, iy, clampi(iz - 1, 0, a.g.nz - 1));
+        cand[6] = linearize(a.g, ix, iy, clampi(iz + 1, 0, a.g.nz - 1));
+        int64_t slot[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) slot[c] = a.indexer[cand[c]];
+        float w[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? a.obs[slot[c]] : a.ignore_th;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) word[c] = (w[c] > a.ignore_th) ? marks.bits[cand[c] >> 5] : 0xFFFFFFFFu;
+    }
+    const int n = *n_ptr;
+    const bool mine = flag && s < n;
+    int offset = block_sum(before, smem);
+    const int total = block_sum(all, smem);
+    int chunk_total;
+    const int ex = block_excl_scan(mine ? 1 : 0, smem, chunk_total);
+    if (mine) {
+        a.dirty[s] = 0;
+        if (offset + ex < a.max_voxels) {
+            a.valid_blocks[offset + ex] = lin;
+            uint32_t prev[7];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const uint32_t b = 1u << (cand[c] & 31);
+                prev[c] = (word[c] & b) ? 0xFFFFFFFFu : atomicOr(marks.bits + (cand[c] >> 5), b);
+            }
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+                if (!(prev[c] & (1u << (cand[c] & 31)))) atomicAdd(marks.tot + (cand[c] >> 5) / marks.per_words, 1);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int t = total;
+        if (t > a.max_voxels) { t = (int)a.max_voxels; a.counters[DIF_C_OVERFLOW] = 2; }
+        a.counters[DIF_C_K] = t;
+    }
+}
+
 struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm[slot] = b; clears the bitmap
     uint32_t* bits;
     const int64_t* indexer;

@@ -10,6 +10,6 @@ print(d["value"], d["ms_per_step"], r["other_ms_per_frame"])
 PY
 done
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python bench.py --no-cpu-baseline --no-secondary > /dev/null 2>&1
-python tools/rocpd_stats.py $(find $out/trace -name "*.db" | head -1) --after-nth k_prune_mark 160 --frames 50 | grep -i "onepass\|finish\|sum of"
-python tools/rocpd_stats.py $(find $out/trace -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 200 | grep -i "onepass\|finish\|sum of"
+python tools/rocpd_stats.py $(find $out/trace -name "*.db" | head -1) --after-nth k_prune_mark 160 --frames 50 | grep -i "onepass\|finish\|sum of\|dirty\|Occ\|Alloc"
+python tools/rocpd_stats.py $(find $out/trace -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 200 | grep -i "onepass\|finish\|sum of\|dirty\|Occ\|Alloc"
 rm -rf $out/trace
