@@ -445,6 +445,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
         int* dir = rec_dir + (int64_t)s * DIF_DIR_WORDS;
         const int n_rec = dir[0];
         const int my_id = (f < DIF_DIR_IDS && f < n_rec) ? dir[2 + f] : -1;       // lane f fetches directory entry f
+        const float w_old = obs[s];                                               // (requested beside the directory, not behind the records)
+        const float z_old = f < L ? latent[(int64_t)s * L + f] : 0.0f;
         long long Si = 0;
         int cnt = 0;
         const int n_dir = n_rec < DIF_DIR_IDS ? n_rec : DIF_DIR_IDS;
@@ -461,15 +463,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
             }
         if (f < L) {
             float S = (float)Si * (1.0f / DIF_FIX_SCALE);    // one rounding: exact integer sum -> nearest float
-            float w_old = obs[s];
-            float z_old = latent[(int64_t)s * L + f];
             S = S + z_old * w_old;                           // map.py:449
             float w_new = w_old + (float)cnt;                // map.py:450
             latent[(int64_t)s * L + f] = S / w_new;          // map.py:451
         }
         __builtin_amdgcn_wave_barrier();
         if (f == 31) {                                       // after every lane of the group has read obs[s]
-            obs[s] = obs[s] + (float)cnt;
+            obs[s] = w_old + (float)cnt;
             dirty[s] = 1;                                    // map.py:452
             dir[0] = 0;
             dir[1] = 0;
