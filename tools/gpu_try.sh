@@ -1,4 +1,5 @@
 #!/bin/bash
+# a quick look after a kernel change: the map / marching-cubes / stream / tiling tests, two bench lines, steady-state and whole-run kernel stats of the changed kernels
 tag=${1:-q}; out=gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests/test_gpu_map.py tests/test_gpu_mc_exhaustive.py tests/test_gpu_stream.py tests/test_gpu_parallel.py "tests/test_gpu_fuzz.py::test_fuzz_marching_cubes" "tests/test_gpu_fuzz.py::test_fuzz_integrate_extract_query[0]" -m gpu -q -x 2>&1 | tail -6
