@@ -766,8 +766,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         }
     }
     {
-        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels,
-                     buf->refine_queue ? buf->refine_queue + buf->max_voxels * (int64_t)R3 : nullptr};
+        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
         if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // the markers kept the block totals
 
     }
@@ -796,21 +795,6 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         }
         int64_t blocks = (buf->max_voxels + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
-        static const bool one_launch = [] { const char* e = getenv("DIF_DECODE_ONE_LAUNCH"); return !(e && e[0] == '0'); }();
-        if (x6 && one_launch && R3 <= VDF_LIST_CAP && buf->refine_queue && blocks < VDF_MAX_VB) {
-            // lattice + refine of a voxel by one pair of waves in one launch (k_decode_voxels_refine)
-            static bool attr_set2[64] = {};
-            const int bytes = (int)((size_t)X6_LDS_BYTES + 4 * VDF_PAIR_FLOATS * 4);
-            if (dev < 64 && !attr_set2[dev]) {
-                if (hipFuncSetAttribute((const void*)k_decode_voxels_refine, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return DIF_ELAUNCH;
-                attr_set2[dev] = true;
-            }
-            V.queue = buf->refine_queue; V.queue_rows = buf->max_voxels * (int64_t)R3;
-            Lattice hi; hi.res = R; hi.a = (float)sample_a; hi.vsize = (float)((sample_b - sample_a) / (R - 1));
-            ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
-            hipLaunchKernelGGL(k_decode_voxels_refine, dim3((int)blocks), dim3(512), (size_t)bytes, s, V, hi, (const float*)w->dec_x6_packed);
-            DIF_CHECK_LAUNCH();
-        } else {
         {
             ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
             if (x6) hipLaunchKernelGGL(k_decode_voxels<true>, dim3((int)blocks), dim3(512), lds_bytes, s, V, (const float*)w->dec_x6_packed);
@@ -834,7 +818,6 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             rc = launch_decode(Rf, w, buf->max_voxels * (int64_t)(R3 / 32), s);
         }
         if (rc != DIF_OK) return rc;
-        }
     } else if (fast) {
         // low lattice decode (map.py:644-653)
         DecodeArgs A = {};

@@ -178,7 +178,6 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
     int32_t* vbm;
     int* counters;
     int64_t max_voxels;
-    int32_t* decode_done;       // control word of the one-launch decode's queue (zero before every launch), or NULL
     __device__ int count(int w) const { return __popc(bits[w]); }
     __device__ void emit(int w, int offset) const {
         uint32_t word = bits[w];
@@ -199,9 +198,6 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
         counters[DIF_C_B] = total;
         counters[DIF_C_VH] = 0;
         counters[DIF_C_WORK] = 0;
-        counters[DIF_C_DECODE_TICKET] = 0;
-        counters[DIF_C_DECODE_TAIL] = 0;
-        if (decode_done) *decode_done = 0;
     }
 };
 
@@ -536,8 +532,6 @@ struct VoxelDecodeArgs {
     int* counters;
     const float* fold_w;            // packing.py:pack_decoder_fold, or NULL (latent carried through the MFMAs)
     float* fold_table;              // [batch voxel][256] out, for the refine pass
-    int32_t* queue;                 // k_decode_voxels_refine: refine tiles (32 entries each) in flight, all -1 between launches
-    int64_t queue_rows;
 };
 
 #define VD_MAX_L3 64
@@ -668,262 +662,3 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
     VD_STAMP(5);
 }
 
-// Lattice + refine in ONE launch on the bf16 matrix pipe (fast two-level decode, resolution <= 4).
-//
-// Phase L — a pair of waves owns a voxel: fold constants, the two 32-sample tiles of the low lattice into the pair's LDS record, the
-// trilinear x2 (each wave half of the z samples; an interpolated value is written only where the sample is NOT re-decoded), the
-// |sdf| < 0.05 samples compacted into the pair's LDS list (wave 0 from the front, wave 1 from the back).  Wave 0 then publishes the
-// voxel's refine work: the fold constants to the voxel's row of the fold table and the selected samples, padded to whole 32-row
-// tiles, to a queue in HBM whose space it reserves with ONE atomic.  The only synchronisation of the phase is between the two waves
-// of a pair (two hand-overs per voxel through an LDS arrival counter): the pairs of a workgroup drift apart, one pair's VALU / store
-// phases overlap the other's tiles.
-// Phase R — every wave of the launch, once its workgroup has no voxels left, decodes queue tiles (tile t belongs to wave
-// t mod waves, the waves with the least lattice work first): it polls the tile's 128-byte line until the 32 entries are there, stages
-// the voxel's fold constants into its LDS record, runs the same MLP tile, writes the cube samples and hands the line back empty.
-//
-// Cross-XCD visibility without fences: everything a consumer reads from another workgroup is written with sc1 (write-through)
-// stores and read with sc1 loads — table row, then `s_waitcnt vmcnt(0)`, then the tile's entries, which double as its ready flag
-// (all 32 != -1); the end of production is a counter of finished (virtual) workgroups behind drained stores.
-// No deadlock without co-residency: voxels belong to VIRTUAL workgroups that the resident ones claim through a ticket until none is
-// left, and only then does a wave start to wait for queue entries — every entry it can wait for is being produced by a running wave.
-// Per-row results do not depend on which rows share a tile: bit-identical to k_decode_voxels + k_decode_refine_x6.
-#define VDF_LIST_CAP 512                    /* R^3 <= 512 samples per voxel (R <= 8) */
-#define VDF_PAIR_FLOATS (2 * VD_MAX_L3 + 2 * 256 + VDF_LIST_CAP / 2 + 4)      /* low sdf | low std | fold constants x2 | u16 list | n0 n1 arrivals - */
-#define VDF_MAX_VB 257                      /* virtual workgroups a resident one may end up claiming (grid <= 256) + the failed claim */
-#ifndef DIF_VDF_SLEEP
-#define DIF_VDF_SLEEP 8
-#endif
-#define VDF_SC1 16                          /* aux bits of the raw buffer intrinsics: sc1 */
-
-// hand-over between the two waves of a pair: arrival counter in LDS, counts up for the whole launch; target = 2 x (hand-overs so far).
-// LDS operations of a wave execute in order, so the arrival is behind the wave's earlier LDS writes; the compiler must not move any.
-__device__ __forceinline__ void pair_sync(int* arrivals, int target) {
-    asm volatile("" ::: "memory");
-    if (lane_id() == 0) {
-        __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-
-__device__ __forceinline__ int load_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__global__ void __launch_bounds__(512, 1) k_decode_voxels_refine(VoxelDecodeArgs A, Lattice hi, const float* __restrict__ wblob) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LDS_W = X6_LDS_BYTES / 4;
-    constexpr int UNCLAIMED = -2, CLAIMING = -3;
-    __shared__ int s_vh[8], s_vb[VDF_MAX_VB], s_fin[VDF_MAX_VB], s_end, s_next;
-    const int lane = lane_id(), half = lane >> 5, col = lane & 31, wid = threadIdx.x >> 6;
-    const int pair = wid >> 1, tsel = wid & 1, G = (int)gridDim.x;
-    float* p_low_sdf = lds + LDS_W + pair * VDF_PAIR_FLOATS;
-    float* p_low_std = p_low_sdf + VD_MAX_L3;
-    float* w_fold = p_low_std + VD_MAX_L3 + tsel * 256;
-    unsigned short* p_list = reinterpret_cast<unsigned short*>(p_low_std + VD_MAX_L3 + 2 * 256);
-    int* p_n = reinterpret_cast<int*>(p_list + VDF_LIST_CAP);         // [0], [1]: the two waves' counts; [2]: arrivals
-    int* const C = A.counters;
-    VD_STAMP(0);
-    int dbg_tiles = 0, dbg_polls = 0;
-    if (lane == 0 && tsel == 0) p_n[2] = 0;
-    if (threadIdx.x == 0) { s_end = 0; s_next = 0; }
-    int32_t* const done_word = A.queue + A.queue_rows;           // its own 128-byte line: polled, unlike the counters the atomics go to
-    for (int i = (int)threadIdx.x; i < VDF_MAX_VB; i += (int)blockDim.x) { s_vb[i] = UNCLAIMED; s_fin[i] = 0; }
-    __syncthreads();
-    if (threadIdx.x == 0) s_vb[0] = __hip_atomic_fetch_add(C + DIF_C_DECODE_TICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stage_weights(lds, wblob, X6_LDS_BYTES / 4);                        // ends with a workgroup barrier
-    const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
-    const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
-    const float scale = (float)(l - 1) / (float)(R - 1);
-    const int B = C[DIF_C_B];
-    const int jz0 = tsel * (R >> 1), jz1 = jz0 + (R >> 1);      // this wave's share of the z samples
-    // phase R: tile t of the queue belongs to workgroup t mod G; inside the workgroup the waves take the tiles as they come free
-    // (an LDS ticket): the pairs without voxels start at once, a pair with many voxels joins late or never
-    int64_t tile = -1;
-    int vh = 0, syncs = 0, k = 0, vb = -1, b = B;
-    bool producing = true;
-    for (;;) {
-        int s = 0;
-        bool live = false, is_lattice = false;
-        float px = 0.0f, py = 0.0f, pz = 0.0f;
-        int64_t eb = 0;
-        if (producing) {
-            // ---- the next voxel of this pair: b = pair G + vb + round 4 G over the virtual workgroups vb this workgroup claims ----
-            if (vb >= 0) b += 4 * G;
-            while (b >= B) {
-                if (vb >= 0) {      // this wave is through with virtual workgroup k - 1: its queue stores are drained before it says so
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0 && __hip_atomic_fetch_add(&s_fin[k - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 7)
-                        __hip_atomic_fetch_add(done_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                int v = 0;
-                if (lane == 0) {
-                    v = __hip_atomic_load(&s_vb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (v == UNCLAIMED) {
-                        int expected = UNCLAIMED;
-                        if (__hip_atomic_compare_exchange_strong(&s_vb[k], &expected, CLAIMING, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                            v = __hip_atomic_fetch_add(C + DIF_C_DECODE_TICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&s_vb[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        } else v = expected;
-                    }
-                    while (v == CLAIMING) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(&s_vb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-                }
-                vb = __builtin_amdgcn_readfirstlane(v);
-                ++k;
-                if (vb >= G) { producing = false; VD_STAMP(1); break; }
-                b = pair * G + vb;
-            }
-        }
-        if (producing) {
-            is_lattice = true;
-            decoder_fold_consts_x6(lds, A.fold_w, A.latent + (int64_t)A.occ_slot[b] * L, w_fold, lane);
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (tsel == 0) {        // the voxel's row of the fold table goes out now: it has landed long before the queue entries that point at it
-                const __amdgpu_buffer_rsrc_t fr = make_rsrc(A.fold_table + (int64_t)b * 256, 256);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, reinterpret_cast<const f4v*>(w_fold)[lane]), fr, lane * 16, 0, VDF_SC1);
-            }
-            eb = (int64_t)b * R3;
-            s = tsel * 32 + col;
-            live = s < l3;
-            px = A.low.coord(s / (l * l)); py = A.low.coord((s / l) % l); pz = A.low.coord(s % l);
-        } else {
-#if defined(DIF_VDF_EXP) && (DIF_VDF_EXP == 1 || DIF_VDF_EXP == 2)
-            break;
-#endif
-            // ---- the next queue tile of this wave: wait for its 32 entries, or for the end of production ----
-            int pop = 0;
-            if (lane == 0) pop = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            tile = (int64_t)__builtin_amdgcn_readfirstlane(pop) * G + (int)blockIdx.x;
-            const __amdgpu_buffer_rsrc_t q = make_rsrc(reinterpret_cast<const float*>(A.queue + tile * 32), 32);
-            int e;
-            bool end = false;
-            for (int polls = 0;; ++polls) {
-                e = (tile * 32 < A.queue_rows) ? (int)__builtin_amdgcn_raw_buffer_load_b32(q, col * 4, 0, VDF_SC1) : -1;
-                ++dbg_polls;
-                if (__builtin_amdgcn_ballot_w64(e == -1) == 0) break;
-                // the end of production: looked up once in a while, one wave's sighting serves the workgroup
-                int over = __hip_atomic_load(&s_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!over && (polls & 7) == 7 && load_agent(done_word) >= G) {
-                    over = 1;
-                    if (lane == 0) __hip_atomic_store(&s_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                if (over) {                                                  // every reservation is in, every entry is visible
-                    if (tile * 32 >= (int64_t)load_agent(C + DIF_C_DECODE_TAIL)) { end = true; break; }
-                } else __builtin_amdgcn_s_sleep(DIF_VDF_SLEEP);
-            }
-            if (end) break;
-            if (dbg_tiles == 0) VD_STAMP(2);
-            const int e0 = __builtin_amdgcn_readfirstlane(e);                 // the first entry of a tile is always a sample
-            const int tb = e0 / R3;
-            eb = (int64_t)tb * R3;
-            // the voxel's fold constants: one 16-byte sc1 load per lane into this wave's LDS record
-            const __amdgpu_buffer_rsrc_t fr = make_rsrc(A.fold_table + (int64_t)tb * 256, 256);
-            const f4v rec = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(fr, lane * 16, 0, VDF_SC1));
-            reinterpret_cast<f4v*>(w_fold)[lane] = rec;
-            if (lane < 8) {                                                   // the line goes back empty
-                const u4v empty = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-                __builtin_amdgcn_raw_buffer_store_b128(empty, q, lane * 16, 0, VDF_SC1);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            live = e >= 0;
-            s = live ? e - tb * R3 : 0;
-            px = hi.coord(s / R2); py = hi.coord((s / R) % R); pz = hi.coord(s % R);
-        }
-        float sdf = 0.0f, sd = 0.0f;
-        if (!is_lattice || tsel * 32 < l3) decoder_tile_folded_x6(lds, wfwd, FoldInitLds{w_fold}, px, py, pz, lane, sdf, sd);
-        if (!is_lattice) {
-            if (live) {
-                if (half == 0) A.cube_sdf[eb + s] = -sdf;
-                else A.cube_std[eb + s] = sd;
-            }
-            if (dbg_tiles == 0) VD_STAMP(3);
-            ++dbg_tiles;
-            continue;
-        }
-        if (live) {
-            if (half == 0) p_low_sdf[s] = sdf;
-            else p_low_std[s] = sd;
-        }
-        syncs += 2; pair_sync(p_n + 2, syncs);                  // both tiles of the low lattice are in LDS
-        // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z, this wave's half of them ----
-        unsigned sel = 0;
-        float keep_s[4] = {}, keep_d[4] = {};                             // the interpolated samples are stored after the hand-over (R <= 8: 4 z per wave)
-        if (lane < R2) {
-            const int jx = lane / R, jy = lane % R;
-            int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
-            tri_axis(jx, l, scale, x0, x1, wx0, wx1);
-            tri_axis(jy, l, scale, y0, y1, wy0, wy1);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int jz = jz0 + u;
-                if (u < (R >> 1)) {
-                    int z0, z1; float wz0, wz1;
-                    tri_axis(jz, l, scale, z0, z1, wz0, wz1);
-                    const float sv = tri_sample(p_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                    const float dv = tri_sample(p_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                    if (fabsf(sv) < 0.05f) sel |= 1u << jz;     // re-decoded in phase R: the exact value is the only one written
-                    keep_s[u] = -sv; keep_d[u] = dv;
-                }
-            }
-        }
-        const unsigned sel_all = sel;
-        const int c = __popc(sel);
-        const int incl = wave_incl_scan(c);
-        const int total = __shfl(incl, 63);
-        int o = incl - c;
-        while (sel) {
-            const int jz = __ffs((int)sel) - 1;
-            sel &= sel - 1;
-            p_list[tsel ? VDF_LIST_CAP - 1 - o : o] = (unsigned short)(lane * R + jz);
-            ++o;
-        }
-        if (lane == 0) p_n[tsel] = total;
-        vh += total;
-        syncs += 2; pair_sync(p_n + 2, syncs);                  // the list and both counts are complete
-#if defined(DIF_VDF_EXP) && DIF_VDF_EXP == 2
-        if (false) {
-#else
-        if (tsel == 0) {
-#endif
-            // ---- publish the voxel's refine work ----
-            const int n0 = p_n[0], n = n0 + p_n[1];
-            if (n > 0) {
-                const int padded = (n + 31) & ~31;
-                int base = 0;
-                if (lane == 0) base = __hip_atomic_fetch_add(C + DIF_C_DECODE_TAIL, padded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                base = __builtin_amdgcn_readfirstlane(base);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the table row is out before any entry says "ready"
-                const __amdgpu_buffer_rsrc_t q = make_rsrc(reinterpret_cast<const float*>(A.queue + base), padded);
-                for (int r0 = lane * 4; r0 < padded; r0 += 256) {
-                    u4v ev;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int r = r0 + u;
-                        ev[u] = (r < n) ? (unsigned)((int)eb + (int)p_list[r < n0 ? r : VDF_LIST_CAP - 1 - (r - n0)]) : 0xfffffffeu;      // -2: padding
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(ev, q, r0 * 4, 0, VDF_SC1);
-                }
-            }
-            VD_STAMP(6);
-        }
-        if (lane < R2) {
-            const int64_t e0 = eb + (int64_t)lane * R;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < (R >> 1) && !((sel_all >> (jz0 + u)) & 1u)) { A.cube_sdf[e0 + jz0 + u] = keep_s[u]; A.cube_std[e0 + jz0 + u] = keep_d[u]; }
-        }
-    }
-    VD_STAMP(4);
-#ifdef DIF_TRACE
-    if (lane == 0) { g_vd_trace[(wid * gridDim.x + blockIdx.x) * 8 + 5] = dbg_tiles; g_vd_trace[(wid * gridDim.x + blockIdx.x) * 8 + 7] = dbg_polls; }
-#endif
-    // the number of re-decoded rows of the launch (DIF_C_VH): one atomic per workgroup
-    if (lane == 0) s_vh[wid] = vh;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int sum = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += s_vh[w];
-        if (sum) atomicAdd(C + DIF_C_VH, sum);
-    }
-}

@@ -613,8 +613,7 @@ class DenseIndexedMap:
                      block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev),
                      chunk_sum=torch.zeros(((max_vox + 255) // 256 + (max_vox + 65535) // 65536,), dtype=torch.int32, device=dev),
                      mc_status=torch.zeros(((max_vox + 3) // 4 + 1,), dtype=torch.int32, device=dev),
-                     fold_table=torch.zeros((max_vox, 256), dtype=torch.float32, device=dev),
-                     refine_queue=torch.full((max_vox * R ** 3 + 32,), -1, dtype=torch.int32, device=dev))
+                     fold_table=torch.empty((max_vox, 256), dtype=torch.float32, device=dev))
             self._xbuf = (key, t)
         t = self._xbuf[1]
         # the log must always have room for two calls' worth of output beyond what the host last saw (counters lag one frame

@@ -59,9 +59,6 @@ enum {
     DIF_C_HALO_L = 20,      /* entries appended to the LEFT / RIGHT boundary change list (dif_map_t.halo_list) since the last    */
     DIF_C_HALO_R = 21,      /* halo export; may exceed halo_list_cap (then the list is incomplete and the delta export says so)   */
     DIF_C_HALO_TICKET = 22, /* idle 0: workgroups of dif_export_halo_delta that are done                                          */
-    DIF_C_DECODE_TICKET = 23, /* one-launch decode: virtual workgroups claimed / finished with their lattice work, rows (padded to    */
-    DIF_C_DECODE_DONE = 24,   /* whole 32-row tiles) reserved in dif_extract_buffers_t.refine_queue; zeroed by the extract's scan      */
-    DIF_C_DECODE_TAIL = 25,
     DIF_C_COUNT = 32
 };
 
@@ -293,10 +290,6 @@ typedef struct dif_extract_buffers {
                                      * four voxels and emits straight away (same canonical order) */
     int32_t defer_export;           /* != 0 (with out_* and dif_map_t.pending_export): do not copy the new triangles to out_* now, leave a
                                      * dif_pending_export_t for the next dif_integrate_frame / dif_export_pending */
-    int32_t* refine_queue;          /* optional [max_voxels*R^3 + 32], all -1 between calls (the consumers hand every line back empty; the last 32
-                                     * entries are control words the library resets itself): with it (and
-                                     * fold_table, the bf16 decoder blobs, resolution <= 4) the fast two-level decode is ONE launch — refine rows
-                                     * travel from the waves that select them to the waves that decode them as 32-entry tiles of this queue */
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
