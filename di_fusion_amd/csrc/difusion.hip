@@ -240,7 +240,7 @@ struct CloudWs {
     CloudGrid g;
     int* block_tmp;
     int64_t T;
-    size_t o_keys, o_cnt, o_end, o_sorted, keys_cnt_bytes, sorted_bytes;
+    size_t o_tab, o_sorted, tab_bytes, sorted_bytes;
     int64_t total_bytes;
 };
 
@@ -253,19 +253,15 @@ static int carve_cloud(int64_t n, void* base, CloudWs& ws) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     ws.T = T;
-    ws.o_keys = take((size_t)T * 8);
-    ws.o_cnt = take((size_t)T * 4);             // keys and cnt are adjacent: one memset region each
-    ws.o_end = take((size_t)T * 4);
+    ws.o_tab = take((size_t)T * sizeof(CloudEntry));
     ws.o_sorted = take((size_t)n * 16);
     size_t o_slot = take((size_t)n * 4), o_tmp = take(4096 * 4);
-    ws.keys_cnt_bytes = (size_t)T * 8;
+    ws.tab_bytes = (size_t)T * sizeof(CloudEntry);
     ws.sorted_bytes = (size_t)n * 16;
     ws.total_bytes = (int64_t)off;
     if (base) {
         char* b = (char*)base;
-        ws.g.keys = (unsigned long long*)(b + ws.o_keys);
-        ws.g.cnt = (int*)(b + ws.o_cnt);
-        ws.g.end = (int*)(b + ws.o_end);
+        ws.g.tab = (CloudEntry*)(b + ws.o_tab);
         ws.g.sorted = (float4*)(b + ws.o_sorted);
         ws.g.slot = (int*)(b + o_slot);
         ws.block_tmp = (int*)(b + o_tmp);
@@ -282,12 +278,11 @@ static int cloud_build(const float* pc, int64_t n, int stride, float radius, int
     if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
     ws.g.c = radius / (float)rings * 1.002f;    // ring `rings` then bounds every unvisited point beyond the radius (see k_cloud_query)
     ws.g.inv_c = 1.0f / ws.g.c;
-    if (hipMemsetAsync(ws.g.keys, 0xFF, ws.keys_cnt_bytes, s) != hipSuccess) return DIF_ELAUNCH;
-    if (hipMemsetAsync(ws.g.cnt, 0, (size_t)ws.T * 4, s) != hipSuccess) return DIF_ELAUNCH;
-    if (hipMemsetAsync(ws.g.sorted, 0xFF, ws.sorted_bytes, s) != hipSuccess) return DIF_ELAUNCH;   // original index -1 = unused row
+    // the table (key = empty, count - 1 = -1) and the rows (original index -1 = unused row) are adjacent: one all-ones fill
+    if (hipMemsetAsync(ws.g.tab, 0xFF, (size_t)((char*)ws.g.sorted - (char*)ws.g.tab) + ws.sorted_bytes, s) != hipSuccess) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_cloud_insert, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, ws.g, pc, (int)n, stride);
     DIF_CHECK_LAUNCH();
-    CloudStartFunctor f{ws.g.cnt, ws.g.end};
+    CloudStartFunctor f{ws.g.tab};
     if (launch_scan(f, nullptr, (int)ws.T, ws.T, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_cloud_place, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, ws.g, pc, (int)n, stride);
     DIF_CHECK_LAUNCH();
@@ -304,6 +299,12 @@ static int cloud_query(const CloudWs& ws, const float* pc, int64_t n, int stride
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
+
+// Cell size = radius / rings.  Any value gives the same (exact) result; what changes is the cost split between cells walked (a sparse
+// neighbourhood walks all (2 rings + 1)^3 of them, and a wave waits for its slowest lane) and candidates tested per cell.  Measured on
+// depth-frame clouds (tools/bench_cloud.py): at the tracker's half resolution (76.8 k points) the coarser grid wins by 1.6-2.1x, at full
+// resolution (307 k points, 4x the density) the finer one by 1.1-1.25x; the point count is the only density cue the host has.
+static int cloud_rings(int64_t n, int sparse, int dense) { return n <= 131072 ? sparse : dense; }
 
 static bool cloud_args_ok(const float* pc, int64_t n, int stride, int k, float radius, const void* out, const void* ws) {
     return n >= 0 && (stride == 3 || stride == 4) && k >= 1 && k <= 32 && radius > 0.0f && radius < 1e6f && (n == 0 || (pc && out && ws));
@@ -322,7 +323,7 @@ int dif_knn(const float* pc, int64_t n, int32_t stride, int32_t k, float radius,
     if (!cloud_args_ok(pc, n, stride, k, radius, out_idx, wsp) || (n > 0 && !out_dist)) return DIF_EINVAL;
     if (n == 0) return DIF_OK;
     CloudWs ws;
-    const int rings = 4;
+    const int rings = cloud_rings(n, 2, 4);
     int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
     if (rc != DIF_OK) return rc;
     CloudQueryOut out{};
@@ -335,7 +336,7 @@ int dif_remove_radius_outlier(const float* pc, int64_t n, int32_t stride, int32_
     if (!cloud_args_ok(pc, n, stride, nb_points, radius, out_mask, wsp)) return DIF_EINVAL;
     if (n == 0) return DIF_OK;
     CloudWs ws;
-    const int rings = 2;        // only "are there nb_points inside the radius" is asked: coarse cells, at most 125 of them
+    const int rings = cloud_rings(n, 1, 2);      // only "are there nb_points inside the radius" is asked: coarse cells, 27 or 125 of them at most
     int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
     if (rc != DIF_OK) return rc;
     CloudQueryOut out{};
@@ -348,7 +349,7 @@ int dif_estimate_normals(const float* pc, int64_t n, int32_t stride, int32_t max
     if (!cloud_args_ok(pc, n, stride, max_nn, radius, out_normals, wsp) || !cam_xyz) return DIF_EINVAL;
     if (n == 0) return DIF_OK;
     CloudWs ws;
-    const int rings = 4;
+    const int rings = cloud_rings(n, 2, 4);
     int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
     if (rc != DIF_OK) return rc;
     CloudQueryOut out{};

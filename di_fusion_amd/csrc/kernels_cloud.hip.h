@@ -9,10 +9,12 @@
 #define CLOUD_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define CLOUD_OFF (1 << 20)
 
+// One table entry = one 16-byte load: the cell key, its point count MINUS ONE (the table is cleared to all-ones, the first point of a
+// cell brings the count to 0) and, after placement, one past the cell's last row in `sorted`.
+struct CloudEntry { unsigned long long key; int cnt_m1; int end; };
+
 struct CloudGrid {
-    unsigned long long* keys;   // [T] cell key or CLOUD_EMPTY
-    int* cnt;                   // [T] points in the cell
-    int* end;                   // [T] after placement: one past the cell's last row in `sorted`
+    CloudEntry* tab;            // [T]
     float4* sorted;             // [n] (x, y, z, original index as int bits), grouped by cell
     int* slot;                  // [n] table slot of point i, -1 = not a finite point
     unsigned mask;              // T - 1
@@ -39,16 +41,6 @@ __device__ __forceinline__ unsigned cloud_hash(const CloudGrid& g, unsigned long
     return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> g.shift);
 }
 
-__device__ __forceinline__ int cloud_find(const CloudGrid& g, unsigned long long key) {
-    unsigned h = cloud_hash(g, key);
-    while (true) {
-        unsigned long long k = g.keys[h];
-        if (k == key) return (int)h;
-        if (k == CLOUD_EMPTY) return -1;
-        h = (h + 1) & g.mask;
-    }
-}
-
 __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_insert(CloudGrid g, const float* __restrict__ pc, int n, int stride) {
     for (int i = blockIdx.x * DIF_BLOCK + threadIdx.x; i < n; i += gridDim.x * DIF_BLOCK) {
         const float* p = pc + (size_t)i * stride;
@@ -58,22 +50,21 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_insert(CloudGrid g, const f
             unsigned long long key = cloud_key(cx, cy, cz);
             unsigned h = cloud_hash(g, key);
             while (true) {
-                unsigned long long prev = atomicCAS(&g.keys[h], CLOUD_EMPTY, key);
+                unsigned long long prev = atomicCAS(&g.tab[h].key, CLOUD_EMPTY, key);
                 if (prev == CLOUD_EMPTY || prev == key) break;
                 h = (h + 1) & g.mask;
             }
             slot = (int)h;
-            atomicAdd(&g.cnt[h], 1);
+            atomicAdd(&g.tab[h].cnt_m1, 1);
         }
         g.slot[i] = slot;
     }
 }
 
 struct CloudStartFunctor {
-    const int* cnt;
-    int* end;
-    __device__ int count(int i) const { return cnt[i]; }
-    __device__ void emit(int i, int off) const { end[i] = off; }     // becomes the placement cursor
+    CloudEntry* tab;
+    __device__ int count(int i) const { return tab[i].key == CLOUD_EMPTY ? 0 : tab[i].cnt_m1 + 1; }
+    __device__ void emit(int i, int off) const { tab[i].end = off; }     // becomes the placement cursor
     __device__ void finish(int) const {}
 };
 
@@ -82,41 +73,40 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_place(CloudGrid g, const fl
         int slot = g.slot[i];
         if (slot < 0) continue;
         const float* p = pc + (size_t)i * stride;
-        int pos = atomicAdd(&g.end[slot], 1);
+        int pos = atomicAdd(&g.tab[slot].end, 1);
         g.sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
     }
 }
 
 // ---- bounded top-K under the total order (d2, index) -------------------------------------------------------------------
+// Entries are 64-bit keys (float bits of d2 in the high word — d2 >= 0 and never NaN, so the bit patterns order like the values — and
+// the point index in the low word): one unsigned compare decides the order.
+__device__ __forceinline__ unsigned long long cloud_pack(float d2, int idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)idx; }
+
 template <int K>
 struct TopK {
-    // vector-typed so the list lives in VGPRs whatever the unroller decides (a plain array of 16 landed in scratch)
-    float __attribute__((ext_vector_type(K))) d;
-    int __attribute__((ext_vector_type(K))) id;
+    unsigned long long kv[K];       // fully unrolled accesses only: stays in registers
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int j = 0; j < K; ++j) { d[j] = __builtin_inff(); id[j] = 0x7FFFFFFF; }
+        for (int j = 0; j < K; ++j) kv[j] = cloud_pack(__builtin_inff(), 0x7FFFFFFF);
     }
-    __device__ __forceinline__ void push(float dist, int idx) {
-        if (!(dist < d[K - 1] || (dist == d[K - 1] && idx < id[K - 1]))) return;
-        float cd = dist;
-        int ci = idx;
+    __device__ __forceinline__ unsigned long long worst() const { return kv[K - 1]; }
+    __device__ __forceinline__ void insert(unsigned long long ck) {        // ck < worst() is the caller's business; branch-free
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            bool lt = cd < d[j] || (cd == d[j] && ci < id[j]);
-            float td = d[j];
-            int ti = id[j];
-            d[j] = lt ? cd : td;
-            id[j] = lt ? ci : ti;
-            cd = lt ? td : cd;
-            ci = lt ? ti : ci;
+            const bool lt = ck < kv[j];
+            const unsigned long long t = kv[j];
+            kv[j] = lt ? ck : t;
+            ck = lt ? t : ck;
         }
     }
-    __device__ __forceinline__ float kth(int k) const {   // d[k-1] without dynamic register indexing
-        float v = d[K - 1];
+    __device__ __forceinline__ float d(int j) const { return __uint_as_float((unsigned)(kv[j] >> 32)); }
+    __device__ __forceinline__ int id(int j) const { return (int)(unsigned)kv[j]; }
+    __device__ __forceinline__ float kth(int k) const {   // d(k-1) without dynamic register indexing
+        unsigned long long v = kv[K - 1];
 #pragma unroll
-        for (int j = 0; j < K - 1; ++j) v = (j == k - 1) ? d[j] : v;
-        return v;
+        for (int j = 0; j < K - 1; ++j) v = (j == k - 1) ? kv[j] : v;
+        return __uint_as_float((unsigned)(v >> 32));
     }
 };
 
@@ -170,9 +160,17 @@ struct CloudQueryOut {
 
 // One thread per point, in cell order (so a wave's lanes walk the same few cells).  Ring rho = the shell of cells at Chebyshev
 // distance rho from the query's cell; once rings 0..rho are done every unvisited point is farther than rho*c.
+// The search is a chain of dependent look-ups (cell -> table entry -> rows) over 27-125 cells per point, and a frame's cloud is barely
+// one wave per SIMD: what a thread has in flight decides the run time.  So a shell is walked CLOUD_NB cells at a time — their first-probe
+// table entries (one 16-byte load each: key, count, row range) are requested together — and the rows of the batch's non-empty cells are
+// walked as one flat sequence, CLOUD_U row loads at a time (the cells' row ranges wait in a per-thread strip of LDS).
+#define CLOUD_NB 16
+#define CLOUD_U 4
+
 template <int K, int MODE>
 __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const float* __restrict__ pc, int n, int stride, int k, float radius,
                                                            int max_ring, CloudQueryOut out) {
+    __shared__ int2 s_run[CLOUD_NB * DIF_BLOCK];           // [cell of the batch][thread]: (first row - rows before it in the batch, rows before it)
     const int row = blockIdx.x * DIF_BLOCK + threadIdx.x;
     // rows of `sorted` beyond the finite points do not exist; the finite count is the table's total
     if (row >= n) return;
@@ -183,28 +181,105 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
     int cx, cy, cz;
     cloud_cell(g, q.x, q.y, q.z, cx, cy, cz);
     const float r2 = radius * radius;
+    const uint4* __restrict__ tab4 = reinterpret_cast<const uint4*>(g.tab);
+    int2* const run = s_run + threadIdx.x;
     TopK<K> top;
     top.init();
+    int inside = 0;
     for (int rho = 0; rho <= max_ring; ++rho) {
-        for (int dx = -rho; dx <= rho; ++dx) {
-            for (int dy = -rho; dy <= rho; ++dy) {
-                const bool face = (dx == -rho) || (dx == rho) || (dy == -rho) || (dy == rho);
-                const int step = (face || rho == 0) ? 1 : 2 * rho;      // interior columns: only the two end caps
-                for (int dz = -rho; dz <= rho; dz += step) {
-                    int s = cloud_find(g, cloud_key(cx + dx, cy + dy, cz + dz));
-                    if (s < 0) continue;
-                    const int e = g.end[s], b = e - g.cnt[s];
-                    for (int j = b; j < e; ++j) {
-                        const float4 p = g.sorted[j];
-                        const float ex = p.x - q.x, ey = p.y - q.y, ez = p.z - q.z;
+        int dx = -rho, dy = -rho, dz = -rho;               // the shell in the order of three nested loops, interior columns reduced to their end caps
+        bool more = true;
+        while (more) {
+            uint4 ent[CLOUD_NB];
+            int off[CLOUD_NB];
+            // kNN / normals: a cell whose nearest corner is strictly farther than the k-th distance so far (ties go by index) is not looked up
+            // at all.  The cell's box from the integer coordinates, shrunk by the same 1e-3 c that the ring bound below allows for floor()
+            // rounding.  (For the outlier count the same test against the radius costs more than it saves: measured.)
+            const float far2 = top.kth(k);
+#pragma unroll
+            for (int b = 0; b < CLOUD_NB; ++b) {
+                off[b] = -1;
+                ent[b] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+                if (more) {
+                    bool look = true;
+                    if (MODE != CLOUD_OUTLIER) {
+                        const float gx = dx < 0 ? q.x - (float)(cx + dx + 1) * g.c : dx > 0 ? (float)(cx + dx) * g.c - q.x : 0.0f;
+                        const float gy = dy < 0 ? q.y - (float)(cy + dy + 1) * g.c : dy > 0 ? (float)(cy + dy) * g.c - q.y : 0.0f;
+                        const float gz = dz < 0 ? q.z - (float)(cz + dz + 1) * g.c : dz > 0 ? (float)(cz + dz) * g.c - q.z : 0.0f;
+                        const float slack = 1e-3f * g.c;
+                        const float hx = fmaxf(gx - slack, 0.0f), hy = fmaxf(gy - slack, 0.0f), hz = fmaxf(gz - slack, 0.0f);
+                        look = (hx * hx + hy * hy) + hz * hz <= far2;
+                    }
+                    if (look) {
+                        off[b] = ((dx + 64) << 16) | ((dy + 64) << 8) | (dz + 64);
+                        ent[b] = tab4[cloud_hash(g, cloud_key(cx + dx, cy + dy, cz + dz))];
+                    }
+                    const bool face = (dx == -rho) || (dx == rho) || (dy == -rho) || (dy == rho);
+                    dz += (face || rho == 0) ? 1 : 2 * rho;
+                    if (dz > rho) { dz = -rho; if (++dy > rho) { dy = -rho; if (++dx > rho) more = false; } }
+                }
+            }
+            // ---- which of them exist, and where their rows are ----
+            int m = 0, tot = 0;
+#pragma unroll
+            for (int b = 0; b < CLOUD_NB; ++b) {
+                if (off[b] < 0) continue;
+                const unsigned long long key = cloud_key(cx + (off[b] >> 16) - 64, cy + ((off[b] >> 8) & 0xFF) - 64, cz + (off[b] & 0xFF) - 64);
+                unsigned long long got = ((unsigned long long)ent[b].y << 32) | ent[b].x;
+                int c = (int)ent[b].z + 1, e = (int)ent[b].w;
+                if (got != key && got != CLOUD_EMPTY) {                 // the first probe hit another cell's entry (rare): walk on
+                    unsigned h = (cloud_hash(g, key) + 1) & g.mask;
+                    while (true) {
+                        const uint4 v = tab4[h];
+                        got = ((unsigned long long)v.y << 32) | v.x;
+                        c = (int)v.z + 1; e = (int)v.w;
+                        if (got == key || got == CLOUD_EMPTY) break;
+                        h = (h + 1) & g.mask;
+                    }
+                }
+                if (got == key) {
+                    run[m * DIF_BLOCK] = make_int2(e - c - tot, tot);
+                    tot += c;
+                    ++m;
+                }
+            }
+            // ---- the batch's rows as one sequence ----
+            int cur = 0, base = 0, lim = 0;
+            if (m > 0) { base = run[0].x; lim = m > 1 ? run[DIF_BLOCK].y : tot; }
+            for (int t0 = 0; t0 < tot; t0 += CLOUD_U) {
+                float4 p[CLOUD_U];
+#pragma unroll
+                for (int u = 0; u < CLOUD_U; ++u) {
+                    const int t = t0 + u;
+                    if (t < tot) {
+                        while (t >= lim) {
+                            ++cur;
+                            base = run[cur * DIF_BLOCK].x;
+                            lim = cur + 1 < m ? run[(cur + 1) * DIF_BLOCK].y : tot;
+                        }
+                        p[u] = g.sorted[base + t];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CLOUD_U; ++u) {
+                    if (t0 + u < tot) {
+                        const float ex = p[u].x - q.x, ey = p[u].y - q.y, ez = p[u].z - q.z;
                         const float d2 = (ex * ex + ey * ey) + ez * ez;       // CudaL2::dist (cuda_kdtree.cu:1152-1155)
-                        top.push(d2, __float_as_int(p.w));
+                        if (MODE == CLOUD_OUTLIER) inside += d2 < r2 ? 1 : 0;  // "the k-th distance is inside the radius" = "k points are": no list needed
+                        else {
+                            const unsigned long long ck = cloud_pack(d2, __float_as_int(p[u].w));
+                            if (ck < top.worst()) top.insert(ck);
+                        }
                     }
                 }
             }
+            if (MODE == CLOUD_OUTLIER && inside >= k) break;
+        }
+        if (MODE == CLOUD_OUTLIER) {
+            if (inside >= k) break;                        // decided: at least k points inside the radius
+            continue;                                      // (ring max_ring covers the radius: the count is complete when the loop ends)
         }
         const float kth = top.kth(k);
-        if (MODE == CLOUD_OUTLIER && kth < r2) break;      // decided: at least k points inside the radius
         const float lb = ((float)rho - 1e-3f) * g.c;       // every unvisited point is at least this far (1e-3: floor() rounding)
         if (lb > 0.0f && kth < lb * lb) break;             // (the host sizes c so that ring max_ring covers the radius)
     }
@@ -212,13 +287,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (j < k) {
-                bool in = top.d[j] < r2;
-                out.idx[(size_t)qi * k + j] = in ? top.id[j] : -1;
-                out.dist[(size_t)qi * k + j] = in ? top.d[j] : __builtin_inff();
+                bool in = top.d(j) < r2;
+                out.idx[(size_t)qi * k + j] = in ? top.id(j) : -1;
+                out.dist[(size_t)qi * k + j] = in ? top.d(j) : __builtin_inff();
             }
         }
     } else if (MODE == CLOUD_OUTLIER) {
-        out.mask[qi] = top.kth(k) < r2 ? 1 : 0;           // pcproc.cu:98-105
+        out.mask[qi] = inside >= k ? 1 : 0;               // pcproc.cu:98-105 (k-th distance < radius^2)
     } else {
         // pcproc.cu:107-158: neighbours 1..k-1 of the sorted list while inside the radius; mean, covariance, smallest eigenvector,
         // flipped towards the camera.  Fewer than 5 neighbours -> NaN.
@@ -226,9 +301,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
         bool open = true;
 #pragma unroll
         for (int j = 1; j < K; ++j) {
-            open = open && (j < k) && (top.d[j] < r2);
+            open = open && (j < k) && (top.d(j) < r2);
             if (open) {
-                const float* p = pc + (size_t)top.id[j] * stride;
+                const float* p = pc + (size_t)top.id(j) * stride;
                 mx += p[0]; my += p[1]; mz += p[2];
                 cntf += 1.0f;
             }
@@ -243,9 +318,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
         open = true;
 #pragma unroll
         for (int j = 1; j < K; ++j) {
-            open = open && (j < k) && (top.d[j] < r2);
+            open = open && (j < k) && (top.d(j) < r2);
             if (open) {
-                const float* p = pc + (size_t)top.id[j] * stride;
+                const float* p = pc + (size_t)top.id(j) * stride;
                 const float px = p[0] - mx, py = p[1] - my, pz = p[2] - mz;
                 c11 += px * px; c12 += px * py; c13 += px * pz;
                 c21 += py * px; c22 += py * py; c23 += py * pz;
