@@ -249,7 +249,7 @@ static int carve_cloud(int64_t n, void* base, CloudWs& ws) {
     if (n >= ((int64_t)1 << 28)) return DIF_EINVAL;
     int64_t T = 4096;
     int bits = 12;
-    while (T < 4 * n) { T <<= 1; ++bits; }
+    while (T < 2 * n) { T <<= 1; ++bits; }           // cells are fewer than points: the table stays under half full even when they are not
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     ws.T = T;
@@ -271,8 +271,10 @@ static int carve_cloud(int64_t n, void* base, CloudWs& ws) {
     return DIF_OK;
 }
 
-// Builds the cell table for `pc` with `rings` rings covering `radius`.
-static int cloud_build(const float* pc, int64_t n, int stride, float radius, int rings, void* wsp, int64_t ws_bytes, hipStream_t s, CloudWs& ws) {
+// Builds the cell table for `pc` with `rings` rings covering `radius` (and answers for the points that own no cell).
+template <int MODE>
+static int cloud_build(const float* pc, int64_t n, int stride, float radius, int rings, void* wsp, int64_t ws_bytes, hipStream_t s, CloudWs& ws, int k,
+                       const CloudQueryOut& out) {
     int rc = carve_cloud(n, wsp, ws);
     if (rc != DIF_OK) return rc;
     if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
@@ -284,7 +286,7 @@ static int cloud_build(const float* pc, int64_t n, int stride, float radius, int
     DIF_CHECK_LAUNCH();
     CloudStartFunctor f{ws.g.tab};
     if (launch_scan(f, nullptr, (int)ws.T, ws.T, ws.block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_cloud_place, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, ws.g, pc, (int)n, stride);
+    hipLaunchKernelGGL(k_cloud_place<MODE>, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, ws.g, pc, (int)n, stride, k, out);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -295,7 +297,6 @@ static int cloud_query(const CloudWs& ws, const float* pc, int64_t n, int stride
     if (k <= 8) hipLaunchKernelGGL((k_cloud_query<8, MODE>), grid, block, 0, s, ws.g, pc, (int)n, stride, k, radius, rings, out);
     else if (k <= 16) hipLaunchKernelGGL((k_cloud_query<16, MODE>), grid, block, 0, s, ws.g, pc, (int)n, stride, k, radius, rings, out);
     else hipLaunchKernelGGL((k_cloud_query<32, MODE>), grid, block, 0, s, ws.g, pc, (int)n, stride, k, radius, rings, out);
-    hipLaunchKernelGGL(k_cloud_invalid<MODE>, dim3(grid_for(n)), block, 0, s, ws.g, (int)n, k, out);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -324,10 +325,10 @@ int dif_knn(const float* pc, int64_t n, int32_t stride, int32_t k, float radius,
     if (n == 0) return DIF_OK;
     CloudWs ws;
     const int rings = cloud_rings(n, 2, 4);
-    int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
-    if (rc != DIF_OK) return rc;
     CloudQueryOut out{};
     out.idx = out_idx; out.dist = out_dist;
+    int rc = cloud_build<CLOUD_KNN>(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws, k, out);
+    if (rc != DIF_OK) return rc;
     return cloud_query<CLOUD_KNN>(ws, pc, n, stride, k, radius, rings, out, (hipStream_t)stream);
 }
 
@@ -337,10 +338,10 @@ int dif_remove_radius_outlier(const float* pc, int64_t n, int32_t stride, int32_
     if (n == 0) return DIF_OK;
     CloudWs ws;
     const int rings = cloud_rings(n, 1, 2);      // only "are there nb_points inside the radius" is asked: coarse cells, 27 or 125 of them at most
-    int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
-    if (rc != DIF_OK) return rc;
     CloudQueryOut out{};
     out.mask = out_mask;
+    int rc = cloud_build<CLOUD_OUTLIER>(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws, nb_points, out);
+    if (rc != DIF_OK) return rc;
     return cloud_query<CLOUD_OUTLIER>(ws, pc, n, stride, nb_points, radius, rings, out, (hipStream_t)stream);
 }
 
@@ -350,11 +351,11 @@ int dif_estimate_normals(const float* pc, int64_t n, int32_t stride, int32_t max
     if (n == 0) return DIF_OK;
     CloudWs ws;
     const int rings = cloud_rings(n, 2, 4);
-    int rc = cloud_build(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws);
-    if (rc != DIF_OK) return rc;
     CloudQueryOut out{};
     out.normal = out_normals;
     out.cam[0] = cam_xyz[0]; out.cam[1] = cam_xyz[1]; out.cam[2] = cam_xyz[2];
+    int rc = cloud_build<CLOUD_NORMAL>(pc, n, stride, radius, rings, wsp, ws_bytes, (hipStream_t)stream, ws, max_nn, out);
+    if (rc != DIF_OK) return rc;
     return cloud_query<CLOUD_NORMAL>(ws, pc, n, stride, max_nn, radius, rings, out, (hipStream_t)stream);
 }
 

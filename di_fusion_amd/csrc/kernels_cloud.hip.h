@@ -68,10 +68,31 @@ struct CloudStartFunctor {
     __device__ void finish(int) const {}
 };
 
-__global__ void __launch_bounds__(DIF_BLOCK) k_cloud_place(CloudGrid g, const float* __restrict__ pc, int n, int stride) {
+enum { CLOUD_KNN = 0, CLOUD_OUTLIER = 1, CLOUD_NORMAL = 2 };
+
+struct CloudQueryOut {
+    int* idx;            // KNN: (n, k)
+    float* dist;         // KNN: (n, k)
+    uint8_t* mask;       // OUTLIER: (n)
+    float* normal;       // NORMAL: (n, 3)
+    float cam[3];
+};
+
+// Rows grouped by cell; a point that owns no cell (NaN / inf / outside the key range) has no neighbours and gets its answer here.
+template <int MODE>
+__global__ void __launch_bounds__(DIF_BLOCK) k_cloud_place(CloudGrid g, const float* __restrict__ pc, int n, int stride, int k, CloudQueryOut out) {
     for (int i = blockIdx.x * DIF_BLOCK + threadIdx.x; i < n; i += gridDim.x * DIF_BLOCK) {
         int slot = g.slot[i];
-        if (slot < 0) continue;
+        if (slot < 0) {
+            if (MODE == CLOUD_KNN) {
+                for (int j = 0; j < k; ++j) { out.idx[(size_t)i * k + j] = -1; out.dist[(size_t)i * k + j] = __builtin_inff(); }
+            } else if (MODE == CLOUD_OUTLIER) {
+                out.mask[i] = 0;
+            } else {
+                out.normal[(size_t)i * 3 + 0] = out.normal[(size_t)i * 3 + 1] = out.normal[(size_t)i * 3 + 2] = __builtin_nanf("");
+            }
+            continue;
+        }
         const float* p = pc + (size_t)i * stride;
         int pos = atomicAdd(&g.tab[slot].end, 1);
         g.sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
@@ -148,16 +169,6 @@ __device__ inline Row3 smallest_eigenvector(Row3 m0, Row3 m1, Row3 m2) {
     return Row3{c.x / len, c.y / len, c.z / len};
 }
 
-enum { CLOUD_KNN = 0, CLOUD_OUTLIER = 1, CLOUD_NORMAL = 2 };
-
-struct CloudQueryOut {
-    int* idx;            // KNN: (n, k)
-    float* dist;         // KNN: (n, k)
-    uint8_t* mask;       // OUTLIER: (n)
-    float* normal;       // NORMAL: (n, 3)
-    float cam[3];
-};
-
 // One thread per point, in cell order (so a wave's lanes walk the same few cells).  Ring rho = the shell of cells at Chebyshev
 // distance rho from the query's cell; once rings 0..rho are done every unvisited point is farther than rho*c.
 // The search is a chain of dependent look-ups (cell -> table entry -> rows) over 27-125 cells per point, and a frame's cloud is barely
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
     const int row = blockIdx.x * DIF_BLOCK + threadIdx.x;
     // rows of `sorted` beyond the finite points do not exist; the finite count is the table's total
     if (row >= n) return;
-    // non-finite points never got a row: they are handled by k_cloud_invalid
+    // non-finite points never got a row: k_cloud_place answered for them
     const float4 q = g.sorted[row];
     const int qi = __float_as_int(q.w);
     if (qi < 0) return;                                    // unused tail row (sorted is pre-filled with index -1)
@@ -335,19 +346,3 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
         o[0] = nx; o[1] = ny; o[2] = nz;
     }
 }
-
-// Points that own no cell (NaN / inf / outside the key range): no neighbours.
-template <int MODE>
-__global__ void __launch_bounds__(DIF_BLOCK) k_cloud_invalid(CloudGrid g, int n, int k, CloudQueryOut out) {
-    for (int i = blockIdx.x * DIF_BLOCK + threadIdx.x; i < n; i += gridDim.x * DIF_BLOCK) {
-        if (g.slot[i] >= 0) continue;
-        if (MODE == CLOUD_KNN) {
-            for (int j = 0; j < k; ++j) { out.idx[(size_t)i * k + j] = -1; out.dist[(size_t)i * k + j] = __builtin_inff(); }
-        } else if (MODE == CLOUD_OUTLIER) {
-            out.mask[i] = 0;
-        } else {
-            out.normal[(size_t)i * 3 + 0] = out.normal[(size_t)i * 3 + 1] = out.normal[(size_t)i * 3 + 2] = __builtin_nanf("");
-        }
-    }
-}
-
