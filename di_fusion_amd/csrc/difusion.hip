@@ -203,19 +203,19 @@ int dif_point_box_filter(const float* points, const float* normals, int64_t N, f
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) return hipMemsetAsync(out_count, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
     if (!points || !normals || !out_points || !out_normals || !bits || !word_rank || !sums || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
-    // scratch: [0..4095] scan block totals, [4096..4101] ordered-uint bounds, [4102] status
+    // scratch: [0..4095] scan block totals, [4096..4101] ordered-uint bounds, [4102] status, [4103] bitmap words in use
     unsigned* mm = (unsigned*)(scratch + 4096);
     int* status = scratch + 4102;
-    static const unsigned init_mm[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
+    static const unsigned init_mm[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
     if (hipMemcpyAsync(mm, init_mm, sizeof(init_mm), hipMemcpyHostToDevice, s) != hipSuccess) return DIF_ELAUNCH;
     if (hipMemsetAsync(sums, 0, (size_t)N * 8 * sizeof(int64_t), s) != hipSuccess) return DIF_ELAUNCH;      // <= N boxes
-    hipLaunchKernelGGL(k_pbf_bounds, dim3(grid_for(N, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, points, N, mm);
+    hipLaunchKernelGGL(k_pbf_bounds, dim3(grid_for(N, DIF_BLOCK * 4, 64)), dim3(DIF_BLOCK), 0, s, points, N, mm);
     hipLaunchKernelGGL(k_pbf_mark, dim3(grid_for(N)), dim3(DIF_BLOCK), 0, s, points, N, voxel_size, (const unsigned*)mm, bits, max_cells, status);
     DIF_CHECK_LAUNCH();
     BoxRankFunctor f{bits, word_rank, out_count};
     const int64_t nwords = (max_cells + 31) / 32;
     if (nwords >= ((int64_t)1 << 31)) return DIF_EINVAL;
-    if (launch_scan(f, nullptr, (int)nwords, nwords, scratch, s) != DIF_OK) return DIF_ELAUNCH;
+    if (launch_scan(f, (const int*)(status + 1), 0, nwords, scratch, s) != DIF_OK) return DIF_ELAUNCH;      // device-side length: the cloud's own box grid
     hipLaunchKernelGGL(k_pbf_accumulate, dim3(grid_for(N)), dim3(DIF_BLOCK), 0, s, points, normals, N, voxel_size, (const unsigned*)mm,
                        (const uint32_t*)bits, (const int*)word_rank, (long long*)sums, (const int*)status);
     hipLaunchKernelGGL(k_pbf_finish, dim3(grid_for(N)), dim3(DIF_BLOCK), 0, s, (const long long*)sums, (const int*)out_count, out_points, out_normals,

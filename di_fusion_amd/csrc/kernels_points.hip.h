@@ -242,7 +242,10 @@ struct BoxGrid { float minb[3]; int n[3]; };
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 
+// (a few dozen workgroups, one set of six atomics each: a wave-level atomic per 64 points queues ~6,000 of them on six addresses — 75 us
+// for the tracker's 67 k points)
 __global__ void __launch_bounds__(DIF_BLOCK) k_pbf_bounds(const float* __restrict__ pts, int64_t N, unsigned* __restrict__ mm /* [6]: min xyz, max xyz (ordered uint) */) {
+    __shared__ unsigned s_lo[3][DIF_BLOCK / 64], s_hi[3][DIF_BLOCK / 64];
     unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
 #pragma unroll
@@ -250,7 +253,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_pbf_bounds(const float* __restric
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int d = 32; d >= 1; d >>= 1) { lo[a] = min(lo[a], (unsigned)__shfl_xor((int)lo[a], d)); hi[a] = max(hi[a], (unsigned)__shfl_xor((int)hi[a], d)); }
-        if (lane_id() == 0) { atomicMin(mm + a, lo[a]); atomicMax(mm + 3 + a, hi[a]); }
+        if (lane_id() == 0) { s_lo[a][threadIdx.x >> 6] = lo[a]; s_hi[a][threadIdx.x >> 6] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = (int)threadIdx.x;
+        unsigned l = s_lo[a][0], h = s_hi[a][0];
+        for (int w = 1; w < DIF_BLOCK / 64; ++w) { l = min(l, s_lo[a][w]); h = max(h, s_hi[a][w]); }
+        atomicMin(mm + a, l);
+        atomicMax(mm + 3 + a, h);
     }
 }
 
@@ -273,7 +284,9 @@ __device__ __forceinline__ int64_t pbf_cell(const BoxGrid& G, const float* p, fl
 __global__ void __launch_bounds__(DIF_BLOCK) k_pbf_mark(const float* __restrict__ pts, int64_t N, float vs, const unsigned* __restrict__ mm,
                                                       uint32_t* __restrict__ bits, int64_t max_cells, int* __restrict__ status) {
     const BoxGrid G = pbf_grid(mm, vs);
-    if ((int64_t)G.n[0] * G.n[1] * G.n[2] > max_cells) { if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 1; return; }
+    const int64_t cells = (int64_t)G.n[0] * G.n[1] * G.n[2];
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[1] = cells > max_cells ? 0 : (int)((cells + 31) >> 5);      // bitmap words in use: all the rank scan walks
+    if (cells > max_cells) { if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 1; return; }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t c = pbf_cell(G, pts + i * 3, vs);
         uint32_t b = 1u << (c & 31);

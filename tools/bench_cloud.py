@@ -1,5 +1,5 @@
-"""Times the tracker-side point-cloud pre-processing on the GPU: remove_radius_outlier(16, 0.05) and
-estimate_normals(16, 0.1) on a synthetic room frame at half (tracker.py:88-95) and full resolution.
+"""Times the tracker-side point-cloud pre-processing on the GPU: remove_radius_outlier(16, 0.05),
+estimate_normals(16, 0.1) and point_box_filter(0.02) (tracker.py:105-116) on a synthetic room frame at half (tracker.py:88-95) and full resolution.
 Usage: python tools/bench_cloud.py [--reps 20] [--cpu-sample 4000]"""
 import argparse
 import json
@@ -49,9 +49,14 @@ def main():
         kept = pc[ext.remove_radius_outlier(pc, 16, 0.05)].contiguous()
         t_nrm = timed(lambda: ext.estimate_normals(kept, 16, 0.1, [0.0, 0.0, 0.0]), args.reps)
         t_knn = timed(lambda: ext.knn_search(kept, 16, 0.1), args.reps)
+        nrm = ext.estimate_normals(kept, 16, 0.1, [0.0, 0.0, 0.0])
+        ok = ~torch.isnan(nrm[:, 0])
+        p3, n3 = kept[ok, :3].contiguous(), nrm[ok].contiguous()
+        t_box = timed(lambda: ext.point_box_filter(p3, n3, 0.02), args.reps)       # (host wrapper included: two counter reads per call)
         out[name] = {"points": int(pc.shape[0]), "kept": int(kept.shape[0]), "remove_radius_outlier_ms": round(t_out, 4),
                      "estimate_normals_ms": round(t_nrm, 4), "knn16_ms": round(t_knn, 4),
-                     "points_per_s_normals": round(kept.shape[0] / t_nrm * 1e3)}
+                     "points_per_s_normals": round(kept.shape[0] / t_nrm * 1e3),
+                     "point_box_filter_ms": round(t_box, 4), "boxes": int(ext.point_box_filter(p3, n3, 0.02)[0].shape[0])}
         if args.cpu_sample and name == "320x240":
             from oracle import difusion_oracle as O
             sub = kept[:args.cpu_sample].cpu().numpy()
