@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="F > 0: between the sampled frames, F consecutive frames go into ONE captured hipGraph "
                     "(no kernel boundaries inside, one ~33 us launch gap per F frames); for streams whose poses are known ahead; F = sample-every - 1 "
                     "fills the space between two sampled frames")
+    ap.add_argument("--streams-per-gpu", type=int, default=0, help="S >= 1: every rank fuses S independent subsequences (S private maps) whose frames share "
+                    "their twelve launches (dif_integrate_frames + dif_extract_streams): `value` is then the aggregate over all world x S streams.  "
+                    "0 (default): ONE stream per GPU is the measured configuration, and at N = 1 the aggregate rates for S = 2, 4, 8 are reported beside "
+                    "it (config.frames_per_s_with_S_streams_per_gpu, roofline.by_streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra run with the mesh left in HBM (keeps profiler traces to one stream)")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed per thread setting by the CPU baseline (after 2 warm-ups)")
@@ -214,6 +218,101 @@ def frame_runner(stream, a, d2h):
     return run, drain
 
 
+class GroupBench:
+    """S streams of one rank driven as a `FusionStreamGroup`: frame 0 eagerly per stream (sizes the buffers), every later frame with two C
+    calls for the whole group; on the sampled frames of the timed region with HIP events around the MFMA / marching-cubes launches."""
+
+    def __init__(self, streams, a, d2h, lib):
+        from di_fusion_amd.stream import FusionStreamGroup
+        self.streams, self.a, self.d2h, self.lib = streams, a, d2h, lib
+        self.group = FusionStreamGroup(streams)
+
+    def run(self, i):
+        a = self.a
+        if i == 0:
+            for st in self.streams:
+                st.step(0, self.d2h)
+            return
+        timed = (i % a.sample_every) == 0 and a.timed_from is not None and i >= a.timed_from
+        if timed:
+            self.lib.dif_profile_enable(1)
+        self.group.step(i, self.d2h)
+        if timed:
+            self.lib.dif_profile_enable(0)
+
+    def drain(self):
+        for st in self.streams:
+            st.flush_all(self.d2h)
+
+    def frame_stats(self, first):
+        """Counters per frame from frame `first` on, summed over the streams (rows per LAUNCH)."""
+        n = min(len(st.stats) for st in self.streams)
+        return [{k: sum(st.stats[f][k] for st in self.streams) for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")} for f in range(first, n)]
+
+
+def timed_run(run, drain, a, n_frames, lib, barrier):
+    """Warm-up frames, then EXACTLY a.steps frames between two barriers; returns (seconds, [(kernel, ms)] event records in launch order)."""
+    import gc
+    for i in range(a.warmup):
+        run(i)
+    drain()
+    cap = 1 << 16
+    p_which, p_ms = (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
+    lib.dif_profile_dump(p_which, p_ms, cap, 1)
+    lib.dif_profile_enable(1)               # (fills the library's event pool outside the clock)
+    lib.dif_profile_enable(0)
+    a.timed_from = a.warmup
+    gc.collect()
+    gc.disable()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, n_frames):
+        run(i)
+    drain()
+    barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    lib.dif_profile_enable(0)
+    n_rec = int(lib.dif_profile_dump(p_which, p_ms, cap, 1))
+    if n_rec < 0:
+        raise SystemExit("dif_profile_dump failed")
+    from di_fusion_amd import _lib
+    recs = [((_lib.PROF_NAMES[p_which[k]] if p_which[k] < len(_lib.PROF_NAMES) else "?"), float(p_ms[k])) for k in range(n_rec)]
+    return dt, recs
+
+
+def split_frames(recs):
+    """Event records in launch order -> one list per event-timed frame (a frame starts with its encoder launch)."""
+    per_frame = []
+    for name, ms in recs:
+        if name == "encode" or not per_frame:
+            per_frame.append([])
+        per_frame[-1].append((name, ms))
+    return per_frame
+
+
+def streams_leg(make_stream_j, S, a, n_frames, lib, pipe):
+    """Aggregate rate of S independent subsequences on this GPU sharing their launches (secondary figure at N = 1)."""
+    import gc
+    streams = [make_stream_j(j) for j in range(S)]
+    aa = argparse.Namespace(**{**vars(a), "timed_from": None})
+    gb = GroupBench(streams, aa, a.d2h, lib)
+    dt, recs = timed_run(gb.run, gb.drain, aa, n_frames, lib, torch.cuda.synchronize)
+    st = gb.frame_stats(a.warmup)
+    timed_idx = [j for j in range(a.steps) if (a.warmup + j) >= 1 and ((a.warmup + j) % a.sample_every) == 0]
+    per_frame = split_frames(recs)
+    blk = None
+    if len(per_frame) == len(timed_idx) and per_frame:
+        blk = roofline_block(per_frame, [st[j] for j in timed_idx], pipe, short_run=(a.steps <= 30), streams=S)
+    rate = round(S * a.steps / dt, 3)
+    del gb, streams
+    gc.collect()
+    torch.cuda.empty_cache()
+    keep = ("kernel", "achieved", "frac", "frac_executed", "pmc_mfma_busy_frac", "pmc_mfma_busy_source", "avg_launch_ms", "rows_per_launch", "per_kernel",
+            "other_ms_per_frame", "event_timed_frames")
+    return rate, ({k: blk[k] for k in keep if k in blk} if blk else None)
+
+
 def secondary_rate(make_stream, a, n_frames, d2h, batch):
     """Secondary figures (N=1 only, reported next to `value`, never instead of it): the same stream (i) without the per-frame hand-over
     of the new triangles to pinned host memory — the difference is PCIe traffic, not kernels — and (ii) with 5 frames per captured
@@ -238,7 +337,7 @@ def _secondary_pass(make_stream, a, n_frames, d2h, batch):
     return round(a.steps / (time.perf_counter() - t2), 3)
 
 
-def global_map_merge(stream, model, cfg, dev, barrier):
+def global_map_merge(local_maps, model, cfg, dev, barrier):
     """BASELINE config C4: after the independent subsequences, ONE all-gather of voxel records over RCCL and a fold into a global map
     (identical on every rank), meshed once.  Outside the clock (once per sequence, not per frame); reported, never fatal."""
     try:
@@ -246,13 +345,13 @@ def global_map_merge(stream, model, cfg, dev, barrier):
         from di_fusion_amd.system.map import DenseIndexedMap
         barrier()
         tm = time.perf_counter()
-        gmap = parallel.build_global_map(stream.map, lambda: DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1 << 17))
+        gmap = parallel.build_global_map(local_maps, lambda: DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1 << 17))
         torch.cuda.synchronize()
         t_merge = time.perf_counter() - tm
         gmesh = gmap.extract_mesh_arrays(4, int(8e6), max_std=0.15, no_cache=True, to_host=False)
         torch.cuda.synchronize()
         return {"all_gather_and_fold_ms": round(t_merge * 1e3, 2), "global_voxels": int(gmap.n_occupied),
-                "local_voxels_rank0": int(stream.map.n_occupied), "global_mesh_triangles": int(gmesh[0].shape[0]) if gmesh else 0,
+                "local_voxels_rank0": int(sum(m.n_occupied for m in (local_maps if isinstance(local_maps, (list, tuple)) else [local_maps]))), "global_mesh_triangles": int(gmesh[0].shape[0]) if gmesh else 0,
                 "extract_global_ms": round((time.perf_counter() - tm - t_merge) * 1e3, 2)}
     except Exception as e:      # the headline number must survive a failure of the optional epilogue
         return {"error": repr(e)[:200]}
@@ -286,7 +385,7 @@ def roofline_of(records, sst):
     return kern
 
 
-def roofline_block(per_frame, sst, pipe, short_run=False):
+def roofline_block(per_frame, sst, pipe, short_run=False, streams=1):
     """`roofline` for the MFMA kernel with the longest average launch.  per_frame: for every event-timed frame the [(kernel, ms)] list
     from the library's HIP events (recorded on the launch stream); sst: the counters of those frames (rows per launch come from there).
     The same figures are also given for the first and the second half of the timed frames: a short run sits in the map-building
@@ -307,17 +406,20 @@ def roofline_block(per_frame, sst, pipe, short_run=False):
     # summaries of separate --pmc passes OF THE SAME INVOCATION — `--steps 20 --warmup 5` (what the driver runs: map-building transient)
     # has its own set (profiles/rNN_pmc_*_k20.json), every longer run uses the 200-step set
     pmc, pmc_file, busy_pmc, busy_file = {}, None, {}, None
+    sfx = "" if streams == 1 else f"_s{streams}"
     try:
-        pmc_file = sorted((ROOT / "profiles").glob("r*_pmc_hbm_k20.json" if short_run else "r*_pmc_hbm.json"))[-1]
+        pmc_file = sorted((ROOT / "profiles").glob(f"r*_pmc_hbm{sfx}_k20.json" if short_run else f"r*_pmc_hbm{sfx}.json"))[-1]
         pmc = json.loads(pmc_file.read_text())["kernels"]
     except Exception:
         pass
     try:
-        busy_file = sorted((ROOT / "profiles").glob("r*_pmc_mfma_k20.json" if short_run else "r*_pmc_mfma_stream.json"))[-1]
+        busy_file = sorted((ROOT / "profiles").glob(f"r*_pmc_mfma{sfx}_k20.json" if short_run else (f"r*_pmc_mfma{sfx}.json" if streams > 1 else "r*_pmc_mfma_stream.json")))[-1]
         busy_pmc = json.loads(busy_file.read_text())["kernels"]
     except Exception:
         pass
     kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode_refine_x6" if pipe == "bf16x6" else "k_decode<false>"}[dom]
+    if streams > 1:
+        kname += "_batch"
     half = len(per_frame) // 2
     phases = {}
     if half >= 1:
@@ -434,8 +536,21 @@ def main():
         return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise),
                             initial_capacity=cap0)   # own arc of the orbit
 
-    stream = make_stream()
+    S_main = int(a.streams_per_gpu)
+    if S_main < 0 or S_main > _lib.MAX_STREAMS or (S_main >= 1 and (tiled or a.graph or a.batch)):
+        raise SystemExit(f"bench.py --streams-per-gpu: 0..{_lib.MAX_STREAMS}, with --mode c4 and direct launches")
+
+    def make_stream_j(j, S):
+        """Stream j of S on this rank: its own arc of the orbit, its own map."""
+        return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=((rank * S + j) * 45.0) % 360.0, noise=bool(a.noise))
+
     lib = _lib.load()
+    gb = None
+    if S_main >= 1:
+        gb = GroupBench([make_stream_j(j, S_main) for j in range(S_main)], a, a.d2h, lib)
+        stream = gb.streams[0]
+    else:
+        stream = make_stream()
     if os.environ.get("DIF_BENCH_NO_PRIME") != "1":
         prime_process(FusionStream, syn, model, syn.Intrinsic(), dev, a.d2h)
 
@@ -445,7 +560,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run, drain = frame_runner(stream, a, a.d2h)
+    run, drain = (gb.run, gb.drain) if gb is not None else frame_runner(stream, a, a.d2h)
     for i in range(a.warmup):
         run(i)
     drain()
@@ -483,18 +598,29 @@ def main():
         dt = float(tt.item())
     hbm_resident = batched = None
     # (secondary figures need a run long enough to amortise their own one-time costs — a fresh stream's buffer growth, graph captures)
-    if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled and a.steps >= 100:
+    if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled and a.steps >= 100 and gb is None:
         hbm_resident = secondary_rate(make_stream, a, n_frames, "none", 0)
         if a.batch == 0 and a.direct and not a.graph:        # (a per-frame-graph run would mix two sets of captured graphs on one stream)
             batched = secondary_rate(make_stream, a, n_frames, a.d2h, 5)
-    merge_info = global_map_merge(stream, model, cfg, dev, barrier) if (use_dist and not tiled) else None
+    # S independent subsequences per GPU sharing their launches: aggregate frames/s and the MFMA kernels' roofline at S = 2, 4, 8
+    by_streams = {}
+    if world == 1 and not a.no_secondary and not tiled and gb is None and a.direct and not a.graph and a.batch == 0 and a.warmup + a.steps >= 2:
+        for S in (2, 4, 8):
+            try:
+                by_streams[S] = streams_leg(lambda j, S=S: make_stream_j(j, S), S, a, n_frames, lib, pipe)
+            except Exception as e:      # the headline number must survive a failure of a secondary leg
+                by_streams[S] = (None, {"error": repr(e)[:200]})
+    merge_info = global_map_merge([st.map for st in gb.streams] if gb is not None else stream.map, model, cfg, dev, barrier) if (use_dist and not tiled) else None
 
     out = None
     if rank == 0:
-        st = stream.stats[stats_base:]
+        st = gb.frame_stats(stats_base) if gb is not None else stream.stats[stats_base:]
         # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
         sampled_only = bool(a.graph or a.direct)
-        timed_idx = [j for j in range(a.steps) if not (sampled_only and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
+        if gb is not None:
+            timed_idx = [j for j in range(a.steps) if (a.warmup + j) >= 1 and ((a.warmup + j) % a.sample_every) == 0]
+        else:
+            timed_idx = [j for j in range(a.steps) if not (sampled_only and (a.warmup + j) >= 2 and ((a.warmup + j) % a.sample_every) != 0)]
         # the event records come in launch order, one k_encode per event-timed frame: cut the list into frames there
         per_frame = []
         for k in range(n_rec):
@@ -504,13 +630,16 @@ def main():
             per_frame[-1].append((name, float(p_ms[k])))
         if len(per_frame) != len(timed_idx):        # (an empty frame launches no encoder) fall back to one group
             per_frame, timed_idx = [[r for f in per_frame for r in f]], timed_idx[:1] if timed_idx else []
-        launch = ("eager, host one frame ahead" if not sampled_only else
+        launch = (f"direct launches, two C calls per frame of ALL {S_main} streams of the rank (dif_integrate_frames + dif_extract_streams: blockIdx.y = stream in "
+                  f"the point / scan / fusion / marching-cubes kernels, concatenated tile ranges in the persistent MLP kernels), host one frame ahead, HIP events "
+                  f"on 1 frame in {a.sample_every}" if gb is not None else
+                  "eager, host one frame ahead" if not sampled_only else
                   f"{a.batch} frames per captured hipGraph between the sampled frames; 1 frame in {a.sample_every} launched directly with HIP events "
                   "(roofline sample)" if a.batch > 0 else
                   f"hipGraph replay; 1 frame in {a.sample_every} launched directly with HIP events (roofline sample)" if a.graph else
                   f"direct launches (two C calls per frame), host one frame ahead, HIP events on 1 frame in {a.sample_every} (roofline sample)")
         pixels = intr.width * intr.height
-        value = (a.steps if tiled else world * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
+        value = (a.steps if tiled else world * max(S_main, 1) * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
         out = {"metric": f"frames/s integrate+decode+mesh, {intr.width}x{intr.height} synthetic stream", "value": round(value, 3),
                "unit": "frames/s", "n_gpus": world, "rccl_ranks": (0 if rehearsal else world) if use_dist else 0,
                **({"rehearsal": "all ranks on one GPU over gloo: a functional run of the multi-rank paths, not a measurement"} if rehearsal else {}), "steps": a.steps, "warmup": a.warmup,
@@ -526,17 +655,22 @@ def main():
                           "parallelism": (f"slab {a.loopback // 2} of {a.loopback} x-slabs of one stream on ONE GPU, halo exchange with itself (loopback) after every integrate"
                                           if a.loopback > 1 else
                                           f"one stream, grid cut into {world} x-slabs, halo exchange (RCCL send/recv, 3 boundary layers) after every integrate"
-                                          if tiled else f"{world} independent subsequences (one map per GPU)"),
+                                          if tiled else f"{world * S_main} independent subsequences, {S_main} private maps per GPU sharing their launches" if gb is not None
+                                          else f"{world} independent subsequences (one map per GPU)"),
+                          "streams_per_gpu": max(S_main, 1),
                           "d2h_per_frame": a.d2h,
                           "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1, "launch": launch,
                           "avg_per_frame_rank0": {k: round(float(np.mean([s[k] for s in st])), 1)
                                                   for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
                           "frames_per_s_with_5_frames_per_hipgraph": batched,
+                          "frames_per_s_with_S_streams_per_gpu": ({str(S): v[0] for S, v in by_streams.items()} if by_streams else None),
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info,
                           "halo_exchange": halo_summary(stream, a)},
-               "roofline": roofline_block(per_frame, [st[j] for j in timed_idx], pipe, short_run=(a.steps <= 30))}
+               "roofline": roofline_block(per_frame, [st[j] for j in timed_idx], pipe, short_run=(a.steps <= 30), streams=max(S_main, 1))}
+        if by_streams and out["roofline"] is not None:
+            out["roofline"]["by_streams"] = {str(S): v[1] for S, v in by_streams.items()}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(stream, a.config, scene, cfg, intr, n_frames, a.cpu_frames)
     if use_dist:

@@ -78,19 +78,40 @@ def needs_build() -> bool:
     return lib_build_id() != source_hash()
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
+def build(force: bool = False, verbose: bool = True, shared: bool = False) -> Path:
+    """Compile into a temporary file and rename it onto LIB under an exclusive file lock: several processes that find a stale library at
+    once (torchrun ranks, multi-process tests) must neither compile onto a file another one is dlopen-ing nor each pay for a build
+    (`shared`: a forced build is satisfied by one that another process finished while this one waited)."""
     if not force and not needs_build():
         return LIB
+    import fcntl
+    with open(str(LIB) + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not needs_build() and (not force or shared):
+                return LIB                       # another process built it while this one waited for the lock
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> Path:
     ver = hipcc_version()
     if not ver.startswith(VALIDATED_HIPCC) and os.environ.get("DIF_ALLOW_OTHER_HIPCC") != "1":
         print(f"WARNING: libdifusion is being built with hipcc {ver}; the tree was validated with {VALIDATED_HIPCC}. Run `pytest -m gpu` and "
               "`python tools/determinism_stress.py 400` on the GPU before trusting the MLP kernels of this build.", flush=True)
-    cmd = [hipcc()] + HIPCC_FLAGS + [f'-DDIF_BUILD_ID="{source_hash()}:{ver}"'] + [str(s) for s in SOURCES] + ["-o", str(LIB)]
+    tmp = LIB.with_name(f".{LIB.name}.{os.getpid()}.tmp")
+    cmd = [hipcc()] + HIPCC_FLAGS + [f'-DDIF_BUILD_ID="{source_hash()}:{ver}"'] + [str(s) for s in SOURCES] + ["-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    if lib_build_id() != source_hash():
-        raise RuntimeError("libdifusion.so was built but does not carry the hash of this tree")
+    try:
+        subprocess.check_call(cmd)
+        if lib_build_id(tmp) != source_hash():
+            raise RuntimeError("libdifusion.so was built but does not carry the hash of this tree")
+        os.replace(tmp, LIB)                     # atomic: a concurrent dlopen sees the old file or the new one, never a partial write
+    finally:
+        if tmp.exists():
+            tmp.unlink()
     return LIB
 
 

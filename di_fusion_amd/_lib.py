@@ -58,6 +58,15 @@ class DifExtractBuffers(Structure):
                 ("chunk_sum", c_void_p), ("fold_table", c_void_p), ("mc_status", c_void_p), ("defer_export", c_int32)]
 
 
+MAX_STREAMS = 8          # DIF_MAX_STREAMS
+
+
+class DifStreamFrame(Structure):
+    """dif_stream_frame_t: one stream's share of a batched frame (dif_integrate_frames / dif_extract_streams)."""
+    _fields_ = [("map", POINTER(DifMap)), ("frame_dev", c_void_p), ("xyz_world", c_void_p), ("normal_world", c_void_p), ("unq_mask", c_void_p),
+                ("ws", c_void_p), ("ws_bytes", c_int64), ("buf", POINTER(DifExtractBuffers))]
+
+
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)
 SIGNATURES = {
     "dif_version": (c_int32, []),
@@ -90,6 +99,9 @@ SIGNATURES = {
                                        c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "dif_extract": (c_int32, [POINTER(DifMap), POINTER(DifWeights), POINTER(DifExtractBuffers), c_int32, c_int32, c_float,
                               c_int32, c_int32, c_void_p]),
+    "dif_integrate_frames": (c_int32, [POINTER(DifStreamFrame), c_int32, POINTER(DifWeights), c_int32, c_int32, c_float, c_float, c_float, c_float,
+                                       c_void_p]),
+    "dif_extract_streams": (c_int32, [POINTER(DifStreamFrame), c_int32, POINTER(DifWeights), c_int32, c_float, c_int32, c_void_p]),
     "dif_export_pending": (c_int32, [POINTER(DifMap), c_void_p]),
     "dif_mesh_cache_export": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dif_mesh_cache_compact": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -135,7 +147,7 @@ def load() -> ctypes.CDLL:
             have, want = _build.lib_build_id(), _build.source_hash()
             if have != want:
                 try:
-                    _build.build(force=True, verbose=False)
+                    _build.build(force=True, verbose=False, shared=True)      # (processes racing for the same stale library share one build)
                 except Exception as e:
                     raise RuntimeError(f"{LIB_PATH} was built from other sources (build id {have}, tree {want}) and rebuilding it failed: {e!r}")
         lib = ctypes.CDLL(str(LIB_PATH))

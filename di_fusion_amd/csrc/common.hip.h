@@ -232,6 +232,80 @@ __global__ void __launch_bounds__(1024) k_scan_single(F f, const int* n_ptr, int
     if (threadIdx.x == 0) f.finish(total);
 }
 
+// ---- several independent maps per launch (dif_integrate_frames / dif_extract_streams) ---------------------------------------------------
+// The per-map arguments of a kernel travel as an ARRAY in the kernel-argument segment; blockIdx.y (kernels whose workgroups belong to
+// one map) or a wave-uniform index (the persistent MLP kernels, which walk the maps' tiles as one concatenated range) selects the entry:
+// scalar loads from constant memory, nothing to upload or keep in sync on the device.
+template <class A, int NS>
+struct BatchN { A s[NS]; };
+template <class A>
+using Batch = BatchN<A, DIF_MAX_STREAMS>;
+
+// The work items (tiles, voxels) of up to NS maps as ONE range: map j owns [pre[j], pre[j + 1]).  Everything is indexed with compile-time
+// constants (select chains), so the tables live in scalar registers.
+template <int NS, class T>
+struct Ranges {
+    T pre[NS + 1], cnt[NS];
+    __device__ __forceinline__ T total() const { return pre[NS]; }
+    // map `sm`, position `lt` inside it and that map's element count `n` for position x < total() of the concatenated range
+    __device__ __forceinline__ void locate(T x, int& sm, T& lt, T& n) const {
+        sm = 0; lt = x; n = cnt[0];
+#pragma unroll
+        for (int j = 1; j < NS; ++j)
+            if (x >= pre[j]) { sm = j; lt = x - pre[j]; n = cnt[j]; }
+    }
+};
+
+// k_scan_pass2 / k_scan_single over S maps in one launch: blockIdx.y = map.  Same partition and order per map as the single launch.
+template <class F>
+struct ScanBatch { F f[DIF_MAX_STREAMS]; const int* tot[DIF_MAX_STREAMS]; };
+
+template <class F>
+__global__ void __launch_bounds__(DIF_BLOCK) k_scan_pass2_batch(ScanBatch<F> b, int n_static) {
+    __shared__ int smem[8];
+    const F& f = b.f[blockIdx.y];
+    const int* __restrict__ block_tot = b.tot[blockIdx.y];
+    const int n = n_static;
+    int lo, hi;
+    scan_range(n, lo, hi);
+    int before = 0, all = 0;
+    for (int k = (int)threadIdx.x; k < (int)gridDim.x; k += DIF_BLOCK) {
+        int t = block_tot[k];
+        all += t;
+        if (k < (int)blockIdx.x) before += t;
+    }
+    int offset = block_sum(before, smem);
+    int total = block_sum(all, smem);
+    for (int base = lo; base < hi; base += DIF_BLOCK) {
+        int i = base + (int)threadIdx.x;
+        int c = (i < hi) ? f.count(i) : 0;
+        int chunk_total;
+        int ex = block_excl_scan(c, smem, chunk_total);
+        if (i < hi && c > 0) f.emit(i, offset + ex);
+        offset += chunk_total;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.finish(total);
+}
+
+template <class F>
+__global__ void __launch_bounds__(1024) k_scan_single_batch(ScanBatch<F> b, int n_static) {
+    __shared__ int smem[16];
+    const F& f = b.f[blockIdx.y];
+    const int n = n_static;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += f.count(i);
+    int total;
+    int offset = block_excl_scan(c, smem, total);
+    for (int i = lo; i < hi; ++i) {
+        int ci = f.count(i);
+        if (ci > 0) f.emit(i, offset);
+        offset += ci;
+    }
+    if (threadIdx.x == 0) f.finish(total);
+}
+
 inline int scan_blocks(int64_t n_upper) {
     int64_t b = (n_upper + DIF_BLOCK - 1) / DIF_BLOCK;      // one 256-element chunk per workgroup while that fits 1024 workgroups: shortest chain
     if (b < 1) b = 1;
@@ -294,6 +368,17 @@ inline int launch_counted_scan(F f, int n, const int* tot, hipStream_t s) {
         hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(1024), 0, s, f, (const int*)nullptr, n);
     } else {
         hipLaunchKernelGGL(k_scan_pass2<F>, dim3(scan_blocks(n)), dim3(DIF_BLOCK), 0, s, f, (const int*)nullptr, n, tot);
+    }
+    return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
+}
+
+// launch_counted_scan for S maps (same n for all of them): one launch, blockIdx.y = map
+template <class F>
+inline int launch_counted_scan_batch(const ScanBatch<F>& b, int S, int n, hipStream_t s) {
+    if (n <= 4096) {
+        hipLaunchKernelGGL(k_scan_single_batch<F>, dim3(1, S), dim3(1024), 0, s, b, n);
+    } else {
+        hipLaunchKernelGGL(k_scan_pass2_batch<F>, dim3(scan_blocks(n), S), dim3(DIF_BLOCK), 0, s, b, n);
     }
     return hipGetLastError() == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }

@@ -398,68 +398,92 @@ struct FrameSource {            // integrate straight from a depth frame: the fi
     float fx, fy, cx, cy;
 };
 
-static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
-                          void* wsp, int64_t ws_bytes, const FrameSource* src, void* stream_) {
-    if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0 || !map->grid_tot) return DIF_EINVAL;
-    if (N == 0) return DIF_OK;
+// Everything the six launches of an integrate need for ONE map, derived once from the C arguments: the single-map entry points pass the
+// pieces to the kernels by value, dif_integrate_frames collects the pieces of S maps into the kernels' argument arrays.
+struct IntegratePlan {
+    UvcArgs uvc; PruneArgs prune; AllocFunctor alloc; const int* alloc_tot; GatherArgs gather; EncArgs enc; FuseArgs fuse;
+    int64_t grid; bool has_pending;
+};
+
+static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
+                          void* wsp, int64_t ws_bytes, const FrameSource* src, IntegratePlan& P) {
+    if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N <= 0 || !map->grid_tot) return DIF_EINVAL;
     if (!xyz || !normal || !unq_mask || !wsp) return DIF_EINVAL;
     if (8 * N + 64 >= (int64_t)1 << 31 || map->capacity >= (int64_t)1 << 31) return DIF_EINVAL;      // record ids and slots are int32
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     if (grid >= ((int64_t)1 << 31)) return DIF_EINVAL;
-    hipStream_t s = (hipStream_t)stream_;
     IntegrateWs ws;
     if (carve_integrate(N, wsp, ws) != DIF_OK) return DIF_ELAUNCH;
     if (ws.total_bytes > ws_bytes) return DIF_ENOSPACE;
-    Geo g = geo_of(map);
+    const Geo g = geo_of(map);
     int* C = map->counters;
-    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK);
-
-    // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
     const int own_lo = map->own_x_hi > map->own_x_lo ? map->own_x_lo : 0, own_hi = map->own_x_hi > map->own_x_lo ? map->own_x_hi : map->nx;
     // a deferred triangle export of the previous extract rides with the three point passes of a streaming frame: nb_x leading workgroups each
     dif_pending_export_t* const pending = src ? (dif_pending_export_t*)map->pending_export : nullptr;
-    const int nb_x = pending ? DIF_EXPORT_WGS : 0;
-    if (src)
-        hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, g, src->frame, src->H, src->W,
-                           src->fx, src->fy, src->cx, src->cy, const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C,
-                           own_lo - map->halo, own_hi + map->halo, (const dif_pending_export_t*)pending, nb_x);
-    else
-        hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, g, xyz, N, ws.pt_lin, map->frame_count, C, own_lo - map->halo,
-                           own_hi + map->halo);
-    hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, g, (int)map->prune_min_vox_obs, (const int*)ws.pt_lin, N,
-                       (const int*)map->frame_count, (const int64_t*)map->indexer, unq_mask, grid_marks_of(map), C, (const dif_pending_export_t*)pending, nb_x);
-    DIF_CHECK_LAUNCH();
-    {
-        AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
-        if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // k_prune_mark kept the block totals
+    P.grid = grid;
+    P.has_pending = pending != nullptr;
+    P.uvc = UvcArgs{g, src ? src->frame : nullptr, const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C,
+                    own_lo - map->halo, own_hi + map->halo, pending};
+    P.prune = PruneArgs{g, (int)map->prune_min_vox_obs, ws.pt_lin, map->frame_count, map->indexer, unq_mask, grid_marks_of(map), C, pending};
+    P.alloc = AllocFunctor{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
+    P.alloc_tot = map->grid_tot;                                   // k_prune_mark kept the block totals
+    P.gather = GatherArgs{g, map->encoder_count_th, xyz, ws.pt_lin, unq_mask, map->frame_count, map->indexer, map->voxel_obs_count, ws.pair_list, C,
+                          map->capacity, map->grid_tot, own_lo, own_hi, pending};
+    P.enc = EncArgs{g, xyz, normal, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, map->dirty_tot};
+    P.fuse = FuseArgs{ws.rec, ws.rec_next, map->rec_dir, map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->latent_vecs_pos,
+                      halo_lists_of(map), pending};
+    return DIF_OK;
+}
+
+static int encoder_attributes() {
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ENC_FLOATS * 4)) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_BYTES) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_encode_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ENC_FLOATS * 4)) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_encode_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_BYTES) != hipSuccess) return DIF_ELAUNCH;
+        attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, g, map->encoder_count_th, xyz, (const int*)ws.pt_lin,
-                       (const uint8_t*)unq_mask, N, map->frame_count, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count,
-                       ws.pair_list, C, map->capacity, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, map->grid_tot, own_lo, own_hi,
-                       (const dif_pending_export_t*)pending, nb_x);
+    return DIF_OK;
+}
+
+static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
+                          void* wsp, int64_t ws_bytes, const FrameSource* src, void* stream_) {
+    if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0 || !map->grid_tot) return DIF_EINVAL;
+    if (N == 0) return DIF_OK;
+    IntegratePlan P;
+    const int rc = integrate_plan(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, src, P);
+    if (rc != DIF_OK) return rc;
+    hipStream_t s = (hipStream_t)stream_;
+    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK);
+    const int nb_x = P.has_pending ? DIF_EXPORT_WGS : 0;
+    // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
+    if (src)
+        hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, P.uvc, ImageGeo{src->H, src->W, src->fx, src->fy, src->cx, src->cy}, nb_x);
+    else
+        hipLaunchKernelGGL(k_voxel_count, dim3(nb_pts), dim3(DIF_BLOCK), 0, s, P.uvc.g, xyz, N, P.uvc.pt_lin, P.uvc.frame_count, P.uvc.counters, P.uvc.px_lo,
+                           P.uvc.px_hi);
+    hipLaunchKernelGGL(k_prune_mark, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, P.prune, N, nb_x);
+    DIF_CHECK_LAUNCH();
+    if (launch_counted_scan(P.alloc, (int)((P.grid + 31) / 32), P.alloc_tot, s) != DIF_OK) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_focus_gather, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, P.gather, N, (src && src->W % 16 == 0 && src->H % 16 == 0) ? src->W : 0, nb_x);
     DIF_CHECK_LAUNCH();
     {
         const bool x6 = w->enc_x6_packed && w->enc_x6_packed_bytes == E6_BYTES;          // tiles on the bf16 matrix pipe (mlp.hip.h)
         const size_t lds_bytes = x6 ? (size_t)E6_BYTES : (size_t)ENC_FLOATS * 4;
-        static bool attr_set[64] = {};
-        int dev = 0; (void)hipGetDevice(&dev);
-        if (dev < 64 && !attr_set[dev]) {
-            if (hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ENC_FLOATS * 4)) != hipSuccess) return DIF_ELAUNCH;
-            if (hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_BYTES) != hipSuccess) return DIF_ELAUNCH;
-            attr_set[dev] = true;
-        }
+        if (encoder_attributes() != DIF_OK) return DIF_ELAUNCH;
+        const EncArgs& e = P.enc;
         ProfScope prof(DIF_PROF_ENCODE, s);
         if (x6)
-            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(512), lds_bytes, s, g, (const float*)w->enc_x6_packed, xyz, normal, N, (const uint2*)ws.pair_list,
-                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, (const uint8_t*)map->dirty, map->dirty_tot);
+            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.xyz, e.normal, N, e.pair_list,
+                               e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         else
-            hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, g, w->enc_packed, xyz, normal, N, (const uint2*)ws.pair_list,
-                               map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, (const uint8_t*)map->dirty, map->dirty_tot);
+            hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.xyz, e.normal, N, e.pair_list,
+                               e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         DIF_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const long long*)ws.rec, (const int*)ws.rec_next,
-                       map->rec_dir, (const int*)map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, (const int64_t*)map->latent_vecs_pos,
-                       halo_lists_of(map), pending);
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, P.fuse);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -474,6 +498,62 @@ int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_
     if (!frame_dev || H <= 0 || W <= 0 || !xyz_world || !normal_world) return DIF_EINVAL;
     FrameSource src{frame_dev, H, W, fx, fy, cx, cy};
     return integrate_impl(map, w, xyz_world, normal_world, (int64_t)H * W, unq_mask, wsp, ws_bytes, &src, stream_);
+}
+
+// S maps, one frame each, through the same six launches (include/difusion.h: dif_stream_frame_t)
+static bool batch_maps_ok(const dif_stream_frame_t* st, int S) {
+    if (!st || S < 1 || S > DIF_MAX_STREAMS) return false;
+    for (int j = 0; j < S; ++j) {
+        const dif_map_t* m = st[j].map;
+        if (!m || map_is_tiled(m) || !m->dirty_tot || !m->grid_tot || !m->pending_export) return false;
+        if (m->nx != st[0].map->nx || m->ny != st[0].map->ny || m->nz != st[0].map->nz || m->capacity != st[0].map->capacity) return false;
+        for (int i = 0; i < j; ++i)
+            if (st[i].map->counters == m->counters || st[i].map->indexer == m->indexer) return false;      // the same map twice in one batch
+    }
+    return true;
+}
+
+int dif_integrate_frames(const dif_stream_frame_t* st, int32_t S, const dif_weights_t* w, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
+                         void* stream_) {
+    if (!batch_maps_ok(st, S) || !w || H <= 0 || W <= 0) return DIF_EINVAL;
+    const bool x6 = w->enc_x6_packed && w->enc_x6_packed_bytes == E6_BYTES;
+    if (!w->enc_packed || w->enc_packed_floats != ENC_FLOATS) return DIF_EINVAL;
+    const int64_t N = (int64_t)H * W;
+    static thread_local Batch<UvcArgs> uvc; static thread_local Batch<PruneArgs> prune; static thread_local ScanBatch<AllocFunctor> alloc;
+    static thread_local Batch<GatherArgs> gather; static thread_local Batch<EncArgs> enc; static thread_local Batch<FuseArgs> fuse;
+    int64_t grid = 0;
+    for (int j = 0; j < S; ++j) {
+        if (!st[j].frame_dev || !st[j].xyz_world || !st[j].normal_world) return DIF_EINVAL;
+        FrameSource src{st[j].frame_dev, H, W, fx, fy, cx, cy};
+        IntegratePlan P;
+        const int rc = integrate_plan(st[j].map, w, st[j].xyz_world, st[j].normal_world, N, st[j].unq_mask, st[j].ws, st[j].ws_bytes, &src, P);
+        if (rc != DIF_OK) return rc;
+        uvc.s[j] = P.uvc; prune.s[j] = P.prune; alloc.f[j] = P.alloc; alloc.tot[j] = P.alloc_tot; gather.s[j] = P.gather; enc.s[j] = P.enc; fuse.s[j] = P.fuse;
+        grid = P.grid;
+    }
+    for (int j = S; j < DIF_MAX_STREAMS; ++j) {          // unused entries: never dereferenced, but never garbage either
+        uvc.s[j] = uvc.s[0]; prune.s[j] = prune.s[0]; alloc.f[j] = alloc.f[0]; alloc.tot[j] = alloc.tot[0]; gather.s[j] = gather.s[0]; enc.s[j] = enc.s[0];
+        fuse.s[j] = fuse.s[0];
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK), nb_x = DIF_EXPORT_WGS;
+    hipLaunchKernelGGL(k_unproject_voxel_count_batch, dim3(nb_pts + nb_x, S), dim3(DIF_BLOCK), 0, s, uvc, ImageGeo{H, W, fx, fy, cx, cy}, nb_x);
+    hipLaunchKernelGGL(k_prune_mark_batch, dim3(nb_pts + nb_x, S), dim3(DIF_BLOCK), 0, s, prune, N, nb_x);
+    DIF_CHECK_LAUNCH();
+    if (launch_counted_scan_batch(alloc, S, (int)((grid + 31) / 32), s) != DIF_OK) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_focus_gather_batch, dim3(nb_pts + nb_x, S), dim3(DIF_BLOCK), 0, s, gather, N, (W % 16 == 0 && H % 16 == 0) ? W : 0, nb_x);
+    DIF_CHECK_LAUNCH();
+    {
+        const size_t lds_bytes = x6 ? (size_t)E6_BYTES : (size_t)ENC_FLOATS * 4;
+        if (encoder_attributes() != DIF_OK) return DIF_ELAUNCH;
+        ProfScope prof(DIF_PROF_ENCODE, s);
+        if (x6) hipLaunchKernelGGL(k_encode_batch<true>, dim3(num_cus()), dim3(512), lds_bytes, s, enc, (int)S, (const float*)w->enc_x6_packed, N);
+        else hipLaunchKernelGGL(k_encode_batch<false>, dim3(num_cus()), dim3(512), lds_bytes, s, enc, (int)S, w->enc_packed, N);
+        DIF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_fuse_batch, dim3(grid_for(st[0].map->capacity * 32, DIF_BLOCK, 256), S), dim3(DIF_BLOCK), 0, s, fuse);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
 }
 
 // ---- 8f-4: latent optimisation -----------------------------------------------------------------------------------
@@ -726,6 +806,117 @@ int dif_marching_cubes(const int64_t* indexer, int32_t nx, int32_t ny, int32_t n
 }
 
 // ---- extract ---------------------------------------------------------------------------------------------------
+// The per-map pieces of an extract, shared by dif_extract and dif_extract_streams
+struct ExtractGeo { int r, R, l, R3; double sample_a, sample_b; };
+static ExtractGeo extract_geo(int resolution) {
+    ExtractGeo e;
+    e.r = resolution; e.R = 2 * resolution; e.l = resolution;                 // fast two-level: low lattice l = R/2 (map.py:642-644)
+    e.R3 = e.R * e.R * e.R;
+    e.sample_a = -(double)(e.r / 2) * (1.0 / e.r);                          // map.py:640-641
+    e.sample_b = 1.0 + (double)((e.r - 1) / 2) * (1.0 / e.r);
+    return e;
+}
+
+static DirtySet dirty_set_of(const dif_map_t* map, const dif_extract_buffers_t* buf, int no_cache) {
+    const int64_t grid = (int64_t)map->nx * map->ny * map->nz, plane = (int64_t)map->ny * map->nz;
+    const bool tiled = map_is_tiled(map);
+    const int64_t own_lo = tiled ? map->own_x_lo * plane : 0, own_hi = tiled ? map->own_x_hi * plane : grid;
+    return DirtySet{map->dirty, map->latent_vecs_pos, buf->valid_blocks, map->counters, no_cache, buf->max_voxels, geo_of(map), map->ignore_count_th,
+                    map->indexer, map->voxel_obs_count, grid_marks_of(map), own_lo, own_hi, tiled};
+}
+
+static VoxelDecodeArgs voxel_decode_args_of(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, const ExtractGeo& e, bool fold) {
+    VoxelDecodeArgs V = {};
+    V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std; V.counters = map->counters;
+    V.refine_list = buf->refine_list; V.R = e.R;
+    V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
+    V.low.res = e.l; V.low.a = (float)e.sample_a; V.low.vsize = (e.l > 1) ? (float)((e.sample_b - e.sample_a) / (e.l - 1)) : 0.0f;
+    return V;
+}
+
+static DecodeArgs refine_args_of(const dif_map_t* map, const dif_extract_buffers_t* buf, const ExtractGeo& e, bool fold) {
+    DecodeArgs Rf = {};
+    Rf.mode = 1; Rf.n_ptr = map->counters + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
+    Rf.lat.res = e.R; Rf.lat.a = (float)e.sample_a; Rf.lat.vsize = (float)((e.sample_b - e.sample_a) / (e.R - 1));
+    Rf.fold_table = fold ? buf->fold_table : nullptr;
+    Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
+    return Rf;
+}
+
+static McArgs mc_args_of(const dif_map_t* map, const dif_extract_buffers_t* buf, const ExtractGeo& e, float max_std, int scale_vertices) {
+    int* C = map->counters;
+    McArgs a = {};
+    a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
+    a.vbm = map->vbm; a.V = map->capacity; a.cube_sdf = buf->cube_sdf; a.cube_std = buf->cube_std; a.R = e.R; a.max_std = max_std;
+    a.max_triangles = buf->cache_capacity; a.new_limit = buf->max_triangles; a.base_ptr = C + DIF_C_CACHE_KEPT;  // append at the log's end (frozen by the scan)
+    a.triangles = buf->cache_tri; a.tri_id = buf->cache_id; a.tri_std = buf->cache_std; a.tri_alive = buf->cache_alive;
+    a.scale = scale_vertices ? 1 : 0; a.vs = map->voxel_size; a.bx = map->bound_min[0]; a.by = map->bound_min[1]; a.bz = map->bound_min[2];
+    a.log_counters = C;
+    a.grid_tot = map->grid_tot;
+    if (2 * (e.r + 1) * (e.r + 1) * (e.r + 1) <= e.R3) {  // the refine list is idle from here on: it carries the blended corners between the passes
+        a.corner_cache = reinterpret_cast<float*>(buf->refine_list);
+        a.corner_stride = e.R3;
+    }
+    return a;
+}
+
+static bool defer_export_of(const dif_map_t* map, const dif_extract_buffers_t* buf) {
+    // deferred export: the copy of the new triangles to the caller's arrays is left to the next frame's first kernel (dif_map_t.pending_export)
+    return buf->defer_export && map->pending_export && buf->out_tri && buf->out_id && buf->out_std;
+}
+
+// the one-pass marching cubes of the stream path: McArgs completed for it
+static void mc_onepass_args(McArgs& a, const dif_map_t* map, const dif_extract_buffers_t* buf, bool defer) {
+    a.tri_start = map->tri_start; a.tri_n = map->tri_n; a.tri_count = buf->tri_count; a.tri_offset = nullptr;
+    if (!defer && buf->out_tri && buf->out_id && buf->out_std) {      // the emitting waves also write the caller's copy (PCIe overlaps the launch)
+        a.out_tri = buf->out_tri; a.out_id = buf->out_id; a.out_std = buf->out_std; a.out_capacity = buf->out_capacity;
+    }
+}
+
+static FinishArgs finish_args_of(const dif_map_t* map, const dif_extract_buffers_t* buf, bool fused_scan, bool onepass, bool exported, bool defer) {
+    int32_t* const super_sum = buf->chunk_sum ? buf->chunk_sum + (buf->max_voxels + 255) / 256 : nullptr;
+    return FinishArgs{buf->occ_slot, map->vbm, map->counters, buf->max_triangles, buf->cache_capacity, buf->cache_tri, buf->cache_id, buf->cache_std,
+                      ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity, (exported || defer) ? 1 : 0,
+                                 defer ? (dif_pending_export_t*)map->pending_export : nullptr},
+                      (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
+                      onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr};
+}
+
+static int voxel_decode_attributes() {
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set[dev]) {
+        const int fp32_bytes = (int)(((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 4 * VD_WAVE_LDS_FLOATS) * 4);
+        const int x6_bytes = (int)((size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4);
+        if (hipFuncSetAttribute((const void*)k_decode_voxels<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fp32_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode_voxels<true>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode_refine_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode_voxels_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode_refine_x6_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+        attr_set[dev] = true;
+    }
+    return DIF_OK;
+}
+
+static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int64_t max_voxels) {
+    int blocks;
+    const int rc = mc_setup(a, lds_bytes, blocks, max_voxels);
+    if (rc != DIF_OK) return rc;
+    static bool attr_set1[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set1[dev]) {
+        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        attr_set1[dev] = true;
+    }
+    // two workgroups per CU (54 KB of LDS each at resolution 4); groups of four voxels are claimed through a ticket counter
+    const int64_t need = (max_voxels + 3) / 4;
+    grid1 = 2 * num_cus();
+    if (lds_bytes * 2 > 150 * 1024) grid1 = num_cus();
+    if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
+    return DIF_OK;
+}
+
 static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                         float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
@@ -739,23 +930,20 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     Geo g = geo_of(map);
     int* C = map->counters;
-    const int r = resolution, R = 2 * r, l = r;               // fast two-level: low lattice l = R/2 (map.py:642-644)
-    const int R3 = R * R * R;
+    const ExtractGeo e = extract_geo(resolution);
+    const int r = e.r, R = e.R, l = e.l, R3 = e.R3;
     if (buf->max_voxels * (int64_t)R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
-    const double sample_a = -(double)(r / 2) * (1.0 / r), sample_b = 1.0 + (double)((r - 1) / 2) * (1.0 / r);   // map.py:640-641
+    const double sample_a = e.sample_a, sample_b = e.sample_b;
 
     {   // dirty slots -> valid_blocks
-        const int64_t plane = (int64_t)map->ny * map->nz;
-        const bool tiled = map->own_x_hi > map->own_x_lo && (map->own_x_lo > 0 || map->own_x_hi < map->nx);
-        const int64_t own_lo = tiled ? map->own_x_lo * plane : 0, own_hi = tiled ? map->own_x_hi * plane : grid;
+        const DirtySet ds = dirty_set_of(map, buf, no_cache);
+        const bool tiled = ds.tiled;
         if (tiled) {
             hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th, map->dirty,
                                (const int64_t*)map->latent_vecs_pos, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, bits,
-                               n_slots, own_lo, own_hi);
+                               n_slots, ds.own_lin_lo, ds.own_lin_hi);
             DIF_CHECK_LAUNCH();
         }
-        DirtySet ds{map->dirty, map->latent_vecs_pos, buf->valid_blocks, C, no_cache, buf->max_voxels, g, map->ignore_count_th,
-                    map->indexer, map->voxel_obs_count, bits, own_lo, own_hi, tiled};
         {
             DirtyFunctor f{ds};
             // every writer of the flags kept the per-block totals (k_fuse; the host recomputes them after anything else): no counting pass
@@ -776,25 +964,12 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     if (fast && l * l * l <= VD_MAX_L3 && R * R <= VD_MAX_R2) {
         // fused per-voxel low lattice + upsample + threshold, then the balanced exact re-decode (map.py:644-679)
         if (!w->dec_packed || w->dec_packed_floats != DEC_FLOATS) return DIF_EINVAL;
-        VoxelDecodeArgs V = {};
-        V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std; V.counters = C;
-        V.refine_list = buf->refine_list; V.R = R;
         const bool fold = w->dec_fold_packed && w->dec_fold_packed_floats == DECF_FLOATS && buf->fold_table;
-        V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
-        V.low.res = l; V.low.a = (float)sample_a; V.low.vsize = (l > 1) ? (float)((sample_b - sample_a) / (l - 1)) : 0.0f;
+        const VoxelDecodeArgs V = voxel_decode_args_of(map, w, buf, e, fold);
         const bool x6 = fold && w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES;       // tiles on the bf16 matrix pipe (mlp.hip.h)
         const size_t lds_bytes = x6 ? (size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4
                                     : ((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 4 * VD_WAVE_LDS_FLOATS) * 4;       // four pairs of waves
-        static bool attr_set[64] = {};
-        int dev = 0; (void)hipGetDevice(&dev);
-        if (dev < 64 && !attr_set[dev]) {
-            const int fp32_bytes = (int)(((size_t)((DEC_LDS_FLOATS + 3) & ~3) + 4 * VD_WAVE_LDS_FLOATS) * 4);
-            const int x6_bytes = (int)((size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4);
-            if (hipFuncSetAttribute((const void*)k_decode_voxels<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fp32_bytes) != hipSuccess) return DIF_ELAUNCH;
-            if (hipFuncSetAttribute((const void*)k_decode_voxels<true>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
-            if (hipFuncSetAttribute((const void*)k_decode_refine_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
-            attr_set[dev] = true;
-        }
+        if (voxel_decode_attributes() != DIF_OK) return DIF_ELAUNCH;
         int64_t blocks = (buf->max_voxels + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
         {
@@ -803,11 +978,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             else hipLaunchKernelGGL(k_decode_voxels<false>, dim3((int)blocks), dim3(512), lds_bytes, s, V, w->dec_packed);
         }
         DIF_CHECK_LAUNCH();
-        DecodeArgs Rf = {};
-        Rf.mode = 1; Rf.n_ptr = C + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
-        Rf.lat.res = R; Rf.lat.a = (float)sample_a; Rf.lat.vsize = (float)((sample_b - sample_a) / (R - 1));
-        Rf.fold_table = fold ? buf->fold_table : nullptr;
-        Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
+        const DecodeArgs Rf = refine_args_of(map, buf, e, fold);
         if (x6) {
             int64_t rblocks = (buf->max_voxels * (int64_t)(R3 / 32) + 7) / 8;
             if (rblocks < 1) rblocks = 1;
@@ -834,10 +1005,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
                            (const float*)buf->low_sdf, (const float*)buf->low_std, l, R, buf->cube_sdf, buf->cube_std, buf->refine_list, C);
         DIF_CHECK_LAUNCH();
         // exact re-decode of the near-surface samples (map.py:668-679)
-        DecodeArgs Rf = {};
-        Rf.mode = 1; Rf.n_ptr = C + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
-        Rf.lat.res = R; Rf.lat.a = (float)sample_a; Rf.lat.vsize = (float)((sample_b - sample_a) / (R - 1));
-        Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
+        const DecodeArgs Rf = refine_args_of(map, buf, e, false);
         rc = launch_decode(Rf, w, buf->max_voxels * (int64_t)(R3 / 32), s);
         if (rc != DIF_OK) return rc;
     } else {
@@ -850,47 +1018,21 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (rc != DIF_OK) return rc;
     }
     // marching cubes (map.py:689-691)
-    McArgs a = {};
-    a.indexer = map->indexer; a.nx = map->nx; a.ny = map->ny; a.nz = map->nz; a.valid_blocks = buf->valid_blocks; a.K_ptr = C + DIF_C_K; a.K_static = 0;
-    a.vbm = map->vbm; a.V = map->capacity; a.cube_sdf = buf->cube_sdf; a.cube_std = buf->cube_std; a.R = R; a.max_std = max_std;
-    a.max_triangles = buf->cache_capacity; a.new_limit = buf->max_triangles; a.base_ptr = C + DIF_C_CACHE_KEPT;  // append at the log's end (frozen by the scan)
-    a.triangles = buf->cache_tri; a.tri_id = buf->cache_id; a.tri_std = buf->cache_std; a.tri_alive = buf->cache_alive;
-    a.scale = scale_vertices ? 1 : 0; a.vs = map->voxel_size; a.bx = map->bound_min[0]; a.by = map->bound_min[1]; a.bz = map->bound_min[2];
+    McArgs a = mc_args_of(map, buf, e, max_std, scale_vertices);
     if (no_cache) {                                                                                               // map.py:614-616
         if (hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
         if (hipMemsetAsync(C + DIF_C_CACHE_DEAD, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
         if (hipMemsetAsync(map->tri_n, 0, sizeof(int32_t) * (size_t)map->capacity, s) != hipSuccess) return DIF_ELAUNCH;
     }
-    a.log_counters = C;
-    a.grid_tot = map->grid_tot;
-    if (2 * (r + 1) * (r + 1) * (r + 1) <= R3) {         // the refine list is idle from here on: it carries the blended corners between the passes
-        a.corner_cache = reinterpret_cast<float*>(buf->refine_list);
-        a.corner_stride = R3;
-    }
-    // deferred export: the copy of the new triangles to the caller's arrays is left to the next frame's first kernel (dif_map_t.pending_export)
-    const bool defer = buf->defer_export && map->pending_export && buf->out_tri && buf->out_id && buf->out_std;
+    const bool defer = defer_export_of(map, buf);
     const bool fused_scan = buf->chunk_sum && buf->max_voxels <= ((int64_t)1 << 24);      // three levels of 256: beyond that the scan kernel
     int32_t* const super_sum = buf->chunk_sum ? buf->chunk_sum + (buf->max_voxels + 255) / 256 : nullptr;
     const bool onepass = fused_scan && buf->mc_status && r * r * r <= 64;                // count, look-back and emit in one launch
     if (onepass) {
-        a.tri_start = map->tri_start; a.tri_n = map->tri_n; a.tri_count = buf->tri_count; a.tri_offset = nullptr;
-        if (!defer && buf->out_tri && buf->out_id && buf->out_std) {      // the emitting waves also write the caller's copy (PCIe overlaps the launch)
-            a.out_tri = buf->out_tri; a.out_id = buf->out_id; a.out_std = buf->out_std; a.out_capacity = buf->out_capacity;
-        }
-        size_t lds_bytes; int blocks;
-        rc = mc_setup(a, lds_bytes, blocks, buf->max_voxels);
+        mc_onepass_args(a, map, buf, defer);
+        size_t lds_bytes; int grid1;
+        rc = mc_onepass_setup(a, lds_bytes, grid1, buf->max_voxels);
         if (rc != DIF_OK) return rc;
-        static bool attr_set1[64] = {};
-        int dev = 0; (void)hipGetDevice(&dev);
-        if (dev < 64 && !attr_set1[dev]) {
-            if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
-            attr_set1[dev] = true;
-        }
-        // two workgroups per CU (54 KB of LDS each at resolution 4); groups of four voxels are claimed through a ticket counter
-        int64_t need = (buf->max_voxels + 3) / 4;
-        int grid1 = 2 * num_cus();
-        if (lds_bytes * 2 > 150 * 1024) grid1 = num_cus();
-        if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
         {
             ProfScope prof(DIF_PROF_MC_COUNT, s);
             hipLaunchKernelGGL(k_marching_cubes_onepass, dim3(grid1), dim3(DIF_BLOCK), lds_bytes, s, a, buf->mc_status, buf->mc_status + (buf->max_voxels + 3) / 4);
@@ -920,12 +1062,79 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         rc = mc_emit(a, buf->max_voxels, buf->tri_count, buf->tri_offset, s);
         if (rc != DIF_OK) return rc;
     }
-    hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, (const int32_t*)buf->occ_slot, map->vbm,
-                       C, buf->max_triangles, buf->cache_capacity, (const float*)buf->cache_tri, (const int64_t*)buf->cache_id,
-                       (const float*)buf->cache_std, ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity, ((onepass && a.out_tri) || defer) ? 1 : 0,
-                                  defer ? (dif_pending_export_t*)map->pending_export : nullptr},
-                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
-                       onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr);
+    hipLaunchKernelGGL(k_extract_finish, dim3(grid_for(buf->max_voxels, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s,
+                       finish_args_of(map, buf, fused_scan, onepass, onepass && a.out_tri, defer));
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+// S maps through the six launches of the stream's extract (dirty scan, batch scan, lattice decode, refine decode, one-pass marching cubes,
+// finish): only the configuration a streaming caller runs — see include/difusion.h
+int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weights_t* w, int32_t resolution, float max_std, int32_t scale_vertices,
+                        void* stream_) {
+    if (!batch_maps_ok(st, S) || !w || resolution < 1 || resolution > 4) return DIF_EINVAL;
+    const ExtractGeo e = extract_geo(resolution);
+    if (e.l * e.l * e.l > VD_MAX_L3 || e.R * e.R > VD_MAX_R2 || e.r * e.r * e.r > 64) return DIF_EINVAL;
+    if (!w->dec_packed || w->dec_packed_floats != DEC_FLOATS || !w->dec_fold_packed || w->dec_fold_packed_floats != DECF_FLOATS || !w->dec_x6_packed ||
+        w->dec_x6_packed_bytes != X6_BYTES)
+        return DIF_EINVAL;
+    const dif_map_t* m0 = st[0].map;
+    if (m0->capacity <= 4096 || m0->capacity % DIF_BLOCK != 0) return DIF_EINVAL;
+    const int64_t grid = (int64_t)m0->nx * m0->ny * m0->nz;
+    static thread_local Batch<DirtyScanArgs> dirty; static thread_local ScanBatch<OccFunctor> occ; static thread_local Batch<VoxelDecodeArgs> vd;
+    static thread_local Batch<DecodeArgs> rf; static thread_local Batch<McStream> mc; static thread_local Batch<FinishArgs> fin;
+    for (int j = 0; j < S; ++j) {
+        const dif_map_t* map = st[j].map;
+        const dif_extract_buffers_t* buf = st[j].buf;
+        if (!buf || buf->max_voxels <= 0 || buf->max_voxels != st[0].buf->max_voxels || buf->max_voxels * (int64_t)e.R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
+        if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_tri || !buf->cache_id || !buf->cache_std || !buf->cache_alive)
+            return DIF_EINVAL;
+        if (!map->tri_start || !map->tri_n || !buf->fold_table || !buf->chunk_sum || !buf->mc_status || buf->max_voxels > ((int64_t)1 << 24)) return DIF_EINVAL;
+        dirty.s[j] = DirtyScanArgs{dirty_set_of(map, buf, 0), map->counters + DIF_C_N_OCCUPIED, map->dirty_tot};
+        occ.f[j] = OccFunctor{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, map->counters, buf->max_voxels};
+        occ.tot[j] = map->grid_tot;
+        vd.s[j] = voxel_decode_args_of(map, w, buf, e, true);
+        rf.s[j] = refine_args_of(map, buf, e, true);
+        const bool defer = defer_export_of(map, buf);
+        McArgs a = mc_args_of(map, buf, e, max_std, scale_vertices);
+        mc_onepass_args(a, map, buf, defer);
+        mc.s[j] = McStream{a, buf->mc_status, buf->mc_status + (buf->max_voxels + 3) / 4};
+        fin.s[j] = finish_args_of(map, buf, true, true, a.out_tri != nullptr, defer);
+    }
+    for (int j = S; j < DIF_MAX_STREAMS; ++j) {
+        dirty.s[j] = dirty.s[0]; occ.f[j] = occ.f[0]; occ.tot[j] = occ.tot[0]; vd.s[j] = vd.s[0]; rf.s[j] = rf.s[0]; mc.s[j] = mc.s[0]; fin.s[j] = fin.s[0];
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    const int64_t max_voxels = st[0].buf->max_voxels;
+    hipLaunchKernelGGL(k_dirty_scan_batch, dim3((int)(m0->capacity / DIF_BLOCK), S), dim3(DIF_BLOCK), 0, s, dirty);
+    DIF_CHECK_LAUNCH();
+    if (launch_counted_scan_batch(occ, S, (int)((grid + 31) / 32), s) != DIF_OK) return DIF_ELAUNCH;
+    if (voxel_decode_attributes() != DIF_OK) return DIF_ELAUNCH;
+    {
+        int64_t blocks = (max_voxels * S + 3) / 4;
+        if (blocks > num_cus()) blocks = num_cus();
+        ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
+        hipLaunchKernelGGL(k_decode_voxels_batch<true>, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4, s, vd, (int)S,
+                           (const float*)w->dec_x6_packed);
+        DIF_CHECK_LAUNCH();
+    }
+    {
+        int64_t rblocks = (max_voxels * S * (int64_t)(e.R3 / 32) + 7) / 8;
+        if (rblocks < 1) rblocks = 1;
+        if (rblocks > num_cus()) rblocks = num_cus();
+        ProfScope prof(DIF_PROF_DECODE_POINTS, s);
+        hipLaunchKernelGGL(k_decode_refine_x6_batch, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, rf, (int)S, (const float*)w->dec_x6_packed);
+        DIF_CHECK_LAUNCH();
+    }
+    {
+        size_t lds_bytes; int grid1;
+        const int rc = mc_onepass_setup(mc.s[0].a, lds_bytes, grid1, max_voxels);
+        if (rc != DIF_OK) return rc;
+        ProfScope prof(DIF_PROF_MC_COUNT, s);
+        hipLaunchKernelGGL(k_marching_cubes_onepass_batch, dim3(grid1, S), dim3(DIF_BLOCK), lds_bytes, s, mc);
+        DIF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_extract_finish_batch, dim3(grid_for(max_voxels, DIF_BLOCK, 256), S), dim3(DIF_BLOCK), 0, s, fin);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

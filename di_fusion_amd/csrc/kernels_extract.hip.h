@@ -105,7 +105,7 @@ struct DirtyFunctor {
 // were kept by whoever set the flags) with its memory chain started EARLY: a thread reads its flag without waiting for n_occupied (flags
 // beyond it are never set), and a dirty slot's position -> 7 neighbour look-ups -> 7 observation counts -> 7 bitmap words are requested
 // before the two block-wide sums of the prefix, not after them — nine dependent hops become six.
-__global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan(DirtySet a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot) {
+__device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot) {
     __shared__ int smem[8];
     const int s = (int)blockIdx.x * DIF_BLOCK + (int)threadIdx.x;           // grid covers the capacity (a multiple of DIF_BLOCK)
     const bool flag = a.dirty[s] != 0;
@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan(DirtySet a, const int*
     uint32_t word[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) { cand[c] = 0; word[c] = 0xFFFFFFFFu; }
-    if (flag) {
-        lin = (int)a.pos[s];
+    // (a stray flag on a slot without a voxel — position -1 beyond n_occupied — is never followed: nothing hangs off an invalid position)
+    if (flag && (lin = (int)a.pos[s]) >= 0) {
         int ix, iy, iz;
         unlinearize(a.g, lin, ix, iy, iz);
         cand[0] = lin;
@@ -169,6 +169,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan(DirtySet a, const int*
         if (t > a.max_voxels) { t = (int)a.max_voxels; a.counters[DIF_C_OVERFLOW] = 2; }
         a.counters[DIF_C_K] = t;
     }
+}
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan(DirtySet a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot) {
+    dirty_scan_body(a, n_ptr, block_tot);
+}
+struct DirtyScanArgs { DirtySet a; const int* n_ptr; const int* block_tot; };
+__global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan_batch(Batch<DirtyScanArgs> b) {
+    const DirtyScanArgs& a = b.s[blockIdx.y];
+    dirty_scan_body(a.a, a.n_ptr, a.block_tot);
 }
 
 struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm[slot] = b; clears the bitmap
@@ -410,33 +419,57 @@ __global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArg
 }
 
 // Refine rows (mode 1 with the lattice pass's fold table) on the bf16 matrix pipe; wblob = packing.py:pack_decoder_x6.
-__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
+// NS > 1: the refine lists of S <= NS maps walked as one range of tiles (see encode_body); lattice and sign are those of map 0.
+template <int NS>
+__device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, NS>& B, int S, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
-    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x));
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int res3 = A.lat.res * A.lat.res * A.lat.res, r = A.lat.res;
-    const int64_t n_rows = A.n_ptr ? (int64_t)(*A.n_ptr) : A.n_static;
-    const int64_t n_tiles = (n_rows + 31) / 32;
+    const Lattice lat = B.s[0].lat;
+    const float sign = B.s[0].sign;
+    const int res3 = lat.res * lat.res * lat.res, r = lat.res;
+    Ranges<NS, int64_t> rg;              // cnt: refine rows of map j; pre: its first tile in the concatenated range
+    rg.pre[0] = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        rg.cnt[j] = (j < S) ? (B.s[j].n_ptr ? (int64_t)(*B.s[j].n_ptr) : B.s[j].n_static) : 0;
+        rg.pre[j + 1] = rg.pre[j] + (rg.cnt[j] + 31) / 32;
+    }
+    const int64_t n_tiles = rg.total();
     // the first tile's list entries are requested before the weights are staged (one dependent hop off the critical path)
-    int e_next = ((int64_t)wave * 32 + col < n_rows) ? A.list[(int64_t)wave * 32 + col] : 0;
+    int sm_n; int64_t lt_n, rows_n;
+    rg.locate(wave, sm_n, lt_n, rows_n);
+    int e_next = (wave < n_tiles && lt_n * 32 + col < rows_n) ? B.s[sm_n].list[lt_n * 32 + col] : 0;
     __builtin_amdgcn_sched_barrier(0);
     stage_weights(lds, wblob, X6_LDS_BYTES / 4);
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
-    for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+    for (int64_t T = wave; T < n_tiles; T += nwaves) {
+        const int sm = sm_n;
+        const int64_t tile = lt_n, n_rows = rows_n;
+        const DecodeArgs& A = B.s[sm];
         const int64_t row = tile * 32 + col;
         const bool live = row < n_rows;
         const int e = e_next;
-        e_next = (row + (int64_t)nwaves * 32 < n_rows) ? A.list[row + (int64_t)nwaves * 32] : 0;
-        const int b = e / res3, s = e - b * res3;
-        const float px = A.lat.coord(s / (r * r)), py = A.lat.coord((s / r) % r), pz = A.lat.coord(s % r);
+        rg.locate(T + nwaves, sm_n, lt_n, rows_n);
+        e_next = (T + nwaves < n_tiles && lt_n * 32 + col < rows_n) ? B.s[sm_n].list[lt_n * 32 + col] : 0;
+        const int b = e / res3, sb = e - b * res3;
+        const float px = lat.coord(sb / (r * r)), py = lat.coord((sb / r) % r), pz = lat.coord(sb % r);
         float sdf, sd;
         decoder_tile_folded_x6(lds, wfwd, FoldInitGlobal{A.fold_table + (int64_t)b * 256}, px, py, pz, lane, sdf, sd);
         if (live) {
-            if (half == 0) A.out_sdf[e] = A.sign * sdf;
+            if (half == 0) A.out_sdf[e] = sign * sdf;
             else A.out_std[e] = sd;
         }
     }
+}
+
+__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
+    const BatchN<DecodeArgs, 1> B{{A}};
+    decode_refine_x6_body<1>(B, 1, wblob);
+}
+__global__ void __launch_bounds__(512, 1) k_decode_refine_x6_batch(Batch<DecodeArgs> B, int S, const float* __restrict__ wblob) {
+    decode_refine_x6_body<DIF_MAX_STREAMS>(B, S, wblob);
 }
 
 // Trilinear x2 upsample (align_corners) of the low lattice + selection of samples to re-decode (map.py:655-667).
@@ -545,9 +578,12 @@ __device__ unsigned long long g_vd_trace[2048 * 8];
 #define VD_STAMP(slot) do { } while (0)
 #endif
 
-// X6: the tiles run on the bf16 matrix pipe (decoder_tile_folded_x6; wblob = packing.py:pack_decoder_x6, folding required)
-template <bool X6>
-__global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
+// X6: the tiles run on the bf16 matrix pipe (decoder_tile_folded_x6; wblob = packing.py:pack_decoder_x6, folding required).
+// NS > 1: the decoded batches of S <= NS maps are walked as ONE range of voxels (map 0's, then map 1's, ...): weights staged once per
+// workgroup, S frames' worth of pairs per launch.  A pair's voxel belongs to one map (scalar loads of that map's pointers from the
+// kernel-argument array); lattice, resolution and fold weights are those of map 0; refine-list space is reserved per map.
+template <bool X6, int NS>
+__device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs, NS>& AB, int S, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     VD_STAMP(0);
     constexpr int LDS_W = X6 ? X6_LDS_BYTES / 4 : ((DEC_LDS_FLOATS + 3) & ~3);
@@ -565,30 +601,41 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
     float* w_low_sdf = lds + LDS_W + pair * VD_WAVE_LDS_FLOATS;       // shared by the pair
     float* w_low_std = w_low_sdf + VD_MAX_L3;
     float* w_fold = w_low_std + VD_MAX_L3 + tsel * 256;        // [c0 | c3], see decoder_fold_consts: each wave keeps its own copy (no barrier before the MFMAs)
-    const int l = A.low.res, R = A.R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
+    const Lattice low = AB.s[0].low;
+    const float* const fold_w = AB.s[0].fold_w;
+    const int l = low.res, R = AB.s[0].R, l3 = l * l * l, R2 = R * R, R3 = R2 * R;
     const float scale = (float)(l - 1) / (float)(R - 1);
-    const int B = A.counters[DIF_C_B];
+    int pre[NS + 1];                                           // first voxel of map j in the concatenated range
+    pre[0] = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) pre[j + 1] = pre[j] + ((j < S) ? AB.s[j].counters[DIF_C_B] : 0);
+    const int B = pre[NS];
     const int pairs_per_block = (int)(blockDim.x >> 7), n_pairs = (int)gridDim.x * pairs_per_block;
-    const int first = pair * (int)gridDim.x + (int)blockIdx.x;  // spread over CUs first
+    const int first = __builtin_amdgcn_readfirstlane(pair * (int)gridDim.x + (int)blockIdx.x);  // spread over CUs first
     // uniform trip count: the barriers below are workgroup-wide (the pair's hand-over, and the refine-list reservation: one global
-    // atomic per workgroup and round instead of one per voxel — 900 same-address atomics at the end of the launch queued up for ~5 us)
-    __shared__ int s_tot[8], s_base;
+    // atomic per workgroup, map and round instead of one per voxel — 900 same-address atomics at the end of the launch queued up for ~5 us)
+    __shared__ int s_tot[8], s_map[8], s_base[NS];
     const int rounds = (B + n_pairs - 1) / n_pairs;
     for (int round = 0; round < rounds; ++round) {
-        const int b = first + round * n_pairs;
+        const int bg = first + round * n_pairs;                // index in the concatenated range
+        int sm = 0, b = bg;                                    // map and index in that map's batch
+#pragma unroll
+        for (int j = 1; j < NS; ++j)
+            if (bg >= pre[j]) { sm = j; b = bg - pre[j]; }
+        const VoxelDecodeArgs& A = AB.s[sm];
         unsigned sel = 0;
         const int jz0 = tsel * (R >> 1), jz1 = jz0 + (R >> 1);  // this wave's share of the z samples
         const int64_t e0 = (int64_t)b * R3 + (int64_t)lane * R;
-        if (b < B && tsel * 32 < l3) {
+        if (bg < B && tsel * 32 < l3) {
             const float* lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
             const int s = tsel * 32 + col;
-            const float px = A.low.coord(s / (l * l)), py = A.low.coord((s / l) % l), pz = A.low.coord(s % l);
+            const float px = low.coord(s / (l * l)), py = low.coord((s / l) % l), pz = low.coord(s % l);
             float sdf = 0.0f, sd = 0.0f;
             // ---- this wave's tile of the low lattice -> LDS (map.py:644-653) ----
-            if (X6 || A.fold_w) {
+            if (X6 || fold_w) {
                 // the voxel's latent goes through lin0 / lin3 once (VALU), every sample then only adds its coordinate columns (MFMA)
-                if constexpr (X6) decoder_fold_consts_x6(lds, A.fold_w, lat_row, w_fold, lane);
-                else decoder_fold_consts(lds, A.fold_w, lat_row, w_fold, lane);
+                if constexpr (X6) decoder_fold_consts_x6(lds, fold_w, lat_row, w_fold, lane);
+                else decoder_fold_consts(lds, fold_w, lat_row, w_fold, lane);
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 if (tsel == 0) {
@@ -620,18 +667,20 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
         __syncthreads();                        // both tiles of every pair are in LDS
         VD_STAMP(2);
         // ---- trilinear x2 + threshold (map.py:655-667): lane = (jx, jy) row of R samples along z, this wave's half of them ----
-        if (b < B && lane < R2) {
+        if (bg < B && lane < R2) {
             const int jx = lane / R, jy = lane % R;
             int x0, x1, y0, y1; float wx0, wx1, wy0, wy1;
             tri_axis(jx, l, scale, x0, x1, wx0, wx1);
             tri_axis(jy, l, scale, y0, y1, wy0, wy1);
+            float* const cube_sdf = A.cube_sdf;
+            float* const cube_std = A.cube_std;
             for (int jz = jz0; jz < jz1; ++jz) {
                 int z0, z1; float wz0, wz1;
                 tri_axis(jz, l, scale, z0, z1, wz0, wz1);
                 float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
                 float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                A.cube_sdf[e0 + jz] = -sv;
-                A.cube_std[e0 + jz] = dv;
+                cube_sdf[e0 + jz] = -sv;
+                cube_std[e0 + jz] = dv;
                 if (fabsf(sv) < 0.05f) sel |= 1u << jz;
             }
         }
@@ -639,21 +688,29 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
         const int c = __popc(sel);
         const int incl = wave_incl_scan(c);
         const int total = __shfl(incl, 63);
-        if (lane == 0) s_tot[wid] = total;
+        if (lane == 0) { s_tot[wid] = total; if (NS > 1) s_map[wid] = sm; }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (NS == 1) {
+            if (threadIdx.x == 0) {
+                int sum = 0;
+                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += s_tot[w];
+                s_base[0] = sum ? atomicAdd(A.counters + DIF_C_VH, sum) : 0;
+            }
+        } else if ((int)threadIdx.x < S) {      // thread j reserves for map j what this workgroup's waves selected in map j's voxels
+            const int j = (int)threadIdx.x;
             int sum = 0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += s_tot[w];
-            s_base = sum ? atomicAdd(A.counters + DIF_C_VH, sum) : 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += (s_map[w] == j) ? s_tot[w] : 0;
+            s_base[j] = sum ? atomicAdd(AB.s[j].counters + DIF_C_VH, sum) : 0;
         }
         __syncthreads();
         if (total > 0) {
-            int o = s_base + incl - c;
-            for (int w = 0; w < wid; ++w) o += s_tot[w];
+            int o = s_base[NS == 1 ? 0 : sm] + incl - c;
+            for (int w = 0; w < wid; ++w) o += (NS == 1 || s_map[w] == sm) ? s_tot[w] : 0;
+            int32_t* const refine_list = A.refine_list;
             while (sel) {
                 const int jz = __ffs((int)sel) - 1;
                 sel &= sel - 1;
-                A.refine_list[o++] = (int32_t)(e0 + jz);
+                refine_list[o++] = (int32_t)(e0 + jz);
             }
         }
         __syncthreads();                        // s_tot / s_base and the pair's LDS record are rewritten by the next round
@@ -662,3 +719,12 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeAr
     VD_STAMP(5);
 }
 
+template <bool X6>
+__global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
+    const BatchN<VoxelDecodeArgs, 1> B{{A}};
+    decode_voxels_body<X6, 1>(B, 1, wblob);
+}
+template <bool X6>
+__global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels_batch(Batch<VoxelDecodeArgs> B, int S, const float* __restrict__ wblob) {
+    decode_voxels_body<X6, DIF_MAX_STREAMS>(B, S, wblob);
+}

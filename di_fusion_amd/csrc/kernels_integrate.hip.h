@@ -38,10 +38,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* _
 
 // a1 + a2 + a3 in one pass for a streaming caller: depth pixel -> world point and normal (written out for the later stages) -> voxel id
 // and per-voxel count, without re-reading the points.
-__global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(Geo g, const dif_frame_t* __restrict__ frame, int H, int W, float fx, float fy,
-                                                                   float cx, float cy, float* __restrict__ xyz, float* __restrict__ nrm,
-                                                                   int* __restrict__ pt_lin, int* __restrict__ frame_count, int* __restrict__ counters,
-                                                                   int px_lo, int px_hi, const dif_pending_export_t* __restrict__ pending, int nb_x) {
+__device__ __forceinline__ void unproject_voxel_count_body(const Geo& g, const dif_frame_t* __restrict__ frame, int H, int W, float fx, float fy,
+                                                           float cx, float cy, float* __restrict__ xyz, float* __restrict__ nrm,
+                                                           int* __restrict__ pt_lin, int* __restrict__ frame_count, int* __restrict__ counters,
+                                                           int px_lo, int px_hi, const dif_pending_export_t* __restrict__ pending, int nb_x) {
     // The first nb_x workgroups (dispatched first, so that the copy runs beside the whole point pass and not at its tail) carry out a third of
     // the previous extract's deferred triangle export; the other two thirds ride with the next two kernels.
     if ((int)blockIdx.x < nb_x) {
@@ -65,12 +65,28 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(Geo g, cons
     voxel_count_point(g, in, p[0], p[1], p[2], i, pt_lin, frame_count, counters, px_lo, px_hi);
 }
 
+struct UvcArgs {            // per map; the image geometry is shared by the maps of a batched launch
+    Geo g; const dif_frame_t* frame; float* xyz; float* nrm; int* pt_lin; int* frame_count; int* counters; int px_lo, px_hi;
+    const dif_pending_export_t* pending;
+};
+struct ImageGeo { int H, W; float fx, fy, cx, cy; };
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(UvcArgs a, ImageGeo im, int nb_x) {
+    unproject_voxel_count_body(a.g, a.frame, im.H, im.W, im.fx, im.fy, im.cx, im.cy, a.xyz, a.nrm, a.pt_lin, a.frame_count, a.counters, a.px_lo, a.px_hi,
+                               a.pending, nb_x);
+}
+__global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count_batch(Batch<UvcArgs> b, ImageGeo im, int nb_x) {
+    const UvcArgs& a = b.s[blockIdx.y];
+    unproject_voxel_count_body(a.g, a.frame, im.H, im.W, im.fx, im.fy, im.cx, im.cy, a.xyz, a.nrm, a.pt_lin, a.frame_count, a.counters, a.px_lo, a.px_hi,
+                               a.pending, nb_x);
+}
+
 // K2: prune mask + candidate voxels.  mask[i] = count(voxel of i) > prune_min_vox_obs (map.py:375).  A kept point whose
 // voxel has no slot marks that voxel and its 6 clamped neighbours (if empty) in the bitmap (map.py:383-386).
-__global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, const int* __restrict__ pt_lin, int64_t N,
-                                                        const int* __restrict__ frame_count, const int64_t* __restrict__ indexer,
-                                                        uint8_t* __restrict__ unq_mask, GridMarks marks,
-                                                        int* __restrict__ counters, const dif_pending_export_t* __restrict__ pending, int nb_x) {
+__device__ __forceinline__ void prune_mark_body(const Geo& g, int prune_min, const int* __restrict__ pt_lin, int64_t N,
+                                                const int* __restrict__ frame_count, const int64_t* __restrict__ indexer,
+                                                uint8_t* __restrict__ unq_mask, const GridMarks& marks,
+                                                int* __restrict__ counters, const dif_pending_export_t* __restrict__ pending, int nb_x) {
     if ((int)blockIdx.x < nb_x) {           // leading workgroups: the second third of a deferred triangle export
         export_pending_rows(pending, nb_x + (int)blockIdx.x, 3 * nb_x);
         return;
@@ -113,6 +129,19 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(Geo g, int prune_min, 
     }
 }
 
+struct PruneArgs {
+    Geo g; int prune_min; const int* pt_lin; const int* frame_count; const int64_t* indexer; uint8_t* unq_mask; GridMarks marks; int* counters;
+    const dif_pending_export_t* pending;
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(PruneArgs a, int64_t N, int nb_x) {
+    prune_mark_body(a.g, a.prune_min, a.pt_lin, N, a.frame_count, a.indexer, a.unq_mask, a.marks, a.counters, a.pending, nb_x);
+}
+__global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark_batch(Batch<PruneArgs> b, int64_t N, int nb_x) {
+    const PruneArgs& a = b.s[blockIdx.y];
+    prune_mark_body(a.g, a.prune_min, a.pt_lin, N, a.frame_count, a.indexer, a.unq_mask, a.marks, a.counters, a.pending, nb_x);
+}
+
 // K3: ordered compaction of the candidate bitmap -> slots n_occupied, n_occupied+1, ... in ASCENDING lin order
 // (torch.unique order, map.py:385-387, 310-319).  Clears the bitmap as it goes.
 struct AllocFunctor {
@@ -153,12 +182,12 @@ struct AllocFunctor {
 __device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
 
 #define FG_TABLE 256            /* == DIF_BLOCK: one table entry per thread in the scan below */
-__global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
-                                                          const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
-                                                          const int64_t* __restrict__ indexer, const float* __restrict__ obs,
-                                                          uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w,
-                                                          int* __restrict__ grid_tot, int own_lo, int own_hi,
-                                                          const dif_pending_export_t* __restrict__ pending, int nb_x) {
+__device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
+                                                  const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
+                                                  const int64_t* __restrict__ indexer, const float* __restrict__ obs,
+                                                  uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w,
+                                                  int* __restrict__ grid_tot, int own_lo, int own_hi,
+                                                  const dif_pending_export_t* __restrict__ pending, int nb_x) {
     if ((int)blockIdx.x < nb_x) {           // leading workgroups: the last third of a deferred triangle export
         export_pending_rows(pending, 2 * nb_x + (int)blockIdx.x, 3 * nb_x);
         return;
@@ -270,6 +299,21 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(Geo g, float enc_th,
             pair_list[s_base + (where[o] >= 0 ? tcnt[where[o]] : grouped) + rank[o]] = make_uint2(key[o], (uint32_t)((int64_t)o * N + i));
 }
 
+struct GatherArgs {
+    Geo g; float enc_th; const float* xyz; const int* pt_lin; const uint8_t* unq_mask; int* frame_count; const int64_t* indexer; const float* obs;
+    uint2* pair_list; int* counters; int64_t capacity; int* grid_tot; int own_lo, own_hi; const dif_pending_export_t* pending;
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(GatherArgs a, int64_t N, int img_w, int nb_x) {
+    focus_gather_body(a.g, a.enc_th, a.xyz, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
+                      a.own_lo, a.own_hi, a.pending, nb_x);
+}
+__global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather_batch(Batch<GatherArgs> b, int64_t N, int img_w, int nb_x) {
+    const GatherArgs& a = b.s[blockIdx.y];
+    focus_gather_body(a.g, a.enc_th, a.xyz, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
+                      a.own_lo, a.own_hi, a.pending, nb_x);
+}
+
 // =================================================================================================================
 // a7..a9 : gather + encoder (MFMA) + per-voxel sums
 // =================================================================================================================
@@ -296,58 +340,79 @@ __device__ unsigned long long g_en_trace[2048 * 8];
 #define EN_STAMP(slot) do { } while (0)
 #endif
 
-// X6: the tile runs on the bf16 matrix pipe (encoder_tile_x6; wblob = packing.py:pack_encoder_x6)
-template <bool X6>
-__global__ void __launch_bounds__(512, X6 ? 1 : 2)
-k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
-         const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
-         int* __restrict__ upd_list, int* __restrict__ counters, const uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
+// X6: the tile runs on the bf16 matrix pipe (encoder_tile_x6; wblob = packing.py:pack_encoder_x6).
+// NS > 1: the tiles of S <= NS maps are walked as ONE range (map 0's tiles, then map 1's, ...): the weights are staged once per
+// workgroup and the launch carries S frames' worth of tiles per SIMD.  Which map a tile belongs to is wave-uniform (scalar loads of
+// that map's pointers from the kernel-argument array); per map nothing changes — same tiles, same records, same directory.
+struct EncArgs {
+    Geo g; const float* xyz; const float* normal; const uint2* pair_list; int* rec_dir; int* rec_next; long long* rec; int* upd_list; int* counters;
+    const uint8_t* dirty; int* dirty_tot;
+};
+template <bool X6, int NS>
+__device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S, const float* __restrict__ wblob, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     EN_STAMP(0);
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
     // tile t goes to wave (t / #blocks) of block (t % #blocks): a partly filled launch spreads over all CUs and SIMDs first
-    const int wave = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x));
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int M = counters[DIF_C_M];
-    const int n_tiles = (M + 31) >> 5;
+    Ranges<NS, int> rg;                   // cnt: gathered rows of map j; pre: its first tile in the concatenated range (maps beyond S: empty)
+    rg.pre[0] = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        rg.cnt[j] = (j < S) ? B.s[j].counters[DIF_C_M] : 0;
+        rg.pre[j + 1] = rg.pre[j] + ((rg.cnt[j] + 31) >> 5);
+    }
+    const int n_tiles = rg.total();
     // a tile's inputs: its 32 list entries and, through them, the points' coordinates and normals (two dependent gathers).  They are
     // requested one tile ahead: the first tile's before the weights are staged into LDS, the next tile's before the current tile's MFMA
     // chain — neither wait is on the critical path any more
     struct TileIn { uint2 e; float x0, x1, x2; };
-    auto gather = [&](int tile) __attribute__((always_inline)) {
+    // (sm, lt, M: the tile's map, its index in that map and the map's row count — located by the caller, so that the range tables never
+    // travel through a closure and stay in scalar registers)
+    auto gather = [&](bool any, int sm, int lt, int M) __attribute__((always_inline)) {
         TileIn t;
         t.e = make_uint2(DIF_INVALID_KEY, 0u);
         t.x0 = t.x1 = t.x2 = 0.f;
-        const int row = tile * 32 + col;
-        if (tile < n_tiles && row < M) {
-            t.e = pair_list[row];
-            const uint32_t v = t.e.y;
-            int o = 0;
+        if (any) {
+            const EncArgs& a = B.s[sm];
+            const Geo g = a.g;
+            const int row = lt * 32 + col;
+            if (row < M) {
+                t.e = a.pair_list[row];
+                const uint32_t v = t.e.y;
+                int o = 0;
 #pragma unroll
-            for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
-            int64_t i = (int64_t)v - (int64_t)o * N;
-            float xn = normalize1(xyz[i * 3 + 0], g.bx, g.vs);
-            float yn = normalize1(xyz[i * 3 + 1], g.by, g.vs);
-            float zn = normalize1(xyz[i * 3 + 2], g.bz, g.vs);
-            float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
-            float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
-            float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
-            float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
-            float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
-            float nxv = normal[i * 3 + 0], nyv = normal[i * 3 + 1], nzv = normal[i * 3 + 2];
-            t.x0 = half ? ry : rx;
-            t.x1 = half ? nxv : rz;
-            t.x2 = half ? nzv : nyv;
+                for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
+                int64_t i = (int64_t)v - (int64_t)o * N;
+                float xn = normalize1(a.xyz[i * 3 + 0], g.bx, g.vs);
+                float yn = normalize1(a.xyz[i * 3 + 1], g.by, g.vs);
+                float zn = normalize1(a.xyz[i * 3 + 2], g.bz, g.vs);
+                float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
+                float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
+                float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
+                float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
+                float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
+                float nxv = a.normal[i * 3 + 0], nyv = a.normal[i * 3 + 1], nzv = a.normal[i * 3 + 2];
+                t.x0 = half ? ry : rx;
+                t.x1 = half ? nxv : rz;
+                t.x2 = half ? nzv : nyv;
+            }
         }
         return t;
     };
-    TileIn nxt = gather(wave);
+    int sm_n, lt_n, M_n;
+    rg.locate(wave, sm_n, lt_n, M_n);
+    TileIn nxt = gather(wave < n_tiles, sm_n, lt_n, M_n);
     __builtin_amdgcn_sched_barrier(0);
     stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
     EN_STAMP(1);
-    for (int tile = wave; tile < n_tiles; tile += nwaves) {
+    for (int T = wave; T < n_tiles; T += nwaves) {
         const TileIn cur = nxt;
-        nxt = gather(tile + nwaves);
+        const int sm = sm_n, tile = lt_n, M = M_n;
+        rg.locate(T + nwaves, sm_n, lt_n, M_n);
+        nxt = gather(T + nwaves < n_tiles, sm_n, lt_n, M_n);
+        const EncArgs& a = B.s[sm];
         const int row = tile * 32 + col;
         const bool live = row < M;
         const uint2 e = cur.e;
@@ -365,13 +430,13 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
         EN_STAMP(2);
         int dir_pos = 0;
         const bool pusher = live && run_tail && half == 0;
-        int* dir = rec_dir + (int64_t)key * DIF_DIR_WORDS;
+        int* dir = a.rec_dir + (int64_t)key * DIF_DIR_WORDS;
         if (pusher) dir_pos = atomicAdd(dir, 1);
         f16v out;
         if constexpr (X6) out = encoder_tile_x6(lds, x0, x1, x2, lane);
         else out = encoder_tile(lds, x0, x1, x2, lane);
         EN_STAMP(3);
-        long long* p = rec + (int64_t)rec_id * DIF_REC_WORDS + half * 16;
+        long long* p = a.rec + (int64_t)rec_id * DIF_REC_WORDS + half * 16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             long long v = live ? __float2ll_rn(out[r] * DIF_FIX_SCALE) : 0ll;
@@ -381,17 +446,33 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
         }
         if (pusher) {
             if (dir_pos < DIF_DIR_IDS) dir[2 + dir_pos] = rec_id;
-            else rec_next[rec_id] = atomicExch(dir + 1, rec_id + 1);                        // a voxel fed by many workgroups: chained
+            else a.rec_next[rec_id] = atomicExch(dir + 1, rec_id + 1);                      // a voxel fed by many workgroups: chained
             if (dir_pos == 0) {                                                             // first run of this slot in the frame (C of map.py:437)
-                upd_list[atomicAdd(counters + DIF_C_C, 1)] = (int)key;
+                a.upd_list[atomicAdd(a.counters + DIF_C_C, 1)] = (int)key;
                 // k_fuse will set the slot's dirty flag: if it is not set yet, count it into the total of its 256-slot block here (extract's
                 // ordered compaction of the dirty set then needs no counting pass) — one lane per updated slot and frame, off k_fuse's tail
-                if (dirty_tot && !dirty[key]) atomicAdd(dirty_tot + (key >> 8), 1);
+                if (a.dirty_tot && !a.dirty[key]) atomicAdd(a.dirty_tot + (key >> 8), 1);
             }
         }
         EN_STAMP(4);
     }
     EN_STAMP(5);
+}
+
+// One map: the pointers arrive as noalias kernel arguments (the body's accesses keep that provenance).
+template <bool X6>
+__global__ void __launch_bounds__(512, X6 ? 1 : 2)
+k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
+         const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
+         int* __restrict__ upd_list, int* __restrict__ counters, const uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
+    const BatchN<EncArgs, 1> B{{EncArgs{g, xyz, normal, pair_list, rec_dir, rec_next, rec, upd_list, counters, dirty, dirty_tot}}};
+    encode_body<X6, 1>(B, 1, wblob, N);
+}
+
+template <bool X6>
+__global__ void __launch_bounds__(512, X6 ? 1 : 2)
+k_encode_batch(Batch<EncArgs> B, int S, const float* __restrict__ wblob, int64_t N) {
+    encode_body<X6, DIF_MAX_STREAMS>(B, S, wblob, N);
 }
 
 // encoder on explicit rows (flat op / tests): per-row outputs instead of per-voxel sums, so a dedicated small kernel
@@ -429,10 +510,10 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 
 // a10: fusion update (map.py:448-452).  One 32-lane group per updated slot: sum the slot's run records (directory entries fetched
 // together, overflow chain walked), fuse, return the directory to its idle state.
-__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
-                                                  const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
-                                                  uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, HaloLists hl,
-                                                  dif_pending_export_t* __restrict__ pending) {
+__device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
+                                          const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
+                                          uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, const HaloLists& hl,
+                                          dif_pending_export_t* __restrict__ pending) {
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) pending->pending = 0;      // the point kernels' extra workgroups have done the copy
     const int n_upd = counters[DIF_C_C];
     const int first_new = counters[DIF_C_N_OCCUPIED] - counters[DIF_C_ALLOC_NEW];      // this frame's new slots are already in the halo delta
@@ -479,3 +560,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(const long long* __restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_ITEMS] = (counters[DIF_C_M] + 31) >> 5;   // encoder tiles of this frame
 }
 
+struct FuseArgs {
+    const long long* rec; const int* rec_next; int* rec_dir; const int* upd_list; float* latent; float* obs; uint8_t* dirty; int* counters;
+    const int64_t* slot_lin; HaloLists hl; dif_pending_export_t* pending;
+};
+
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse(FuseArgs a) {
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending);
+}
+__global__ void __launch_bounds__(DIF_BLOCK) k_fuse_batch(Batch<FuseArgs> b) {
+    const FuseArgs& a = b.s[blockIdx.y];
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending);
+}

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 #define MC_ST_VALUE 0x3FFFFFFFu
 #define MC_SPIN_LIMIT (1 << 22)
 
-__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
+__device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_cnt[DIF_BLOCK / 64];
     __shared__ int s_excl;
@@ -437,6 +437,17 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, 
     }
 }
 
+__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
+    mc_onepass_body(a, status, ticket);
+}
+// S maps in one launch: blockIdx.y = map, each with its own look-back words and ticket (a group only ever waits for groups of ITS map that a
+// running or finished workgroup has claimed, exactly as in the single launch)
+struct McStream { McArgs a; unsigned* status; unsigned* ticket; };
+__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass_batch(Batch<McStream> b) {
+    const McStream& m = b.s[blockIdx.y];
+    mc_onepass_body(m.a, m.status, m.ticket);
+}
+
 // ---- a16 : device-resident mesh cache as an append-only log (map.py:703-714) -----------------------------------------
 // A voxel that produced >= 1 new triangle replaces its previous batch (the reference drops cached triangles whose voxel id
 // occurs among the new ones, map.py:708-709): TriScanFunctor::emit marks the old batch dead and points the voxel at its new one.
@@ -497,11 +508,11 @@ struct ExtractOut {
     dif_pending_export_t* defer;    // deferred export: leave the copy to the next frame's first kernel (dif_map_t.pending_export)
 };
 
-__global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
-                                                            int* __restrict__ counters, int64_t new_limit, int64_t capacity,
-                                                            const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
-                                                            const float* __restrict__ log_std, ExtractOut out, int32_t* __restrict__ chunk_sum,
-                                                            int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket) {
+__device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
+                                                    int* __restrict__ counters, int64_t new_limit, int64_t capacity,
+                                                    const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
+                                                    const float* __restrict__ log_std, const ExtractOut& out, int32_t* __restrict__ chunk_sum,
+                                                    int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket) {
     const int B = counters[DIF_C_B];
     if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
     {
@@ -551,6 +562,20 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(const int32_t* __r
             counters[DIF_C_CACHE_T] = (int)tot;
         }
     }
+}
+
+struct FinishArgs {
+    const int32_t* occ_slot; int32_t* vbm; int* counters; int64_t new_limit, capacity; const float* log_tri; const int64_t* log_id; const float* log_std;
+    ExtractOut out; int32_t* chunk_sum; int32_t* super_sum; int32_t* dirty_tot; int n_dirty_tot; uint32_t* mc_status; uint32_t* mc_ticket;
+};
+__global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(FinishArgs a) {
+    extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket);
+}
+__global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish_batch(Batch<FinishArgs> b) {
+    const FinishArgs& a = b.s[blockIdx.y];
+    extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket);
 }
 
 struct TriScanFunctor {         // exclusive scan of the per-voxel triangle counts; on the mesh-cache path also the log bookkeeping

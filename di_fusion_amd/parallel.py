@@ -57,12 +57,15 @@ def all_gather_records(rec: torch.Tensor, group=None) -> List[torch.Tensor]:
 
 def build_global_map(local_map, make_map, group=None):
     """All-gather every rank's voxel records and fold them, in rank order, into the map returned by `make_map()`.
+    `local_map`: one map, or the list of this rank's maps (several subsequences per GPU, the same number on every rank): one all-gather per
+    list position, folded in (rank, position) order.
     :return: the global DenseIndexedMap (identical on every rank)."""
-    rec = local_map.export_records()
-    chunks = all_gather_records(rec, group)
+    maps = list(local_map) if isinstance(local_map, (list, tuple)) else [local_map]
+    gathered = [all_gather_records(m.export_records(), group) for m in maps]
     g = make_map()
-    for c in chunks:
-        g.merge_records(c)
+    for r in range(len(gathered[0])):
+        for chunks in gathered:
+            g.merge_records(chunks[r])
     return g
 
 
@@ -106,6 +109,12 @@ def slab_range(nx: int, rank: int, world: int):
 def restart_halo_exchange(buffers: dict):
     """Forget the exchange history: the next two exchanges use whole-layer messages.  To be called ON EVERY RANK after a tiled map was
     changed by anything but integrate (merge_records, load, latent optimisation): those changes are not in the boundary change lists."""
+    # the rotating pinned note slots are zeroed by the host when a frame takes one: every kernel that may still write a header into
+    # them (exports / merges of the frames before the restart) has to be done first, or a stale header would be read as frame f's and
+    # flip the delta / whole-layer decision on this rank only
+    for h in buffers.get("hist", {}).values():
+        if not h.get("done") and h.get("event") is not None:
+            h["event"].synchronize()
     buffers["frame"] = 0
     buffers["hist"] = {}
 

@@ -120,6 +120,7 @@ class FusionStream:
         behind, so the next frame does not wait for it — unless the log is about to be compacted."""
         if self.map._gc_wanted:
             self._complete_batch_before_gc(self._d2h_mode)
+            self._export_deferred_now(self._pending)      # (the pending copy reads log positions that the compaction moves)
             if self._copy_done is not None:
                 self._copy_done.synchronize()
                 self._copy_done = None
@@ -248,7 +249,7 @@ class FusionStream:
             self._export_deferred_now(self._pending)
             self._d_bufs = []
             for sl in self._d_slots:
-                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=self._stream_extract_voxels())
                 buf.counters_out = _lib.ptr(sl["counters"])
                 self._d_bufs.append(buf)
             self._d_sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES)
@@ -256,8 +257,24 @@ class FusionStream:
             self._d_lib = _lib.load()
             self._d_args = (self.intr.height, self.intr.width, self.intr.fx, self.intr.fy, self.intr.cx, self.intr.cy)
 
-    def step_direct(self, i: int, d2h: str = "new"):
-        """One frame enqueued with two C calls (no graph), host one frame ahead; returns the previous frame's output like `step_pipelined`."""
+    def _stream_extract_voxels(self) -> int:
+        """Rows of the per-voxel extract buffers of the direct / graph / batch paths.  Sized for the map's CAPACITY (a frame can then
+        never overflow them and their addresses stay put while the occupancy grows) — ~7.7 KB per voxel at resolution 4, i.e. ~4 GB for
+        the default 524,288-slot map of a 640x480 stream — but never beyond `map.extract_buffer_bytes` (default 8 GB; several streams
+        on one GPU lower it): a frame that would need more rows raises the map's overflow error instead of tying up HBM for a bound
+        (7 new voxels per 17 points) that no stream comes near."""
+        m = self.map
+        R = 2 * self.resolution
+        per_voxel = (R ** 3) * 12 + (self.resolution ** 3) * 8 + 1024 + 64
+        rows = m._capacity
+        while rows > 4096 and rows * per_voxel > m.extract_buffer_bytes:
+            rows //= 2
+        return rows
+
+    def _direct_begin(self, i: int, d2h: str):
+        """Everything of a direct frame that precedes its launches: room in the map for the frames in flight, a due log compaction,
+        the frame's pinned slot and buffer descriptor, the frame descriptor written.  To be called with the device current.  Returns
+        (slot index, slot, extract buffers, export?, output of a frame that had to be completed early or None)."""
         m = self.map
         self._no_async_meshing()
         self._d2h_mode = d2h
@@ -267,54 +284,70 @@ class FusionStream:
         if self.tiling is not None:         # the halo refresh between integrate and extract may allocate too: room for it is made up front, so that
             may_add += 2 * m.halo_message_rows(3)   # no buffer moves between the two C calls whose descriptors are prepared below
         out = None
-        with torch.cuda.device(self.device):
-            if m._ws is None or m._xbuf is None or m._cache is None:
-                raise RuntimeError("run at least one eager step before step_direct (buffers are sized there)")
-            if m._n_occ_ub + may_add > m._capacity and self._pending is not None:
-                done = self._finish_pending(d2h)                 # make the bound exact before deciding to grow
-                self.backlog += done[:-1]
-                out = done[-1]
-            m._ensure_capacity(may_add)
-            self._before_frame()
-            if m._gc_wanted:
-                self._complete_batch_before_gc(d2h)
-                self._export_deferred_now(self._pending)      # (the pending copy reads log positions that the compaction moves)
-                m._cache_gc()
-            self._direct_prepare()
-            k = self._d_seq % self.DIRECT_SLOTS
-            self._d_seq += 1
-            sl, buf = self._d_slots[k], self._d_bufs[k]
-            export = d2h == "new"
-            buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"]) if export else (None, None, None)
-            buf.out_capacity = self.HOST_OUT_TRIANGLES if export else 0
-            # Deferred export: this frame's extract leaves the copy of its new triangles (~0.5 MB over PCIe) to the FIRST kernel of the next
-            # frame, where it overlaps the point pass instead of lengthening marching cubes; the host picks a frame's triangles up behind
-            # that kernel (`export_event`), still before it enqueues the frame after.
-            buf.defer_export = 1 if (export and self.defer_export) else 0
-            sl["frame_np"][:] = self._d_desc[i]
-            lib, w, sp = self._d_lib, self._d_w, _lib.stream_ptr()
-            H, W, fx, fy, cx, cy = self._d_args
-            _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, _lib.ptr(self.xyz),
-                                               _lib.ptr(self.nrm), _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
-            p = self._pending
-            if isinstance(p, dict) and p.get("deferred") and "export_event" not in p:
-                ev = p["host_slots"][p["host_out"]]["export_event"]      # the pending frame's triangles have just been copied by this frame's first kernel
-                ev.record()
-                p["export_event"] = ev
-            if self.tiling is not None:
-                self._exchange_halo(reserved=True)              # export -> send/recv -> merge, all on this stream, no host wait
-            _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std), 0, 1, sp),
-                       "dif_extract")
-            m.mesh_cache.invalidate_host_copy()
-            sl["event"].record()
-            h = dict(event=sl["event"], counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
-                     host_out=(k if export else None), host_slots=self._d_slots, deferred=bool(buf.defer_export))
+        if m._ws is None or m._xbuf is None or m._cache is None:
+            raise RuntimeError("run at least one eager step before step_direct (buffers are sized there)")
+        if m._n_occ_ub + may_add > m._capacity and self._pending is not None:
+            done = self._finish_pending(d2h)                 # make the bound exact before deciding to grow
+            self.backlog += done[:-1]
+            out = done[-1]
+        m._ensure_capacity(may_add)
+        self._before_frame()
+        if m._gc_wanted:
+            self._complete_batch_before_gc(d2h)
+            self._export_deferred_now(self._pending)      # (the pending copy reads log positions that the compaction moves)
+            m._cache_gc()
+        self._direct_prepare()
+        k = self._d_seq % self.DIRECT_SLOTS
+        self._d_seq += 1
+        sl, buf = self._d_slots[k], self._d_bufs[k]
+        export = d2h == "new"
+        buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"]) if export else (None, None, None)
+        buf.out_capacity = self.HOST_OUT_TRIANGLES if export else 0
+        # Deferred export: this frame's extract leaves the copy of its new triangles (~0.5 MB over PCIe) to the FIRST kernel of the next
+        # frame, where it overlaps the point pass instead of lengthening marching cubes; the host picks a frame's triangles up behind
+        # that kernel (`export_event`), still before it enqueues the frame after.
+        buf.defer_export = 1 if (export and self.defer_export) else 0
+        sl["frame_np"][:] = self._d_desc[i]
+        return k, sl, buf, export, out
+
+    def _direct_integrated(self):
+        """Right behind the frame's integrate launches: the PREVIOUS frame's deferred triangle export has just been carried out by this
+        frame's point kernels — record the event its host side waits for."""
+        p = self._pending
+        if isinstance(p, dict) and p.get("deferred") and "export_event" not in p:
+            ev = p["host_slots"][p["host_out"]]["export_event"]
+            ev.record()
+            p["export_event"] = ev
+
+    def _direct_end(self, k, sl, buf, export, d2h, out):
+        """Behind the frame's extract launches: the frame's handle; completes the previous frame on the host."""
+        m = self.map
+        m.mesh_cache.invalidate_host_copy()
+        sl["event"].record()
+        h = dict(event=sl["event"], counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
+                 host_out=(k if export else None), host_slots=self._d_slots, deferred=bool(buf.defer_export))
         done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
         if done:
             self.backlog += done[:-1]
             out = done[-1]
         self._pending = h
         return out
+
+    def step_direct(self, i: int, d2h: str = "new"):
+        """One frame enqueued with two C calls (no graph), host one frame ahead; returns the previous frame's output like `step_pipelined`."""
+        m = self.map
+        with torch.cuda.device(self.device):
+            k, sl, buf, export, out = self._direct_begin(i, d2h)
+            lib, w, sp = self._d_lib, self._d_w, _lib.stream_ptr()
+            H, W, fx, fy, cx, cy = self._d_args
+            _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, _lib.ptr(self.xyz),
+                                               _lib.ptr(self.nrm), _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
+            self._direct_integrated()
+            if self.tiling is not None:
+                self._exchange_halo(reserved=True)              # export -> send/recv -> merge, all on this stream, no host wait
+            _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std), 0, 1, sp),
+                       "dif_extract")
+            return self._direct_end(k, sl, buf, export, d2h, out)
 
     # ---- batched variant: F consecutive frames captured into ONE hipGraph -------------------------------------------------------------
     # Inside a replayed graph the kernels follow each other without the ~2 us boundary of separate launches, but consecutive graph
@@ -353,7 +386,7 @@ class FusionStream:
             for g in range(2):
                 bufs = []
                 for sl in self._b_slots[g]:
-                    _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+                    _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=self._stream_extract_voxels())
                     buf.counters_out = _lib.ptr(sl["counters"])
                     if export:
                         buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"])
@@ -478,7 +511,7 @@ class FusionStream:
             torch.cuda.synchronize()
             graphs = []
             for k in range(2):
-                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=m._capacity)
+                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=self._stream_extract_voxels())
                 buf.counters_out = _lib.ptr(self._zc[1][k])
                 if self._graph_export:                           # the frame's last kernel also writes its new triangles to pinned host memory
                     buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in self._zc[2][k])
@@ -543,3 +576,71 @@ class FusionStream:
             out = done[-1]
         self._pending = h
         return out
+
+
+class FusionStreamGroup:
+    """S independent subsequences on ONE GPU whose frames share their twelve launches (`dif_integrate_frames` + `dif_extract_streams`):
+    BASELINE config C4's unit of work — an independent stream with a private map — batched inside a GPU.  A steady-state frame of one
+    stream is 1-2 MLP tiles per SIMD and nine launches on their latency floors; S of them per launch fill the SIMDs and pay each floor
+    once.  Every stream keeps its own map, pinned slots, deferred export and host bookkeeping (`FusionStream`), and its results are
+    bit-identical to stepping it alone (`tests/test_gpu_stream.py::test_stream_group_matches_single_streams`)."""
+
+    def __init__(self, streams: List[FusionStream]):
+        if not 1 <= len(streams) <= _lib.MAX_STREAMS:
+            raise ValueError(f"1..{_lib.MAX_STREAMS} streams per group")
+        a = streams[0]
+        for st in streams:
+            if st.tiling is not None:
+                raise ValueError("spatially tiled streams exchange halos inside a frame: not groupable")
+            if st.device != a.device or (st.intr.height, st.intr.width) != (a.intr.height, a.intr.width) or st.map.n_xyz != a.map.n_xyz \
+                    or st.resolution != a.resolution or st.max_std != a.max_std or st.map.model is not a.map.model:
+                raise ValueError("the streams of a group share device, network, frame size, grid shape and extract parameters")
+        self.streams = list(streams)
+        self.device = a.device
+        self._frames = (_lib.DifStreamFrame * len(streams))()
+
+    def _equalise_capacity(self):
+        """The batched launches are shaped by ONE capacity: a map that has grown pulls the others along (rare: the capacity covers three
+        frames of worst-case allocations, see FusionStream.__init__)."""
+        cap = max(st.map._capacity for st in self.streams)
+        for st in self.streams:
+            if st.map._capacity != cap:
+                st._export_deferred_now(st._pending)
+                with st.map._state_lock:
+                    st.map._alloc_state(cap)
+
+    def step(self, idx, d2h: str = "new"):
+        """Frame idx[j] (or the same index for all, if an int) of every stream j, enqueued with two C calls for the whole group; returns the
+        list of the streams' previous-frame outputs (None entries on the first call), like `FusionStream.step_direct`."""
+        S = len(self.streams)
+        idx = [idx] * S if isinstance(idx, int) else list(idx)
+        a = self.streams[0]
+        with torch.cuda.device(self.device):
+            begun = [st._direct_begin(i, d2h) for st, i in zip(self.streams, idx)]
+            caps = {st.map._capacity for st in self.streams}
+            if len(caps) > 1:
+                self._equalise_capacity()
+                for st in self.streams:
+                    st._direct_prepare()                       # descriptors of re-allocated buffers
+                begun = [(k, sl, st._d_bufs[k], export, out) for st, (k, sl, _, export, out) in zip(self.streams, begun)]
+                for st, (k, sl, buf, export, out) in zip(self.streams, begun):
+                    buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"]) if export else (None, None, None)
+                    buf.out_capacity = st.HOST_OUT_TRIANGLES if export else 0
+                    buf.defer_export = 1 if (export and st.defer_export) else 0
+            for j, (st, (k, sl, buf, export, out)) in enumerate(zip(self.streams, begun)):
+                f, m = self._frames[j], st.map
+                f.map = ctypes.pointer(m._cmap)
+                f.frame_dev = _lib.ptr(sl["frame"])
+                f.xyz_world, f.normal_world, f.unq_mask = _lib.ptr(st.xyz), _lib.ptr(st.nrm), _lib.ptr(st._d_mask)
+                f.ws, f.ws_bytes = _lib.ptr(m._ws), m._ws.numel()
+                f.buf = ctypes.pointer(buf)
+            lib, w, sp = a._d_lib, a._d_w, _lib.stream_ptr()
+            H, W, fx, fy, cx, cy = a._d_args
+            _lib.check(lib.dif_integrate_frames(self._frames, S, ctypes.byref(w), H, W, fx, fy, cx, cy, sp), "dif_integrate_frames")
+            for st in self.streams:
+                st._direct_integrated()
+            _lib.check(lib.dif_extract_streams(self._frames, S, ctypes.byref(w), int(a.resolution), float(a.max_std), 1, sp), "dif_extract_streams")
+            return [st._direct_end(k, sl, buf, export, d2h, out) for st, (k, sl, buf, export, out) in zip(self.streams, begun)]
+
+    def flush(self, d2h: str = "new"):
+        return [st.flush(d2h) for st in self.streams]

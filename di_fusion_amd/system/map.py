@@ -553,6 +553,10 @@ class DenseIndexedMap:
 
     def _cache_gc(self):
         """Drop the dead entries: the compacted copy becomes the log (same content and order as before for the live part)."""
+        with torch.cuda.device(self.device):
+            # a deferred triangle export (dif_map_t.pending_export) names ABSOLUTE log rows: it is carried out, in stream order, before
+            # the compaction moves them — whichever stepping mode enqueued it and whichever one reaches this safe point
+            _lib.check(_lib.load().dif_export_pending(ctypes.byref(self._cmap), _lib.stream_ptr()), "dif_export_pending")
         n = self._cache_compact()
         with torch.cuda.device(self.device):
             # copied back rather than swapped in: the log keeps its addresses, so launch graphs captured over it stay valid

@@ -28,6 +28,8 @@ extern "C" {
 #define DIF_VERSION 100          /* 0.1.0 */
 #define DIF_LATENT_DIM 29        /* ckpt/default/hyper.json:34 */
 
+#define DIF_MAX_STREAMS 8        /* independent maps one batched launch chain can carry (dif_integrate_frames / dif_extract_streams) */
+
 #define DIF_OK 0
 #define DIF_EINVAL (-1)
 #define DIF_ELAUNCH (-2)
@@ -301,6 +303,28 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
 
 /* Perform the copy a deferred export left pending (dif_map_t.pending_export), if any, and mark it done. */
 int dif_export_pending(const dif_map_t* map, void* stream);
+
+/* ---- several independent subsequences per launch (SURVEY.md section 8e "C4", here INSIDE one GPU) ------------------------------------
+ * A steady-state frame of ONE stream is 1-2 MLP tiles per SIMD and nine launches that sit on their latency floors.  These two entry points
+ * run the frame of S <= DIF_MAX_STREAMS independent streams (S private maps over grids of the same shape, S frames of the same size)
+ * through the SAME twelve launches: the point / scan / fusion / marching-cubes kernels get a second grid dimension (blockIdx.y = stream),
+ * the persistent encoder / decoder kernels walk the streams' tiles as one concatenated range (weights staged once per workgroup).
+ * Every stream's results are bit-identical to dif_integrate_frame + dif_extract on that stream alone.
+ * Requirements (else DIF_EINVAL): the maps have the same nx, ny, nz and capacity, are not spatially tiled, carry dirty_tot / grid_tot /
+ * pending_export like a streaming map; the extract buffers have the same max_voxels, chunk_sum / mc_status / fold_table set; the weights
+ * carry the bf16-sliced blobs (the default pipe); resolution <= 4, fast two-level decode. */
+typedef struct dif_stream_frame {
+    const dif_map_t* map;                   /* [host] */
+    const dif_frame_t* frame_dev;           /* as dif_integrate_frame */
+    float* xyz_world; float* normal_world;  /* (H*W,3) each, out */
+    uint8_t* unq_mask;                      /* (H*W) out */
+    void* ws; int64_t ws_bytes;             /* dif_integrate_workspace_bytes(H*W) */
+    const dif_extract_buffers_t* buf;       /* [host] as dif_extract (dif_extract_streams only; may be NULL for dif_integrate_frames) */
+} dif_stream_frame_t;
+int dif_integrate_frames(const dif_stream_frame_t* streams /* [host][S] */, int32_t S, const dif_weights_t* w, int32_t H, int32_t W, float fx,
+                         float fy, float cx, float cy, void* stream);
+int dif_extract_streams(const dif_stream_frame_t* streams /* [host][S] */, int32_t S, const dif_weights_t* w, int32_t resolution, float max_std,
+                        int32_t scale_vertices, void* stream);
 
 /* Log entries [lo, lo+n) -> (out_tri, out_id, out_std) in one launch.  The destinations may be device-mapped pinned HOST memory: a
  * streaming caller ships each call's new triangles (lo = DIF_C_CACHE_KEPT, n = DIF_C_CACHE_T - lo) without copy-engine transfers. */

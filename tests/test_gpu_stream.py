@@ -6,6 +6,8 @@ import torch
 
 from di_fusion_amd import synthetic as S
 
+S_ = S          # (tests below use `S` for the number of streams)
+
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 N_FRAMES = 6
@@ -144,6 +146,46 @@ def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
         assert in_stream == 0 and early <= 1               # only the last frame (at flush) needed the stand-alone copy
 
 
+@pytest.mark.parametrize("other", ["graph", "pipelined", "eager"])
+def test_compaction_with_a_deferred_export_pending(other, gpu_model):
+    """A `step_direct` frame leaves its triangle export pending (absolute log rows); the NEXT frame is driven by another stepping mode on
+    a frame where the mesh log is compacted.  The pending copy must be carried out before the compaction moves the rows (ADVICE r3:
+    `step_graph` / `step_pipelined` / `step` compacted first and the direct frame's triangles came out wrong)."""
+    ref = make_stream(gpu_model)
+    want = [tuple(x.clone() for x in ref.step(i, d2h="new")) for i in range(N_FRAMES)]
+    torch.cuda.synchronize()
+    want_state = snapshot(ref)
+    st = make_stream(gpu_model, initial_capacity=None)
+    got = {0: tuple(x.clone() for x in st.step(0, d2h="new"))}
+    pending = None                                          # index of the frame whose output the next pipelined call hands back
+
+    def take(o, idx):
+        if o is not None:
+            torch.cuda.synchronize()
+            got[idx] = tuple(x.clone() for x in o)
+
+    for i in range(1, N_FRAMES):
+        if i % 2 == 1:
+            take(st.step_direct(i, d2h="new"), pending)
+            pending = i
+        else:
+            st.map._gc_wanted = True                        # the frame behind a direct frame compacts the log
+            if other == "graph":
+                take(st.step_graph(i, d2h="new"), pending)
+                pending = i
+            elif other == "pipelined":
+                take(st.step_pipelined(i, d2h="new"), pending)
+                pending = i
+            else:
+                take(st.step(i, d2h="new"), i)              # eager: its own output; the direct frame stays pending
+    take(st.flush(), pending)
+    assert st.map._gc_epoch >= 2
+    assert sorted(got) == list(range(N_FRAMES))
+    for f in range(N_FRAMES):
+        assert all(torch.equal(x, y) for x, y in zip(want[f], got[f])), f"frame {f}"
+    same(want_state, snapshot(st))
+
+
 def test_batched_graph_matches_frame_by_frame(gpu_model):
     """F frames captured into one hipGraph (`step_batch`): every frame's mesh update and the final map must equal the eager run bit for
     bit — with a tiny pinned staging area (fallback export for larger updates), mixed with a direct frame, and across a compaction."""
@@ -255,3 +297,113 @@ def test_c3_full_size_invariants(gpu_model):
         assert torch.equal(m.mesh_cache_tensors()[0], before)
         finals.append((m.latent_vecs[:n].clone(), before, tid.clone()))
     assert all(torch.equal(a, b) for a, b in zip(finals[0], finals[1]))
+
+
+def _solo_and_group(gpu_model, make, S, n_frames):
+    """Every stream alone (eager: the reference run of this file), then the same S streams as one group; returns per-stream
+    (per-frame outputs, final snapshot) of both."""
+    from di_fusion_amd.stream import FusionStreamGroup
+    solo = []
+    for j in range(S):
+        st = make(j)
+        per = [tuple(x.clone() for x in st.step(i, d2h="new")) for i in range(n_frames)]
+        torch.cuda.synchronize()
+        solo.append((per, snapshot(st)))
+        del st
+    torch.cuda.empty_cache()
+    streams = [make(j) for j in range(S)]
+    got = [[tuple(x.clone() for x in st.step(0, d2h="new"))] for st in streams]      # sizes the buffers; the group takes over from frame 1
+    grp = FusionStreamGroup(streams)
+    for i in range(1, n_frames):
+        outs = grp.step(i, d2h="new")
+        torch.cuda.synchronize()
+        for j, o in enumerate(outs):
+            if o is not None:
+                got[j].append(tuple(x.clone() for x in o))
+    for j, o in enumerate(grp.flush()):
+        got[j].append(tuple(x.clone() for x in o))
+    return solo, [(got[j], snapshot(streams[j])) for j in range(S)], streams
+
+
+@pytest.mark.parametrize("S", [1, 3, 4])
+def test_stream_group_matches_single_streams(S, gpu_model):
+    """S independent subsequences (different arcs of the orbit, private maps) whose frames share their twelve launches
+    (`dif_integrate_frames` + `dif_extract_streams`): every stream's per-frame triangles and final map equal that stream stepped alone,
+    bit for bit — including across a forced mesh-log compaction of one stream and a capacity growth that one stream pulls the others
+    through."""
+    from di_fusion_amd.stream import FusionStream
+    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
+    intr = S_.Intrinsic().scaled(0.25)
+
+    def make(j):
+        return FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, N_FRAMES, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=None)
+
+    solo, grp, streams = _solo_and_group(gpu_model, make, S, N_FRAMES)
+    for j in range(S):
+        assert len(grp[j][0]) == N_FRAMES
+        for f, (a, b) in enumerate(zip(solo[j][0], grp[j][0])):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), f"stream {j} frame {f}"
+        same(solo[j][1], grp[j][1])
+    if S > 1:       # the streams really are different subsequences
+        assert not torch.equal(solo[0][1]["indexer"], solo[1][1]["indexer"])
+
+
+def test_stream_group_survives_compaction_and_growth(gpu_model):
+    from di_fusion_amd.stream import FusionStream, FusionStreamGroup
+    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
+    intr = S_.Intrinsic().scaled(0.25)
+
+    def make(j):
+        return FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, N_FRAMES, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=None)
+
+    solo = []
+    for j in range(2):
+        st = make(j)
+        per = [tuple(x.clone() for x in st.step(i, d2h="new")) for i in range(N_FRAMES)]
+        torch.cuda.synchronize()
+        solo.append((per, snapshot(st)))
+    streams = [make(j) for j in range(2)]
+    got = [[tuple(x.clone() for x in st.step(0, d2h="new"))] for st in streams]
+    grp = FusionStreamGroup(streams)
+    for i in range(1, N_FRAMES):
+        if i == 2:
+            streams[1].map._gc_wanted = True                    # one stream compacts its mesh log with a deferred export pending
+        if i == 4:
+            with streams[0].map._state_lock:                    # one stream's map grows: the group re-shapes every map
+                streams[0]._export_deferred_now(streams[0]._pending)
+                streams[0].map._alloc_state(2 * streams[0].map._capacity)
+        outs = grp.step(i, d2h="new")
+        torch.cuda.synchronize()
+        for j, o in enumerate(outs):
+            if o is not None:
+                got[j].append(tuple(x.clone() for x in o))
+    for j, o in enumerate(grp.flush()):
+        got[j].append(tuple(x.clone() for x in o))
+    assert streams[1].map._gc_epoch == 1 and streams[0].map._capacity == streams[1].map._capacity
+    for j in range(2):
+        assert len(got[j]) == N_FRAMES
+        for f, (a, b) in enumerate(zip(solo[j][0], got[j])):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), f"stream {j} frame {f}"
+        same(solo[j][1], snapshot(streams[j]))
+
+
+def test_stream_group_c3_four_streams(gpu_model):
+    """BASELINE config C3 (128^3 grid, 640x480 frames), four subsequences starting 45 degrees apart, 6 frames each, as one group against
+    each stream alone: per-frame mesh updates and final maps bit-identical."""
+    from di_fusion_amd.stream import FusionStream
+    scene, cfg = S_.config_c3()
+
+    def make(j):
+        st = FusionStream(gpu_model, scene, cfg, S_.Intrinsic(), DEV, 6, deg_per_frame=0.5, phase_deg=45.0 * j)
+        st.map.extract_buffer_bytes = 1 << 30                   # (eight maps live in this test: keep the per-voxel extract buffers at 1 GB each)
+        return st
+
+    solo, grp, streams = _solo_and_group(gpu_model, make, 4, 6)
+    for j in range(4):
+        assert len(grp[j][0]) == 6
+        for f, (a, b) in enumerate(zip(solo[j][0], grp[j][0])):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), f"stream {j} frame {f}"
+        a, b = solo[j][1], grp[j][1]
+        assert a["n"] == b["n"] > 10000
+        for k in ("indexer", "latent", "obs", "tri", "tid", "tstd"):
+            assert torch.equal(a[k], b[k]), (j, k)
