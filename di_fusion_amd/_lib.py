@@ -15,6 +15,7 @@ LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "
 
 # counters (difusion.h)
 C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS, C_HALO_L, C_HALO_R, C_HALO_TICKET = range(23)
+C_STAMP = 31
 C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge"]
 PROF_COUNT = 8
@@ -55,7 +56,8 @@ class DifExtractBuffers(Structure):
                 ("max_triangles", c_int64), ("cache_capacity", c_int64),
                 ("cache_tri", c_void_p), ("cache_id", c_void_p), ("cache_std", c_void_p), ("cache_alive", c_void_p),
                 ("counters_out", c_void_p), ("out_tri", c_void_p), ("out_id", c_void_p), ("out_std", c_void_p), ("out_capacity", c_int64),
-                ("chunk_sum", c_void_p), ("fold_table", c_void_p), ("mc_status", c_void_p), ("defer_export", c_int32)]
+                ("chunk_sum", c_void_p), ("fold_table", c_void_p), ("mc_status", c_void_p), ("defer_export", c_int32),
+                ("stamp", c_int32), ("export_notify", c_void_p)]
 
 
 MAX_STREAMS = 8          # DIF_MAX_STREAMS
@@ -157,6 +159,20 @@ def load() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def spin_until(words, index: int, value: int, what: str, timeout_s: float = 30.0):
+    """Busy-wait until `words[index] == value` — a word of pinned host memory that a kernel writes when it is done (a completion signal
+    that needs no event in the HIP queue: an event record costs the GPU ~5 us between two kernels).  Raises after `timeout_s`."""
+    import time
+    if words[index] == value:
+        return
+    t0 = time.perf_counter()
+    n = 0
+    while words[index] != value:
+        n += 1
+        if (n & 0x3FFF) == 0 and time.perf_counter() - t0 > timeout_s:
+            raise RuntimeError(f"libdifusion: {what} did not complete within {timeout_s:.0f} s (expected stamp {value}, have {int(words[index])})")
 
 
 def check(rc: int, what: str):

@@ -877,7 +877,7 @@ static FinishArgs finish_args_of(const dif_map_t* map, const dif_extract_buffers
     int32_t* const super_sum = buf->chunk_sum ? buf->chunk_sum + (buf->max_voxels + 255) / 256 : nullptr;
     return FinishArgs{buf->occ_slot, map->vbm, map->counters, buf->max_triangles, buf->cache_capacity, buf->cache_tri, buf->cache_id, buf->cache_std,
                       ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity, (exported || defer) ? 1 : 0,
-                                 defer ? (dif_pending_export_t*)map->pending_export : nullptr},
+                                 defer ? (dif_pending_export_t*)map->pending_export : nullptr, buf->stamp, defer ? buf->export_notify : nullptr},
                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
                       onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr};
 }

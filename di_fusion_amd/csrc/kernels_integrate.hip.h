@@ -514,7 +514,10 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
                                           const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
                                           uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, const HaloLists& hl,
                                           dif_pending_export_t* __restrict__ pending) {
-    if (pending && blockIdx.x == 0 && threadIdx.x == 0) pending->pending = 0;      // the point kernels' extra workgroups have done the copy
+    if (pending && blockIdx.x == 0 && threadIdx.x == 0) {       // the point kernels' extra workgroups have done the copy (kernels ago: complete)
+        pending->pending = 0;
+        if (pending->notify) *pending->notify = pending->seq;   // tell the host without an event in the queue (dif_extract_buffers_t.export_notify)
+    }
     const int n_upd = counters[DIF_C_C];
     const int first_new = counters[DIF_C_N_OCCUPIED] - counters[DIF_C_ALLOC_NEW];      // this frame's new slots are already in the halo delta
     const int grp = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5), ngrp = (int)((gridDim.x * blockDim.x) >> 5);

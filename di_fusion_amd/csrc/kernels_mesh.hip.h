@@ -506,6 +506,7 @@ struct ExtractOut {
     float* tri; int64_t* id; float* sd; int64_t capacity;      // this call's new triangles (first `capacity` of them) or NULL
     int already_exported;           // the one-pass marching cubes wrote them while it emitted (or the copy is deferred)
     dif_pending_export_t* defer;    // deferred export: leave the copy to the next frame's first kernel (dif_map_t.pending_export)
+    int32_t stamp; int32_t* notify; // dif_extract_buffers_t.stamp / export_notify
 };
 
 __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ occ_slot, int32_t* __restrict__ vbm,
@@ -545,14 +546,19 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
         int v = lane < DIF_C_COUNT ? counters[lane] : 0;
         if (lane == DIF_C_CACHE_T) v = (int)tot;
         if (lane == DIF_C_OVERFLOW && over) v = 5;
-        if (out.counters_out && lane < DIF_C_COUNT) out.counters_out[lane] = v;
+        if (out.counters_out && lane < DIF_C_STAMP) out.counters_out[lane] = v;
         if (lane == 0 && out.defer) {
             const int64_t n = n_new < out.capacity ? n_new : out.capacity;
             dif_pending_export_t d;
-            d.pending = n > 0 ? 1 : 0; d.kept = (int)kept; d.n = (int)n; d.reserved = 0;
+            d.pending = n > 0 ? 1 : 0; d.kept = (int)kept; d.n = (int)n; d.seq = out.stamp;
             d.log_tri = log_tri; d.log_id = log_id; d.log_std = log_std;
             d.out_tri = out.tri; d.out_id = out.id; d.out_std = out.sd;
+            d.notify = out.notify;
             *out.defer = d;
+        }
+        if (out.counters_out) {                      // the stamp goes out behind the snapshot: whoever sees it has all of it
+            __threadfence_system();
+            if (lane == 0) out.counters_out[DIF_C_STAMP] = out.stamp;
         }
         if (lane == 0) {
             // a flag that has just been handed to the caller with this snapshot is reported: cleared here, in stream order, so that the next

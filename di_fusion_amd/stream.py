@@ -149,7 +149,8 @@ class FusionStream:
             self._pin = (torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
                          torch.empty((cap, 3), dtype=torch.float32).pin_memory())
         with torch.cuda.device(self.device):
-            self._copy_stream.wait_event(handle["event"])
+            if "event" in handle:            # (a stamped frame is complete by the time its handle gets here: extract_mesh_finish has seen the stamp)
+                self._copy_stream.wait_event(handle["event"])
             with torch.cuda.stream(self._copy_stream):
                 lo = tri.storage_offset() // 9
                 b = self.map._cache_struct()
@@ -164,7 +165,7 @@ class FusionStream:
     def _export_deferred_now(self, handle):
         """A frame whose triangle export was deferred and that no later frame's first kernel has carried out yet: do the copy now
         (stream-ordered; `dif_export_pending`)."""
-        if isinstance(handle, dict) and handle.get("deferred") and "export_event" not in handle:
+        if isinstance(handle, dict) and handle.get("deferred") and "export_event" not in handle and not handle.get("export_carried"):
             with torch.cuda.device(self.device):
                 _lib.check(_lib.load().dif_export_pending(ctypes.byref(self.map._cmap), _lib.stream_ptr()), "dif_export_pending")
                 ev = handle["host_slots"][handle["host_out"]]["export_event"]
@@ -175,7 +176,10 @@ class FusionStream:
         self._export_deferred_now(handle)
         tri, tid, tstd = self.map.extract_mesh_finish(handle)
         if handle.get("deferred"):
-            handle["export_event"].synchronize()
+            if "export_event" in handle:
+                handle["export_event"].synchronize()
+            else:                           # carried out by the next frame's kernels, which stamp the slot's `notify` word when the copy is complete
+                _lib.spin_until(handle["host_slots"][handle["host_out"]]["notify_np"], 0, handle["stamp"], "deferred triangle export")
         out = (tri, tid, tstd)
         if d2h == "new":
             n = tri.size(0)
@@ -235,10 +239,12 @@ class FusionStream:
                                   counters=torch.zeros((_lib.C_COUNT,), dtype=torch.int32).pin_memory(),
                                   out=(torch.empty((cap, 3, 3), dtype=torch.float32).pin_memory(), torch.empty((cap,), dtype=torch.long).pin_memory(),
                                        torch.empty((cap, 3), dtype=torch.float32).pin_memory()),
+                                  notify=torch.zeros((2,), dtype=torch.int32).pin_memory(),
                                   event=torch.cuda.Event(), export_event=torch.cuda.Event()) for _ in range(self.DIRECT_SLOTS)]
             for sl in self._d_slots:
                 sl["frame_np"] = sl["frame"].numpy()
                 sl["counters_np"] = sl["counters"].numpy()
+                sl["notify_np"] = sl["notify"].numpy()
             self._d_mask = torch.empty((H * W,), dtype=torch.uint8, device=dev)
             self._d_seq = 0
             self._d_desc = [np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8).copy()
@@ -307,6 +313,13 @@ class FusionStream:
         # frame, where it overlaps the point pass instead of lengthening marching cubes; the host picks a frame's triangles up behind
         # that kernel (`export_event`), still before it enqueues the frame after.
         buf.defer_export = 1 if (export and self.defer_export) else 0
+        # Completion without events: the extract's last kernel stamps the pinned counter snapshot, and the kernels that carry the deferred
+        # copy out stamp `notify` — the host polls those words instead of waiting on events (an event record costs the queue ~5 us
+        # between two kernels, twice per frame).  (Without a deferred export this frame's triangles are written by the one-pass
+        # marching cubes, a kernel before the stamp.)
+        self._stamp = (getattr(self, "_stamp", 0) % 0x3FFFFFFF) + 1
+        buf.stamp = self._stamp
+        buf.export_notify = _lib.ptr(sl["notify"]) if buf.defer_export else None
         sl["frame_np"][:] = self._d_desc[i]
         return k, sl, buf, export, out
 
@@ -315,16 +328,13 @@ class FusionStream:
         frame's point kernels — record the event its host side waits for."""
         p = self._pending
         if isinstance(p, dict) and p.get("deferred") and "export_event" not in p:
-            ev = p["host_slots"][p["host_out"]]["export_event"]
-            ev.record()
-            p["export_event"] = ev
+            p["export_carried"] = True      # its fusion kernel stamps the slot's `notify` word: nothing to record
 
     def _direct_end(self, k, sl, buf, export, d2h, out):
         """Behind the frame's extract launches: the frame's handle; completes the previous frame on the host."""
         m = self.map
         m.mesh_cache.invalidate_host_copy()
-        sl["event"].record()
-        h = dict(event=sl["event"], counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
+        h = dict(stamp=int(buf.stamp), counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
                  host_out=(k if export else None), host_slots=self._d_slots, deferred=bool(buf.defer_export))
         done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
         if done:

@@ -173,7 +173,7 @@ class DenseIndexedMap:
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._grid_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
-            self._pending_export = torch.zeros((16,), device=device, dtype=torch.int32)        # dif_pending_export_t, idle all-zero
+            self._pending_export = torch.zeros((32,), device=device, dtype=torch.int32)        # dif_pending_export_t (72 bytes), idle all-zero
         self._capacity = 0
         self._alloc_state(_next_pow2(max(int(initial_capacity), 1024)))
         self._n_occ_ub = 0                  # host-side upper bound of n_occupied (exact after a counter read)
@@ -662,7 +662,10 @@ class DenseIndexedMap:
     def extract_mesh_finish(self, handle):
         """Wait for an enqueued extract and publish its counters (`last_counters`).  Returns the device views of the triangles that
         extract produced (vertices (T,3,3), voxel ids (T,), std (T,3)) — valid until the next-but-one extract overwrites the buffer."""
-        handle["event"].synchronize()
+        if "stamp" in handle:       # the extract's last kernel stamps its pinned counter snapshot: no event sits in the queue for this wait
+            _lib.spin_until(handle["counters"], _lib.C_STAMP, handle["stamp"], "extract")
+        else:
+            handle["event"].synchronize()
         c = self._publish_counters(handle["counters"].tolist(), handle["add_total"])
         if c["T"] >= handle["max_n_triangles"]:
             logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {handle['max_n_triangles']}")

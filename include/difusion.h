@@ -61,6 +61,7 @@ enum {
     DIF_C_HALO_L = 20,      /* entries appended to the LEFT / RIGHT boundary change list (dif_map_t.halo_list) since the last    */
     DIF_C_HALO_R = 21,      /* halo export; may exceed halo_list_cap (then the list is incomplete and the delta export says so)   */
     DIF_C_HALO_TICKET = 22, /* idle 0: workgroups of dif_export_halo_delta that are done                                          */
+    DIF_C_STAMP = 31,       /* snapshots handed to the caller only (dif_extract_buffers_t.counters_out): the extract's `stamp`, written LAST        */
     DIF_C_COUNT = 32
 };
 
@@ -112,9 +113,10 @@ typedef struct dif_map {
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
 typedef struct dif_pending_export {
-    int32_t pending, kept, n, reserved;
+    int32_t pending, kept, n, seq;          /* seq: the `stamp` of the extract that left this export */
     const float* log_tri; const int64_t* log_id; const float* log_std;
     float* out_tri; int64_t* out_id; float* out_std;
+    int32_t* notify;                        /* optional (pinned host memory): receives `seq` once the copy is complete (dif_extract_buffers_t.export_notify) */
 } dif_pending_export_t;
 
 /* Network weights packed for the MFMA kernels by di_fusion_amd/network/packing.py (layout documented there). */
@@ -292,6 +294,15 @@ typedef struct dif_extract_buffers {
                                      * four voxels and emits straight away (same canonical order) */
     int32_t defer_export;           /* != 0 (with out_* and dif_map_t.pending_export): do not copy the new triangles to out_* now, leave a
                                      * dif_pending_export_t for the next dif_integrate_frame / dif_export_pending */
+    /* Completion without stream events (an event record costs the queue ~5 us between two kernels; a frame has two):
+     *   stamp          — written into counters_out[DIF_C_STAMP] by the extract's last kernel AFTER the other words (system-scope fence in
+     *                    between): a caller that polls that word of its pinned snapshot for the stamp it passed has the whole snapshot.  Valid
+     *                    as a completion signal for out_* too when the triangles were written by the one-pass marching cubes or deferred —
+     *                    not when the last kernel itself copies them (two-pass marching cubes without defer_export);
+     *   export_notify  — with defer_export: int32 in pinned host memory that receives `stamp` from the last kernel of the
+     *                    dif_integrate_frame(s) that carried the deferred copy out (its point kernels copy, its fusion kernel notifies). */
+    int32_t stamp;
+    int32_t* export_notify;
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,

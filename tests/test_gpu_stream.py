@@ -123,7 +123,7 @@ def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
 
     def counting(handle):
         nonlocal early
-        if isinstance(handle, dict) and handle.get("deferred") and "export_event" not in handle:
+        if isinstance(handle, dict) and handle.get("deferred") and "export_event" not in handle and not handle.get("export_carried"):
             early += 1
         return orig(handle)
     st._export_deferred_now = counting
@@ -152,11 +152,10 @@ def test_compaction_with_a_deferred_export_pending(other, gpu_model):
     a frame where the mesh log is compacted.  The pending copy must be carried out before the compaction moves the rows (ADVICE r3:
     `step_graph` / `step_pipelined` / `step` compacted first and the direct frame's triangles came out wrong)."""
     ref = make_stream(gpu_model)
-    want = [tuple(x.clone() for x in ref.step(i, d2h="new")) for i in range(N_FRAMES)]
-    torch.cuda.synchronize()
+    want = [_eager(ref, i) for i in range(N_FRAMES)]
     want_state = snapshot(ref)
     st = make_stream(gpu_model, initial_capacity=None)
-    got = {0: tuple(x.clone() for x in st.step(0, d2h="new"))}
+    got = {0: _eager(st, 0)}
     pending = None                                          # index of the frame whose output the next pipelined call hands back
 
     def take(o, idx):
@@ -299,6 +298,13 @@ def test_c3_full_size_invariants(gpu_model):
     assert all(torch.equal(a, b) for a, b in zip(finals[0], finals[1]))
 
 
+def _eager(st, i):
+    """One eager frame; its new triangles (an async copy into pinned memory) cloned once the copy is complete."""
+    o = st.step(i, d2h="new")
+    torch.cuda.synchronize()
+    return tuple(x.clone() for x in o)
+
+
 def _solo_and_group(gpu_model, make, S, n_frames):
     """Every stream alone (eager: the reference run of this file), then the same S streams as one group; returns per-stream
     (per-frame outputs, final snapshot) of both."""
@@ -306,13 +312,12 @@ def _solo_and_group(gpu_model, make, S, n_frames):
     solo = []
     for j in range(S):
         st = make(j)
-        per = [tuple(x.clone() for x in st.step(i, d2h="new")) for i in range(n_frames)]
-        torch.cuda.synchronize()
+        per = [_eager(st, i) for i in range(n_frames)]
         solo.append((per, snapshot(st)))
         del st
     torch.cuda.empty_cache()
     streams = [make(j) for j in range(S)]
-    got = [[tuple(x.clone() for x in st.step(0, d2h="new"))] for st in streams]      # sizes the buffers; the group takes over from frame 1
+    got = [[_eager(st, 0)] for st in streams]      # sizes the buffers; the group takes over from frame 1
     grp = FusionStreamGroup(streams)
     for i in range(1, n_frames):
         outs = grp.step(i, d2h="new")
@@ -359,11 +364,10 @@ def test_stream_group_survives_compaction_and_growth(gpu_model):
     solo = []
     for j in range(2):
         st = make(j)
-        per = [tuple(x.clone() for x in st.step(i, d2h="new")) for i in range(N_FRAMES)]
-        torch.cuda.synchronize()
+        per = [_eager(st, i) for i in range(N_FRAMES)]
         solo.append((per, snapshot(st)))
     streams = [make(j) for j in range(2)]
-    got = [[tuple(x.clone() for x in st.step(0, d2h="new"))] for st in streams]
+    got = [[_eager(st, 0)] for st in streams]
     grp = FusionStreamGroup(streams)
     for i in range(1, N_FRAMES):
         if i == 2:
