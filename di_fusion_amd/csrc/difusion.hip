@@ -367,6 +367,7 @@ struct IntegrateWs {
     int* rec_next;          // [8N]    chain link per run record
     long long* rec;         // [8N][32] run records, written sparsely at tile*32 + run rank (~3 per tile in a stream)
     int* block_tmp;         // [4096]
+    dif_frame_t* frame_copy; // device copy of a streaming frame's descriptor (read by the kernels behind the first one)
     int64_t total_bytes;
 };
 
@@ -375,12 +376,13 @@ static int carve_integrate(int64_t N, void* base, IntegrateWs& ws) {
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     // 8N bounds the gathered rows (map.py:419-435), hence tiles * 32 and the run records: a run holds at least one row
     const size_t rows = (size_t)(8 * N + 32);
-    size_t o_lin = take((size_t)N * 4), o_list = take(rows * 8), o_next = take(rows * 4), o_rec = take(rows * DIF_REC_WORDS * 8), o_tmp = take(4096 * 4);
+    size_t o_lin = take((size_t)N * 4), o_list = take(rows * 8), o_next = take(rows * 4), o_rec = take(rows * DIF_REC_WORDS * 8), o_tmp = take(4096 * 4),
+           o_frame = take(sizeof(dif_frame_t));
     ws.total_bytes = (int64_t)off;
     if (base) {
         char* b = (char*)base;
         ws.pt_lin = (int*)(b + o_lin); ws.pair_list = (uint2*)(b + o_list); ws.rec_next = (int*)(b + o_next);
-        ws.rec = (long long*)(b + o_rec); ws.block_tmp = (int*)(b + o_tmp);
+        ws.rec = (long long*)(b + o_rec); ws.block_tmp = (int*)(b + o_tmp); ws.frame_copy = (dif_frame_t*)(b + o_frame);
     }
     return DIF_OK;
 }
@@ -408,7 +410,8 @@ struct IntegratePlan {
 static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
                           void* wsp, int64_t ws_bytes, const FrameSource* src, IntegratePlan& P) {
     if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N <= 0 || !map->grid_tot) return DIF_EINVAL;
-    if (!xyz || !normal || !unq_mask || !wsp) return DIF_EINVAL;
+    // a streaming frame may leave xyz / normal out (both): the later stages then recompute the few points they need from the depth pixel
+    if ((xyz == nullptr) != (normal == nullptr) || (!xyz && !src) || !unq_mask || !wsp) return DIF_EINVAL;
     if (8 * N + 64 >= (int64_t)1 << 31 || map->capacity >= (int64_t)1 << 31) return DIF_EINVAL;      // record ids and slots are int32
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     if (grid >= ((int64_t)1 << 31)) return DIF_EINVAL;
@@ -422,14 +425,16 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
     dif_pending_export_t* const pending = src ? (dif_pending_export_t*)map->pending_export : nullptr;
     P.grid = grid;
     P.has_pending = pending != nullptr;
+    const ImageGeo im = src ? ImageGeo{src->H, src->W, src->fx, src->fy, src->cx, src->cy} : ImageGeo{};
+    const PointSrc ps{xyz, normal, src ? ws.frame_copy : nullptr, im};
     P.uvc = UvcArgs{g, src ? src->frame : nullptr, const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C,
-                    own_lo - map->halo, own_hi + map->halo, pending};
+                    own_lo - map->halo, own_hi + map->halo, pending, src ? ws.frame_copy : nullptr};
     P.prune = PruneArgs{g, (int)map->prune_min_vox_obs, ws.pt_lin, map->frame_count, map->indexer, unq_mask, grid_marks_of(map), C, pending};
     P.alloc = AllocFunctor{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
     P.alloc_tot = map->grid_tot;                                   // k_prune_mark kept the block totals
-    P.gather = GatherArgs{g, map->encoder_count_th, xyz, ws.pt_lin, unq_mask, map->frame_count, map->indexer, map->voxel_obs_count, ws.pair_list, C,
+    P.gather = GatherArgs{g, map->encoder_count_th, ps, ws.pt_lin, unq_mask, map->frame_count, map->indexer, map->voxel_obs_count, ws.pair_list, C,
                           map->capacity, map->grid_tot, own_lo, own_hi, pending};
-    P.enc = EncArgs{g, xyz, normal, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, map->dirty_tot};
+    P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, map->dirty_tot};
     P.fuse = FuseArgs{ws.rec, ws.rec_next, map->rec_dir, map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->latent_vecs_pos,
                       halo_lists_of(map), pending};
     return DIF_OK;
@@ -452,6 +457,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
                           void* wsp, int64_t ws_bytes, const FrameSource* src, void* stream_) {
     if (!map || !w || !w->enc_packed || w->enc_packed_floats != ENC_FLOATS || N < 0 || !map->grid_tot) return DIF_EINVAL;
     if (N == 0) return DIF_OK;
+    if (!src && (!xyz || !normal)) return DIF_EINVAL;
     IntegratePlan P;
     const int rc = integrate_plan(map, w, xyz, normal, N, unq_mask, wsp, ws_bytes, src, P);
     if (rc != DIF_OK) return rc;
@@ -476,11 +482,11 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         const EncArgs& e = P.enc;
         ProfScope prof(DIF_PROF_ENCODE, s);
         if (x6)
-            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.xyz, e.normal, N, e.pair_list,
-                               e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
+            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
+                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         else
-            hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.xyz, e.normal, N, e.pair_list,
-                               e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
+            hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.src.xyz, e.src.normal, e.src.frame,
+                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         DIF_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, P.fuse);
@@ -495,7 +501,7 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
 
 int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_frame_t* frame_dev, int32_t H, int32_t W, float fx, float fy, float cx,
                         float cy, float* xyz_world, float* normal_world, uint8_t* unq_mask, void* wsp, int64_t ws_bytes, void* stream_) {
-    if (!frame_dev || H <= 0 || W <= 0 || !xyz_world || !normal_world) return DIF_EINVAL;
+    if (!frame_dev || H <= 0 || W <= 0 || (xyz_world == nullptr) != (normal_world == nullptr)) return DIF_EINVAL;
     FrameSource src{frame_dev, H, W, fx, fy, cx, cy};
     return integrate_impl(map, w, xyz_world, normal_world, (int64_t)H * W, unq_mask, wsp, ws_bytes, &src, stream_);
 }
@@ -523,7 +529,7 @@ int dif_integrate_frames(const dif_stream_frame_t* st, int32_t S, const dif_weig
     static thread_local Batch<GatherArgs> gather; static thread_local Batch<EncArgs> enc; static thread_local Batch<FuseArgs> fuse;
     int64_t grid = 0;
     for (int j = 0; j < S; ++j) {
-        if (!st[j].frame_dev || !st[j].xyz_world || !st[j].normal_world) return DIF_EINVAL;
+        if (!st[j].frame_dev) return DIF_EINVAL;
         FrameSource src{st[j].frame_dev, H, W, fx, fy, cx, cy};
         IntegratePlan P;
         const int rc = integrate_plan(st[j].map, w, st[j].xyz_world, st[j].normal_world, N, st[j].unq_mask, st[j].ws, st[j].ws_bytes, &src, P);

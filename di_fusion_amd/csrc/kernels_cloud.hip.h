@@ -106,29 +106,30 @@ __device__ __forceinline__ unsigned long long cloud_pack(float d2, int idx) { re
 
 template <int K>
 struct TopK {
-    unsigned long long kv[K];       // fully unrolled accesses only: stays in registers
-    __device__ __forceinline__ void init() {
+    // The list has K slots (K = 8, 16, 32: the compiled sizes) for a run-time k <= K.  The K - k LEADING slots hold a sentinel that
+    // nothing sorts below (key 0), so the k best real entries always sit in slots K - k .. K - 1 and the k-th best is simply the LAST slot:
+    // no run-time index into the list anywhere in the search loop.  (Selecting slot k - 1 of a plain list with a run-time k made the compiler
+    // park the whole list in scratch memory and load the one entry back — K x 8 bytes stored per batch of cells.)  Fully unrolled accesses
+    // only: the list stays in registers.
+    unsigned long long kv[K];
+    __device__ __forceinline__ void init(int k) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) kv[j] = cloud_pack(__builtin_inff(), 0x7FFFFFFF);
+        for (int j = 0; j < K; ++j) kv[j] = (j < K - k) ? 0ull : cloud_pack(__builtin_inff(), 0x7FFFFFFF);
     }
     __device__ __forceinline__ unsigned long long worst() const { return kv[K - 1]; }
     __device__ __forceinline__ void insert(unsigned long long ck) {        // ck < worst() is the caller's business; branch-free
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const bool lt = ck < kv[j];
+            const bool lt = ck < kv[j];                                     // (never true for a sentinel slot)
             const unsigned long long t = kv[j];
             kv[j] = lt ? ck : t;
             ck = lt ? t : ck;
         }
     }
+    // slot j of the K (compile-time index); its rank among the real entries is j - (K - k)
     __device__ __forceinline__ float d(int j) const { return __uint_as_float((unsigned)(kv[j] >> 32)); }
     __device__ __forceinline__ int id(int j) const { return (int)(unsigned)kv[j]; }
-    __device__ __forceinline__ float kth(int k) const {   // d(k-1) without dynamic register indexing
-        unsigned long long v = kv[K - 1];
-#pragma unroll
-        for (int j = 0; j < K - 1; ++j) v = (j == k - 1) ? kv[j] : v;
-        return __uint_as_float((unsigned)(v >> 32));
-    }
+    __device__ __forceinline__ float kth() const { return __uint_as_float((unsigned)(kv[K - 1] >> 32)); }      // distance of the k-th best so far
 };
 
 // Unit eigenvector of the smallest eigenvalue of a symmetric 3x3 matrix M (rows m0, m1, m2), as pcproc.cu:21-96 computes it:
@@ -195,7 +196,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
     const uint4* __restrict__ tab4 = reinterpret_cast<const uint4*>(g.tab);
     int2* const run = s_run + threadIdx.x;
     TopK<K> top;
-    top.init();
+    top.init(k);
+    const int lead = K - k;                                 // sentinel slots in front of the list
     int inside = 0;
     for (int rho = 0; rho <= max_ring; ++rho) {
         int dx = -rho, dy = -rho, dz = -rho;               // the shell in the order of three nested loops, interior columns reduced to their end caps
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
             // kNN / normals: a cell whose nearest corner is strictly farther than the k-th distance so far (ties go by index) is not looked up
             // at all.  The cell's box from the integer coordinates, shrunk by the same 1e-3 c that the ring bound below allows for floor()
             // rounding.  (For the outlier count the same test against the radius costs more than it saves: measured.)
-            const float far2 = top.kth(k);
+            const float far2 = top.kth();
 #pragma unroll
             for (int b = 0; b < CLOUD_NB; ++b) {
                 off[b] = -1;
@@ -290,17 +292,17 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
             if (inside >= k) break;                        // decided: at least k points inside the radius
             continue;                                      // (ring max_ring covers the radius: the count is complete when the loop ends)
         }
-        const float kth = top.kth(k);
+        const float kth = top.kth();
         const float lb = ((float)rho - 1e-3f) * g.c;       // every unvisited point is at least this far (1e-3: floor() rounding)
         if (lb > 0.0f && kth < lb * lb) break;             // (the host sizes c so that ring max_ring covers the radius)
     }
     if (MODE == CLOUD_KNN) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if (j < k) {
+            if (j >= lead) {
                 bool in = top.d(j) < r2;
-                out.idx[(size_t)qi * k + j] = in ? top.id(j) : -1;
-                out.dist[(size_t)qi * k + j] = in ? top.d(j) : __builtin_inff();
+                out.idx[(size_t)qi * k + (j - lead)] = in ? top.id(j) : -1;
+                out.dist[(size_t)qi * k + (j - lead)] = in ? top.d(j) : __builtin_inff();
             }
         }
     } else if (MODE == CLOUD_OUTLIER) {
@@ -311,8 +313,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
         float mx = 0.f, my = 0.f, mz = 0.f, cntf = 0.f;
         bool open = true;
 #pragma unroll
-        for (int j = 1; j < K; ++j) {
-            open = open && (j < k) && (top.d(j) < r2);
+        for (int j = 1; j < K; ++j) {                      // real entries 1 .. k-1 (entry 0 is the query itself) sit in slots lead+1 .. K-1
+            if (j <= lead) continue;
+            open = open && (top.d(j) < r2);
             if (open) {
                 const float* p = pc + (size_t)top.id(j) * stride;
                 mx += p[0]; my += p[1]; mz += p[2];
@@ -329,7 +332,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_cloud_query(CloudGrid g, const fl
         open = true;
 #pragma unroll
         for (int j = 1; j < K; ++j) {
-            open = open && (j < k) && (top.d(j) < r2);
+            if (j <= lead) continue;
+            open = open && (top.d(j) < r2);
             if (open) {
                 const float* p = pc + (size_t)top.id(j) * stride;
                 const float px = p[0] - mx, py = p[1] - my, pz = p[2] - mz;

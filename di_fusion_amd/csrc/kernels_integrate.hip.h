@@ -38,10 +38,47 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_voxel_count(Geo g, const float* _
 
 // a1 + a2 + a3 in one pass for a streaming caller: depth pixel -> world point and normal (written out for the later stages) -> voxel id
 // and per-voxel count, without re-reading the points.
+struct ImageGeo { int H, W; float fx, fy, cx, cy; };
+
+// Where the stages behind the first kernel get a point's world coordinates and normal from: the (N,3) arrays (written by the first
+// kernel or supplied by the caller), or — arrays NULL, a streaming frame — recomputed from the depth pixel and the pose with the very
+// operations of the first kernel (unproject_point: same order, no contraction => the same bits).  A frame's ~3 % of points that pass
+// the focus test and its gathered encoder rows are all that ever need them: writing 24 bytes per pixel for every pixel of every frame
+// (7.4 MB at 640x480) just to read a few per cent back was the first kernel's largest cost.
+struct PointSrc {
+    const float* xyz; const float* normal;
+    const dif_frame_t* frame; ImageGeo im;
+};
+
+__device__ __forceinline__ Pose pose_of(const dif_frame_t* __restrict__ frame) {
+    Pose P;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.r[k] = frame->pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.t[k] = frame->pose[9 + k];
+    return P;
+}
+
+__device__ __forceinline__ void src_point(const PointSrc& s, const Pose& P, int64_t i, float (&p)[3]) {
+    if (s.xyz) { p[0] = s.xyz[i * 3 + 0]; p[1] = s.xyz[i * 3 + 1]; p[2] = s.xyz[i * 3 + 2]; return; }
+    float nv[3];
+    unproject_point(s.frame->depth, nullptr, i, s.im.W, s.im.fx, s.im.fy, s.im.cx, s.im.cy, P, p, nv);
+}
+
+__device__ __forceinline__ void src_point_normal(const PointSrc& s, const Pose& P, int64_t i, float (&p)[3], float (&nv)[3]) {
+    if (s.xyz) {
+        p[0] = s.xyz[i * 3 + 0]; p[1] = s.xyz[i * 3 + 1]; p[2] = s.xyz[i * 3 + 2];
+        nv[0] = s.normal[i * 3 + 0]; nv[1] = s.normal[i * 3 + 1]; nv[2] = s.normal[i * 3 + 2];
+        return;
+    }
+    unproject_point(s.frame->depth, s.frame->normal_cam, i, s.im.W, s.im.fx, s.im.fy, s.im.cx, s.im.cy, P, p, nv);
+}
+
 __device__ __forceinline__ void unproject_voxel_count_body(const Geo& g, const dif_frame_t* __restrict__ frame, int H, int W, float fx, float fy,
                                                            float cx, float cy, float* __restrict__ xyz, float* __restrict__ nrm,
                                                            int* __restrict__ pt_lin, int* __restrict__ frame_count, int* __restrict__ counters,
-                                                           int px_lo, int px_hi, const dif_pending_export_t* __restrict__ pending, int nb_x) {
+                                                           int px_lo, int px_hi, const dif_pending_export_t* __restrict__ pending, int nb_x,
+                                                           dif_frame_t* __restrict__ frame_copy) {
     // The first nb_x workgroups (dispatched first, so that the copy runs beside the whole point pass and not at its tail) carry out a third of
     // the previous extract's deferred triangle export; the other two thirds ride with the next two kernels.
     if ((int)blockIdx.x < nb_x) {
@@ -51,16 +88,18 @@ __device__ __forceinline__ void unproject_voxel_count_body(const Geo& g, const d
     const int64_t N = (int64_t)H * W;
     const int64_t i = (int64_t)((int)blockIdx.x - nb_x) * blockDim.x + threadIdx.x;
     const bool in = i < N;
+    if ((int)blockIdx.x == nb_x && threadIdx.x < 16 && frame_copy)       // the descriptor, for the later kernels of this frame
+        reinterpret_cast<uint32_t*>(frame_copy)[threadIdx.x] = reinterpret_cast<const uint32_t*>(frame)[threadIdx.x];
     float p[3] = {0.f, 0.f, 0.f}, nv[3];
     if (in) {
-        Pose P;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) P.r[k] = frame->pose[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) P.t[k] = frame->pose[9 + k];
-        unproject_point(frame->depth, frame->normal_cam, i, W, fx, fy, cx, cy, P, p, nv);
-        xyz[i * 3 + 0] = p[0]; xyz[i * 3 + 1] = p[1]; xyz[i * 3 + 2] = p[2];
-        nrm[i * 3 + 0] = nv[0]; nrm[i * 3 + 1] = nv[1]; nrm[i * 3 + 2] = nv[2];
+        const Pose P = pose_of(frame);
+        if (xyz) {
+            unproject_point(frame->depth, frame->normal_cam, i, W, fx, fy, cx, cy, P, p, nv);
+            xyz[i * 3 + 0] = p[0]; xyz[i * 3 + 1] = p[1]; xyz[i * 3 + 2] = p[2];
+            nrm[i * 3 + 0] = nv[0]; nrm[i * 3 + 1] = nv[1]; nrm[i * 3 + 2] = nv[2];
+        } else {
+            unproject_point(frame->depth, nullptr, i, W, fx, fy, cx, cy, P, p, nv);      // (the normals are not needed before the encoder)
+        }
     }
     voxel_count_point(g, in, p[0], p[1], p[2], i, pt_lin, frame_count, counters, px_lo, px_hi);
 }
@@ -68,17 +107,17 @@ __device__ __forceinline__ void unproject_voxel_count_body(const Geo& g, const d
 struct UvcArgs {            // per map; the image geometry is shared by the maps of a batched launch
     Geo g; const dif_frame_t* frame; float* xyz; float* nrm; int* pt_lin; int* frame_count; int* counters; int px_lo, px_hi;
     const dif_pending_export_t* pending;
+    dif_frame_t* frame_copy;        // device copy of the descriptor for the later kernels of the frame (the caller's may sit in pinned host memory)
 };
-struct ImageGeo { int H, W; float fx, fy, cx, cy; };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(UvcArgs a, ImageGeo im, int nb_x) {
     unproject_voxel_count_body(a.g, a.frame, im.H, im.W, im.fx, im.fy, im.cx, im.cy, a.xyz, a.nrm, a.pt_lin, a.frame_count, a.counters, a.px_lo, a.px_hi,
-                               a.pending, nb_x);
+                               a.pending, nb_x, a.frame_copy);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count_batch(Batch<UvcArgs> b, ImageGeo im, int nb_x) {
     const UvcArgs& a = b.s[blockIdx.y];
     unproject_voxel_count_body(a.g, a.frame, im.H, im.W, im.fx, im.fy, im.cx, im.cy, a.xyz, a.nrm, a.pt_lin, a.frame_count, a.counters, a.px_lo, a.px_hi,
-                               a.pending, nb_x);
+                               a.pending, nb_x, a.frame_copy);
 }
 
 // K2: prune mask + candidate voxels.  mask[i] = count(voxel of i) > prune_min_vox_obs (map.py:375).  A kept point whose
@@ -182,7 +221,7 @@ struct AllocFunctor {
 __device__ __forceinline__ bool in_encode_set(int64_t slot, const float* __restrict__ obs, float th) { return slot >= 0 && obs[slot] < th; }
 
 #define FG_TABLE 256            /* == DIF_BLOCK: one table entry per thread in the scan below */
-__device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, const float* __restrict__ xyz, const int* __restrict__ pt_lin,
+__device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, const PointSrc& src, const int* __restrict__ pt_lin,
                                                   const uint8_t* __restrict__ unq_mask, int64_t N, int* __restrict__ frame_count,
                                                   const int64_t* __restrict__ indexer, const float* __restrict__ obs,
                                                   uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w,
@@ -249,7 +288,9 @@ __device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, co
     focus = __shfl((int)focus, my_head) != 0;
     if (kept && focus) {
         float xn, yn, zn; int ix, iy, iz;
-        voxel_of(g, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], xn, yn, zn, ix, iy, iz);
+        float p[3];
+        src_point(src, src.xyz ? Pose{} : pose_of(src.frame), i, p);
+        voxel_of(g, p[0], p[1], p[2], xn, yn, zn, ix, iy, iz);
         int64_t slot[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -300,17 +341,17 @@ __device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, co
 }
 
 struct GatherArgs {
-    Geo g; float enc_th; const float* xyz; const int* pt_lin; const uint8_t* unq_mask; int* frame_count; const int64_t* indexer; const float* obs;
+    Geo g; float enc_th; PointSrc src; const int* pt_lin; const uint8_t* unq_mask; int* frame_count; const int64_t* indexer; const float* obs;
     uint2* pair_list; int* counters; int64_t capacity; int* grid_tot; int own_lo, own_hi; const dif_pending_export_t* pending;
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(GatherArgs a, int64_t N, int img_w, int nb_x) {
-    focus_gather_body(a.g, a.enc_th, a.xyz, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
+    focus_gather_body(a.g, a.enc_th, a.src, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
                       a.own_lo, a.own_hi, a.pending, nb_x);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather_batch(Batch<GatherArgs> b, int64_t N, int img_w, int nb_x) {
     const GatherArgs& a = b.s[blockIdx.y];
-    focus_gather_body(a.g, a.enc_th, a.xyz, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
+    focus_gather_body(a.g, a.enc_th, a.src, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
                       a.own_lo, a.own_hi, a.pending, nb_x);
 }
 
@@ -345,7 +386,7 @@ __device__ unsigned long long g_en_trace[2048 * 8];
 // workgroup and the launch carries S frames' worth of tiles per SIMD.  Which map a tile belongs to is wave-uniform (scalar loads of
 // that map's pointers from the kernel-argument array); per map nothing changes — same tiles, same records, same directory.
 struct EncArgs {
-    Geo g; const float* xyz; const float* normal; const uint2* pair_list; int* rec_dir; int* rec_next; long long* rec; int* upd_list; int* counters;
+    Geo g; PointSrc src; const uint2* pair_list; int* rec_dir; int* rec_next; long long* rec; int* upd_list; int* counters;
     const uint8_t* dirty; int* dirty_tot;
 };
 template <bool X6, int NS>
@@ -385,15 +426,17 @@ __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S,
 #pragma unroll
                 for (int k = 1; k < 8; ++k) o += ((int64_t)v >= (int64_t)k * N) ? 1 : 0;
                 int64_t i = (int64_t)v - (int64_t)o * N;
-                float xn = normalize1(a.xyz[i * 3 + 0], g.bx, g.vs);
-                float yn = normalize1(a.xyz[i * 3 + 1], g.by, g.vs);
-                float zn = normalize1(a.xyz[i * 3 + 2], g.bz, g.vs);
+                float pw[3], nw[3];
+                src_point_normal(a.src, a.src.xyz ? Pose{} : pose_of(a.src.frame), i, pw, nw);
+                float xn = normalize1(pw[0], g.bx, g.vs);
+                float yn = normalize1(pw[1], g.by, g.vs);
+                float zn = normalize1(pw[2], g.bz, g.vs);
                 float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
                 float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
                 float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
                 float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
                 float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
-                float nxv = a.normal[i * 3 + 0], nyv = a.normal[i * 3 + 1], nzv = a.normal[i * 3 + 2];
+                float nxv = nw[0], nyv = nw[1], nzv = nw[2];
                 t.x0 = half ? ry : rx;
                 t.x1 = half ? nxv : rz;
                 t.x2 = half ? nzv : nyv;
@@ -462,10 +505,10 @@ __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S,
 // One map: the pointers arrive as noalias kernel arguments (the body's accesses keep that provenance).
 template <bool X6>
 __global__ void __launch_bounds__(512, X6 ? 1 : 2)
-k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, int64_t N,
-         const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
+k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, const dif_frame_t* __restrict__ frame,
+         ImageGeo im, int64_t N, const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
          int* __restrict__ upd_list, int* __restrict__ counters, const uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
-    const BatchN<EncArgs, 1> B{{EncArgs{g, xyz, normal, pair_list, rec_dir, rec_next, rec, upd_list, counters, dirty, dirty_tot}}};
+    const BatchN<EncArgs, 1> B{{EncArgs{g, PointSrc{xyz, normal, frame, im}, pair_list, rec_dir, rec_next, rec, upd_list, counters, dirty, dirty_tot}}};
     encode_body<X6, 1>(B, 1, wblob, N);
 }
 

@@ -78,7 +78,13 @@ class FusionStream:
         self._b_slots = None
         self._d2h_mode = "new"
         self.defer_export = True            # step_direct: a frame's new triangles travel to the host beside the NEXT frame's first kernel
+        # direct / graph / batch / group frames: False = world points and normals are NOT written out per pixel (dif_integrate_frame with
+        # xyz_world = normal_world = NULL: the stages that need a point recompute it from the depth pixel, bit-identically); True = into self.xyz / self.nrm
+        self.keep_points = False
         self.backlog = []                   # outputs of a pending batch's earlier frames, when a frame-by-frame step had to complete it
+
+    def _pts(self):
+        return (_lib.ptr(self.xyz), _lib.ptr(self.nrm)) if self.keep_points else (_lib.ptr(None), _lib.ptr(None))
 
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
@@ -350,8 +356,8 @@ class FusionStream:
             k, sl, buf, export, out = self._direct_begin(i, d2h)
             lib, w, sp = self._d_lib, self._d_w, _lib.stream_ptr()
             H, W, fx, fy, cx, cy = self._d_args
-            _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, _lib.ptr(self.xyz),
-                                               _lib.ptr(self.nrm), _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
+            _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, *self._pts(),
+                                               _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
             self._direct_integrated()
             if self.tiling is not None:
                 self._exchange_halo(reserved=True)              # export -> send/recv -> merge, all on this stream, no host wait
@@ -407,7 +413,7 @@ class FusionStream:
                     sp = _lib.stream_ptr()
                     for sl, buf in zip(self._b_slots[g], bufs):
                         _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, intr.fx, intr.fy, intr.cx,
-                                                           intr.cy, _lib.ptr(self.xyz), _lib.ptr(self.nrm), _lib.ptr(self._b_mask), _lib.ptr(m._ws),
+                                                           intr.cy, *self._pts(), _lib.ptr(self._b_mask), _lib.ptr(m._ws),
                                                            m._ws.numel(), sp), "dif_integrate_frame")
                         _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1,
                                                    float(self.max_std), 0, 1, sp), "dif_extract")
@@ -531,7 +537,7 @@ class FusionStream:
                 with torch.cuda.graph(g):
                     sp = _lib.stream_ptr()
                     _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(frame), H, W, intr.fx, intr.fy, intr.cx, intr.cy,
-                                                       _lib.ptr(self.xyz), _lib.ptr(self.nrm), _lib.ptr(mask), _lib.ptr(m._ws), m._ws.numel(), sp),
+                                                       *self._pts(), _lib.ptr(mask), _lib.ptr(m._ws), m._ws.numel(), sp),
                                "dif_integrate_frame")
                     _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std),
                                                0, 1, sp), "dif_extract")
@@ -641,7 +647,8 @@ class FusionStreamGroup:
                 f, m = self._frames[j], st.map
                 f.map = ctypes.pointer(m._cmap)
                 f.frame_dev = _lib.ptr(sl["frame"])
-                f.xyz_world, f.normal_world, f.unq_mask = _lib.ptr(st.xyz), _lib.ptr(st.nrm), _lib.ptr(st._d_mask)
+                f.xyz_world, f.normal_world = st._pts()
+                f.unq_mask = _lib.ptr(st._d_mask)
                 f.ws, f.ws_bytes = _lib.ptr(m._ws), m._ws.numel()
                 f.buf = ctypes.pointer(buf)
             lib, w, sp = a._d_lib, a._d_w, _lib.stream_ptr()

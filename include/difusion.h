@@ -234,8 +234,11 @@ int dif_integrate(const dif_map_t* map, const dif_weights_t* w, const float* xyz
                   uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* stream);
 
 /* a1 + a2 + a3..a10 for a streaming caller: integrate straight from a depth frame behind a device-readable descriptor (see
- * dif_unproject_transform_frame).  The first kernel back-projects, transforms AND counts points per voxel; xyz_world / normal_world
- * ((H*W,3) each) are outputs that the later stages read.  Same results as dif_unproject_transform_frame followed by dif_integrate. */
+ * dif_unproject_transform_frame).  The first kernel back-projects, transforms AND counts points per voxel.  xyz_world / normal_world
+ * ((H*W,3) each) are optional outputs (both or neither): with them the later stages read the points there; without, the few points those
+ * stages need (the ~3 % that pass the focus test, the gathered encoder rows) are recomputed from the depth pixel with the same operations —
+ * nothing H*W*24 bytes large is written per frame.  Same results either way, and the same as dif_unproject_transform_frame followed by
+ * dif_integrate. */
 int dif_integrate_frame(const dif_map_t* map, const dif_weights_t* w, const dif_frame_t* frame_dev, int32_t H, int32_t W, float fx, float fy,
                         float cx, float cy, float* xyz_world, float* normal_world, uint8_t* unq_mask, void* ws, int64_t ws_bytes, void* stream);
 
@@ -327,7 +330,7 @@ int dif_export_pending(const dif_map_t* map, void* stream);
 typedef struct dif_stream_frame {
     const dif_map_t* map;                   /* [host] */
     const dif_frame_t* frame_dev;           /* as dif_integrate_frame */
-    float* xyz_world; float* normal_world;  /* (H*W,3) each, out */
+    float* xyz_world; float* normal_world;  /* (H*W,3) each, out; or both NULL (see dif_integrate_frame) */
     uint8_t* unq_mask;                      /* (H*W) out */
     void* ws; int64_t ws_bytes;             /* dif_integrate_workspace_bytes(H*W) */
     const dif_extract_buffers_t* buf;       /* [host] as dif_extract (dif_extract_streams only; may be NULL for dif_integrate_frames) */

@@ -12,7 +12,12 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 LATENT_TOL = 2e-5        # |z_gpu - z_ref| : fp32 sums of ~10^3 encoder outputs in a different order
-SDF_TOL = 5e-5           # cube values away from the 0.05 refinement threshold
+# Cube values away from the 0.05 refinement threshold, end to end: the latents differ from the reference's by ~1e-6 (another summation
+# order, another matrix pipe) and the decoder amplifies that by up to ~25x at a few samples (tests/test_oracle_golden.py: the oracle's
+# own worst sample is 1.56e-5 from the reference with its own latents and 4.6e-6 with the reference's).  With the REFERENCE's latents
+# loaded into the map the decode meets BASELINE.md's 1e-5 (test_decode_of_reference_latents_within_1e5).
+SDF_TOL = 3e-5
+SDF_TOL_REF_LATENTS = 1e-5
 
 CASES = {
     "seq_small": (syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6,) * 3, (1.6,) * 3, 0.4), syn.Intrinsic().scaled(0.125)),
@@ -115,6 +120,43 @@ def test_sequence_vs_golden_and_oracle(name, gpu_model, oracle_net):
     assert np.array_equal(qmask.cpu().numpy(), g["probe_mask"])
     assert np.abs(sdf.cpu().numpy() - g["probe_sdf"]).max() < SDF_TOL
     assert np.abs(std.cpu().numpy() - g["probe_std"]).max() < SDF_TOL
+
+
+@pytest.mark.parametrize("pipe", ["bf16x6", "f32"])
+@pytest.mark.parametrize("name", ["seq_small", "seq_room16", "seq_c2", "seq_c3"])
+def test_decode_of_reference_latents_within_1e5(name, pipe, gpu_model, gpu_model_f32):
+    """BASELINE.md section 4's tolerance made honest: every frame's map state is checked against the reference run, then the map's
+    latents are REPLACED by the reference's before the extract, so the decoded cubes isolate the decode path (lattice, folded MLP tiles on
+    either matrix pipe, ATen-exact trilinear x2, threshold + refine): <= 1e-5 on SDF and std against the reference's cubes at every
+    fixture size up to C3, near-threshold samples excluded as everywhere."""
+    from oracle import difusion_oracle as O
+    scene, cfg, intr = CASES[name]
+    g = np.load(GOLDEN / f"{name}.npz")
+    m = make_map(gpu_model if pipe == "bf16x6" else gpu_model_f32, cfg)
+    worst = 0.0
+    for f in range(int(g["n_frames"])):
+        xyz, nrm = frame_inputs(g, name, f)
+        m.integrate_keyframe(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV))
+        check_state(m, g, f)
+        n = int(g[f"f{f}_int_n_occupied"])
+        m._latent[:n] = torch.from_numpy(g[f"f{f}_int_latent_vecs"]).to(DEV)
+        m.extract_mesh_arrays(4, int(4e6), max_std=0.15, to_host=False)
+        B = m.last_counters["B"]
+        assert B == int(g[f"f{f}_mc_B"])
+        tens = m._xbuf[1]
+        cs = tens["cube_sdf"][:B].cpu().numpy(); cd = tens["cube_std"][:B].cpu().numpy()
+        sel = g[f"f{f}_mc_cube_sel"] if f"f{f}_mc_cube_sel" in g else np.arange(B)
+        # near-threshold samples from the reference's own interpolated values: |  |low-lattice interpolation| - 0.05 | < 1e-5 cannot be told
+        # from the cubes alone, so a sample counts as a flip when it differs by more than the bar AND its reference value is a re-decoded or
+        # interpolated value within 2e-3 of the threshold band edge ... (counted, bounded)
+        ds = np.abs(cs[sel] - g[f"f{f}_mc_cube_sdf"]); dd = np.abs(cd[sel] - g[f"f{f}_mc_cube_std"])
+        bad = (ds >= SDF_TOL_REF_LATENTS) | (dd >= SDF_TOL_REF_LATENTS)
+        near = np.abs(np.abs(g[f"f{f}_mc_cube_sdf"]) - 0.05) < 5e-3
+        print(f"  {name} {pipe} frame {f}: B={B} sdf max {ds[~bad].max():.2e} std max {dd[~bad].max():.2e} over-the-bar samples {int(bad.sum())} "
+              f"(all near the 0.05 threshold: {bool((near | ~bad).all())})")
+        assert bad.sum() <= 8 and (near | ~bad).all()          # only refinement flips at the threshold may exceed the bar
+        worst = max(worst, float(ds[~bad].max()), float(dd[~bad].max()))
+    assert worst < SDF_TOL_REF_LATENTS
 
 
 def test_mesh_cache_replace_by_voxel(gpu_model, oracle_net):

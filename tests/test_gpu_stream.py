@@ -411,3 +411,31 @@ def test_stream_group_c3_four_streams(gpu_model):
         assert a["n"] == b["n"] > 10000
         for k in ("indexer", "latent", "obs", "tri", "tid", "tstd"):
             assert torch.equal(a[k], b[k]), (j, k)
+
+
+def test_direct_frames_with_and_without_point_arrays(gpu_model):
+    """`dif_integrate_frame` with xyz_world / normal_world (the first kernel writes every pixel's world point and normal, the later stages
+    read them) and without (the later stages recompute the few points they need from the depth pixel): identical maps and meshes, and the
+    arrays — when asked for — equal the stand-alone unproject + transform of the same frame."""
+    import ctypes
+    from di_fusion_amd import _lib
+    snaps = {}
+    for keep in (False, True):
+        st = make_stream(gpu_model, initial_capacity=None)
+        st.keep_points = keep
+        if keep:
+            st.xyz.fill_(7.0); st.nrm.fill_(7.0)
+        st.step(0, d2h="new")
+        for i in range(1, N_FRAMES):
+            st.step_direct(i, d2h="new")
+        st.flush()
+        snaps[keep] = snapshot(st)
+        if keep:
+            intr = st.intr
+            R, t = st.poses[N_FRAMES - 1]
+            want_xyz, want_nrm = torch.empty_like(st.xyz), torch.empty_like(st.nrm)
+            _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(st.depth[N_FRAMES - 1]), _lib.ptr(st.ncam[N_FRAMES - 1]), _lib.ptr(want_xyz), _lib.ptr(want_nrm),
+                                                           intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()), "dif_unproject_transform")
+            nan = lambda x: torch.nan_to_num(x, nan=123.0)
+            assert torch.equal(nan(st.xyz), nan(want_xyz)) and torch.equal(nan(st.nrm), nan(want_nrm))
+    same(snaps[False], snaps[True])
