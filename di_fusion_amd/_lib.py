@@ -118,6 +118,7 @@ SIGNATURES = {
     "dif_query_select": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "dif_query_decode": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dif_query_grad_scatter": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dif_query_grad_gather": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "dif_export_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "dif_merge_records": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "dif_export_halo": (c_int32, [POINTER(DifMap), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),

@@ -1205,7 +1205,7 @@ int dif_query_select(const dif_map_t* map, const float* xyz, int64_t N, uint8_t*
         return hipMemsetAsync(map->counters + DIF_C_QUERY_M, 0, sizeof(int), s) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
     }
     if (!xyz || !mask || !sel || !scratch) return DIF_EINVAL;
-    QueryFunctor f{geo_of(map), map->ignore_count_th, xyz, map->indexer, map->voxel_obs_count, mask, sel, map->counters, count_out, seq};
+    QueryFunctor f{geo_of(map), map->ignore_count_th, xyz, map->indexer, map->voxel_obs_count, mask, sel, map->counters, count_out, seq, scratch + 4096};
     return launch_scan(f, nullptr, (int)N, N, scratch, s);
 }
 
@@ -1234,6 +1234,14 @@ int dif_query_grad_scatter(const float* grad, const float* g_sdf, const int32_t*
     if (M < 0 || (M > 0 && (!grad || !g_sdf || !sel || !out))) return DIF_EINVAL;
     if (M == 0) return DIF_OK;
     hipLaunchKernelGGL(k_query_grad_scatter, dim3(grid_for(M * 3, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, grad, g_sdf, sel, M, out);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+int dif_query_grad_gather(const float* grad, const float* g_sdf, const int32_t* scratch, int64_t N, float* out, void* stream) {
+    if (N < 0 || (N > 0 && (!grad || !g_sdf || !scratch || !out))) return DIF_EINVAL;
+    if (N == 0) return DIF_OK;
+    hipLaunchKernelGGL(k_query_grad_gather, dim3(grid_for(N * 3, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, grad, g_sdf, scratch + 4096, N, out);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

@@ -628,6 +628,7 @@ struct QueryFunctor {
     int* counters;
     int32_t* count_out;          // optional (pinned host memory allowed): [0] = M, [1] = the caller's sequence number — the host slices its outputs
     int32_t seq;                 //   as soon as THIS kernel is done, while the decode of the M rows is still running
+    int32_t* inv;                // [N]: row of point i among the valid ones, -1 = invalid (the inverse of sel; dif_query_grad_gather)
     __device__ int count(int i) const {
         float xn, yn, zn; int ix, iy, iz;
         bool ok = voxel_of(g, xyz[(int64_t)i * 3 + 0], xyz[(int64_t)i * 3 + 1], xyz[(int64_t)i * 3 + 2], xn, yn, zn, ix, iy, iz);
@@ -636,12 +637,17 @@ struct QueryFunctor {
             ok = slot >= 0 && obs[slot] > ignore_th;
         }
         mask[i] = ok ? 1 : 0;
+        if (!ok) inv[i] = -1;                    // (both passes of the scan call count(): the same value twice)
         return ok ? 1 : 0;
     }
-    __device__ void emit(int i, int offset) const { sel[offset] = i; }
+    __device__ void emit(int i, int offset) const { sel[offset] = i; inv[i] = offset; }
     __device__ void finish(int total) const {
         counters[DIF_C_QUERY_M] = total;
-        if (count_out) { count_out[0] = total; count_out[1] = seq; }
+        if (count_out) {                         // M first, the sequence number behind a system-scope fence: a host that polls for its seq has M
+            count_out[0] = total;
+            __threadfence_system();
+            count_out[1] = seq;
+        }
     }
 };
 
@@ -651,6 +657,16 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_query_grad_scatter(const float* _
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M * 3; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = e / 3;
         out[(int64_t)sel[m] * 3 + (e - m * 3)] = grad[e] * g_sdf[m];
+    }
+}
+
+// The same over ALL N points through the inverse map (no zero fill of `out` needed: one launch is the whole backward)
+__global__ void __launch_bounds__(DIF_BLOCK) k_query_grad_gather(const float* __restrict__ grad, const float* __restrict__ g_sdf, const int32_t* __restrict__ inv,
+                                                               int64_t N, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * 3; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / 3;
+        const int m = inv[i];
+        out[e] = m >= 0 ? grad[(int64_t)m * 3 + (e - i * 3)] * g_sdf[m] : 0.0f;
     }
 }
 

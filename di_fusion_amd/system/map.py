@@ -86,22 +86,24 @@ class _GetSdfFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, owner):
-        sdf, std, mask, sel, grad = owner._query(xyz, True)
-        ctx.save_for_backward(sel, grad)
+        sdf, std, mask, sel, grad = owner._query(xyz, True, keep_inverse=True)
+        inv = owner._query_inverse                          # this query's own inverse map (point -> row among the valid ones)
+        ctx.save_for_backward(sel, grad, inv)
         ctx.n = xyz.size(0)
         ctx.mark_non_differentiable(std, mask)
         return sdf, std, mask
 
     @staticmethod
     def backward(ctx, g_sdf, g_std, g_mask):
-        sel, grad = ctx.saved_tensors
-        out = torch.zeros((ctx.n, 3), dtype=torch.float32, device=grad.device)
-        M = grad.size(0)
-        if M:
-            g = g_sdf.contiguous().float()
-            with torch.cuda.device(grad.device):      # one launch: out[sel[m]] = grad[m] * g_sdf[m]
-                _lib.check(_lib.load().dif_query_grad_scatter(_lib.ptr(grad), _lib.ptr(g), _lib.ptr(sel), M, _lib.ptr(out), _lib.stream_ptr()),
-                           "dif_query_grad_scatter")
+        sel, grad, inv = ctx.saved_tensors
+        n = ctx.n
+        if n == 0 or grad.size(0) == 0:
+            return torch.zeros((n, 3), dtype=torch.float32, device=grad.device), None
+        out = torch.empty((n, 3), dtype=torch.float32, device=grad.device)
+        g = g_sdf.contiguous().float()
+        with _on_device(grad.device):                 # ONE launch, every row written: out[i] = grad[inv[i]] * g_sdf[inv[i]], or 0 for an invalid point
+            _lib.check(_lib.load().dif_query_grad_gather(_lib.ptr(grad), _lib.ptr(g), _lib.ptr(inv), n, _lib.ptr(out), _lib.stream_ptr()),
+                       "dif_query_grad_gather")
         return out, None
 
 
@@ -110,6 +112,24 @@ _OVERFLOW_WHAT = {8: "a delta halo message overflowed: the neighbours' halo copi
                   1: "more voxels than latent rows", 2: "more dirty voxels than extract buffers", 3: "more decoded voxels than extract buffers",
                   5: "mesh-cache log full", 6: "more records than the export buffer",
                   7: "marching cubes gave up waiting for an earlier workgroup (the GPU was shared with another kernel for seconds)"}
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on_device(dev):
+    """`torch.cuda.device(dev)` only when `dev` is not the current device already (the context manager costs ~10 us of host time per use)."""
+    if torch.cuda.current_device() == (dev.index if dev.index is not None else 0):
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
 
 
 def _next_pow2(n: int) -> int:
@@ -444,7 +464,7 @@ class DenseIndexedMap:
         self.merge_records(rec)
 
     # ---- get_sdf ----------------------------------------------------------------------------------------------
-    def _query(self, xyz: torch.Tensor, want_grad: bool):
+    def _query(self, xyz: torch.Tensor, want_grad: bool, keep_inverse: bool = False):
         """`dif_query_select` (mask + ordered compaction of the valid points), then `dif_query_decode` over the M selected rows.  The host
         needs M to hand back M-row tensors (the reference's return shapes): the compaction's last workgroup writes it into pinned host
         memory and the host waits for THAT small kernel only — the decoder is still running when this returns (the tracker calls
@@ -454,12 +474,19 @@ class DenseIndexedMap:
         N = xyz.size(0)
         dev = self.device
         lib = _lib.load()
-        with torch.cuda.device(dev):
-            mask = torch.empty((N,), dtype=torch.uint8, device=dev)
-            sel = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
-            sdf = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
-            std = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
-            grad = torch.empty((max(N, 1), 3), dtype=torch.float32, device=dev) if want_grad else None
+        # (the tracker calls this once per Gauss-Newton iteration and waits for the result: what counts here is HOST time per call — one
+        # allocation for the five outputs, no device-context switch when the map's device is current already, no event in the queue)
+        with _on_device(dev):
+            n1 = max(N, 1)
+            blob = torch.empty((n1 * (6 if want_grad else 3) + (n1 + 3) // 4,), dtype=torch.float32, device=dev)
+            sdf, std = blob[:n1], blob[n1:2 * n1]
+            sel = blob[2 * n1:3 * n1].view(torch.int32)
+            grad = blob[3 * n1:6 * n1].view(n1, 3) if want_grad else None
+            mask = blob[(6 if want_grad else 3) * n1:].view(torch.uint8)[:N]
+            if keep_inverse:
+                # (the autograd path keeps the compaction's inverse map for its backward: a scratch of its own per call, so that a later query
+                # cannot overwrite it; the pinned count slots stay shared)
+                self._query_inverse = torch.empty((N + 4096,), dtype=torch.int32, device=dev)
             if N == 0:
                 return sdf[:0], std[:0], mask.view(torch.bool), sel[:0], (grad[:0] if want_grad else None)
             q = self._query_ws
@@ -475,16 +502,15 @@ class DenseIndexedMap:
             k = seq & 3
             note, ev = q["notes"][k], q["events"][k]
             sp = _lib.stream_ptr()
-            _lib.check(lib.dif_query_select(ctypes.byref(self._cmap), _lib.ptr(xyz), N, _lib.ptr(mask), _lib.ptr(sel), _lib.ptr(q["scratch"]),
-                                            _lib.ptr(note), seq, sp), "dif_query_select")
-            ev.record()
+            _lib.check(lib.dif_query_select(ctypes.byref(self._cmap), _lib.ptr(xyz), N, _lib.ptr(mask), _lib.ptr(sel),
+                                            _lib.ptr(self._query_inverse if keep_inverse else q["scratch"]), _lib.ptr(note), seq, sp), "dif_query_select")
             w = self.model.packed.weights_struct(dev)
             _lib.check(lib.dif_query_decode(ctypes.byref(self._cmap), ctypes.byref(w), _lib.ptr(xyz), N, _lib.ptr(sel), _lib.ptr(sdf), _lib.ptr(std),
                                             _lib.ptr(grad), sp), "dif_query_decode")
-            ev.synchronize()                                    # the compaction only; the decoder keeps running
+            # the compaction's last workgroup writes (M, seq) into the pinned note — M first, then a system-scope fence, then seq — and the host
+            # polls for ITS sequence number: it waits for the compaction only (the decoder keeps running), with no event in the queue
             got = q["notes_np"][k]
-            if int(got[1]) != seq:
-                raise RuntimeError("libdifusion: get_sdf lost its row count (pinned slot overwritten)")
+            _lib.spin_until(got, 1, seq, "get_sdf's compaction")
             M = int(got[0])
         return sdf[:M], std[:M], mask.view(torch.bool), sel[:M], (grad[:M] if want_grad else None)
 

@@ -367,7 +367,7 @@ int dif_decode_rows(const dif_weights_t* w, const float* rows, int64_t n, float*
 int dif_encode_rows(const dif_weights_t* w, const float* rows, int64_t n, float* out, void* stream);
 /* get_sdf: xyz (N,3) -> mask (N) u8, and for the M valid points IN ORDER: sdf (M), std (M), grad (M,3) = d sdf / d xyz
  * in world units (NULL to skip; reference tracker.py:186-192 obtains it by autograd), sel (M) = index of the point.  M -> counters[DIF_C_QUERY_M].
- * scratch: int32 [N + 4096]. */
+ * scratch: int32 [N + 4096]; on return scratch[4096 + i] = row of point i among the valid ones or -1 (the inverse of sel). */
 int dif_query_sdf(const dif_map_t* map, const dif_weights_t* w, const float* xyz, int64_t N, uint8_t* mask,
                   int32_t* sel, float* sdf, float* std_out, float* grad, int32_t* scratch, void* stream);
 /* The same in two steps, for a caller that has to hand back M-row tensors (map.py:559-579 does) without waiting for the decoder:
@@ -381,6 +381,9 @@ int dif_query_decode(const dif_map_t* map, const dif_weights_t* w, const float* 
 /* Backward of get_sdf for the caller's autograd (the reference differentiates through the decoder, tracker.py:186-192):
  * out[sel[m]][:] = grad[m][:] * g_sdf[m] for m < M; out (N,3) is zeroed by the caller. */
 int dif_query_grad_scatter(const float* grad, const float* g_sdf, const int32_t* sel, int64_t M, float* out, void* stream);
+/* The same in one launch WITHOUT the zero fill: every row of out (N,3) is written, through the inverse of `sel` that dif_query_select leaves in
+ * its scratch (scratch[4096 + i] = row of point i among the valid ones, -1 = invalid).  `scratch`: the array that call was given, untouched since. */
+int dif_query_grad_gather(const float* grad, const float* g_sdf, const int32_t* scratch, int64_t N, float* out, void* stream);
 
 /* ---- multi-GPU map merge (no reference counterpart) ----------------------------------- */
 /* Pack the allocated voxels whose x index lies in [x_lo, x_hi) as 32-word records, in slot order:

@@ -199,7 +199,7 @@ def test_merge_of_eight_c3_maps_vs_oracle(gpu_model, oracle_net):
     assert v is not None and v[0].shape[0] > 10_000
 
 
-@pytest.mark.parametrize("mode", ["c4", "tiled"])
+@pytest.mark.parametrize("mode", ["c4", "c4s2", "tiled"])
 def test_bench_multi_rank_paths_rehearsal(mode):
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), both ranks on this box's one
     GPU over gloo (`DIF_BENCH_REHEARSAL=1`): barrier, max-over-ranks timing, the JSON contract, and — c4 — the all-gather merge of the
@@ -214,17 +214,20 @@ def test_bench_multi_rank_paths_rehearsal(mode):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline",
-           "--mode", mode]
+           "--mode", "tiled" if mode == "tiled" else "c4"] + (["--streams-per-gpu", "2"] if mode == "c4s2" else [])       # c4s2: two streams per rank, batched launches
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     line = [l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3 and d["value"] > 0 and d["higher_is_better"] is True
-    assert d["scaling"] == ("weak" if mode == "c4" else "strong") and "rehearsal" in d
-    if mode == "c4":
+    assert d["scaling"] == ("strong" if mode == "tiled" else "weak") and "rehearsal" in d
+    if mode != "tiled":
         m = d["config"]["global_map_merge_after_the_clock"]
         assert "error" not in m, m
-        assert m["global_voxels"] > m["local_voxels_rank0"] > 0 and m["global_mesh_triangles"] > 0
+        assert m["global_voxels"] > 0 and m["local_voxels_rank0"] > 0 and m["global_mesh_triangles"] > 0
+        assert d["config"]["streams_per_gpu"] == (2 if mode == "c4s2" else 1)
+        if mode == "c4":
+            assert m["global_voxels"] > m["local_voxels_rank0"]
     else:
         h = d["config"]["halo_exchange"]
         assert h["mode"] == "delta" and h["bytes_sent_per_frame"] > 0
