@@ -5,6 +5,9 @@ for f in bench_n1 bench_graph bench_k20 bench_c1 bench_c2 bench_tiled_n1 bench_t
          bench_cloud bench_query pmc_hbm pmc_hbm_k20 pmc_mfma_stream pmc_mfma_k20 bench_batch5 bench_rccl_1rank; do
   [ -s $S/$f.json ] && cp $S/$f.json ${P}_$f.json
 done
+for n in 2 4 8; do for f in bench_s$n pmc_mfma_s$n pmc_mfma_s${n}_k20 pmc_hbm_s$n; do [ -s $S/$f.json ] && cp $S/$f.json ${P}_$f.json; done; done
+for f in kernel_stats_s4.md kernel_stats_s4_steady.md timeline_s4.txt kernel_stats_query.md kernel_stats_cloud.md kernel_stats_frows.md; do [ -s $S/$f ] && cp $S/$f ${P}_$f; done
+[ -s $S/bench_frows.json ] && cp $S/bench_frows.json ${P}_bench_frows.json
 [ -s $S/stress_full.json ] && cp $S/stress_full.json ${P}_stress_full_occupancy.json
 [ -s $S/stress_integrate.json ] && cp $S/stress_integrate.json ${P}_stress_integrate.json
 [ -s $S/sweep_decode.jsonl ] && cp $S/sweep_decode.jsonl ${P}_sweep_decode.jsonl

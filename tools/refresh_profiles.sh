@@ -29,6 +29,30 @@ python tools/pmc_summary.py $(find $O/pmc_fetch -name "*counter_collection.csv" 
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- $B --no-cpu-baseline --no-secondary > $O/pmc_mfma.log 2>&1
 python tools/pmc_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_mfma_stream.json > $O/pmc_mfma_summary.log 2>&1
 rm -rf $O/pmc_mfma $O/pmc_fetch $O/pmc_write
+# ---- S streams per launch (bench.py --streams-per-gpu S): kernel stats, PMC MFMA busy and HBM bytes, 200-step and the driver's K = 20 shape ----
+for S in 2 4 8; do
+  BS="$B --no-cpu-baseline --no-secondary --streams-per-gpu $S"
+  timeout 300 $BS > $O/bench_s$S.json 2> $O/bench_s$S.err
+  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_ms -o m -- $BS > $O/pmc_mfma_s$S.log 2>&1
+  python tools/pmc_mfma.py $(find $O/pmc_ms -name "*counter_collection.csv" | head -1) $O/pmc_mfma_s$S.json > $O/pmc_mfma_s${S}_summary.log 2>&1
+  rm -rf $O/pmc_ms
+  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_ms -o m -- $BS --steps 20 --warmup 5 > $O/pmc_mfma_s${S}_k20.log 2>&1
+  python tools/pmc_mfma.py $(find $O/pmc_ms -name "*counter_collection.csv" | head -1) $O/pmc_mfma_s${S}_k20.json --last 20 > $O/pmc_mfma_s${S}_k20_summary.log 2>&1
+  rm -rf $O/pmc_ms
+done
+for S in 4; do
+  BS="$B --no-cpu-baseline --no-secondary --streams-per-gpu $S"
+  timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_s -o bench -- $BS > $O/trace_s$S.log 2>&1
+  python tools/rocpd_stats.py $(find $O/trace_s -name "*.db" | head -1) --after-nth k_prune_mark 160 --frames 50 > $O/kernel_stats_s${S}_steady.md 2>&1
+  python tools/rocpd_stats.py $(find $O/trace_s -name "*.db" | head -1) --after-nth k_prune_mark 9 --frames 200 > $O/kernel_stats_s$S.md 2>&1
+  python tools/rocpd_stats.py $(find $O/trace_s -name "*.db" | head -1) --timeline k_prune_mark 150 > $O/timeline_s$S.txt 2>&1
+  rm -rf $O/trace_s
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fs -o f -- $BS --steps 40 --warmup 4 > $O/pmc_fetch_s$S.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_ws -o w -- $BS --steps 40 --warmup 4 > $O/pmc_write_s$S.log 2>&1
+  python tools/pmc_summary.py $(find $O/pmc_fs -name "*counter_collection.csv" | head -1) $(find $O/pmc_ws -name "*counter_collection.csv" | head -1) $O/pmc_hbm_s$S.json > $O/pmc_summary_s$S.log 2>&1
+  rm -rf $O/pmc_fs $O/pmc_ws
+done
+bash tools/gpu_frows_prof.sh $(basename $O) > $O/frows.log 2>&1
 # ---- C5: the 1280x960 stream on one GPU, and slab 4 of 8 exchanging halos with itself ----
 timeout 600 $B --mode tiled --no-cpu-baseline --steps 100 > $O/bench_tiled_n1.json 2> $O/bench_tiled_n1.err
 timeout 600 $B --mode tiled --loopback 8 --no-cpu-baseline --steps 100 > $O/bench_tiled_loopback8_delta.json 2> $O/bench_tiled_loopback8_delta.err
