@@ -13,6 +13,9 @@ rm -rf $O/trace
 # ---- the DRIVER's invocation: --steps 20 --warmup 5 (map-building transient) ----
 K20="--steps 20 --warmup 5 --no-cpu-baseline"
 timeout 300 $B $K20 > $O/bench_k20.json 2> $O/bench_k20.err
+# (the rocprofv3 passes of this invocation run WITHOUT the secondary legs — the S-streams-per-GPU rates that follow the timed region since round 4:
+# their streams' first frames launch the same kernels and would land in "the last 20 dispatches"; the timed region itself is identical)
+K20="$K20 --no-secondary"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace20 -o bench -- $B $K20 > $O/trace20.log 2>&1
 python tools/rocpd_stats.py $(find $O/trace20 -name "*.db" | head -1) --after-nth k_prune_mark 9 --frames 20 > $O/kernel_stats_k20.md 2>&1
 rm -rf $O/trace20
