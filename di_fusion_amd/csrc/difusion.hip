@@ -911,8 +911,10 @@ static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int6
     static bool attr_set1[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 64 && !attr_set1[dev]) {
-        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
-        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass_batch<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass_batch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
         attr_set1[dev] = true;
     }
     // two workgroups per CU (54 KB of LDS each at resolution 4); groups of four voxels are claimed through a ticket counter
@@ -1041,7 +1043,9 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (rc != DIF_OK) return rc;
         {
             ProfScope prof(DIF_PROF_MC_COUNT, s);
-            hipLaunchKernelGGL(k_marching_cubes_onepass, dim3(grid1), dim3(DIF_BLOCK), lds_bytes, s, a, buf->mc_status, buf->mc_status + (buf->max_voxels + 3) / 4);
+            // (resolution 4 — main.py:93's — with the resolution as a compile-time constant)
+            if (r == 4) hipLaunchKernelGGL(k_marching_cubes_onepass<4>, dim3(grid1), dim3(DIF_BLOCK), lds_bytes, s, a, buf->mc_status, buf->mc_status + (buf->max_voxels + 3) / 4);
+            else hipLaunchKernelGGL(k_marching_cubes_onepass<0>, dim3(grid1), dim3(DIF_BLOCK), lds_bytes, s, a, buf->mc_status, buf->mc_status + (buf->max_voxels + 3) / 4);
         }
         DIF_CHECK_LAUNCH();
     } else if (fused_scan) {
@@ -1137,7 +1141,8 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
         const int rc = mc_onepass_setup(mc.s[0].a, lds_bytes, grid1, max_voxels);
         if (rc != DIF_OK) return rc;
         ProfScope prof(DIF_PROF_MC_COUNT, s);
-        hipLaunchKernelGGL(k_marching_cubes_onepass_batch, dim3(grid1, S), dim3(DIF_BLOCK), lds_bytes, s, mc);
+        if (e.r == 4) hipLaunchKernelGGL(k_marching_cubes_onepass_batch<4>, dim3(grid1, S), dim3(DIF_BLOCK), lds_bytes, s, mc);
+        else hipLaunchKernelGGL(k_marching_cubes_onepass_batch<0>, dim3(grid1, S), dim3(DIF_BLOCK), lds_bytes, s, mc);
         DIF_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_extract_finish_batch, dim3(grid_for(max_voxels, DIF_BLOCK, 256), S), dim3(DIF_BLOCK), 0, s, fin);
