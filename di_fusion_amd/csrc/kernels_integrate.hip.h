@@ -559,7 +559,10 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
                                           dif_pending_export_t* __restrict__ pending) {
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) {       // the point kernels' extra workgroups have done the copy (kernels ago: complete)
         pending->pending = 0;
-        if (pending->notify) *pending->notify = pending->seq;   // tell the host without an event in the queue (dif_extract_buffers_t.export_notify)
+        if (pending->notify) {              // tell the host without an event in the queue (dif_extract_buffers_t.export_notify)
+            __threadfence_system();         // (the copy's stores left with earlier kernels; nothing of this frame may overtake them on the way out)
+            *pending->notify = pending->seq;
+        }
     }
     const int n_upd = counters[DIF_C_C];
     const int first_new = counters[DIF_C_N_OCCUPIED] - counters[DIF_C_ALLOC_NEW];      // this frame's new slots are already in the halo delta
