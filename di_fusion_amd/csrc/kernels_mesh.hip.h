@@ -59,26 +59,38 @@ __device__ __forceinline__ bool mc_corner(const McArgs& a, const int* nb, int r,
         wm[ax] /= (float)r; wp[ax] /= (float)r;
     }
     const int zero_det = zero[0] * 4 + zero[1] * 2 + zero[2];
-    float ts = 0.0f, tw = 0.0f, tsd = 0.0f, twd = 0.0f;     // total_sdf.x, total_weight.x, total_sdf.y, total_weight.y
+    // All eight (sdf, std) samples are requested before any of them is looked at: sixteen independent loads in flight.  (With the loads inside
+    // the blend loop, each behind the previous sample's "is it NaN / is it the voxel's own" test, they went out one after the other — eight
+    // dependent round trips per corner, 6.4 us of a stream frame's 21 us launch: profiles/r04_experiments.md.)  The blend itself is unchanged:
+    // same terms, same order; a missing own sample still drops the corner, whatever the other seven are.
+    float sv[8], dv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int sx = (k >> 2) & 1, sy = (k >> 1) & 1, sz = k & 1;
         const int ddx = sx ? dp[0] : dm[0], ddy = sy ? dp[1] : dm[1], ddz = sz ? dp[2] : dm[2];
         const int b = nb[(ddx + 1) * 9 + (ddy + 1) * 3 + (ddz + 1)];
-        float s = __builtin_nanf(""), d = 0.0f;
-        if (b >= 0) {
+        sv[k] = __builtin_nanf(""); dv[k] = 0.0f;
+        if (b >= 0) {                            // (predicated on the neighbour table only: nothing here waits for a loaded value)
             const int64_t off = (((int64_t)b * R + (sx ? ip[0] : im[0])) * R + (sy ? ip[1] : im[1])) * R + (sz ? ip[2] : im[2]);
-            s = a.cube_sdf[off];
-            d = a.cube_std[off];
+            sv[k] = a.cube_sdf[off];
+            dv[k] = a.cube_std[off];
         }
+    }
+    float ts = 0.0f, tw = 0.0f, tsd = 0.0f, twd = 0.0f;     // total_sdf.x, total_weight.x, total_sdf.y, total_weight.y
+    bool own_missing = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sx = (k >> 2) & 1, sy = (k >> 1) & 1, sz = k & 1;
+        const float s = sv[k], d = dv[k];
         const float w = (sx ? wp[0] : wm[0]) * (sy ? wp[1] : wm[1]) * (sz ? wp[2] : wm[2]);
         if (s == s) {
             ts += s * w * d; tw += w * d;
             tsd += w * d;    twd += w;
         } else if (zero_det == k) {
-            return false;
+            own_missing = true;
         }
     }
+    if (own_missing) return false;
     sdf = ts / tw;
     sd = tsd / twd;
     return sdf == sdf;
@@ -334,6 +346,7 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
             old_n = a.tri_n[slot]; old_s = a.tri_start[slot];
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
+#if !defined(DIF_MC_CUT) || DIF_MC_CUT >= 2          /* measurement builds (tools/: what the launch costs up to a phase): 1 = neighbour look-ups only */
             bool any_neg = false, any_pos = false;
             for (int c = lane; c < nc; c += 64) {
                 float sv, dv;
@@ -346,8 +359,19 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const bool crossing = __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
+#if !defined(DIF_MC_CUT) || DIF_MC_CUT >= 3          /* 2 = ... + blended corners */
             if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, bx, by, bz, tri_row);
+#else
+            ntri = crossing ? (int)(c_sdf[lane] == -12345.f) : 0;
+#endif
+#else
+            ntri = (nb[lane & 31] == -12345 && old_n + old_s == -7) ? 1 : 0;
+#endif
         }
+#if defined(DIF_MC_CUT) && DIF_MC_CUT <= 3           /* 3 = ... + the cells' triangle counts; the whole workgroup leaves here */
+        if (ntri == 12345) a.tri_count[0] = 1;
+        break;
+#endif
         const int incl = wave_incl_scan(ntri);
         voxel_total = __shfl(incl, 63);
         if (lane == 0) {
@@ -388,6 +412,9 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
             }
         }
         __syncthreads();
+#if defined(DIF_MC_CUT) && DIF_MC_CUT == 4           /* 4 = ... + the look-back: everything but the emit */
+        break;
+#endif
         if (active && voxel_total > 0) {
             int voxel_offset = s_excl;
             for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[w];
