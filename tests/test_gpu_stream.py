@@ -439,3 +439,62 @@ def test_direct_frames_with_and_without_point_arrays(gpu_model):
             nan = lambda x: torch.nan_to_num(x, nan=123.0)
             assert torch.equal(nan(st.xyz), nan(want_xyz)) and torch.equal(nan(st.nrm), nan(want_nrm))
     same(snaps[False], snaps[True])
+
+
+def test_stream_group_argument_checks_and_mesh_left_in_hbm(gpu_model):
+    """The batched entry points refuse what they cannot run (a map twice in one batch, maps of different capacity, a spatially tiled map),
+    and a group with the mesh left in HBM (d2h = "none": no export, no notify) ends in the same maps as the streams alone."""
+    import ctypes
+    from di_fusion_amd import _lib
+    from di_fusion_amd.stream import FusionStream, FusionStreamGroup
+    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
+    intr = S_.Intrinsic().scaled(0.25)
+    mk = lambda j, **kw: FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, 4, deg_per_frame=6.0, phase_deg=45.0 * j, **kw)
+    solo = []
+    for j in range(2):
+        st = mk(j)
+        for i in range(4):
+            st.step(i, d2h="none")
+        torch.cuda.synchronize()
+        solo.append(snapshot(st))
+    streams = [mk(j) for j in range(2)]
+    for st in streams:
+        st.step(0, d2h="none")
+    grp = FusionStreamGroup(streams)
+    for i in range(1, 4):
+        assert grp.step(i, d2h="none") is not None
+    grp.flush("none")
+    for j in range(2):
+        same(solo[j], snapshot(streams[j]))
+    # --- refusals (DIF_EINVAL = -1), straight at the C ABI ---
+    lib = _lib.load()
+    a, b = streams
+    w = a.map.model.packed.weights_struct(DEV)
+    frames = (_lib.DifStreamFrame * 2)()
+    H, W = intr.height, intr.width
+
+    def fill(f, st, cmap=None):
+        sl = st._d_slots[0]
+        f.map = ctypes.pointer(cmap if cmap is not None else st.map._cmap)
+        f.frame_dev = _lib.ptr(sl["frame"])
+        f.xyz_world, f.normal_world = _lib.ptr(None), _lib.ptr(None)
+        f.unq_mask = _lib.ptr(st._d_mask)
+        f.ws, f.ws_bytes = _lib.ptr(st.map._ws), st.map._ws.numel()
+        f.buf = ctypes.pointer(st._d_bufs[0])
+    with torch.cuda.device(DEV):
+        sp = _lib.stream_ptr()
+        fill(frames[0], a); fill(frames[1], a)                                  # the same map twice
+        assert lib.dif_integrate_frames(frames, 2, ctypes.byref(w), H, W, intr.fx, intr.fy, intr.cx, intr.cy, sp) == -1
+        assert lib.dif_integrate_frames(frames, 9, ctypes.byref(w), H, W, intr.fx, intr.fy, intr.cx, intr.cy, sp) == -1      # more than DIF_MAX_STREAMS
+        odd = _lib.DifMap.from_buffer_copy(b.map._cmap)
+        odd.capacity = b.map._cmap.capacity // 2                                # maps of different capacity
+        fill(frames[1], b, odd)
+        assert lib.dif_integrate_frames(frames, 2, ctypes.byref(w), H, W, intr.fx, intr.fy, intr.cx, intr.cy, sp) == -1
+        tiled = _lib.DifMap.from_buffer_copy(b.map._cmap)
+        tiled.own_x_lo, tiled.own_x_hi, tiled.halo = 0, b.map.n_xyz[0] // 2, 3   # a spatially tiled map
+        fill(frames[1], b, tiled)
+        assert lib.dif_integrate_frames(frames, 2, ctypes.byref(w), H, W, intr.fx, intr.fy, intr.cx, intr.cy, sp) == -1
+        assert lib.dif_extract_streams(frames, 2, ctypes.byref(w), 5, 0.15, 1, sp) == -1                                      # resolution > 4
+    with pytest.raises(ValueError):
+        FusionStreamGroup([])
+    torch.cuda.synchronize()
