@@ -370,6 +370,8 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
         }
 #if defined(DIF_MC_CUT) && DIF_MC_CUT <= 3           /* 3 = ... + the cells' triangle counts; the whole workgroup leaves here */
         if (ntri == 12345) a.tri_count[0] = 1;
+        __syncthreads();
+        if (use_ticket) continue;                        // (launches with more groups than workgroups: on to the next ticket)
         break;
 #endif
         const int incl = wave_incl_scan(ntri);
@@ -413,6 +415,8 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
         }
         __syncthreads();
 #if defined(DIF_MC_CUT) && DIF_MC_CUT == 4           /* 4 = ... + the look-back: everything but the emit */
+        __syncthreads();
+        if (use_ticket) continue;
         break;
 #endif
         if (active && voxel_total > 0) {
