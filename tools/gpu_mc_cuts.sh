@@ -1,5 +1,9 @@
 #!/bin/bash
-# phase cuts of the one-pass marching cubes (-DDIF_MC_CUT=1..4 builds in ab_old/): event-timed launch per cut on the stream and the K = 20 run
+# phase cuts of the one-pass marching cubes: event-timed launch per cut on the stream and the K = 20 run (stress: tools/stress_full_occupancy.py with DIF_LIB set the same way).
+# Build the cut libraries HERE first (they travel with the snapshot, ab_old/ is git-ignored):
+#   for c in 1 2 3 4; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DNDEBUG -DDIF_MC_CUT=$c \
+#       -DDIF_BUILD_ID='"cut"' di_fusion_amd/csrc/difusion.hip -o ab_old/libdif_mccut$c.so; done
+# (a cut build's results are garbage by design: 1 = launch + neighbour look-ups, 2 = + blended corners, 3 = + cells, 4 = + look-back, no emit)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in 1 2 3 4 full; do
   if [ $c = full ]; then unset DIF_LIB; else export DIF_LIB=$GRAFT_REPO_ROOT/ab_old/libdif_mccut$c.so; fi
