@@ -29,3 +29,11 @@ def test_fuzz_marching_cubes(seed):
 def test_fuzz_cloud_ops(seed):
     import fuzz_cloud
     fuzz_cloud.run(cases=30, seed=seed)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fuzz_stream_group(seed):
+    """S streams through one chain of launches against the same streams alone: bit-identical maps, meshes and per-frame updates on random
+    configurations (tools/fuzz_group.py)."""
+    import fuzz_group
+    fuzz_group.run(cases=5, seed=seed)
