@@ -70,6 +70,60 @@ def test_two_rank_merge_gloo():
     assert np.all(np.diff(pos0[:nl0]) > 0)
 
 
+class _OracleMapAdapter:
+    """The two methods `parallel.build_global_map` needs, played by the oracle (the product's `DenseIndexedMap` needs a GPU)."""
+
+    def __init__(self, O, om):
+        self.O, self.om = O, om
+
+    def export_records(self):
+        return torch.from_numpy(self.O.export_records(self.om))
+
+    def merge_records(self, rec):
+        self.O.merge_records(self.om, rec.numpy())
+
+
+def _worker_lists(rank, world, port, q):
+    """Two maps per rank (several subsequences per GPU): `build_global_map` with a LIST — one all-gather per list position, fold in
+    (rank, position) order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from di_fusion_amd import parallel
+    maps = []
+    for j in range(2):
+        O, net, cfg, om = _build_rank_map(2 * rank + j)
+        maps.append(_OracleMapAdapter(O, om))
+    g = parallel.build_global_map(maps, lambda: _OracleMapAdapter(O, O.OracleMap(net, cfg.bound_min, cfg.bound_max, cfg.voxel_size))).om
+    n = g.n_occupied
+    q.put((rank, n, g.latent_vecs_pos[:n].copy(), g.voxel_obs_count[:n].copy(), g.latent_vecs[:n].copy(),
+           [m.om.n_occupied for m in maps], float(sum(m.om.voxel_obs_count[:m.om.n_occupied].sum() for m in maps))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_two_maps_per_rank_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_lists, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, pos0, w0, z0, nl0, ws0), (_, n1, pos1, w1, z1, nl1, ws1) = res
+    assert n0 == n1 and np.array_equal(pos0, pos1) and np.array_equal(w0, w1) and np.array_equal(z0, z1)      # identical on both ranks
+    assert abs(w0.sum() - (ws0 + ws1)) < 1e-2                                                                  # every map's weight arrived once
+    # the same fold done here, in (rank, position) order = maps 0, 1, 2, 3
+    O, net, cfg, _ = _build_rank_map(0)
+    g = O.OracleMap(net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    for k in range(4):
+        O.merge_records(g, O.export_records(_build_rank_map(k)[3]))
+    assert g.n_occupied == n0 and np.array_equal(g.latent_vecs_pos[:n0], pos0) and np.array_equal(g.latent_vecs[:n0], z0)
+
+
 def test_merge_equals_weighted_mean():
     """merge(A, B) at a voxel seen by both = (wA*zA + wB*zB) / (wA + wB)."""
     from oracle import difusion_oracle as O
