@@ -917,10 +917,11 @@ static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int6
         if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass_batch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
         attr_set1[dev] = true;
     }
-    // two workgroups per CU (54 KB of LDS each at resolution 4); groups of four voxels are claimed through a ticket counter
+    // as many workgroups as the LDS of a CU holds (five of 29 KB at resolution 4); groups of four voxels are claimed through a ticket counter
     const int64_t need = (max_voxels + 3) / 4;
-    grid1 = 2 * num_cus();
-    if (lds_bytes * 2 > 150 * 1024) grid1 = num_cus();
+    int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
+    per_cu = per_cu < 1 ? 1 : per_cu > 5 ? 5 : per_cu;
+    grid1 = per_cu * num_cus();
     if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
     return DIF_OK;
 }

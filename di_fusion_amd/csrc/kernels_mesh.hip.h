@@ -98,23 +98,56 @@ __device__ __forceinline__ bool mc_corner(const McArgs& a, const int* nb, int r,
 
 struct V4 { float x, y, z, w; };
 
-__device__ __forceinline__ V4 mc_interp(const float* p1, const float* p2, float s1, float s2, float v1, float v2) {   // sdf_interp :187-200
-    if (fabsf(0.0f - v1) < 1.0e-5f) return V4{p1[0], p1[1], p1[2], s1};
-    if (fabsf(0.0f - v2) < 1.0e-5f) return V4{p2[0], p2[1], p2[2], s2};
-    if (fabsf(v1 - v2) < 1.0e-5f) return V4{p1[0], p1[1], p1[2], s1};
+// An edge vertex as the cell keeps it in LDS: the weight of the edge's second end point and the interpolated std (8 bytes instead of 16 —
+// the LDS per wave is what bounds the occupancy of these kernels).  sdf_interp (mc_interp_kernel.cu:187-200) returns p1 * w1 + p2 * w2 with
+// w1 = 1 - w2, or one end point unchanged in its three early-outs: those are w2 = 0 and w2 = 1 of the same expression, exactly
+// (p * 1 + q * 0 = p for the finite, non-negative lattice coordinates), so the position is rebuilt from w2 where a triangle is
+// written (mc_vertex) and comes out bit-identical to interpolating it on the spot.
+struct V2 { float w2, sd; };
+
+__device__ __forceinline__ V2 mc_interp(float s1, float s2, float v1, float v2) {
+    if (fabsf(0.0f - v1) < 1.0e-5f) return V2{0.0f, s1};
+    if (fabsf(0.0f - v2) < 1.0e-5f) return V2{1.0f, s2};
+    if (fabsf(v1 - v2) < 1.0e-5f) return V2{0.0f, s1};
     float w2 = (0.0f - v1) / (v2 - v1);
     float w1 = 1 - w2;
-    return V4{p1[0] * w1 + p2[0] * w2, p1[1] * w1 + p2[1] * w2, p1[2] * w1 + p2[2] * w2, s1 * w1 + s2 * w2};
+    return V2{w2, s1 * w1 + s2 * w2};
+}
+
+// The six lattice coordinates a cell's corners are made of, in voxel units (the corner positions of mc_interp_kernel.cu:236-262: the low and
+// the high one per axis), and the vertex on edge e rebuilt from its weight.  Which of the six an end point takes comes from a table of three
+// bits (dx, dy, dz) per edge and end: the emit loop runs with one wave per SIMD in a stream, where every instruction is latency.
+struct CellBox { float x[2], y[2], z[2]; };
+__device__ __forceinline__ CellBox mc_cell_box(int bx, int by, int bz, int rx, int ry, int rz, float sbs) {
+    return CellBox{{(float)bx + (float)rx * sbs, (float)bx + (float)(rx + 1) * sbs}, {(float)by + (float)ry * sbs, (float)by + (float)(ry + 1) * sbs},
+                   {(float)bz + (float)rz * sbs, (float)bz + (float)(rz + 1) * sbs}};
+}
+constexpr unsigned long long mc_end_bits(bool second) {
+    const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+    unsigned long long t = 0;
+    for (int e = 0; e < 12; ++e) {
+        const int q = second ? eb[e] : ea[e];
+        const unsigned long long dx = (q == 1 || q == 2 || q == 5 || q == 6), dy = (q == 2 || q == 3 || q == 6 || q == 7), dz = (q >= 4);
+        t |= (dx | (dy << 1) | (dz << 2)) << (3 * e);
+    }
+    return t;
+}
+__device__ __forceinline__ V4 mc_vertex(V2 v, int e, const CellBox& c) {
+    constexpr unsigned long long TA = mc_end_bits(false), TB = mc_end_bits(true);
+    const unsigned sa = (unsigned)(TA >> (3 * e)), sb = (unsigned)(TB >> (3 * e));
+    const float w2 = v.w2, w1 = 1 - w2;
+    const float ax = (sa & 1) ? c.x[1] : c.x[0], ay = (sa & 2) ? c.y[1] : c.y[0], az = (sa & 4) ? c.z[1] : c.z[0];
+    const float cx = (sb & 1) ? c.x[1] : c.x[0], cy = (sb & 2) ? c.y[1] : c.y[0], cz = (sb & 4) ? c.z[1] : c.z[0];
+    return V4{ax * w1 + cx * w2, ay * w1 + cy * w2, az * w1 + cz * w2, v.sd};
 }
 
 // One cell of a voxel (lane = cell): reads its 8 blended corners from LDS, writes the cell's edge vertices to vl[edge * 64] and returns
 // the number of triangles that survive max_std (mc_interp_kernel.cu:202-320); tri_row = the packed triangle-table row (~0 if none).
-__device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __restrict__ c_sdf, const float* __restrict__ c_std, V4* __restrict__ vl,
-                                            int r, int cell, int bx, int by, int bz, unsigned long long& tri_row) {
+__device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __restrict__ c_sdf, const float* __restrict__ c_std, V2* __restrict__ vl,
+                                            int r, int cell, unsigned long long& tri_row) {
     const int r1 = r + 1;
-    const float sbs = 1.0f / (float)r;
     const int rx = cell / (r * r), ry = (cell / r) % r, rz = cell % r;
-    float val[8], sdv[8], pts[8][3];
+    float val[8], sdv[8];
     bool dropped = false;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -122,9 +155,6 @@ __device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __rest
         const int ci = ((rx + dx) * r1 + (ry + dy)) * r1 + (rz + dz);
         val[q] = c_sdf[ci]; sdv[q] = c_std[ci];
         dropped |= !(val[q] == val[q]);
-        pts[q][0] = (float)bx + (float)(rx + dx) * sbs;
-        pts[q][1] = (float)by + (float)(ry + dy) * sbs;
-        pts[q][2] = (float)bz + (float)(rz + dz) * sbs;
     }
     tri_row = ~0ull;
     if (dropped) return 0;
@@ -136,11 +166,11 @@ __device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __rest
     const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
 #pragma unroll
     for (int e = 0; e < 12; ++e)
-        if (edge_config & (1 << e)) vl[e * 64] = mc_interp(pts[ea[e]], pts[eb[e]], sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
+        if (edge_config & (1 << e)) vl[e * 64] = mc_interp(sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
     tri_row = c_mc_tri_packed[cube_type];
     int ntri = 0;
     for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
-        const float w0 = vl[(int)(t3 & 0xF) * 64].w, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].w, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].w;
+        const float w0 = vl[(int)(t3 & 0xF) * 64].sd, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].sd, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].sd;
         if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
         ++ntri;
     }
@@ -150,7 +180,7 @@ __device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __rest
 // One wave per dirty voxel.  Phase 1: the (r+1)^3 blended corner values are computed ONCE into LDS (the reference
 // recomputes each corner for up to 8 cells).  Phase 2: lane = cell; EMIT=false counts the triangles that survive
 // max_std, EMIT=true writes them at tri_offset[k] + wave-prefix (canonical order: voxel, cell, table order).
-#define MC_WAVE_LDS_FLOATS(nc) (((2 * (nc) + 32 + 3) & ~3) + 12 * 64 * 4)
+#define MC_WAVE_LDS_FLOATS(nc) (((2 * (nc) + 32 + 3) & ~3) + 12 * 64 * 2)
 
 template <bool EMIT>
 __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
@@ -160,12 +190,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     float* c_sdf = lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc);
     float* c_std = c_sdf + nc;
     int* nb = reinterpret_cast<int*>(c_std + nc);            // 27 (+pad to 32)
-    // edge vertices of the lane's cell, [edge][lane] x (x,y,z,std): indexed by the triangle table at run time, so they live in
+    // edge vertices of the lane's cell, [edge][lane] x (weight, std): indexed by the triangle table at run time, so they live in
     // LDS — as a per-lane array they were spilled to scratch memory (13 KB of scratch traffic per voxel).  Measured alternatives
-    // on 2.1 M voxels (count + emit ms): scratch array 9.4 + 18.2, this 11.3 + 14.2, vertices recomputed per triangle 11.9 + 19.2,
-    // LDS-staged neighbour samples instead of gathers 14.2 + 16.7.  PMC (profiles/r01_pmc_sq_stress.json): the waves sit parked on
-    // memory 54-67 % of their cycles at ~3 waves per SIMD — latency-bound; these 12 KB per wave are what caps the occupancy.
-    V4* vl = reinterpret_cast<V4*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
+    // on 2.1 M voxels (count + emit ms): scratch array 9.4 + 18.2, (x,y,z,std) in LDS 11.3 + 14.2, vertices recomputed per triangle
+    // 11.9 + 19.2, LDS-staged neighbour samples instead of gathers 14.2 + 16.7.  PMC (profiles/r01_pmc_sq_stress.json): the waves sit
+    // parked on memory 54-67 % of their cycles at ~3 waves per SIMD — latency-bound, and the LDS per wave is what caps the occupancy:
+    // 6 KB per wave as (weight, std) since round 4 (struct V2), 12 KB before.
+    V2* vl = reinterpret_cast<V2*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
     const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
     if (!EMIT && a.log_counters && blockIdx.x == 0 && threadIdx.x == 0) a.log_counters[DIF_C_CACHE_KEPT] = a.log_counters[DIF_C_CACHE_T];
     if (!EMIT && a.grid_tot && blockIdx.x == 0)
@@ -239,17 +270,19 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
         for (int s0 = 0; crossing && s0 < r3; s0 += 64) {
             const int s = s0 + lane;
             unsigned long long tri_row = ~0ull;
-            const int ntri = (s < r3) ? mc_eval_cell(a, c_sdf, c_std, vl, r, s, bx, by, bz, tri_row) : 0;
+            const int ntri = (s < r3) ? mc_eval_cell(a, c_sdf, c_std, vl, r, s, tri_row) : 0;
             const int incl = wave_incl_scan(ntri);
             const int chunk_total = __shfl(incl, 63);
             if (EMIT && ntri > 0) {
                 int64_t tl = (int64_t)voxel_offset + voxel_total + (incl - ntri);         // index among this call's triangles
                 int64_t t = tl + (a.base_ptr ? (int64_t)(*a.base_ptr) : 0);
+                const CellBox box = mc_cell_box(bx, by, bz, s / (r * r), (s / r) % r, s % r, 1.0f / (float)r);
                 for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
-                    V4 v0 = vl[(int)(t3 & 0xF) * 64], v1 = vl[(int)((t3 >> 4) & 0xF) * 64], v2 = vl[(int)((t3 >> 8) & 0xF) * 64];
-                    if (v0.w > a.max_std || v1.w > a.max_std || v2.w > a.max_std) continue;
+                    const int e0 = (int)(t3 & 0xF), e1 = (int)((t3 >> 4) & 0xF), e2 = (int)((t3 >> 8) & 0xF);
+                    const V2 v0 = vl[e0 * 64], v1 = vl[e1 * 64], v2 = vl[e2 * 64];
+                    if (v0.sd > a.max_std || v1.sd > a.max_std || v2.sd > a.max_std) continue;
                     if (tl < a.new_limit && t < a.max_triangles) {
-                        V4 vv[3] = {v0, v1, v2};
+                        V4 vv[3] = {mc_vertex(v0, e0, box), mc_vertex(v1, e1, box), mc_vertex(v2, e2, box)};
 #pragma unroll
                         for (int vi = 0; vi < 3; ++vi) {
                             float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
@@ -299,11 +332,11 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
     __shared__ int s_cnt[DIF_BLOCK / 64];
     __shared__ int s_excl;
     const int r = RC ? RC : a.R / 2, r1 = r + 1, nc = r1 * r1 * r1, r3 = r * r * r;
-    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform, and the compiler is told so)
     float* c_sdf = lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc);
     float* c_std = c_sdf + nc;
     int* nb = reinterpret_cast<int*>(c_std + nc);
-    V4* vl = reinterpret_cast<V4*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
+    V2* vl = reinterpret_cast<V2*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
     const int K = *a.K_ptr;
     const int n_groups = (K + 3) >> 2;
     const int64_t log_n = a.log_counters[DIF_C_CACHE_T];                 // log length before this call (k_extract_finish advances it)
@@ -334,7 +367,7 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
         unsigned long long tri_row = ~0ull;
         int64_t vb = 0;
         int bx = 0, by = 0, bz = 0;
-        int64_t slot = 0;
+        int slot = 0;                                    // (< capacity < 2^31)
         int old_n = 0, old_s = 0;
         if (active) {
             vb = a.valid_blocks[k];
@@ -342,7 +375,7 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
             if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
             // the voxel's previous triangle batch (needed only by the emit phase, two dependent look-ups): requested here, beside the
             // neighbour look-ups, instead of behind the look-back
-            slot = a.indexer[vb];
+            slot = (int)a.indexer[vb];
             old_n = a.tri_n[slot]; old_s = a.tri_start[slot];
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -360,7 +393,7 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const bool crossing = __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
 #if !defined(DIF_MC_CUT) || DIF_MC_CUT >= 3          /* 2 = ... + blended corners */
-            if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, bx, by, bz, tri_row);
+            if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, tri_row);
 #else
             ntri = crossing ? (int)(c_sdf[lane] == -12345.f) : 0;
 #endif
@@ -433,33 +466,35 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
                 if (old_n) atomicAdd(a.log_counters + DIF_C_CACHE_DEAD, old_n);
             }
             if (ntri > 0) {
-                int64_t tl = (int64_t)voxel_offset + (incl - ntri);                     // index among this call's triangles
-                int64_t t = tl + log_n;
+                unsigned tl = (unsigned)(voxel_offset + (incl - ntri));                 // index among this call's triangles (< 2^30: the look-back word)
+                unsigned t = tl + (unsigned)log_n;                                      // index in the log (log_n < cache_capacity < 2^31)
+                const CellBox box = mc_cell_box(bx, by, bz, lane / (r * r), (lane / r) % r, lane % r, 1.0f / (float)r);
                 for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
-                    const V4 v0 = vl[(int)(t3 & 0xF) * 64], v1 = vl[(int)((t3 >> 4) & 0xF) * 64], v2 = vl[(int)((t3 >> 8) & 0xF) * 64];
-                    if (v0.w > a.max_std || v1.w > a.max_std || v2.w > a.max_std) continue;
-                    if (tl < a.new_limit && t < a.max_triangles) {
-                        const V4 vv[3] = {v0, v1, v2};
+                    const int e0 = (int)(t3 & 0xF), e1 = (int)((t3 >> 4) & 0xF), e2 = (int)((t3 >> 8) & 0xF);
+                    const V2 v0 = vl[e0 * 64], v1 = vl[e1 * 64], v2 = vl[e2 * 64];
+                    if (v0.sd > a.max_std || v1.sd > a.max_std || v2.sd > a.max_std) continue;
+                    if ((int64_t)tl < a.new_limit && (int64_t)t < a.max_triangles) {
+                        const V4 vv[3] = {mc_vertex(v0, e0, box), mc_vertex(v1, e1, box), mc_vertex(v2, e2, box)};
 #pragma unroll
                         for (int vi = 0; vi < 3; ++vi) {
                             float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
                             if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }   // map.py:698
-                            a.triangles[(t * 3 + vi) * 3 + 0] = x;
-                            a.triangles[(t * 3 + vi) * 3 + 1] = y;
-                            a.triangles[(t * 3 + vi) * 3 + 2] = z;
-                            a.tri_std[t * 3 + vi] = vv[vi].w;
+                            a.triangles[((int64_t)t * 3 + vi) * 3 + 0] = x;
+                            a.triangles[((int64_t)t * 3 + vi) * 3 + 1] = y;
+                            a.triangles[((int64_t)t * 3 + vi) * 3 + 2] = z;
+                            a.tri_std[(int64_t)t * 3 + vi] = vv[vi].w;
                         }
                         a.tri_id[t] = vb;
                         a.tri_alive[t] = 1;
-                        if (a.out_tri && tl < a.out_capacity) {
+                        if (a.out_tri && (int64_t)tl < a.out_capacity) {
 #pragma unroll
                             for (int vi = 0; vi < 3; ++vi) {
                                 float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
                                 if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }
-                                a.out_tri[(tl * 3 + vi) * 3 + 0] = x;
-                                a.out_tri[(tl * 3 + vi) * 3 + 1] = y;
-                                a.out_tri[(tl * 3 + vi) * 3 + 2] = z;
-                                a.out_std[tl * 3 + vi] = vv[vi].w;
+                                a.out_tri[((int64_t)tl * 3 + vi) * 3 + 0] = x;
+                                a.out_tri[((int64_t)tl * 3 + vi) * 3 + 1] = y;
+                                a.out_tri[((int64_t)tl * 3 + vi) * 3 + 2] = z;
+                                a.out_std[(int64_t)tl * 3 + vi] = vv[vi].w;
                             }
                             a.out_id[tl] = vb;
                         }
@@ -473,14 +508,14 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
 }
 
 template <int RC>
-__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
+__global__ void __launch_bounds__(DIF_BLOCK, RC == 4 ? 5 : 4) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
     mc_onepass_body<RC>(a, status, ticket);
 }
 // S maps in one launch: blockIdx.y = map, each with its own look-back words and ticket (a group only ever waits for groups of ITS map that a
 // running or finished workgroup has claimed, exactly as in the single launch)
 struct McStream { McArgs a; unsigned* status; unsigned* ticket; };
 template <int RC>
-__global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes_onepass_batch(Batch<McStream> b) {
+__global__ void __launch_bounds__(DIF_BLOCK, RC == 4 ? 5 : 4) k_marching_cubes_onepass_batch(Batch<McStream> b) {
     const McStream& m = b.s[blockIdx.y];
     mc_onepass_body<RC>(m.a, m.status, m.ticket);
 }

@@ -3,6 +3,7 @@
 # Build the cut libraries HERE first (they travel with the snapshot, ab_old/ is git-ignored):
 #   for c in 1 2 3 4; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DNDEBUG -DDIF_MC_CUT=$c \
 #       -DDIF_BUILD_ID='"cut"' di_fusion_amd/csrc/difusion.hip -o ab_old/libdif_mccut$c.so; done
+# (tools/gpu_mc_cuts_stress.sh: the same cuts on the full-occupancy stress)
 # (a cut build's results are garbage by design: 1 = launch + neighbour look-ups, 2 = + blended corners, 3 = + cells, 4 = + look-back, no emit)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in 1 2 3 4 full; do
