@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=128)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--max-triangles", type=int, default=int(6e7))
+    ap.add_argument("--max-triangles", type=int, default=int(1.1e8))     # above the ~101 M the 128^3 run produces: every triangle is written
     a = ap.parse_args()
     from di_fusion_amd import _lib, synthetic as syn
     from di_fusion_amd.network import utility as net_util
