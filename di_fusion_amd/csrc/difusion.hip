@@ -1,3 +1,4 @@
+#include <cstdlib>
 // libdifusion — MI355X (gfx950) kernels + C ABI for DI-Fusion's per-frame fusion path.  See include/difusion.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC difusion.hip -o libdifusion.so
 //
@@ -905,9 +906,10 @@ static int voxel_decode_attributes() {
 }
 
 static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int64_t max_voxels) {
-    int blocks;
-    const int rc = mc_setup(a, lds_bytes, blocks, max_voxels);
-    if (rc != DIF_OK) return rc;
+    if (upload_tables() != DIF_OK) return DIF_ELAUNCH;
+    const int r = a.R / 2, nc = (r + 1) * (r + 1) * (r + 1);
+    lds_bytes = (size_t)(DIF_BLOCK / 64) * MC_ONEPASS_WAVE_LDS_FLOATS(nc) * sizeof(float);
+    if (lds_bytes > 128 * 1024) return DIF_EINVAL;
     static bool attr_set1[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 64 && !attr_set1[dev]) {
@@ -917,12 +919,15 @@ static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int6
         if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass_batch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
         attr_set1[dev] = true;
     }
-    // as many workgroups as the LDS of a CU holds (five of 29 KB at resolution 4); groups of four voxels are claimed through a ticket counter
+    // as many workgroups as a CU holds (five at resolution 4: 25 KB of LDS and 96 registers each); groups of four voxels are claimed through a ticket counter
     const int64_t need = (max_voxels + 3) / 4;
-    int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
+    int per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
     per_cu = per_cu < 1 ? 1 : per_cu > 5 ? 5 : per_cu;
     grid1 = per_cu * num_cus();
     if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
+    // test hook: DIF_MC_GRID=n caps the grid, so that a small map runs in ticket mode (more groups than workgroups) — the path that otherwise
+    // only a map with more than ~5,000 dirty voxels takes (tests/test_gpu_mesh_anchor.py)
+    if (const char* e = getenv("DIF_MC_GRID")) { const int n = atoi(e); if (n > 0 && n < grid1) grid1 = n; }
     return DIF_OK;
 }
 

@@ -98,11 +98,12 @@ __device__ __forceinline__ bool mc_corner(const McArgs& a, const int* nb, int r,
 
 struct V4 { float x, y, z, w; };
 
-// An edge vertex as the cell keeps it in LDS: the weight of the edge's second end point and the interpolated std (8 bytes instead of 16 —
-// the LDS per wave is what bounds the occupancy of these kernels).  sdf_interp (mc_interp_kernel.cu:187-200) returns p1 * w1 + p2 * w2 with
-// w1 = 1 - w2, or one end point unchanged in its three early-outs: those are w2 = 0 and w2 = 1 of the same expression, exactly
-// (p * 1 + q * 0 = p for the finite, non-negative lattice coordinates), so the position is rebuilt from w2 where a triangle is
-// written (mc_vertex) and comes out bit-identical to interpolating it on the spot.
+// An edge vertex as the cell keeps it in LDS: the weight of the edge's second end point, 4 bytes (16 as (x, y, z, std) until round 4 — the
+// LDS per wave is what bounds the occupancy of these kernels).  sdf_interp (mc_interp_kernel.cu:187-200) returns p1 * w1 + p2 * w2 and
+// s1 * w1 + s2 * w2 with w1 = 1 - w2, or one end point unchanged in its three early-outs: those are w2 = 0 and w2 = 1 of the same
+// expressions, exactly (p * 1 + q * 0 = p for the finite, non-negative lattice coordinates and stds), so position and std are rebuilt
+// from w2 where a triangle is written (mc_vertex) and come out bit-identical to interpolating them on the spot.  What the count needs of
+// the std — is it above max_std? — is one bit per edge, kept in a register (mc_eval_cell's `ok`).
 struct V2 { float w2, sd; };
 
 __device__ __forceinline__ V2 mc_interp(float s1, float s2, float v1, float v2) {
@@ -115,12 +116,14 @@ __device__ __forceinline__ V2 mc_interp(float s1, float s2, float v1, float v2) 
 }
 
 // The six lattice coordinates a cell's corners are made of, in voxel units (the corner positions of mc_interp_kernel.cu:236-262: the low and
-// the high one per axis), and the vertex on edge e rebuilt from its weight.  Which of the six an end point takes comes from a table of three
-// bits (dx, dy, dz) per edge and end: the emit loop runs with one wave per SIMD in a stream, where every instruction is latency.
-struct CellBox { float x[2], y[2], z[2]; };
-__device__ __forceinline__ CellBox mc_cell_box(int bx, int by, int bz, int rx, int ry, int rz, float sbs) {
+// the high one per axis), the cell's first corner in the (r+1)^3 corner arrays, and the vertex on edge e rebuilt from its weight.  Which
+// corner an end point is comes from a table of three bits (dx, dy, dz) per edge and end: the emit loop runs with one wave per SIMD in a
+// stream, where every instruction is latency.
+struct CellBox { float x[2], y[2], z[2]; int c0, r1; };
+__device__ __forceinline__ CellBox mc_cell_box(int bx, int by, int bz, int rx, int ry, int rz, int r) {
+    const float sbs = 1.0f / (float)r;
     return CellBox{{(float)bx + (float)rx * sbs, (float)bx + (float)(rx + 1) * sbs}, {(float)by + (float)ry * sbs, (float)by + (float)(ry + 1) * sbs},
-                   {(float)bz + (float)rz * sbs, (float)bz + (float)(rz + 1) * sbs}};
+                   {(float)bz + (float)rz * sbs, (float)bz + (float)(rz + 1) * sbs}, (rx * (r + 1) + ry) * (r + 1) + rz, r + 1};
 }
 constexpr unsigned long long mc_end_bits(bool second) {
     const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
@@ -132,19 +135,26 @@ constexpr unsigned long long mc_end_bits(bool second) {
     }
     return t;
 }
-__device__ __forceinline__ V4 mc_vertex(V2 v, int e, const CellBox& c) {
+__device__ __forceinline__ V4 mc_vertex(float w2, int e, const CellBox& c, const float* __restrict__ c_std) {
     constexpr unsigned long long TA = mc_end_bits(false), TB = mc_end_bits(true);
     const unsigned sa = (unsigned)(TA >> (3 * e)), sb = (unsigned)(TB >> (3 * e));
-    const float w2 = v.w2, w1 = 1 - w2;
+    const float w1 = 1 - w2;
     const float ax = (sa & 1) ? c.x[1] : c.x[0], ay = (sa & 2) ? c.y[1] : c.y[0], az = (sa & 4) ? c.z[1] : c.z[0];
     const float cx = (sb & 1) ? c.x[1] : c.x[0], cy = (sb & 2) ? c.y[1] : c.y[0], cz = (sb & 4) ? c.z[1] : c.z[0];
-    return V4{ax * w1 + cx * w2, ay * w1 + cy * w2, az * w1 + cz * w2, v.sd};
+    const float s1 = c_std[c.c0 + ((sa & 1) ? c.r1 * c.r1 : 0) + ((sa & 2) ? c.r1 : 0) + ((sa >> 2) & 1)];
+    const float s2 = c_std[c.c0 + ((sb & 1) ? c.r1 * c.r1 : 0) + ((sb & 2) ? c.r1 : 0) + ((sb >> 2) & 1)];
+    return V4{ax * w1 + cx * w2, ay * w1 + cy * w2, az * w1 + cz * w2, s1 * w1 + s2 * w2};
+}
+// does triangle (e0, e1, e2) pass max_std (mc_interp_kernel.cu:304: dropped when any of its three stds is above)?  ok = one bit per edge
+__device__ __forceinline__ bool mc_tri_ok(unsigned ok, unsigned long long t3) {
+    return (((ok >> (unsigned)(t3 & 0xF)) & (ok >> (unsigned)((t3 >> 4) & 0xF)) & (ok >> (unsigned)((t3 >> 8) & 0xF))) & 1u) != 0u;
 }
 
-// One cell of a voxel (lane = cell): reads its 8 blended corners from LDS, writes the cell's edge vertices to vl[edge * 64] and returns
-// the number of triangles that survive max_std (mc_interp_kernel.cu:202-320); tri_row = the packed triangle-table row (~0 if none).
-__device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __restrict__ c_sdf, const float* __restrict__ c_std, V2* __restrict__ vl,
-                                            int r, int cell, unsigned long long& tri_row) {
+// One cell of a voxel (lane = cell): reads its 8 blended corners from LDS, writes the weights of the cell's edge vertices to vl[edge * 64],
+// returns the number of triangles that survive max_std (mc_interp_kernel.cu:202-320); tri_row = the packed triangle-table row (~0 if none),
+// ok = per edge: its interpolated std is not above max_std.
+__device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __restrict__ c_sdf, const float* __restrict__ c_std, float* __restrict__ vl,
+                                            int r, int cell, unsigned long long& tri_row, unsigned& ok) {
     const int r1 = r + 1;
     const int rx = cell / (r * r), ry = (cell / r) % r, rz = cell % r;
     float val[8], sdv[8];
@@ -157,6 +167,7 @@ __device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __rest
         dropped |= !(val[q] == val[q]);
     }
     tri_row = ~0ull;
+    ok = 0u;
     if (dropped) return 0;
     int cube_type = 0;
 #pragma unroll
@@ -166,21 +177,21 @@ __device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __rest
     const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
 #pragma unroll
     for (int e = 0; e < 12; ++e)
-        if (edge_config & (1 << e)) vl[e * 64] = mc_interp(sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
+        if (edge_config & (1 << e)) {
+            const V2 v = mc_interp(sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
+            vl[e * 64] = v.w2;
+            ok |= (v.sd > a.max_std) ? 0u : (1u << e);
+        }
     tri_row = c_mc_tri_packed[cube_type];
     int ntri = 0;
-    for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
-        const float w0 = vl[(int)(t3 & 0xF) * 64].sd, w1 = vl[(int)((t3 >> 4) & 0xF) * 64].sd, w2 = vl[(int)((t3 >> 8) & 0xF) * 64].sd;
-        if (w0 > a.max_std || w1 > a.max_std || w2 > a.max_std) continue;     // :304
-        ++ntri;
-    }
+    for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) ntri += mc_tri_ok(ok, t3) ? 1 : 0;     // :304
     return ntri;
 }
 
 // One wave per dirty voxel.  Phase 1: the (r+1)^3 blended corner values are computed ONCE into LDS (the reference
 // recomputes each corner for up to 8 cells).  Phase 2: lane = cell; EMIT=false counts the triangles that survive
 // max_std, EMIT=true writes them at tri_offset[k] + wave-prefix (canonical order: voxel, cell, table order).
-#define MC_WAVE_LDS_FLOATS(nc) (((2 * (nc) + 32 + 3) & ~3) + 12 * 64 * 2)
+#define MC_WAVE_LDS_FLOATS(nc) (((2 * (nc) + 32 + 3) & ~3) + 12 * 64)
 
 template <bool EMIT>
 __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
@@ -190,13 +201,13 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
     float* c_sdf = lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc);
     float* c_std = c_sdf + nc;
     int* nb = reinterpret_cast<int*>(c_std + nc);            // 27 (+pad to 32)
-    // edge vertices of the lane's cell, [edge][lane] x (weight, std): indexed by the triangle table at run time, so they live in
+    // edge vertices of the lane's cell, [edge][lane] weights: indexed by the triangle table at run time, so they live in
     // LDS — as a per-lane array they were spilled to scratch memory (13 KB of scratch traffic per voxel).  Measured alternatives
     // on 2.1 M voxels (count + emit ms): scratch array 9.4 + 18.2, (x,y,z,std) in LDS 11.3 + 14.2, vertices recomputed per triangle
     // 11.9 + 19.2, LDS-staged neighbour samples instead of gathers 14.2 + 16.7.  PMC (profiles/r01_pmc_sq_stress.json): the waves sit
     // parked on memory 54-67 % of their cycles at ~3 waves per SIMD — latency-bound, and the LDS per wave is what caps the occupancy:
-    // 6 KB per wave as (weight, std) since round 4 (struct V2), 12 KB before.
-    V2* vl = reinterpret_cast<V2*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
+    // 3 KB per wave as weights since round 4 (mc_interp / mc_vertex), 12 KB before.
+    float* vl = lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3) + lane;
     const int64_t K = a.K_ptr ? (int64_t)(*a.K_ptr) : a.K_static;
     if (!EMIT && a.log_counters && blockIdx.x == 0 && threadIdx.x == 0) a.log_counters[DIF_C_CACHE_KEPT] = a.log_counters[DIF_C_CACHE_T];
     if (!EMIT && a.grid_tot && blockIdx.x == 0)
@@ -270,19 +281,19 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
         for (int s0 = 0; crossing && s0 < r3; s0 += 64) {
             const int s = s0 + lane;
             unsigned long long tri_row = ~0ull;
-            const int ntri = (s < r3) ? mc_eval_cell(a, c_sdf, c_std, vl, r, s, tri_row) : 0;
+            unsigned ok = 0u;
+            const int ntri = (s < r3) ? mc_eval_cell(a, c_sdf, c_std, vl, r, s, tri_row, ok) : 0;
             const int incl = wave_incl_scan(ntri);
             const int chunk_total = __shfl(incl, 63);
             if (EMIT && ntri > 0) {
                 int64_t tl = (int64_t)voxel_offset + voxel_total + (incl - ntri);         // index among this call's triangles
                 int64_t t = tl + (a.base_ptr ? (int64_t)(*a.base_ptr) : 0);
-                const CellBox box = mc_cell_box(bx, by, bz, s / (r * r), (s / r) % r, s % r, 1.0f / (float)r);
+                const CellBox box = mc_cell_box(bx, by, bz, s / (r * r), (s / r) % r, s % r, r);
                 for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
                     const int e0 = (int)(t3 & 0xF), e1 = (int)((t3 >> 4) & 0xF), e2 = (int)((t3 >> 8) & 0xF);
-                    const V2 v0 = vl[e0 * 64], v1 = vl[e1 * 64], v2 = vl[e2 * 64];
-                    if (v0.sd > a.max_std || v1.sd > a.max_std || v2.sd > a.max_std) continue;
+                    if (!mc_tri_ok(ok, t3)) continue;
                     if (tl < a.new_limit && t < a.max_triangles) {
-                        V4 vv[3] = {mc_vertex(v0, e0, box), mc_vertex(v1, e1, box), mc_vertex(v2, e2, box)};
+                        V4 vv[3] = {mc_vertex(vl[e0 * 64], e0, box, c_std), mc_vertex(vl[e1 * 64], e1, box, c_std), mc_vertex(vl[e2 * 64], e2, box, c_std)};
 #pragma unroll
                         for (int vi = 0; vi < 3; ++vi) {
                             float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
@@ -312,31 +323,320 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 // count -> offsets -> emit inside ONE launch: after its cells are counted a wave still holds everything the emit needs (edge
 // vertices in LDS, the case row and the per-cell count in registers), so the second pass's reload + recomputation and one kernel
 // boundary go away.  What the waves need from each other is the canonical output offset = number of triangles of all earlier dirty
-// voxels: a decoupled look-back over groups of 4 voxels (one workgroup per group and iteration).  status[g] packs a 2-bit state and
+// voxels: a decoupled look-back over groups of 4 voxels (one workgroup per group).  status[g] packs a 2-bit state and
 // a 30-bit value in one word, so there is no payload to order against the flag; it is published and polled with device-scope atomic
-// read-modify-writes only (the same coherence every other counter in this library relies on).  Groups are claimed through a ticket
-// counter in index order, so a group only ever waits for groups that some running (or finished) workgroup has already claimed —
-// no assumption about how many workgroups of the grid are resident, or about what else shares the GPU.
+// read-modify-writes only (the same coherence every other counter in this library relies on).
+// Which group a workgroup takes: with at most one group per workgroup (a stream frame: ~190 groups) simply its own index — workgroups
+// are dispatched in index order, so every predecessor is running or done (mc_onepass_direct).  Otherwise groups are handed out by a
+// ticket counter, lowest first (mc_onepass_ring): whatever the residency of the grid, a group's predecessors have all been claimed by
+// workgroups that are running (or done), and no look-back can wait for work nobody has started — no assumption about how many
+// workgroups of the grid are resident, or about what else shares the GPU.
 // A poll that does not succeed within MC_SPIN_LIMIT rounds gives up with DIF_C_OVERFLOW = 7 instead of hanging the queue.
 #define MC_ST_AGG 0x40000000u
 #define MC_ST_PREFIX 0x80000000u
 #define MC_ST_VALUE 0x3FFFFFFFu
 #define MC_SPIN_LIMIT (1 << 22)
+// LDS of a wave: MC_RING sets of blended corners (ticket mode: groups that are counted and wait for their prefix; the direct mode uses the
+// first), the 27 neighbour batches, the edge vertices of the cells being evaluated
+#ifndef MC_RING
+#define MC_RING 3
+#endif
+#ifndef MC_WAVES_PER_SIMD
+#define MC_WAVES_PER_SIMD 5
+#endif
+#define MC_CORNER_FLOATS(nc) ((2 * (nc) + 3) & ~3)
+#define MC_ONEPASS_WAVE_LDS_FLOATS(nc) (MC_RING * MC_CORNER_FLOATS(nc) + 32 + 12 * 64)
+
+struct McVoxel {                 // what a wave knows about its voxel (wave-uniform)
+    int64_t vb; int bx, by, bz;  // linear id and coordinates
+    int slot, old_n, old_s;      // map slot, the voxel's previous triangle batch in the log
+};
+
+__device__ __forceinline__ void mc_voxel_coords(const McArgs& a, McVoxel& v) {
+    v.bx = (int)((v.vb / ((int64_t)a.ny * a.nz)) % a.nx); v.by = (int)((v.vb / a.nz) % a.ny); v.bz = (int)(v.vb % a.nz);
+}
+
+// Dirty voxel k of the call: look-ups, the (r+1)^3 blended corners into c_sdf / c_std; returns whether the corners have both signs.
+template <int RC>
+__device__ __forceinline__ bool mc_load_voxel(const McArgs& a, int k, int lane, int r, float* __restrict__ c_sdf, float* __restrict__ c_std,
+                                              int* __restrict__ nb, McVoxel& v) {
+    const int r1 = r + 1, nc = r1 * r1 * r1;
+    v.vb = a.valid_blocks[k];
+    mc_voxel_coords(a, v);
+    if (lane < 27) nb[lane] = mc_batch_of(a, v.bx + lane / 9 - 1, v.by + (lane / 3) % 3 - 1, v.bz + lane % 3 - 1);
+    // the voxel's previous triangle batch (needed only by the emit, two dependent look-ups): requested here, beside the neighbour look-ups
+    v.slot = (int)a.indexer[v.vb];
+    v.old_n = a.tri_n[v.slot]; v.old_s = a.tri_start[v.slot];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    bool any_neg = false, any_pos = false;
+    for (int c = lane; c < nc; c += 64) {
+        float sv, dv;
+        const bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, sv, dv);
+        c_sdf[c] = ok ? sv : __builtin_nanf("");
+        c_std[c] = ok ? dv : 0.0f;
+        any_neg |= ok && sv < 0.0f;
+        any_pos |= ok && !(sv < 0.0f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    return __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
+}
+
+// The voxel's triangles written at `voxel_offset` among this call's triangles (lane = cell: ntri of them, `incl` = inclusive wave scan of ntri,
+// edge vertices in vl), the mesh-cache log's bookkeeping for the voxel (map.py:708-709: its previous batch dies, it points at the new one).
+__device__ __forceinline__ void mc_emit_voxel(const McArgs& a, int lane, int r, const McVoxel& v, int voxel_total, int voxel_offset, int ntri, int incl,
+                                              unsigned long long tri_row, unsigned ok, const float* __restrict__ vl, const float* __restrict__ c_std, int64_t log_n) {
+    for (int j = lane; j < v.old_n; j += 64) a.tri_alive[v.old_s + j] = 0;
+    int64_t n_new = voxel_total;
+    if (voxel_offset + n_new > a.new_limit) n_new = a.new_limit > voxel_offset ? a.new_limit - voxel_offset : 0;      // truncated by max_n_triangles
+    if (log_n + voxel_offset + n_new > a.max_triangles) n_new = a.max_triangles > log_n + voxel_offset ? a.max_triangles - (log_n + voxel_offset) : 0;
+    if (lane == 0) {
+        a.tri_start[v.slot] = (int)(log_n + voxel_offset);
+        a.tri_n[v.slot] = (int)n_new;
+        if (v.old_n) atomicAdd(a.log_counters + DIF_C_CACHE_DEAD, v.old_n);
+    }
+    if (ntri <= 0) return;
+    unsigned tl = (unsigned)(voxel_offset + (incl - ntri));                 // index among this call's triangles (< 2^30: the look-back word)
+    unsigned t = tl + (unsigned)log_n;                                      // index in the log (log_n < cache_capacity < 2^31)
+    const CellBox box = mc_cell_box(v.bx, v.by, v.bz, lane / (r * r), (lane / r) % r, lane % r, r);
+    for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
+        const int e0 = (int)(t3 & 0xF), e1 = (int)((t3 >> 4) & 0xF), e2 = (int)((t3 >> 8) & 0xF);
+        if (!mc_tri_ok(ok, t3)) continue;
+        if ((int64_t)tl < a.new_limit && (int64_t)t < a.max_triangles) {
+            const V4 vv[3] = {mc_vertex(vl[e0 * 64], e0, box, c_std), mc_vertex(vl[e1 * 64], e1, box, c_std), mc_vertex(vl[e2 * 64], e2, box, c_std)};
+#pragma unroll
+            for (int vi = 0; vi < 3; ++vi) {
+                float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
+                if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }   // map.py:698
+                a.triangles[((int64_t)t * 3 + vi) * 3 + 0] = x;
+                a.triangles[((int64_t)t * 3 + vi) * 3 + 1] = y;
+                a.triangles[((int64_t)t * 3 + vi) * 3 + 2] = z;
+                a.tri_std[(int64_t)t * 3 + vi] = vv[vi].w;
+            }
+            a.tri_id[t] = v.vb;
+            a.tri_alive[t] = 1;
+            if (a.out_tri && (int64_t)tl < a.out_capacity) {
+#pragma unroll
+                for (int vi = 0; vi < 3; ++vi) {
+                    float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
+                    if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }
+                    a.out_tri[((int64_t)tl * 3 + vi) * 3 + 0] = x;
+                    a.out_tri[((int64_t)tl * 3 + vi) * 3 + 1] = y;
+                    a.out_tri[((int64_t)tl * 3 + vi) * 3 + 2] = z;
+                    a.out_std[(int64_t)tl * 3 + vi] = vv[vi].w;
+                }
+                a.out_id[tl] = v.vb;
+            }
+        }
+        ++t; ++tl;
+    }
+}
+
+// One window of the look-back: the 64 groups idx, idx-1, ... (lane = distance).  Returns 1 when the window held a group that knows its
+// inclusive prefix (sum = everything from idx down to it), 0 when it held none (sum = all 64 counts: go on at idx - 64), -1 when a group
+// that is needed has not published anything yet and `block` is false (nothing consumed: ask again later).
+__device__ __forceinline__ int mc_lookback_window(const McArgs& a, unsigned* __restrict__ status, int idx, int lane, bool block, int& sum) {
+    const int i = idx - lane;
+    unsigned st = (i >= 0) ? 0u : MC_ST_PREFIX;
+    int spins = 0;
+    unsigned long long pre;
+    int p;
+    while (true) {
+        if ((st & ~MC_ST_VALUE) == 0u) st = atomicOr(status + i, 0u);
+        pre = __ballot((st & MC_ST_PREFIX) != 0u);
+        p = pre ? (__ffsll((long long)pre) - 1) : 64;                          // nearest predecessor that knows its inclusive prefix
+        const unsigned long long missing = __ballot((st & ~MC_ST_VALUE) == 0u) & (p >= 63 ? ~0ull : ((2ull << p) - 1ull));
+        if (missing == 0ull) break;
+        if (!block) return -1;
+        if (++spins > MC_SPIN_LIMIT) { if (lane == 0) a.log_counters[DIF_C_OVERFLOW] = 7; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    int v = (lane <= p) ? (int)(st & MC_ST_VALUE) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    sum = v;
+    return pre ? 1 : 0;
+}
 
 // RC: the resolution as a compile-time constant (0: read it from the arguments).  The index arithmetic of the corners and cells divides by
-// r, r + 1 and their squares: with a run-time r each of those is a ~30-instruction integer division, several per lane and phase
-// (3,546 -> 3,123 instructions, 101 -> 89 VGPRs; 23.0 -> 22.0 ms with every voxel of the 128^3 grid meshed, unchanged on a stream frame).
+// r, r + 1 and their squares: with a run-time r each of those is a ~30-instruction integer division, several per lane and phase.
+//
+// One group per workgroup (group = workgroup index): count, look-back, emit — the stream's frames.
 template <int RC>
-__device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __restrict__ status, float* lds, int K, int n_groups, int64_t log_n) {
     __shared__ int s_cnt[DIF_BLOCK / 64];
     __shared__ int s_excl;
     const int r = RC ? RC : a.R / 2, r1 = r + 1, nc = r1 * r1 * r1, r3 = r * r * r;
     const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform, and the compiler is told so)
-    float* c_sdf = lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc);
+    float* c_sdf = lds + (size_t)wid * MC_ONEPASS_WAVE_LDS_FLOATS(nc);
     float* c_std = c_sdf + nc;
-    int* nb = reinterpret_cast<int*>(c_std + nc);
-    V2* vl = reinterpret_cast<V2*>(lds + (size_t)wid * MC_WAVE_LDS_FLOATS(nc) + ((2 * nc + 32 + 3) & ~3)) + lane;
+    int* nb = reinterpret_cast<int*>(c_sdf + MC_RING * MC_CORNER_FLOATS(nc));
+    float* vl = reinterpret_cast<float*>(nb + 32) + lane;
+    const int g = (int)blockIdx.x;
+    if (g >= n_groups) return;
+    const int k = g * 4 + wid;
+    const bool active = k < K;
+    int ntri = 0;
+    unsigned long long tri_row = ~0ull;
+    unsigned ok = 0u;
+    McVoxel v = {};
+    if (active) {
+        const bool crossing = mc_load_voxel<RC>(a, k, lane, r, c_sdf, c_std, nb, v);
+        if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, tri_row, ok);
+    }
+    const int incl = wave_incl_scan(ntri);
+    const int voxel_total = __shfl(incl, 63);
+    if (lane == 0) {
+        s_cnt[wid] = voxel_total;
+        if (active) a.tri_count[k] = voxel_total;
+    }
+    __syncthreads();
+    if (wid == 0) {
+        const int agg = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int excl = 0;
+        if (g > 0) {
+            if (lane == 0) atomicExch(status + g, MC_ST_AGG | (unsigned)agg);
+            for (int idx = g - 1; idx >= 0; idx -= 64) {
+                int sum;
+                const int found = mc_lookback_window(a, status, idx, lane, true, sum);
+                excl += sum;
+                if (found) break;
+            }
+        }
+        if (lane == 0) {
+            atomicExch(status + g, MC_ST_PREFIX | ((unsigned)(excl + agg) & MC_ST_VALUE));
+            s_excl = excl;
+            if (g == n_groups - 1) a.log_counters[DIF_C_T] = excl + agg;            // triangles of this call (map.py:695 counts them on the host)
+        }
+    }
+    __syncthreads();
+    if (active && voxel_total > 0) {
+        int voxel_offset = s_excl;
+        for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[w];
+        mc_emit_voxel(a, lane, r, v, voxel_total, voxel_offset, ntri, incl, tri_row, ok, vl, c_std, log_n);
+    }
+}
+
+// More groups than workgroups (a map with thousands of dirty voxels): groups are claimed through the ticket counter, and a workgroup does
+// not sit on a counted group until its prefix is known — it parks the group (its blended corners stay in LDS, MC_RING sets per wave) and
+// counts the next one; a parked group is emitted once its look-back succeeds (the cells are evaluated again from the parked corners:
+// cheaper than holding their edge vertices).  The ordered commit otherwise costs what the slowest of the ~1,000 groups in flight in front
+// of a group costs: measured, a third of the launch (profiles/r04_experiments.md).
+// No deadlock: a group's count is published right after counting and counting never waits; a workgroup only blocks on a look-back when
+// its ring is full or the tickets are gone, and what it waits for are counts of groups with lower tickets — held by workgroups that are
+// running (they took those tickets) and that publish them without waiting for anyone.
+template <int RC>
+__device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __restrict__ status, unsigned* __restrict__ ticket, float* lds, int K,
+                                                int n_groups, int64_t log_n) {
+    __shared__ int s_g, s_res, s_excl;
+    __shared__ int s_gid[MC_RING];                                   // parked groups (ring order: head .. head + cnt - 1)
+    __shared__ int s_cnt[MC_RING][DIF_BLOCK / 64];                   // their voxels' triangle counts
+    __shared__ int64_t s_vb[MC_RING][DIF_BLOCK / 64];                // ... and what the emit needs to know about each voxel
+    __shared__ int s_slot[MC_RING][DIF_BLOCK / 64], s_oldn[MC_RING][DIF_BLOCK / 64], s_olds[MC_RING][DIF_BLOCK / 64], s_cross[MC_RING][DIF_BLOCK / 64];
+    const int r = RC ? RC : a.R / 2, r1 = r + 1, nc = r1 * r1 * r1, r3 = r * r * r;
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* ring = lds + (size_t)wid * MC_ONEPASS_WAVE_LDS_FLOATS(nc);
+    int* nb = reinterpret_cast<int*>(ring + MC_RING * MC_CORNER_FLOATS(nc));
+    float* vl = reinterpret_cast<float*>(nb + 32) + lane;
+    int head = 0, cnt = 0;
+    bool exhausted = false;
+    int lb_idx = -2, lb_excl = 0;                                    // wave 0: how far the oldest parked group's look-back has come (-2: not begun)
+    while (true) {
+        const bool claim = cnt < MC_RING && !exhausted;
+        if (claim && threadIdx.x == 0) s_g = (int)atomicAdd(ticket, 1u);
+        __syncthreads();
+        int g = -1;
+        if (claim) {
+            g = s_g;
+            if (g >= n_groups) { exhausted = true; g = -1; }
+        }
+        const int tail = (head + cnt) % MC_RING;
+        if (g >= 0) {                                                // count group g, park it at the tail
+            const int k = g * 4 + wid;
+            int ntri = 0;
+            bool crossing = false;
+            McVoxel v = {};
+            if (k < K) {
+                float* c_sdf = ring + tail * MC_CORNER_FLOATS(nc);
+                crossing = mc_load_voxel<RC>(a, k, lane, r, c_sdf, c_sdf + nc, nb, v);
+                unsigned long long tri_row;
+                unsigned ok;
+                if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_sdf + nc, vl, r, lane, tri_row, ok);
+            }
+            const int voxel_total = __shfl(wave_incl_scan(ntri), 63);
+            if (lane == 0) {
+                s_cnt[tail][wid] = voxel_total;
+                s_vb[tail][wid] = v.vb; s_slot[tail][wid] = v.slot; s_oldn[tail][wid] = v.old_n; s_olds[tail][wid] = v.old_s; s_cross[tail][wid] = crossing;
+                if (k < K) a.tri_count[k] = voxel_total;
+            }
+        }
+        __syncthreads();
+        if (wid == 0) {
+            if (g >= 0) {
+                const int agg = s_cnt[tail][0] + s_cnt[tail][1] + s_cnt[tail][2] + s_cnt[tail][3];
+                if (lane == 0) {
+                    if (g > 0) atomicExch(status + g, MC_ST_AGG | (unsigned)agg);
+                    s_gid[tail] = g;
+                }
+            }
+            const int npend = cnt + (g >= 0 ? 1 : 0);
+            int res = 0;
+            if (npend > 0) {
+                const int gh = cnt > 0 ? s_gid[head] : g;            // the oldest parked group
+                const int aggh = s_cnt[head][0] + s_cnt[head][1] + s_cnt[head][2] + s_cnt[head][3];
+                const bool block = npend == MC_RING || exhausted;    // nothing else to do but wait for it
+                if (lb_idx == -2) { lb_idx = gh - 1; lb_excl = 0; }
+                bool done = false;
+                while (!done) {
+                    if (lb_idx < 0) { done = true; break; }
+                    int sum;
+                    const int found = mc_lookback_window(a, status, lb_idx, lane, block, sum);
+                    if (found < 0) break;
+                    lb_excl += sum;
+                    if (found) done = true; else lb_idx -= 64;
+                }
+                if (done) {
+                    if (lane == 0) {
+                        atomicExch(status + gh, MC_ST_PREFIX | ((unsigned)(lb_excl + aggh) & MC_ST_VALUE));
+                        s_excl = lb_excl;
+                        if (gh == n_groups - 1) a.log_counters[DIF_C_T] = lb_excl + aggh;
+                    }
+                    lb_idx = -2;
+                    res = 1;
+                }
+            }
+            if (lane == 0) s_res = res;
+        }
+        __syncthreads();
+        if (g >= 0) ++cnt;
+        if (s_res) {                                                 // the oldest parked group has its offset: emit it
+            const int k = s_gid[head] * 4 + wid;
+            const int voxel_total = s_cnt[head][wid];
+            if (k < K && voxel_total > 0) {
+                McVoxel v;
+                v.vb = s_vb[head][wid]; v.slot = s_slot[head][wid]; v.old_n = s_oldn[head][wid]; v.old_s = s_olds[head][wid];
+                mc_voxel_coords(a, v);
+                const float* c_sdf = ring + head * MC_CORNER_FLOATS(nc);
+                int ntri = 0;
+                unsigned long long tri_row = ~0ull;
+                unsigned ok = 0u;
+                if (s_cross[head][wid] && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_sdf + nc, vl, r, lane, tri_row, ok);     // (again: the same cells, the same counts)
+                const int incl = wave_incl_scan(ntri);
+                int voxel_offset = s_excl;
+                for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[head][w];
+                mc_emit_voxel(a, lane, r, v, voxel_total, voxel_offset, ntri, incl, tri_row, ok, vl, c_sdf + nc, log_n);
+            }
+            head = (head + 1) % MC_RING;
+            --cnt;
+        }
+        if (exhausted && cnt == 0) break;
+    }
+}
+
+template <int RC>
+__device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = *a.K_ptr;
     const int n_groups = (K + 3) >> 2;
     const int64_t log_n = a.log_counters[DIF_C_CACHE_T];                 // log length before this call (k_extract_finish advances it)
@@ -348,174 +648,19 @@ __device__ __forceinline__ void mc_onepass_body(const McArgs& a, unsigned* __res
         if (a.grid_tot)
             for (int t = (int)threadIdx.x; t < 1024; t += (int)blockDim.x) a.grid_tot[t] = 0;
     }
-    __shared__ int s_g;
-    // Which group a workgroup takes: with at most one group per workgroup (a stream frame: ~150 groups) simply its own index —
-    // workgroups are dispatched in index order, so every predecessor is running or done.  Otherwise groups are handed out by a ticket
-    // counter, lowest first: whatever the residency of the grid, a group's predecessors have all been claimed by workgroups that are
-    // running (or done), and the look-back below cannot wait for work nobody has started.
-    const bool use_ticket = n_groups > (int)gridDim.x;
-    for (int round = 0;; ++round) {
-        if (use_ticket) {
-            if (threadIdx.x == 0) s_g = (int)atomicAdd(ticket, 1u);
-            __syncthreads();
-        }
-        const int g = use_ticket ? s_g : (int)blockIdx.x;
-        if (g >= n_groups || (!use_ticket && round > 0)) break;
-        const int k = g * 4 + wid;
-        const bool active = k < K;
-        int ntri = 0, voxel_total = 0;
-        unsigned long long tri_row = ~0ull;
-        int64_t vb = 0;
-        int bx = 0, by = 0, bz = 0;
-        int slot = 0;                                    // (< capacity < 2^31)
-        int old_n = 0, old_s = 0;
-        if (active) {
-            vb = a.valid_blocks[k];
-            bx = (int)((vb / ((int64_t)a.ny * a.nz)) % a.nx); by = (int)((vb / a.nz) % a.ny); bz = (int)(vb % a.nz);
-            if (lane < 27) nb[lane] = mc_batch_of(a, bx + lane / 9 - 1, by + (lane / 3) % 3 - 1, bz + lane % 3 - 1);
-            // the voxel's previous triangle batch (needed only by the emit phase, two dependent look-ups): requested here, beside the
-            // neighbour look-ups, instead of behind the look-back
-            slot = (int)a.indexer[vb];
-            old_n = a.tri_n[slot]; old_s = a.tri_start[slot];
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-#if !defined(DIF_MC_CUT) || DIF_MC_CUT >= 2          /* measurement builds (tools/: what the launch costs up to a phase): 1 = neighbour look-ups only */
-            bool any_neg = false, any_pos = false;
-            for (int c = lane; c < nc; c += 64) {
-                float sv, dv;
-                const bool ok = mc_corner(a, nb, r, c / (r1 * r1), (c / r1) % r1, c % r1, sv, dv);
-                c_sdf[c] = ok ? sv : __builtin_nanf("");
-                c_std[c] = ok ? dv : 0.0f;
-                any_neg |= ok && sv < 0.0f;
-                any_pos |= ok && !(sv < 0.0f);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            const bool crossing = __ballot(any_neg) != 0ull && __ballot(any_pos) != 0ull;
-#if !defined(DIF_MC_CUT) || DIF_MC_CUT >= 3          /* 2 = ... + blended corners */
-            if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, tri_row);
-#else
-            ntri = crossing ? (int)(c_sdf[lane] == -12345.f) : 0;
-#endif
-#else
-            ntri = (nb[lane & 31] == -12345 && old_n + old_s == -7) ? 1 : 0;
-#endif
-        }
-#if defined(DIF_MC_CUT) && DIF_MC_CUT <= 3           /* 3 = ... + the cells' triangle counts; the whole workgroup leaves here */
-        if (ntri == 12345) a.tri_count[0] = 1;
-        __syncthreads();
-        if (use_ticket) continue;                        // (launches with more groups than workgroups: on to the next ticket)
-        break;
-#endif
-        const int incl = wave_incl_scan(ntri);
-        voxel_total = __shfl(incl, 63);
-        if (lane == 0) {
-            s_cnt[wid] = voxel_total;
-            if (active) a.tri_count[k] = voxel_total;
-        }
-        __syncthreads();
-        if (wid == 0) {
-            const int agg = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-            int excl = 0;
-            if (g > 0) {
-                if (lane == 0) atomicExch(status + g, MC_ST_AGG | (unsigned)agg);
-                int idx = g - 1;
-                while (idx >= 0) {
-                    const int i = idx - lane;
-                    unsigned st = (i >= 0) ? 0u : MC_ST_PREFIX;
-                    int spins = 0;
-                    while (true) {
-                        if ((st & ~MC_ST_VALUE) == 0u) st = atomicOr(status + i, 0u);
-                        if (__ballot((st & ~MC_ST_VALUE) == 0u) == 0ull) break;
-                        if (++spins > MC_SPIN_LIMIT) { if (lane == 0) a.log_counters[DIF_C_OVERFLOW] = 7; break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    const unsigned long long pre = __ballot((st & MC_ST_PREFIX) != 0u);
-                    const int p = pre ? (__ffsll((long long)pre) - 1) : 64;               // nearest predecessor that knows its inclusive prefix
-                    int v = (lane <= p) ? (int)(st & MC_ST_VALUE) : 0;
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-                    excl += v;
-                    if (pre) break;
-                    idx -= 64;
-                }
-            }
-            if (lane == 0) {
-                atomicExch(status + g, MC_ST_PREFIX | ((unsigned)(excl + agg) & MC_ST_VALUE));
-                s_excl = excl;
-                if (g == n_groups - 1) a.log_counters[DIF_C_T] = excl + agg;            // triangles of this call (map.py:695 counts them on the host)
-            }
-        }
-        __syncthreads();
-#if defined(DIF_MC_CUT) && DIF_MC_CUT == 4           /* 4 = ... + the look-back: everything but the emit */
-        __syncthreads();
-        if (use_ticket) continue;
-        break;
-#endif
-        if (active && voxel_total > 0) {
-            int voxel_offset = s_excl;
-            for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[w];
-            // mesh-cache log: this voxel's previous batch dies, the voxel points at its new one (map.py:708-709)
-            for (int j = lane; j < old_n; j += 64) a.tri_alive[old_s + j] = 0;
-            int64_t n_new = voxel_total;
-            if (voxel_offset + n_new > a.new_limit) n_new = a.new_limit > voxel_offset ? a.new_limit - voxel_offset : 0;      // truncated by max_n_triangles
-            if (log_n + voxel_offset + n_new > a.max_triangles) n_new = a.max_triangles > log_n + voxel_offset ? a.max_triangles - (log_n + voxel_offset) : 0;
-            if (lane == 0) {
-                a.tri_start[slot] = (int)(log_n + voxel_offset);
-                a.tri_n[slot] = (int)n_new;
-                if (old_n) atomicAdd(a.log_counters + DIF_C_CACHE_DEAD, old_n);
-            }
-            if (ntri > 0) {
-                unsigned tl = (unsigned)(voxel_offset + (incl - ntri));                 // index among this call's triangles (< 2^30: the look-back word)
-                unsigned t = tl + (unsigned)log_n;                                      // index in the log (log_n < cache_capacity < 2^31)
-                const CellBox box = mc_cell_box(bx, by, bz, lane / (r * r), (lane / r) % r, lane % r, 1.0f / (float)r);
-                for (unsigned long long t3 = tri_row; (t3 & 0xF) != 0xF; t3 >>= 12) {
-                    const int e0 = (int)(t3 & 0xF), e1 = (int)((t3 >> 4) & 0xF), e2 = (int)((t3 >> 8) & 0xF);
-                    const V2 v0 = vl[e0 * 64], v1 = vl[e1 * 64], v2 = vl[e2 * 64];
-                    if (v0.sd > a.max_std || v1.sd > a.max_std || v2.sd > a.max_std) continue;
-                    if ((int64_t)tl < a.new_limit && (int64_t)t < a.max_triangles) {
-                        const V4 vv[3] = {mc_vertex(v0, e0, box), mc_vertex(v1, e1, box), mc_vertex(v2, e2, box)};
-#pragma unroll
-                        for (int vi = 0; vi < 3; ++vi) {
-                            float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
-                            if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }   // map.py:698
-                            a.triangles[((int64_t)t * 3 + vi) * 3 + 0] = x;
-                            a.triangles[((int64_t)t * 3 + vi) * 3 + 1] = y;
-                            a.triangles[((int64_t)t * 3 + vi) * 3 + 2] = z;
-                            a.tri_std[(int64_t)t * 3 + vi] = vv[vi].w;
-                        }
-                        a.tri_id[t] = vb;
-                        a.tri_alive[t] = 1;
-                        if (a.out_tri && (int64_t)tl < a.out_capacity) {
-#pragma unroll
-                            for (int vi = 0; vi < 3; ++vi) {
-                                float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
-                                if (a.scale) { x = x * a.vs + a.bx; y = y * a.vs + a.by; z = z * a.vs + a.bz; }
-                                a.out_tri[((int64_t)tl * 3 + vi) * 3 + 0] = x;
-                                a.out_tri[((int64_t)tl * 3 + vi) * 3 + 1] = y;
-                                a.out_tri[((int64_t)tl * 3 + vi) * 3 + 2] = z;
-                                a.out_std[(int64_t)tl * 3 + vi] = vv[vi].w;
-                            }
-                            a.out_id[tl] = vb;
-                        }
-                    }
-                    ++t; ++tl;
-                }
-            }
-        }
-        __syncthreads();                                 // s_cnt / s_excl are rewritten by the next group
-    }
+    if (n_groups > (int)gridDim.x) mc_onepass_ring<RC>(a, status, ticket, lds, K, n_groups, log_n);
+    else mc_onepass_direct<RC>(a, status, lds, K, n_groups, log_n);
 }
 
 template <int RC>
-__global__ void __launch_bounds__(DIF_BLOCK, RC == 4 ? 5 : 4) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
+__global__ void __launch_bounds__(DIF_BLOCK, RC == 4 ? MC_WAVES_PER_SIMD : 4) k_marching_cubes_onepass(McArgs a, unsigned* __restrict__ status, unsigned* __restrict__ ticket) {
     mc_onepass_body<RC>(a, status, ticket);
 }
 // S maps in one launch: blockIdx.y = map, each with its own look-back words and ticket (a group only ever waits for groups of ITS map that a
 // running or finished workgroup has claimed, exactly as in the single launch)
 struct McStream { McArgs a; unsigned* status; unsigned* ticket; };
 template <int RC>
-__global__ void __launch_bounds__(DIF_BLOCK, RC == 4 ? 5 : 4) k_marching_cubes_onepass_batch(Batch<McStream> b) {
+__global__ void __launch_bounds__(DIF_BLOCK, RC == 4 ? MC_WAVES_PER_SIMD : 4) k_marching_cubes_onepass_batch(Batch<McStream> b) {
     const McStream& m = b.s[blockIdx.y];
     mc_onepass_body<RC>(m.a, m.status, m.ticket);
 }

@@ -305,7 +305,7 @@ def _eager(st, i):
     return tuple(x.clone() for x in o)
 
 
-def _solo_and_group(gpu_model, make, S, n_frames):
+def _solo_and_group(gpu_model, make, S, n_frames, before_group=None):
     """Every stream alone (eager: the reference run of this file), then the same S streams as one group; returns per-stream
     (per-frame outputs, final snapshot) of both."""
     from di_fusion_amd.stream import FusionStreamGroup
@@ -316,6 +316,8 @@ def _solo_and_group(gpu_model, make, S, n_frames):
         solo.append((per, snapshot(st)))
         del st
     torch.cuda.empty_cache()
+    if before_group is not None:
+        before_group()
     streams = [make(j) for j in range(S)]
     got = [[_eager(st, 0)] for st in streams]      # sizes the buffers; the group takes over from frame 1
     grp = FusionStreamGroup(streams)
@@ -351,6 +353,26 @@ def test_stream_group_matches_single_streams(S, gpu_model):
         same(solo[j][1], grp[j][1])
     if S > 1:       # the streams really are different subsequences
         assert not torch.equal(solo[0][1]["indexer"], solo[1][1]["indexer"])
+
+
+def test_stream_group_marching_cubes_in_ticket_mode(gpu_model, monkeypatch):
+    """The grouped launch of the one-pass marching cubes capped at five workgroups per stream (DIF_MC_GRID): every stream's groups of four
+    voxels are claimed through its ticket counter — the path of a map with thousands of dirty voxels — and the triangles still equal the
+    streams stepped alone with a workgroup per group, bit for bit."""
+    from di_fusion_amd.stream import FusionStream
+    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
+    intr = S_.Intrinsic().scaled(0.25)
+
+    def make(j):
+        return FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, N_FRAMES, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=None)
+
+    solo, grp, streams = _solo_and_group(gpu_model, make, 3, N_FRAMES, before_group=lambda: monkeypatch.setenv("DIF_MC_GRID", "5"))
+    print("  dirty voxels of the last frame:", [st.map.last_counters["K"] for st in streams], "(ticket mode above 20)")
+    for j in range(3):
+        assert len(grp[j][0]) == N_FRAMES
+        for f, (a, b) in enumerate(zip(solo[j][0], grp[j][0])):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), f"stream {j} frame {f}"
+        same(solo[j][1], grp[j][1])
 
 
 def test_stream_group_survives_compaction_and_growth(gpu_model):
