@@ -922,7 +922,7 @@ static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int6
     // as many workgroups as a CU holds (five at resolution 4: 25 KB of LDS and 96 registers each); groups of four voxels are claimed through a ticket counter
     const int64_t need = (max_voxels + 3) / 4;
     int per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
-    per_cu = per_cu < 1 ? 1 : per_cu > 5 ? 5 : per_cu;
+    per_cu = per_cu < 1 ? 1 : per_cu > MC_WAVES_PER_SIMD ? MC_WAVES_PER_SIMD : per_cu;
     grid1 = per_cu * num_cus();
     if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
     // test hook: DIF_MC_GRID=n caps the grid, so that a small map runs in ticket mode (more groups than workgroups) — the path that otherwise
