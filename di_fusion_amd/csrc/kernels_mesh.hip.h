@@ -135,12 +135,14 @@ constexpr unsigned long long mc_end_bits(bool second) {
     }
     return t;
 }
-__device__ __forceinline__ V4 mc_vertex(float w2, int e, const CellBox& c, const float* __restrict__ c_std) {
+// (vsd: the edge stds kept beside the weights — the one-group-per-workgroup mode has the LDS for them — or NULL: rebuilt from the corners)
+__device__ __forceinline__ V4 mc_vertex(float w2, int e, const CellBox& c, const float* __restrict__ c_std, const float* __restrict__ vsd = nullptr) {
     constexpr unsigned long long TA = mc_end_bits(false), TB = mc_end_bits(true);
     const unsigned sa = (unsigned)(TA >> (3 * e)), sb = (unsigned)(TB >> (3 * e));
     const float w1 = 1 - w2;
     const float ax = (sa & 1) ? c.x[1] : c.x[0], ay = (sa & 2) ? c.y[1] : c.y[0], az = (sa & 4) ? c.z[1] : c.z[0];
     const float cx = (sb & 1) ? c.x[1] : c.x[0], cy = (sb & 2) ? c.y[1] : c.y[0], cz = (sb & 4) ? c.z[1] : c.z[0];
+    if (vsd) return V4{ax * w1 + cx * w2, ay * w1 + cy * w2, az * w1 + cz * w2, vsd[e * 64]};
     const float s1 = c_std[c.c0 + ((sa & 1) ? c.r1 * c.r1 : 0) + ((sa & 2) ? c.r1 : 0) + ((sa >> 2) & 1)];
     const float s2 = c_std[c.c0 + ((sb & 1) ? c.r1 * c.r1 : 0) + ((sb & 2) ? c.r1 : 0) + ((sb >> 2) & 1)];
     return V4{ax * w1 + cx * w2, ay * w1 + cy * w2, az * w1 + cz * w2, s1 * w1 + s2 * w2};
@@ -154,7 +156,7 @@ __device__ __forceinline__ bool mc_tri_ok(unsigned ok, unsigned long long t3) {
 // returns the number of triangles that survive max_std (mc_interp_kernel.cu:202-320); tri_row = the packed triangle-table row (~0 if none),
 // ok = per edge: its interpolated std is not above max_std.
 __device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __restrict__ c_sdf, const float* __restrict__ c_std, float* __restrict__ vl,
-                                            int r, int cell, unsigned long long& tri_row, unsigned& ok) {
+                                            int r, int cell, unsigned long long& tri_row, unsigned& ok, float* __restrict__ vsd = nullptr) {
     const int r1 = r + 1;
     const int rx = cell / (r * r), ry = (cell / r) % r, rz = cell % r;
     float val[8], sdv[8];
@@ -180,6 +182,7 @@ __device__ __forceinline__ int mc_eval_cell(const McArgs& a, const float* __rest
         if (edge_config & (1 << e)) {
             const V2 v = mc_interp(sdv[ea[e]], sdv[eb[e]], val[ea[e]], val[eb[e]]);
             vl[e * 64] = v.w2;
+            if (vsd) vsd[e * 64] = v.sd;
             ok |= (v.sd > a.max_std) ? 0u : (1u << e);
         }
     tri_row = c_mc_tri_packed[cube_type];
@@ -339,13 +342,15 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 // LDS of a wave: MC_RING sets of blended corners (ticket mode: groups that are counted and wait for their prefix; the direct mode uses the
 // first), the 27 neighbour batches, the edge vertices of the cells being evaluated
 #ifndef MC_RING
-#define MC_RING 3
+#define MC_RING 4
 #endif
 #ifndef MC_WAVES_PER_SIMD
 #define MC_WAVES_PER_SIMD 5
 #endif
 #define MC_CORNER_FLOATS(nc) ((2 * (nc) + 3) & ~3)
-#define MC_ONEPASS_WAVE_LDS_FLOATS(nc) (MC_RING * MC_CORNER_FLOATS(nc) + 32 + 12 * 64)
+#define MC_RING_WAVE_LDS_FLOATS(nc) (MC_RING * MC_CORNER_FLOATS(nc) + 32 + 12 * 64)              /* ticket mode: corner ring | neighbours | edge weights */
+#define MC_DIRECT_WAVE_LDS_FLOATS(nc) (MC_CORNER_FLOATS(nc) + 2 * 12 * 64)                           /* a group per workgroup: corners | edge weights | edge stds */
+#define MC_ONEPASS_WAVE_LDS_FLOATS(nc) (MC_RING_WAVE_LDS_FLOATS(nc) > MC_DIRECT_WAVE_LDS_FLOATS(nc) ? MC_RING_WAVE_LDS_FLOATS(nc) : MC_DIRECT_WAVE_LDS_FLOATS(nc))
 
 struct McVoxel {                 // what a wave knows about its voxel (wave-uniform)
     int64_t vb; int bx, by, bz;  // linear id and coordinates
@@ -386,7 +391,8 @@ __device__ __forceinline__ bool mc_load_voxel(const McArgs& a, int k, int lane, 
 // The voxel's triangles written at `voxel_offset` among this call's triangles (lane = cell: ntri of them, `incl` = inclusive wave scan of ntri,
 // edge vertices in vl), the mesh-cache log's bookkeeping for the voxel (map.py:708-709: its previous batch dies, it points at the new one).
 __device__ __forceinline__ void mc_emit_voxel(const McArgs& a, int lane, int r, const McVoxel& v, int voxel_total, int voxel_offset, int ntri, int incl,
-                                              unsigned long long tri_row, unsigned ok, const float* __restrict__ vl, const float* __restrict__ c_std, int64_t log_n) {
+                                              unsigned long long tri_row, unsigned ok, const float* __restrict__ vl, const float* __restrict__ c_std, int64_t log_n,
+                                              const float* __restrict__ vsd = nullptr) {
     for (int j = lane; j < v.old_n; j += 64) a.tri_alive[v.old_s + j] = 0;
     int64_t n_new = voxel_total;
     if (voxel_offset + n_new > a.new_limit) n_new = a.new_limit > voxel_offset ? a.new_limit - voxel_offset : 0;      // truncated by max_n_triangles
@@ -404,7 +410,7 @@ __device__ __forceinline__ void mc_emit_voxel(const McArgs& a, int lane, int r, 
         const int e0 = (int)(t3 & 0xF), e1 = (int)((t3 >> 4) & 0xF), e2 = (int)((t3 >> 8) & 0xF);
         if (!mc_tri_ok(ok, t3)) continue;
         if ((int64_t)tl < a.new_limit && (int64_t)t < a.max_triangles) {
-            const V4 vv[3] = {mc_vertex(vl[e0 * 64], e0, box, c_std), mc_vertex(vl[e1 * 64], e1, box, c_std), mc_vertex(vl[e2 * 64], e2, box, c_std)};
+            const V4 vv[3] = {mc_vertex(vl[e0 * 64], e0, box, c_std, vsd), mc_vertex(vl[e1 * 64], e1, box, c_std, vsd), mc_vertex(vl[e2 * 64], e2, box, c_std, vsd)};
 #pragma unroll
             for (int vi = 0; vi < 3; ++vi) {
                 float x = vv[vi].x, y = vv[vi].y, z = vv[vi].z;
@@ -469,10 +475,13 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
     __shared__ int s_excl;
     const int r = RC ? RC : a.R / 2, r1 = r + 1, nc = r1 * r1 * r1, r3 = r * r * r;
     const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform, and the compiler is told so)
+    // LDS of a wave in this mode: corners | edge weights | edge stds (the ring's other slots: the stds are kept, not rebuilt at emit — with one
+    // wave per SIMD every instruction of the emit is latency); the 27 neighbour batches sit where the stds go later (they are done by then)
     float* c_sdf = lds + (size_t)wid * MC_ONEPASS_WAVE_LDS_FLOATS(nc);
     float* c_std = c_sdf + nc;
-    int* nb = reinterpret_cast<int*>(c_sdf + MC_RING * MC_CORNER_FLOATS(nc));
-    float* vl = reinterpret_cast<float*>(nb + 32) + lane;
+    float* vl = c_sdf + MC_CORNER_FLOATS(nc) + lane;
+    float* vsd = vl + 12 * 64;
+    int* nb = reinterpret_cast<int*>(c_sdf + MC_CORNER_FLOATS(nc) + 12 * 64);
     const int g = (int)blockIdx.x;
     if (g >= n_groups) return;
     const int k = g * 4 + wid;
@@ -483,7 +492,7 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
     McVoxel v = {};
     if (active) {
         const bool crossing = mc_load_voxel<RC>(a, k, lane, r, c_sdf, c_std, nb, v);
-        if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, tri_row, ok);
+        if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_std, vl, r, lane, tri_row, ok, vsd);
     }
     const int incl = wave_incl_scan(ntri);
     const int voxel_total = __shfl(incl, 63);
@@ -514,7 +523,7 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
     if (active && voxel_total > 0) {
         int voxel_offset = s_excl;
         for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[w];
-        mc_emit_voxel(a, lane, r, v, voxel_total, voxel_offset, ntri, incl, tri_row, ok, vl, c_std, log_n);
+        mc_emit_voxel(a, lane, r, v, voxel_total, voxel_offset, ntri, incl, tri_row, ok, vl, c_std, log_n, vsd);
     }
 }
 
