@@ -423,10 +423,13 @@ def test_get_sdf_gradient_vs_reference_autograd(name, pipe, gpu_model, gpu_model
     assert torch.allclose(g2 / d2.unsqueeze(1), gq[mask], rtol=1e-6, atol=1e-6 * scale)
 
 
-@pytest.mark.parametrize("resolution,fast", [(4, False), (2, True), (8, True), (3, True)])
-def test_other_resolutions_and_exact_decode(resolution, fast, gpu_model, oracle_net):
-    """extract_mesh(voxel_resolution, fast) away from the shipped default (4, True): same pipeline, checked against the oracle."""
+@pytest.mark.parametrize("resolution,fast,mc_grid", [(4, False, 0), (2, True, 0), (8, True, 0), (3, True, 0), (2, True, 3), (3, True, 5), (4, True, 2)])
+def test_other_resolutions_and_exact_decode(resolution, fast, mc_grid, gpu_model, oracle_net, monkeypatch):
+    """extract_mesh(voxel_resolution, fast) away from the shipped default (4, True): same pipeline, checked against the oracle.
+    mc_grid > 0: the one-pass marching cubes capped at that many workgroups (DIF_MC_GRID), i.e. in ticket mode with parked groups."""
     from oracle import difusion_oracle as O
+    if mc_grid:
+        monkeypatch.setenv("DIF_MC_GRID", str(mc_grid))
     scene, cfg, intr = CASES["seq_small"]
     g = np.load(GOLDEN / "seq_small.npz")
     m = make_map(gpu_model, cfg)
