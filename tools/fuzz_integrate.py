@@ -1,7 +1,10 @@
 """Differential fuzzing of integrate + extract against the oracle on random small problems (grid size, voxel size, pruning on/off, point
-order, NaNs, out-of-bounds points, repeated frames).  Bit-exact integer state, latents within 2e-5, dirty / batch counts equal; then random point queries (mask exact, values within 5e-5).
+order, NaNs, out-of-bounds points, repeated frames).  Bit-exact integer state, latents within 2e-5, dirty / batch counts equal; the frame's new
+triangles against the oracle's marching cubes on the GPU's own cubes (ids and order exact, vertices within 1e-5) — in about half of the cases
+with the one-pass kernel capped at 1-5 workgroups (DIF_MC_GRID: ticket mode, parked groups); then random point queries (mask exact, values within 5e-5).
 Usage: python tools/fuzz_integrate.py [--cases 20] [--seed 0]      (GPU; a few seconds per case, the oracle is the slow side)"""
 import argparse
+import os
 import sys
 from pathlib import Path
 
@@ -31,6 +34,11 @@ def run(cases: int, seed: int = 0):
         m = DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1024)
         om = O.OracleMap(onet, cfg.bound_min, cfg.bound_max, cfg.voxel_size, prune_min_vox_obs=prune)
         kind = rng.choice(["sphere", "plane", "blob"])
+        mc_grid = int(rng.integers(1, 6)) if rng.random() < 0.5 else 0
+        if mc_grid:
+            os.environ["DIF_MC_GRID"] = str(mc_grid)
+        else:
+            os.environ.pop("DIF_MC_GRID", None)
         for frame in range(int(rng.integers(1, 4))):
             N = int(rng.integers(500, 20000))
             if kind == "sphere":
@@ -76,6 +84,17 @@ def run(cases: int, seed: int = 0):
                 assert m.last_counters["K"] == 0, (case, frame, "K")
             else:
                 assert m.last_counters["K"] == len(oa["valid_blocks"]) and m.last_counters["B"] == len(oa["occupied_vec_id"]), (case, frame, "K/B")
+                B = m.last_counters["B"]
+                tens = m._xbuf[1]
+                cs, cd = tens["cube_sdf"][:B].cpu().numpy(), tens["cube_std"][:B].cpu().numpy()
+                wt, wi, ws = O.marching_cubes_interp(oa["indexer"], oa["valid_blocks"], oa["vec_batch_mapping"], cs, cd, int(4e6), om.n_xyz, 0.15)
+                new = m.mesh_cache_tensors(new_only=True)
+                nt = 0 if new is None else new[0].size(0)
+                assert nt == wt.shape[0] == m.last_counters["T"], (case, frame, "T", nt, wt.shape[0], mc_grid)
+                if nt:
+                    assert np.array_equal(new[1].cpu().numpy(), wi), (case, frame, "triangle ids", mc_grid)
+                    want = (wt * np.float32(cfg.voxel_size)).astype(np.float32) + om.bound_min
+                    assert np.abs(new[0].cpu().numpy() - want).max() < 1e-5 and np.abs(new[2].cpu().numpy() - ws).max() < 1e-5, (case, frame, "vertices", mc_grid)
         # point queries inside the grid (get_sdf, map.py:559-579): validity mask exact, values within 5e-5
         lo = np.asarray(cfg.bound_min, np.float32)
         hi = lo + np.asarray(om.n_xyz, np.float32) * np.float32(vs)
@@ -85,7 +104,8 @@ def run(cases: int, seed: int = 0):
         assert np.array_equal(qm.cpu().numpy(), oqm), (case, "query mask")
         if oqm.any():
             assert np.abs(sdf.cpu().numpy() - osdf).max() < 5e-5 and np.abs(std.cpu().numpy() - ostd).max() < 5e-5, (case, "query values")
-        print(f"case {case}: grid {n}^3 vs {vs} prune {prune} {kind}: n_occupied {m.n_occupied} triangles {0 if out is None else out[0].shape[0]} ok", flush=True)
+        print(f"case {case}: grid {n}^3 vs {vs} prune {prune} {kind} mc_grid {mc_grid}: n_occupied {m.n_occupied} triangles {0 if out is None else out[0].shape[0]} ok", flush=True)
+    os.environ.pop("DIF_MC_GRID", None)
     print("fuzz ok")
 
 
