@@ -294,7 +294,10 @@ typedef struct dif_extract_buffers {
                                      * decode (used when dif_weights_t.dec_fold_packed is set) */
     uint32_t* mc_status;            /* optional [(max_voxels + 3) / 4 + 1], idle 0: with it (and chunk_sum, resolution <= 4) marching cubes is ONE launch:
                                      * a wave counts its voxel's triangles, learns its output offset by a decoupled look-back over groups of
-                                     * four voxels and emits straight away (same canonical order) */
+                                     * four voxels and emits straight away (same canonical order).  A call with more groups than the launch has
+                                     * workgroups (thousands of dirty voxels) hands the groups out through the ticket word at the end of this
+                                     * array.  Environment variable DIF_MC_GRID=n (a test hook, read at every call) caps that launch at n
+                                     * workgroups so that small maps take the ticket path too */
     int32_t defer_export;           /* != 0 (with out_* and dif_map_t.pending_export): do not copy the new triangles to out_* now, leave a
                                      * dif_pending_export_t for the next dif_integrate_frame / dif_export_pending */
     /* Completion without stream events (an event record costs the queue ~5 us between two kernels; a frame has two):
