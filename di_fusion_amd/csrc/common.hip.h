@@ -29,6 +29,21 @@ __host__ inline Geo geo_of(const dif_map_t* m) {
     return g;
 }
 
+// XCD-aware dealing of n work items to the workgroups of a 1-D range: workgroups go to the eight XCDs round-robin by index and every XCD
+// has its own L2, so items that follow each other (and share what they read: neighbouring voxels, neighbouring image tiles) should sit on
+// ONE XCD.  The n items are cut into blocks of 8 R, R the largest power of two that fits what is left (190 items: 128 + 32 + 16 + 8, the last
+// 6 as they come); within a block workgroup 8 j + x takes item x R + j: an XCD gets a run of R consecutive items and every block loads the
+// eight XCDs evenly.  A permutation of [0, n); b >= n maps to itself.
+__device__ __forceinline__ int xcd_run_item(int b, int n) {
+    if (b >= n) return b;
+    for (int base = 0, rem = n; rem >= 16;) {
+        const int R = 1 << (28 - __clz(rem));                    // 8 R <= rem < 16 R
+        if (b < base + 8 * R) { const int l = b - base; return base + (l & 7) * R + (l >> 3); }
+        base += 8 * R; rem -= 8 * R;
+    }
+    return b;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // xn = (p - bound_min) / voxel_size : IEEE-754 correctly rounded subtraction and DIVISION (map.py:366-367).

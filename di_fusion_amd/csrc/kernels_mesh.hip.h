@@ -482,20 +482,15 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
     float* vl = c_sdf + MC_CORNER_FLOATS(nc) + lane;
     float* vsd = vl + 12 * 64;
     int* nb = reinterpret_cast<int*>(c_sdf + MC_CORNER_FLOATS(nc) + 12 * 64);
-    // Workgroups go to the eight XCDs round-robin by index, and every XCD has its own L2.  The groups are dealt so that an XCD takes RUNS of
-    // consecutive groups (voxels that follow each other along z, then y: their 27-neighbourhoods overlap, and what one of them has pulled
-    // into the L2 the next ones find there): the n groups are cut into blocks of 8 R, R the largest power of two that fits what is left
-    // (190 groups: 128 + 32 + 16 + 8, the last 6 as they come), and within a block workgroup 8 j + x takes group x R + j — every block loads
-    // the eight XCDs evenly.  A group still only waits for groups held by workgroups below n: they all exist, and the lowest unfinished group
-    // never waits for anything unstarted, so the launch gets through whatever part of the grid is resident at a time.
-    int g = (int)blockIdx.x;
-    if (g >= n_groups) return;
+    // The groups are dealt to the XCDs in runs of consecutive groups (xcd_run_item: voxels that follow each other along z, then y — their
+    // 27-neighbourhoods overlap, and what one of them has pulled into the XCD's L2 the next ones find there).  A group still only waits for
+    // groups held by workgroups below n: they all exist, and the lowest unfinished group never waits for anything unstarted, so the launch
+    // gets through whatever part of the grid is resident at a time.
+    if ((int)blockIdx.x >= n_groups) return;
 #ifndef MC_NO_XCD_RUNS
-    for (int base = 0, rem = n_groups; rem >= 16;) {
-        const int R = 1 << (28 - __clz(rem));                    // 8 R <= rem < 16 R
-        if (g < base + 8 * R) { const int l = g - base; g = base + (l & 7) * R + (l >> 3); break; }
-        base += 8 * R; rem -= 8 * R;
-    }
+    const int g = xcd_run_item((int)blockIdx.x, n_groups);
+#else
+    const int g = (int)blockIdx.x;
 #endif
     const int k = g * 4 + wid;
     const bool active = k < K;
