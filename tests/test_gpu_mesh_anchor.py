@@ -176,6 +176,17 @@ def test_onepass_kernel_equals_flat_two_pass_kernels_on_the_extracts_own_cubes(g
         assert torch.equal(got_tri, world)
 
 
+def test_ticket_mode_at_scale_equals_flat_two_pass_kernels():
+    """64,000 dirty voxels (a 40^3 grid fully allocated): 16,000 groups claimed through the ticket counter by the ~1,300 workgroups the chip
+    holds, parked and emitted out of order of completion — against the flat count / scan / emit kernels on the same cubes, bit for bit, twice
+    (tools/stress_mc_ticket.py; the full-occupancy bench's 128^3 run is the same path at 2.1 M voxels)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import stress_mc_ticket
+    assert stress_mc_ticket.run(40, 2, verbose=False) > 1_000_000
+
+
 def test_stream_mesh_against_the_analytic_scene(gpu_model):
     """depth frames of an analytic sphere -> integrate -> decode -> marching cubes, 12 frames on an orbit: what comes out is compared with
     the ANALYTIC surface, not with any restatement.  (i) vertices lie near the sphere (the network reconstructs the surface to well under
