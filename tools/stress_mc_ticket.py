@@ -15,7 +15,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def run(n=64, reps=3, verbose=True):
+def run(n=64, reps=3, verbose=True, max_triangles=None):
+    max_triangles = int(max_triangles or 60 * n ** 3)           # (~48 triangles per voxel with these latents: nothing is truncated)
     from di_fusion_amd import synthetic as syn
     from di_fusion_amd.network import utility as net_util
     from di_fusion_amd.system import ext
@@ -42,7 +43,7 @@ def run(n=64, reps=3, verbose=True):
     assert m.n_occupied == G
     first = None
     for rep in range(reps):
-        tri, tid, tstd = m.extract_mesh_arrays(4, int(6e7), max_std=0.15, no_cache=True, to_host=False)
+        tri, tid, tstd = m.extract_mesh_arrays(4, max_triangles, max_std=0.15, no_cache=True, to_host=False)
         c = m.last_counters
         K, B, T = c["K"], c["B"], c["T"]
         assert K == G and (K + 3) // 4 > 5 * 256, "ticket mode needs more groups than resident workgroups"
@@ -51,7 +52,7 @@ def run(n=64, reps=3, verbose=True):
         vbm[tens["occ_slot"][:B].long()] = torch.arange(B, dtype=torch.int32, device=dev)
         nx, ny, nz = m.n_xyz
         wt, wi, ws = ext.marching_cubes_interp(m.indexer.view(nx, ny, nz), tens["valid_blocks"][:K].clone(), vbm, tens["cube_sdf"][:B], tens["cube_std"][:B],
-                                               int(6e7), [nx, ny, nz], 0.15)
+                                               max_triangles, [nx, ny, nz], 0.15)
         assert tri.size(0) == T == wt.size(0), (tri.size(0), T, wt.size(0))
         assert torch.equal(tid, wi) and torch.equal(tstd, ws)
         world = wt * np.float32(big_cfg.voxel_size) + torch.tensor(big_cfg.bound_min, device=dev, dtype=torch.float32)       # map.py:698
