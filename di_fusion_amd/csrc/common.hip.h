@@ -30,14 +30,15 @@ __host__ inline Geo geo_of(const dif_map_t* m) {
 }
 
 // XCD-aware dealing of n work items to the workgroups of a 1-D range: workgroups go to the eight XCDs round-robin by index and every XCD
-// has its own L2, so items that follow each other (and share what they read: neighbouring voxels, neighbouring image tiles) should sit on
-// ONE XCD.  The n items are cut into blocks of 8 R, R the largest power of two that fits what is left (190 items: 128 + 32 + 16 + 8, the last
-// 6 as they come); within a block workgroup 8 j + x takes item x R + j: an XCD gets a run of R consecutive items and every block loads the
-// eight XCDs evenly.  A permutation of [0, n); b >= n maps to itself.
-__device__ __forceinline__ int xcd_run_item(int b, int n) {
+// has its own L2, so items that follow each other (and share what they read: neighbouring voxels) should sit on ONE XCD.  The n items are
+// cut into blocks of 8 R, R the largest power of two <= max_run that fits what is left (190 items, max_run 16: 128 + 32 + 16 + 8, the last 6
+// as they come); within a block workgroup 8 j + x takes item x R + j: an XCD gets a run of R consecutive items and every block loads the
+// eight XCDs evenly.  A permutation of [0, n) that moves an item at most 8 max_run workgroups away from its own index; b >= n maps to itself.
+__device__ __forceinline__ int xcd_run_item(int b, int n, int max_run) {
     if (b >= n) return b;
     for (int base = 0, rem = n; rem >= 16;) {
-        const int R = 1 << (28 - __clz(rem));                    // 8 R <= rem < 16 R
+        int R = 1 << (28 - __clz(rem));                          // 8 R <= rem < 16 R
+        if (R > max_run) R = max_run;
         if (b < base + 8 * R) { const int l = b - base; return base + (l & 7) * R + (l >> 3); }
         base += 8 * R; rem -= 8 * R;
     }

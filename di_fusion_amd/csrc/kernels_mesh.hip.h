@@ -347,6 +347,9 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 #ifndef MC_WAVES_PER_SIMD
 #define MC_WAVES_PER_SIMD 5
 #endif
+#ifndef MC_XCD_RUN
+#define MC_XCD_RUN 16          /* 1: group = workgroup index */
+#endif
 #define MC_CORNER_FLOATS(nc) ((2 * (nc) + 3) & ~3)
 #define MC_RING_WAVE_LDS_FLOATS(nc) (MC_RING * MC_CORNER_FLOATS(nc) + 32 + 12 * 64)              /* ticket mode: corner ring | neighbours | edge weights */
 #define MC_DIRECT_WAVE_LDS_FLOATS(nc) (MC_CORNER_FLOATS(nc) + 2 * 12 * 64)                           /* a group per workgroup: corners | edge weights | edge stds */
@@ -482,16 +485,15 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
     float* vl = c_sdf + MC_CORNER_FLOATS(nc) + lane;
     float* vsd = vl + 12 * 64;
     int* nb = reinterpret_cast<int*>(c_sdf + MC_CORNER_FLOATS(nc) + 12 * 64);
-    // The groups are dealt to the XCDs in runs of consecutive groups (xcd_run_item: voxels that follow each other along z, then y — their
-    // 27-neighbourhoods overlap, and what one of them has pulled into the XCD's L2 the next ones find there).  A group still only waits for
-    // groups held by workgroups below n: they all exist, and the lowest unfinished group never waits for anything unstarted, so the launch
-    // gets through whatever part of the grid is resident at a time.
+    // The groups are dealt to the XCDs in runs of up to MC_XCD_RUN consecutive groups (xcd_run_item: voxels that follow each other along z,
+    // then y — their 27-neighbourhoods overlap, and what one of them has pulled into the XCD's L2 the next ones find there).
+    // What this costs: a group no longer waits only for LOWER workgroups (which are dispatched first, whatever the residency) — the groups in
+    // front of it may sit on workgroups up to 8 MC_XCD_RUN above its own.  While a run's first groups are being counted, up to 7 (MC_XCD_RUN - 1)
+    // workgroups of the other runs of the block spin in their look-back, so the launch needs 7 MC_XCD_RUN = 112 workgroups resident at a time
+    // (a fifth of ONE XCD's share of this kernel); with fewer — CUs masked away from the queue — a poll runs into MC_SPIN_LIMIT and the call
+    // reports DIF_C_OVERFLOW = 7 instead of hanging.  (The ticket mode below makes no such assumption.)
     if ((int)blockIdx.x >= n_groups) return;
-#ifndef MC_NO_XCD_RUNS
-    const int g = xcd_run_item((int)blockIdx.x, n_groups);
-#else
-    const int g = (int)blockIdx.x;
-#endif
+    const int g = xcd_run_item((int)blockIdx.x, n_groups, MC_XCD_RUN);
     const int k = g * 4 + wid;
     const bool active = k < K;
     int ntri = 0;
