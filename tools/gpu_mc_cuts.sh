@@ -1,5 +1,7 @@
 #!/bin/bash
 # phase cuts of the one-pass marching cubes: event-timed launch per cut on the stream and the K = 20 run (stress: tools/stress_full_occupancy.py with DIF_LIB set the same way).
+# The cuts (#if DIF_MC_CUT blocks in mc_onepass_body) lived in the tree up to commit 3efda2c; the kernel has since been split into
+# mc_onepass_direct / mc_onepass_ring without them: check that commit out to rebuild the cut libraries.
 # Build the cut libraries HERE first (they travel with the snapshot, ab_old/ is git-ignored):
 #   for c in 1 2 3 4; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DNDEBUG -DDIF_MC_CUT=$c \
 #       -DDIF_BUILD_ID='"cut"' di_fusion_amd/csrc/difusion.hip -o ab_old/libdif_mccut$c.so; done
