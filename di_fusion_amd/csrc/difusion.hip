@@ -919,7 +919,7 @@ static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int6
         if (hipFuncSetAttribute((const void*)k_marching_cubes_onepass_batch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return DIF_ELAUNCH;
         attr_set1[dev] = true;
     }
-    // as many workgroups as a CU holds (five at resolution 4: 25 KB of LDS and 96 registers each); groups of four voxels are claimed through a ticket counter
+    // as many workgroups as a CU holds (five at resolution 4: 29 KB of LDS and 96 registers each); groups of four voxels are claimed through a ticket counter
     const int64_t need = (max_voxels + 3) / 4;
     int per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
     per_cu = per_cu < 1 ? 1 : per_cu > MC_WAVES_PER_SIMD ? MC_WAVES_PER_SIMD : per_cu;
