@@ -337,6 +337,28 @@ def _secondary_pass(make_stream, a, n_frames, d2h, batch):
     return round(a.steps / (time.perf_counter() - t2), 3)
 
 
+def within(seconds, fn, what, dev):
+    """fn() on a worker thread, waited for at most `seconds`: the epilogue behind the clock talks over a transport that this repository has
+    only ever run with one rank (RCCL) — a collective that never returns must not take the measured line with it.  Returns (done, value)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            box["value"] = fn()
+        except Exception as e:              # (reported by the caller)
+            box["value"] = {"error": repr(e)[:200]}
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return False, {"error": f"{what}: no answer within {seconds} s (left behind; the process exits without the final barrier)"}
+    return True, box.get("value")
+
+
 def global_map_merge(local_maps, model, cfg, dev, barrier):
     """BASELINE config C4: after the independent subsequences, ONE all-gather of voxel records over RCCL and a fold into a global map
     (identical on every rank), meshed once.  Outside the clock (once per sequence, not per frame); reported, never fatal."""
@@ -610,7 +632,11 @@ def main():
                 by_streams[S] = streams_leg(lambda j, S=S: make_stream_j(j, S), S, a, n_frames, lib, pipe)
             except Exception as e:      # the headline number must survive a failure of a secondary leg
                 by_streams[S] = (None, {"error": repr(e)[:200]})
-    merge_info = global_map_merge([st.map for st in gb.streams] if gb is not None else stream.map, model, cfg, dev, barrier) if (use_dist and not tiled) else None
+    epilogue_ok, merge_info = True, None
+    if use_dist and not tiled:
+        epilogue_ok, merge_info = within(float(os.environ.get("DIF_BENCH_EPILOGUE_TIMEOUT", "120")),
+                                         lambda: global_map_merge([st.map for st in gb.streams] if gb is not None else stream.map, model, cfg, dev, barrier),
+                                         "global map merge", dev)
 
     out = None
     if rank == 0:
@@ -675,12 +701,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(stream, a.config, scene, cfg, intr, n_frames, a.cpu_frames)
     if use_dist:
         flush_c_stdio()
-        dist.barrier()                      # every rank has flushed whatever it had to say before rank 0 prints the one JSON line
-        dist.destroy_process_group()
+        # every rank has flushed whatever it had to say before rank 0 prints the one JSON line — unless the epilogue (here or on another rank)
+        # is stuck in a collective: then the line goes out without the barrier and the process leaves without tearing the group down
+        if epilogue_ok:
+            epilogue_ok, _ = within(60.0, lambda: (dist.barrier(), dist.destroy_process_group()), "final barrier", dev)
     flush_c_stdio()
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    if use_dist and not epilogue_ok:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
