@@ -483,7 +483,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         const EncArgs& e = P.enc;
         ProfScope prof(DIF_PROF_ENCODE, s);
         if (x6)
-            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
+            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(ENC_X6_THREADS), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
                                e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         else
             hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.src.xyz, e.src.normal, e.src.frame,
@@ -554,7 +554,7 @@ int dif_integrate_frames(const dif_stream_frame_t* st, int32_t S, const dif_weig
         const size_t lds_bytes = x6 ? (size_t)E6_BYTES : (size_t)ENC_FLOATS * 4;
         if (encoder_attributes() != DIF_OK) return DIF_ELAUNCH;
         ProfScope prof(DIF_PROF_ENCODE, s);
-        if (x6) hipLaunchKernelGGL(k_encode_batch<true>, dim3(num_cus()), dim3(512), lds_bytes, s, enc, (int)S, (const float*)w->enc_x6_packed, N);
+        if (x6) hipLaunchKernelGGL(k_encode_batch<true>, dim3(num_cus()), dim3(ENC_X6_THREADS), lds_bytes, s, enc, (int)S, (const float*)w->enc_x6_packed, N);
         else hipLaunchKernelGGL(k_encode_batch<false>, dim3(num_cus()), dim3(512), lds_bytes, s, enc, (int)S, w->enc_packed, N);
         DIF_CHECK_LAUNCH();
     }

@@ -390,6 +390,9 @@ struct EncArgs {
     Geo g; PointSrc src; const uint2* pair_list; int* rec_dir; int* rec_next; long long* rec; int* upd_list; int* counters;
     const uint8_t* dirty; int* dirty_tot;
 };
+#ifndef ENC_X6_THREADS
+#define ENC_X6_THREADS 768        /* twelve waves per CU: 3,072 tile slots on the chip */
+#endif
 template <bool X6, int NS>
 __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S, const float* __restrict__ wblob, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -505,7 +508,7 @@ __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S,
 
 // One map: the pointers arrive as noalias kernel arguments (the body's accesses keep that provenance).
 template <bool X6>
-__global__ void __launch_bounds__(512, X6 ? 1 : 2)
+__global__ void __launch_bounds__(X6 ? ENC_X6_THREADS : 512, X6 ? 1 : 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, const dif_frame_t* __restrict__ frame,
          ImageGeo im, int64_t N, const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
          int* __restrict__ upd_list, int* __restrict__ counters, const uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
@@ -514,7 +517,7 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
 }
 
 template <bool X6>
-__global__ void __launch_bounds__(512, X6 ? 1 : 2)
+__global__ void __launch_bounds__(X6 ? ENC_X6_THREADS : 512, X6 ? 1 : 2)
 k_encode_batch(Batch<EncArgs> B, int S, const float* __restrict__ wblob, int64_t N) {
     encode_body<X6, DIF_MAX_STREAMS>(B, S, wblob, N);
 }
