@@ -1,5 +1,7 @@
 #!/bin/bash
-# the one-pass marching cubes of a stream frame with and without the XCD-aware dealing of groups: launch time (HIP events) and counter traffic
+# the one-pass marching cubes of a stream frame with and without the XCD-aware dealing of groups: launch time (HIP events) and counter traffic.
+# Build the variant HERE first (ab_old/ travels with the snapshot): hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared
+#   -DNDEBUG -DMC_XCD_RUN=1 -DDIF_BUILD_ID='"sw"' di_fusion_amd/csrc/difusion.hip -o ab_old/libdif_run1.so      (MC_XCD_RUN=1: group = workgroup index)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/swz; mkdir -p $out
 for v in run1 main run1 main; do
