@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather_batch(Batch<GatherAr
 #define DIF_DIR_IDS (DIF_DIR_WORDS - 2)
 
 #ifdef DIF_TRACE            // tools/trace_decode.py --encode: per-wave phase timestamps (100 MHz wall clock) of the last k_encode launch
-__device__ unsigned long long g_en_trace[2048 * 8];
+__device__ unsigned long long g_en_trace[4096 * 8];       // (up to 16 waves x 256 workgroups; the x6 kernel runs 12 waves per workgroup)
 #define EN_STAMP(slot) do { if (lane_id() == 0) g_en_trace[((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
 #else
 #define EN_STAMP(slot) do { } while (0)

@@ -64,8 +64,9 @@ def main():
            "list_us_median": float(np.median((t[act, 4] - t[act, 3]) / 100.0))}
     print(json.dumps(out))
     # k_encode: 0 entry, 1 staged, 2 last tile's inputs gathered, 3 its MFMA chain done, 4 its records written, 5 exit
-    assert lib.dif_trace_read_encode(buf, 2048 * 8) == 0
-    e = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8).astype(np.int64)
+    buf = (ctypes.c_ulonglong * (4096 * 8))()          # (the x6 encoder runs 12 waves per workgroup: 3,072 of the 4,096 rows)
+    assert lib.dif_trace_read_encode(buf, 4096 * 8) == 0
+    e = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
     e0 = e[:, 0][e[:, 0] > 0].min()
     act = (e[:, 2] > e[:, 1]) & (e[:, 1] >= e0)
     ue = lambda x: (x - e0) / 100.0
