@@ -2,7 +2,7 @@
 # a long seeded soak of the differential fuzzers (seeds the suite does not use) and the repeat-determinism check; the tails go to gpurun_out/soak/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/soak; mkdir -p $out
-for seed in 101 102 103; do
+for seed in ${SOAK_SEEDS:-101 102 103}; do
   timeout 1200 python tools/fuzz_integrate.py --cases 120 --seed $seed > $out/integrate_$seed.log 2>&1; echo "integrate $seed rc=$? $(tail -1 $out/integrate_$seed.log)"
   timeout 900 python tools/fuzz_mc.py --cases 300 --seed $seed > $out/mc_$seed.log 2>&1; echo "mc $seed rc=$? $(tail -1 $out/mc_$seed.log)"
   timeout 900 python tools/fuzz_cloud.py --cases 150 --seed $seed > $out/cloud_$seed.log 2>&1; echo "cloud $seed rc=$? $(tail -1 $out/cloud_$seed.log)"
