@@ -50,7 +50,7 @@ def parse():
                     "itself (device copies of the size that would go over xGMI): export / merge kernels and message sizes land in the timed region")
     ap.add_argument("--halo", default="delta", choices=["delta", "full"], help="--mode tiled: bounded delta halo messages (default) or whole boundary layers")
     ap.add_argument("--noise", type=int, default=0)
-    ap.add_argument("--d2h", default="new", choices=["none", "new", "full"], help="what leaves the GPU each frame")
+    ap.add_argument("--d2h", default="auto", choices=["auto", "none", "new", "dma", "full"], help="what leaves the GPU each frame.  new / dma: the frame's new triangles, to pinned host memory, written by kernels (the next frame's first ones carry them) / by the copy engine beside the next frame's kernels; auto (default): dma for one directly launched stream on one GPU, new for stream groups, graphs, the tiled mode and multi-rank runs")
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the frame's launches from a captured hipGraph (every --sample-every-th frame runs "
                     "eagerly with HIP events around the MFMA kernels); 0 (default): launch them directly, two C calls per frame, HIP events on every "
@@ -296,7 +296,7 @@ def streams_leg(make_stream_j, S, a, n_frames, lib, pipe):
     import gc
     streams = [make_stream_j(j) for j in range(S)]
     aa = argparse.Namespace(**{**vars(a), "timed_from": None})
-    gb = GroupBench(streams, aa, a.d2h, lib)
+    gb = GroupBench(streams, aa, "new" if a.d2h == "dma" else a.d2h, lib)       # (a group's frames carry their export themselves: 3 S copies per group frame cost the host more)
     dt, recs = timed_run(gb.run, gb.drain, aa, n_frames, lib, torch.cuda.synchronize)
     st = gb.frame_stats(a.warmup)
     timed_idx = [j for j in range(a.steps) if (a.warmup + j) >= 1 and ((a.warmup + j) % a.sample_every) == 0]
@@ -559,6 +559,10 @@ def main():
                             initial_capacity=cap0)   # own arc of the orbit
 
     S_main = int(a.streams_per_gpu)
+    if a.d2h == "auto":
+        # (measured: in a process that has initialised RCCL the copy-engine delivery is ~6 % SLOWER than the kernel-carried one, 4,160 against
+        # 4,430 frames/s over 50 frames with one rank — so the multi-rank runs keep "new")
+        a.d2h = "dma" if (a.direct and not a.graph and a.batch == 0 and S_main <= 1 and not tiled and not use_dist) else "new"
     if S_main < 0 or S_main > _lib.MAX_STREAMS or (S_main >= 1 and (tiled or a.graph or a.batch)):
         raise SystemExit(f"bench.py --streams-per-gpu: 0..{_lib.MAX_STREAMS}, with --mode c4 and direct launches")
 
@@ -623,7 +627,7 @@ def main():
     if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled and a.steps >= 100 and gb is None:
         hbm_resident = secondary_rate(make_stream, a, n_frames, "none", 0)
         if a.batch == 0 and a.direct and not a.graph:        # (a per-frame-graph run would mix two sets of captured graphs on one stream)
-            batched = secondary_rate(make_stream, a, n_frames, a.d2h, 5)
+            batched = secondary_rate(make_stream, a, n_frames, "new" if a.d2h == "dma" else a.d2h, 5)
     # S independent subsequences per GPU sharing their launches: aggregate frames/s and the MFMA kernels' roofline at S = 2, 4, 8
     by_streams = {}
     if world == 1 and not a.no_secondary and not tiled and gb is None and a.direct and not a.graph and a.batch == 0 and a.warmup + a.steps >= 2:

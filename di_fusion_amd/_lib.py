@@ -106,6 +106,7 @@ SIGNATURES = {
     "dif_extract_streams": (c_int32, [POINTER(DifStreamFrame), c_int32, POINTER(DifWeights), c_int32, c_float, c_int32, c_void_p]),
     "dif_export_pending": (c_int32, [POINTER(DifMap), c_void_p]),
     "dif_mesh_cache_export": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dif_mesh_cache_export_dma": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dif_mesh_cache_compact": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "dif_mesh_cache_reindex": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_int64, c_void_p]),
     "dif_marching_cubes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p,

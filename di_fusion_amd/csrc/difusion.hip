@@ -1189,6 +1189,16 @@ int dif_mesh_cache_export(const dif_extract_buffers_t* buf, int64_t lo, int64_t 
     return DIF_OK;
 }
 
+int dif_mesh_cache_export_dma(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std, void* stream) {
+    if (!buf || lo < 0 || n < 0 || lo + n > buf->cache_capacity || (n > 0 && (!out_tri || !out_id || !out_std))) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(out_tri, (const float*)buf->cache_tri + lo * 9, (size_t)n * 9 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) return DIF_ELAUNCH;
+    if (hipMemcpyAsync(out_id, (const int64_t*)buf->cache_id + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return DIF_ELAUNCH;
+    if (hipMemcpyAsync(out_std, (const float*)buf->cache_std + lo * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) return DIF_ELAUNCH;
+    return DIF_OK;
+}
+
 int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,
                            int64_t out_capacity, int32_t* scratch, void* stream) {
     if (!map || !buf || !out_tri || !out_id || !out_std || !scratch || out_capacity <= 0) return DIF_EINVAL;

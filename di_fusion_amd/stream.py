@@ -88,7 +88,9 @@ class FusionStream:
 
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
-        d2h: "none" leaves the mesh in HBM; "new" copies this frame's new triangles to pinned host memory (async);
+        d2h: "none" leaves the mesh in HBM; "new" copies this frame's new triangles to pinned host memory (async; written by the frame's
+        kernels, or — direct frames — carried by the next frame's first kernels); "dma": the same delivery by the copy engine on a side stream,
+        once the frame's stamp has been seen (direct frames of one stream; elsewhere it delivers as "new");
         "full" copies the whole merged cache to the host like the reference's numpy cache."""
         intr = self.intr
         R, t = self.poses[i]
@@ -99,7 +101,7 @@ class FusionStream:
         self.map.integrate_keyframe(self.xyz, self.nrm)
         self._exchange_halo()
         out = self.map.extract_mesh_arrays(self.resolution, self.max_n_triangles, max_std=self.max_std, to_host=(d2h == "full"))
-        if d2h == "new" and out is not None:
+        if d2h in ("new", "dma") and out is not None:
             tri, tid, tstd = self.map.mesh_cache_tensors(new_only=True)
             n = tri.size(0)
             if self._pin is None or self._pin[0].size(0) < n:
@@ -195,6 +197,26 @@ class FusionStream:
                 out = (hp[0][:n], hp[1][:n], hp[2][:n])
             else:
                 out = self._export_new(handle, tri, tid, tstd)
+        elif d2h == "dma":
+            # The frame is complete — its stamp, written behind a system-scope fence by the last kernel of its extract, has been seen — and its new
+            # triangles sit in the log (mesh left in HBM).  The copy engine takes them to the frame's pinned slot on a side stream while the
+            # next frame's kernels, enqueued already, run: no kernel carries the PCIe transfer and no event sits in the main queue.
+            # (What the engine reads was written by an EARLIER kernel of the frame than the one that stamps: that kernel's end-of-kernel release
+            # has written its lines back — on gfx942 / gfx950 every release at agent scope does, the eight L2s are not coherent with each other.)
+            n = tri.size(0)
+            k = handle.get("dma_slot")
+            if n and k is not None and n <= self.HOST_OUT_TRIANGLES:
+                sl = handle["host_slots"][k]
+                with torch.cuda.device(self.device):
+                    with torch.cuda.stream(self._copy_stream):
+                        _lib.check(_lib.load().dif_mesh_cache_export_dma(ctypes.byref(self.map._cache_struct()), tri.storage_offset() // 9, n, sl["out_ptr"][0],
+                                                                         sl["out_ptr"][1], sl["out_ptr"][2], _lib.stream_ptr()), "dif_mesh_cache_export_dma")
+                        sl["export_event"].record()
+                    sl["export_event"].synchronize()
+                hp = sl["out"]
+                out = (hp[0][:n], hp[1][:n], hp[2][:n])
+            elif n:
+                out = self._export_new(handle, tri, tid, tstd)
         elif d2h == "full":
             mc = self.map.mesh_cache
             out = (mc.vertices, mc.vertices_flatten_id, mc.vertices_std)
@@ -251,6 +273,7 @@ class FusionStream:
                 sl["frame_np"] = sl["frame"].numpy()
                 sl["counters_np"] = sl["counters"].numpy()
                 sl["notify_np"] = sl["notify"].numpy()
+                sl["out_ptr"] = tuple(_lib.ptr(t) for t in sl["out"])
             self._d_mask = torch.empty((H * W,), dtype=torch.uint8, device=dev)
             self._d_seq = 0
             self._d_desc = [np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8).copy()
@@ -342,6 +365,8 @@ class FusionStream:
         m.mesh_cache.invalidate_host_copy()
         h = dict(stamp=int(buf.stamp), counters=sl["counters_np"], epoch=m._gc_epoch, add_total=m._add_total, max_n_triangles=self.max_n_triangles,
                  host_out=(k if export else None), host_slots=self._d_slots, deferred=bool(buf.defer_export))
+        if d2h == "dma":
+            h["dma_slot"] = k
         done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
         if done:
             self.backlog += done[:-1]

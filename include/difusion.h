@@ -347,6 +347,12 @@ int dif_extract_streams(const dif_stream_frame_t* streams /* [host][S] */, int32
  * streaming caller ships each call's new triangles (lo = DIF_C_CACHE_KEPT, n = DIF_C_CACHE_T - lo) without copy-engine transfers. */
 int dif_mesh_cache_export(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std,
                           void* stream);
+/* The same rows by the COPY ENGINE (three hipMemcpyAsync device -> pinned host on `stream`, no kernel): for a caller that knows the frame
+ * is complete — it has seen the frame's stamp (dif_extract_buffers_t.stamp), or `stream` is ordered behind the extract — and wants the
+ * transfer beside the next frame's kernels instead of inside them.
+ * Replaces the host copy of map.py:703-714 (`.cpu().numpy()` of the three marching-cubes outputs). */
+int dif_mesh_cache_export_dma(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std,
+                              void* stream);
 /* Materialise the live cache entries in log order into (out_tri, out_id, out_std); count -> counters[DIF_C_CACHE_LIVE].
  * scratch: int32 [4096]. */
 int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,

@@ -146,6 +146,44 @@ def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
         assert in_stream == 0 and early <= 1               # only the last frame (at flush) needed the stand-alone copy
 
 
+@pytest.mark.parametrize("grouped", [False, True], ids=["one_stream", "group_of_three"])
+def test_copy_engine_delivery_equals_kernel_delivery(grouped, gpu_model):
+    """d2h="dma": a direct frame's new triangles go to its pinned slot by the copy engine (`dif_mesh_cache_export_dma` on a side stream, once
+    the frame's stamp has been seen) instead of riding with the next frame's kernels — the same triangles, frame by frame, and the same map,
+    also across a forced compaction of the mesh log and mixed with kernel-delivered frames."""
+    from di_fusion_amd.stream import FusionStreamGroup
+    S = 3 if grouped else 1
+
+    def run(mode_of):
+        streams = [make_stream(gpu_model, initial_capacity=None) for _ in range(S)]
+        got = [[] for _ in range(S)]
+        for j, st in enumerate(streams):
+            got[j].append(_eager(st, 0))
+        grp = FusionStreamGroup(streams) if grouped else None
+        for i in range(1, N_FRAMES):
+            if i == 3:
+                for st in streams:
+                    st.map._gc_wanted = True               # a compaction of the log between two frames
+            outs = grp.step(i, d2h=mode_of(i)) if grouped else [streams[0].step_direct(i, d2h=mode_of(i))]
+            torch.cuda.synchronize()        # (a frame finished under another mode than it was launched with is delivered by the async fallback copy)
+            for j, o in enumerate(outs):
+                if o is not None:
+                    got[j].append(tuple(x.clone() for x in o))
+        outs = grp.flush(mode_of(N_FRAMES)) if grouped else [streams[0].flush(mode_of(N_FRAMES))]
+        for j, o in enumerate(outs):
+            got[j].append(tuple(x.clone() for x in o))
+        return got, [snapshot(st) for st in streams]
+
+    want, want_map = run(lambda i: "new")
+    for mode_of in (lambda i: "dma", lambda i: "dma" if i % 2 else "new"):
+        got, got_map = run(mode_of)
+        for j in range(S):
+            assert len(got[j]) == len(want[j]) == N_FRAMES
+            for f, (a, b) in enumerate(zip(want[j], got[j])):
+                assert a[0].shape[0] > 0 and all(torch.equal(x, y) for x, y in zip(a, b)), f"stream {j} frame {f}"
+            same(want_map[j], got_map[j])
+
+
 @pytest.mark.parametrize("other", ["graph", "pipelined", "eager"])
 def test_compaction_with_a_deferred_export_pending(other, gpu_model):
     """A `step_direct` frame leaves its triangle export pending (absolute log rows); the NEXT frame is driven by another stepping mode on
