@@ -50,7 +50,7 @@ def parse():
                     "itself (device copies of the size that would go over xGMI): export / merge kernels and message sizes land in the timed region")
     ap.add_argument("--halo", default="delta", choices=["delta", "full"], help="--mode tiled: bounded delta halo messages (default) or whole boundary layers")
     ap.add_argument("--noise", type=int, default=0)
-    ap.add_argument("--d2h", default="auto", choices=["auto", "none", "new", "dma", "full"], help="what leaves the GPU each frame.  new / dma: the frame's new triangles, to pinned host memory, written by kernels (the next frame's first ones carry them) / by the copy engine beside the next frame's kernels; auto (default): dma for one directly launched stream on one GPU, new for stream groups, graphs, the tiled mode and multi-rank runs")
+    ap.add_argument("--d2h", default="auto", choices=["auto", "none", "new", "dma", "full"], help="what leaves the GPU each frame.  new / dma: the frame's new triangles, to pinned host memory, written by kernels (the next frame's first ones carry them) / by the copy engine beside the next frame's kernels; auto (default): dma for one directly launched stream per GPU, new for stream groups, graphs and the tiled mode")
     ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the frame's launches from a captured hipGraph (every --sample-every-th frame runs "
                     "eagerly with HIP events around the MFMA kernels); 0 (default): launch them directly, two C calls per frame, HIP events on every "
@@ -363,11 +363,18 @@ def global_map_merge(local_maps, model, cfg, dev, barrier):
     """BASELINE config C4: after the independent subsequences, ONE all-gather of voxel records over RCCL and a fold into a global map
     (identical on every rank), meshed once.  Outside the clock (once per sequence, not per frame); reported, never fatal."""
     try:
+        import torch.distributed as dist
         from di_fusion_amd import parallel
         from di_fusion_amd.system.map import DenseIndexedMap
+        grp = None
+        if dist.get_backend() == "gloo" and os.environ.get("DIF_BENCH_REHEARSAL") != "1":
+            grp = dist.new_group(backend="nccl")                     # RCCL comes up here, behind the clock (see main)
+            dist.barrier(group=grp, device_ids=[dev.index])          # (its first collective builds the communicator)
+            torch.cuda.synchronize()
+            flush_c_stdio()
         barrier()
         tm = time.perf_counter()
-        gmap = parallel.build_global_map(local_maps, lambda: DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1 << 17))
+        gmap = parallel.build_global_map(local_maps, lambda: DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1 << 17), group=grp)
         torch.cuda.synchronize()
         t_merge = time.perf_counter() - tm
         gmesh = gmap.extract_mesh_arrays(4, int(8e6), max_std=0.15, no_cache=True, to_host=False)
@@ -517,7 +524,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if rehearsal:
+        # --mode c4 has no collective inside the clock (independent subsequences): the barriers and the max-over-ranks of the time go over
+        # gloo, and RCCL is brought up BEHIND the clock for the exchange step (the global map merge: dist.new_group("nccl") there).  A process
+        # that has initialised RCCL runs the copy-delivered export 10 % slower (5,100 against 5,870 frames/s with one rank, measured; gloo
+        # does not) — this keeps a rank of an N-GPU run on the same path, and at the same rate, as the single-GPU run.  --mode tiled
+        # exchanges halos inside every frame: RCCL from the start.
+        clock_over_gloo = rehearsal or a.mode != "tiled"
+        if clock_over_gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -560,9 +573,7 @@ def main():
 
     S_main = int(a.streams_per_gpu)
     if a.d2h == "auto":
-        # (measured: in a process that has initialised RCCL the copy-engine delivery is ~6 % SLOWER than the kernel-carried one, 4,160 against
-        # 4,430 frames/s over 50 frames with one rank — so the multi-rank runs keep "new")
-        a.d2h = "dma" if (a.direct and not a.graph and a.batch == 0 and S_main <= 1 and not tiled and not use_dist) else "new"
+        a.d2h = "dma" if (a.direct and not a.graph and a.batch == 0 and S_main <= 1 and not tiled) else "new"
     if S_main < 0 or S_main > _lib.MAX_STREAMS or (S_main >= 1 and (tiled or a.graph or a.batch)):
         raise SystemExit(f"bench.py --streams-per-gpu: 0..{_lib.MAX_STREAMS}, with --mode c4 and direct launches")
 
@@ -619,7 +630,7 @@ def main():
     if n_rec < 0:
         raise SystemExit("dif_profile_dump failed")
     if use_dist:
-        tt = torch.tensor([dt], device=("cpu" if rehearsal else dev), dtype=torch.float64)
+        tt = torch.tensor([dt], device=("cpu" if clock_over_gloo else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     hbm_resident = batched = None
