@@ -89,7 +89,7 @@ class FusionStream:
     def step(self, i: int, d2h: str = "new"):
         """One frame: unproject+transform (a1,a2) -> integrate (a3-a10) -> decode + marching cubes + mesh cache (a11-a16).
         d2h: "none" leaves the mesh in HBM; "new" copies this frame's new triangles to pinned host memory (async; written by the frame's
-        kernels, or — direct frames — carried by the next frame's first kernels); "dma": the same delivery by the copy engine on a side stream,
+        kernels, or — direct frames — carried by the next frame's first kernels); "dma": the same delivery by hipMemcpyAsync on a side stream,
         once the frame's stamp has been seen (direct frames of one stream; elsewhere it delivers as "new");
         "full" copies the whole merged cache to the host like the reference's numpy cache."""
         intr = self.intr
@@ -199,10 +199,12 @@ class FusionStream:
                 out = self._export_new(handle, tri, tid, tstd)
         elif d2h == "dma":
             # The frame is complete — its stamp, written behind a system-scope fence by the last kernel of its extract, has been seen — and its new
-            # triangles sit in the log (mesh left in HBM).  The copy engine takes them to the frame's pinned slot on a side stream while the
-            # next frame's kernels, enqueued already, run: no kernel carries the PCIe transfer and no event sits in the main queue.
-            # (What the engine reads was written by an EARLIER kernel of the frame than the one that stamps: that kernel's end-of-kernel release
-            # has written its lines back — on gfx942 / gfx950 every release at agent scope does, the eight L2s are not coherent with each other.)
+            # triangles sit in the log (mesh left in HBM).  Three hipMemcpyAsync (blit kernels on this runtime) take them to the frame's pinned slot
+            # on a side stream while the next frame's kernels, enqueued already, run: none of the frame's own kernels carries the PCIe transfer
+            # and no event sits in the main queue.
+            # (What the copy reads was written by an EARLIER kernel of the frame than the one that stamps: that kernel's end-of-kernel release
+            # has written its lines back — on gfx942 / gfx950 every release at agent scope does, the eight L2s are not coherent with each other —
+            # and the copy kernel starts with the matching acquire.)
             n = tri.size(0)
             k = handle.get("dma_slot")
             if n and k is not None and n <= self.HOST_OUT_TRIANGLES:
