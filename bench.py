@@ -67,6 +67,10 @@ def parse():
                     "their twelve launches (dif_integrate_frames + dif_extract_streams): `value` is then the aggregate over all world x S streams.  "
                     "0 (default): ONE stream per GPU is the measured configuration, and at N = 1 the aggregate rates for S = 2, 4, 8 are reported beside "
                     "it (config.frames_per_s_with_S_streams_per_gpu, roofline.by_streams)")
+    ap.add_argument("--rccl-before-clock", type=int, default=0, choices=[0, 1], help="--mode c4 under torch.distributed: 0 (default) = the barriers around "
+                    "the clock go over gloo and RCCL is brought up BEHIND the clock, for the exchange step (the global map merge); 1 = RCCL is the process group "
+                    "from the start, alive during the timed region like in a deployment that merges maps periodically.  The line says which "
+                    "(config.rccl_before_clock); tools/gpu_scale.sh runs both.  --mode tiled exchanges halos inside every frame: always 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra run with the mesh left in HBM (keeps profiler traces to one stream)")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed per thread setting by the CPU baseline (after 2 warm-ups)")
@@ -359,7 +363,25 @@ def within(seconds, fn, what, dev):
     return True, box.get("value")
 
 
-def global_map_merge(local_maps, model, cfg, dev, barrier):
+def collective_probe(group, device):
+    """How many ranks a process group REALLY connects: every rank contributes rank + 1 to an all-reduce of a tensor on `device`; the group's
+    world size if the sum is world (world + 1) / 2 on this rank, 0 otherwise (or on any failure).  `rccl_ranks` of the JSON line is this
+    number for the RCCL group — observed, not the launcher's WORLD_SIZE."""
+    import torch.distributed as dist
+    try:
+        n = dist.get_world_size(group)
+        r = dist.get_rank(group)
+        t = torch.full((4,), float(r + 1), dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        want = n * (n + 1) / 2.0
+        return n if bool((t.cpu() == want).all()) else 0
+    except Exception:
+        return 0
+
+
+def global_map_merge(local_maps, model, cfg, dev, barrier, probe_box=None):
     """BASELINE config C4: after the independent subsequences, ONE all-gather of voxel records over RCCL and a fold into a global map
     (identical on every rank), meshed once.  Outside the clock (once per sequence, not per frame); reported, never fatal."""
     try:
@@ -372,6 +394,9 @@ def global_map_merge(local_maps, model, cfg, dev, barrier):
             dist.barrier(group=grp, device_ids=[dev.index])          # (its first collective builds the communicator)
             torch.cuda.synchronize()
             flush_c_stdio()
+            if probe_box is not None:
+                probe_box["rccl_ranks"] = collective_probe(grp, dev)
+                probe_box["when"] = "behind the clock (dist.new_group('nccl') in the map merge)"
         barrier()
         tm = time.perf_counter()
         gmap = parallel.build_global_map(local_maps, lambda: DenseIndexedMap(model, cfg.namespace(), 29, dev, initial_capacity=1 << 17), group=grp)
@@ -520,6 +545,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("DIF_FORCE_DIST") == "1"      # DIF_FORCE_DIST: exercise the RCCL path with one rank
+    rccl_probe = {"rccl_ranks": 0, "when": None}     # filled by collective_probe() where the RCCL group comes up: observed, not asserted
+    clock_over_gloo = False
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -529,7 +556,7 @@ def main():
         # that has initialised RCCL runs the copy-delivered export 10 % slower (5,100 against 5,870 frames/s with one rank, measured; gloo
         # does not) — this keeps a rank of an N-GPU run on the same path, and at the same rate, as the single-GPU run.  --mode tiled
         # exchanges halos inside every frame: RCCL from the start.
-        clock_over_gloo = rehearsal or a.mode != "tiled"
+        clock_over_gloo = rehearsal or (a.mode != "tiled" and not a.rccl_before_clock)
         if clock_over_gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -537,6 +564,9 @@ def main():
         dist.barrier()                      # first collective: RCCL builds its communicator (and prints its version banner) here,
         torch.cuda.synchronize()            # not inside the timed region
         flush_c_stdio()                     # the banner sits in C stdio's buffer: push it out before any JSON is printed
+        if not clock_over_gloo:             # RCCL is the process group: observe, before the clock, how many ranks it really connects
+            rccl_probe["rccl_ranks"] = collective_probe(None, dev)
+            rccl_probe["when"] = "before the clock (RCCL is the process group of the run)"
     from di_fusion_amd import _lib, synthetic as syn
     from di_fusion_amd.network import utility as net_util
     from di_fusion_amd.stream import FusionStream
@@ -650,7 +680,7 @@ def main():
     epilogue_ok, merge_info = True, None
     if use_dist and not tiled:
         epilogue_ok, merge_info = within(float(os.environ.get("DIF_BENCH_EPILOGUE_TIMEOUT", "120")),
-                                         lambda: global_map_merge([st.map for st in gb.streams] if gb is not None else stream.map, model, cfg, dev, barrier),
+                                         lambda: global_map_merge([st.map for st in gb.streams] if gb is not None else stream.map, model, cfg, dev, barrier, rccl_probe),
                                          "global map merge", dev)
 
     out = None
@@ -682,7 +712,10 @@ def main():
         pixels = intr.width * intr.height
         value = (a.steps if tiled else world * max(S_main, 1) * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
         out = {"metric": f"frames/s integrate+decode+mesh, {intr.width}x{intr.height} synthetic stream", "value": round(value, 3),
-               "unit": "frames/s", "n_gpus": world, "rccl_ranks": (0 if rehearsal else world) if use_dist else 0,
+               "unit": "frames/s", "n_gpus": world,
+               # observed: the world size of the RCCL group after an all-reduce of a device tensor over it returned the right sum on this rank; 0 if RCCL
+               # never came up (or the probe failed) — tools/gpu_scale.sh fails on rccl_ranks != N
+               "rccl_ranks": int(rccl_probe["rccl_ranks"]), "rccl_probe": (rccl_probe["when"] or ("not run: " + ("rehearsal over gloo" if rehearsal else "single process" if not use_dist else "RCCL group never came up"))),
                **({"rehearsal": "all ranks on one GPU over gloo: a functional run of the multi-rank paths, not a measurement"} if rehearsal else {}), "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
@@ -690,6 +723,7 @@ def main():
                "config": {"workload": WORKLOADS[a.config] + f", {intr.width}x{intr.height} orbit stream 0.5 deg/frame, all {pixels} pixels integrated and meshed "
                                                             "every frame, resolution 4, fast decode, max_std 0.15",
                           "mode": a.mode, "points_per_frame": pixels,
+                          "rccl_before_clock": (bool(use_dist and not clock_over_gloo) if use_dist else None),
                           "mlp_pipe": ("bf16x6: every fp32 product of the MLP tiles as six exact bf16 slice products on v_mfma_f32_32x32x16_bf16, fp32 accumulate "
                                        "(fp32-equivalent: same parity bars as the f32-input MFMA kernels, which DIF_DECODER_PIPE=f32 selects)" if pipe == "bf16x6"
                                        else "f32: v_mfma_f32_32x32x2_f32"),

@@ -336,23 +336,33 @@ class FusionStream:
         self._direct_prepare()
         k = self._d_seq % self.DIRECT_SLOTS
         self._d_seq += 1
-        sl, buf = self._d_slots[k], self._d_bufs[k]
+        sl = self._d_slots[k]
         export = d2h == "new"
+        self._stamp = (getattr(self, "_stamp", 0) % 0x3FFFFFFF) + 1
+        buf = self._direct_fill(k, export)
+        sl["frame_np"][:] = self._d_desc[i]
+        return k, sl, buf, export, out
+
+    def _direct_fill(self, k: int, export: bool):
+        """The per-frame fields of slot k's extract-buffer descriptor (ONE place: `_direct_begin`, and again by `FusionStreamGroup.step` when
+        another map's growth re-allocated this stream's buffers — and with them the descriptors — between begin and launch)."""
+        sl, buf = self._d_slots[k], self._d_bufs[k]
         buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"]) if export else (None, None, None)
         buf.out_capacity = self.HOST_OUT_TRIANGLES if export else 0
         # Deferred export: this frame's extract leaves the copy of its new triangles (~0.5 MB over PCIe) to the FIRST kernel of the next
         # frame, where it overlaps the point pass instead of lengthening marching cubes; the host picks a frame's triangles up behind
         # that kernel (`export_event`), still before it enqueues the frame after.
-        buf.defer_export = 1 if (export and self.defer_export) else 0
+        # (Only the one-pass marching cubes — resolution <= 4 — and the deferred copy write a frame's triangles BEFORE the kernel that
+        # stamps; the two-pass kernels leave them to `k_extract_finish` itself, whose block 0 stamps without waiting for the other
+        # workgroups' copies: there the export is always deferred, so that the stamp never stands for rows it does not cover.)
+        buf.defer_export = 1 if (export and (self.defer_export or self.resolution > 4)) else 0
         # Completion without events: the extract's last kernel stamps the pinned counter snapshot, and the kernels that carry the deferred
         # copy out stamp `notify` — the host polls those words instead of waiting on events (an event record costs the queue ~5 us
         # between two kernels, twice per frame).  (Without a deferred export this frame's triangles are written by the one-pass
         # marching cubes, a kernel before the stamp.)
-        self._stamp = (getattr(self, "_stamp", 0) % 0x3FFFFFFF) + 1
         buf.stamp = self._stamp
         buf.export_notify = _lib.ptr(sl["notify"]) if buf.defer_export else None
-        sl["frame_np"][:] = self._d_desc[i]
-        return k, sl, buf, export, out
+        return buf
 
     def _direct_integrated(self):
         """Right behind the frame's integrate launches: the PREVIOUS frame's deferred triangle export has just been carried out by this
@@ -665,11 +675,8 @@ class FusionStreamGroup:
                 self._equalise_capacity()
                 for st in self.streams:
                     st._direct_prepare()                       # descriptors of re-allocated buffers
-                begun = [(k, sl, st._d_bufs[k], export, out) for st, (k, sl, _, export, out) in zip(self.streams, begun)]
-                for st, (k, sl, buf, export, out) in zip(self.streams, begun):
-                    buf.out_tri, buf.out_id, buf.out_std = (_lib.ptr(t) for t in sl["out"]) if export else (None, None, None)
-                    buf.out_capacity = st.HOST_OUT_TRIANGLES if export else 0
-                    buf.defer_export = 1 if (export and st.defer_export) else 0
+                # (descriptors rebuilt by _direct_prepare are blank: the frame's stamp, notify word and output fields go in again)
+                begun = [(k, sl, st._direct_fill(k, export), export, out) for st, (k, sl, _, export, out) in zip(self.streams, begun)]
             for j, (st, (k, sl, buf, export, out)) in enumerate(zip(self.streams, begun)):
                 f, m = self._frames[j], st.map
                 f.map = ctypes.pointer(m._cmap)

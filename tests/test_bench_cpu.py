@@ -51,3 +51,78 @@ def test_launcher_contract_is_loud():
     env = {k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n + 2)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
+
+
+def _probe_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, str(ROOT))
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    whole = bench.collective_probe(None, torch.device("cpu"))
+    alone = bench.collective_probe(None, torch.device("cpu"))      # (a second probe on the same group)
+    q.put((rank, whole, alone))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_probe_counts_the_ranks_it_really_reaches():
+    """`rccl_ranks` of the bench line is OBSERVED: the world size of the group after an all-reduce over it returned the right sum.  Two
+    live gloo ranks -> 2 on both; a group whose collective fails, or returns a wrong sum, -> 0."""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_probe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, 2, 2), (1, 2, 2)]
+    # no process group at all (the RCCL group "never came up"): the probe reports 0 instead of raising
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert bench.collective_probe(None, torch.device("cpu")) == 0
+
+    class Silent:           # a group whose all-reduce returns without summing (what a half-connected transport would look like)
+        pass
+    import torch.distributed as dist
+    orig = (dist.get_world_size, dist.get_rank, dist.all_reduce)
+    try:
+        dist.get_world_size, dist.get_rank, dist.all_reduce = (lambda g=None: 2), (lambda g=None: 0), (lambda t, op=None, group=None: None)
+        assert bench.collective_probe(Silent(), torch.device("cpu")) == 0
+    finally:
+        dist.get_world_size, dist.get_rank, dist.all_reduce = orig
+
+
+def test_every_json_under_profiles_parses():
+    """profiles/*.json are read by bench.py (static PMC figures) and cited by the judge: none may carry a launcher banner in front of its line
+    (tools/install_profiles.sh strips them)."""
+    import json
+    bad = []
+    for p in sorted((ROOT / "profiles").glob("*.json")):
+        try:
+            json.loads(p.read_text())
+        except Exception as e:
+            bad.append((p.name, repr(e)[:80]))
+    for p in sorted((ROOT / "profiles").glob("*.jsonl")):
+        for k, line in enumerate(p.read_text().strip().splitlines()):
+            try:
+                json.loads(line)
+            except Exception as e:
+                bad.append((f"{p.name}:{k}", repr(e)[:80]))
+    assert not bad, bad
+
+
+def test_scale_script_fails_on_unobserved_rccl():
+    """tools/gpu_scale.sh checks the OBSERVED rank count, the merge outcome and which side of the clock RCCL came up on."""
+    t = (ROOT / "tools" / "gpu_scale.sh").read_text()
+    assert "rccl_ranks" in t and "rccl_probe" in t and "global map merge failed" in t and "rccl_before_clock" in t and "c4rccl" in t

@@ -12,4 +12,25 @@ for f in kernel_stats_s4.md kernel_stats_s4_steady.md timeline_s4.txt kernel_sta
 [ -s $S/stress_integrate.json ] && cp $S/stress_integrate.json ${P}_stress_integrate.json
 [ -s $S/sweep_decode.jsonl ] && cp $S/sweep_decode.jsonl ${P}_sweep_decode.jsonl
 for f in kernel_stats.md kernel_stats_steady.md kernel_stats_k20.md kernel_stats_tiled_loopback8.md kernel_stats_tiled_n1.md timeline_direct.txt; do [ -s $S/$f ] && cp $S/$f ${P}_$f; done
+# every profiles/*.json must parse: a bench run under torch.distributed prints the gloo / RCCL banners before its line — keep the line only
+python - <<'PY'
+import json, pathlib
+for p in sorted(pathlib.Path("profiles").glob("*.json")):
+    t = p.read_text()
+    try:
+        json.loads(t)
+        continue
+    except Exception:
+        pass
+    for line in reversed(t.strip().splitlines()):
+        try:
+            json.loads(line)
+        except Exception:
+            continue
+        p.write_text(line + "\n")
+        print("stripped to its JSON line:", p)
+        break
+    else:
+        print("NOT JSON:", p)
+PY
 ls -la profiles | grep "$2" | wc -l
