@@ -82,6 +82,7 @@ class FusionStream:
         # xyz_world = normal_world = NULL: the stages that need a point recompute it from the depth pixel, bit-identically); True = into self.xyz / self.nrm
         self.keep_points = False
         self.backlog = []                   # outputs of a pending batch's earlier frames, when a frame-by-frame step had to complete it
+        self.last_unq_mask = None           # eager / pipelined frames: the (H*W,) prune mask of the latest integrate (direct frames: `_d_mask`)
 
     def _pts(self):
         return (_lib.ptr(self.xyz), _lib.ptr(self.nrm)) if self.keep_points else (_lib.ptr(None), _lib.ptr(None))
@@ -98,7 +99,7 @@ class FusionStream:
             _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(self.depth[i]), _lib.ptr(self.ncam[i]), _lib.ptr(self.xyz), _lib.ptr(self.nrm),
                                                            intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
                        "dif_unproject_transform")
-        self.map.integrate_keyframe(self.xyz, self.nrm)
+        self.last_unq_mask = self.map.integrate_keyframe(self.xyz, self.nrm)
         self._exchange_halo()
         out = self.map.extract_mesh_arrays(self.resolution, self.max_n_triangles, max_std=self.max_std, to_host=(d2h == "full"))
         if d2h in ("new", "dma") and out is not None:
@@ -142,7 +143,7 @@ class FusionStream:
             _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(self.depth[i]), _lib.ptr(self.ncam[i]), _lib.ptr(self.xyz), _lib.ptr(self.nrm),
                                                            intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
                        "dif_unproject_transform")
-        self.map.integrate_keyframe(self.xyz, self.nrm)
+        self.last_unq_mask = self.map.integrate_keyframe(self.xyz, self.nrm)
         self._exchange_halo()
         return self.map.extract_mesh_enqueue(self.resolution, self.max_n_triangles, max_std=self.max_std)
 

@@ -101,9 +101,24 @@ static f2 get_sdf(const ctx_t* c, unsigned r, unsigned bpx, unsigned bpy, unsign
     return out;
 }
 
+/* Census of sdf_interp's branches (tests/test_oracle_mc.py::test_fma_contraction_bound): [0] edges evaluated, [1..3] early-outs taken
+ * (:189, :190, :191), [4..6] edges whose tested quantity lies within 1e-6 of the 1e-5 epsilon of that early-out — the only places where a build
+ * with contracted multiply-adds (nvcc's default for the reference) could take another branch than this one. */
+static long long census[8];
+void mc_oracle_census_read(long long* out, int reset) {
+    for (int i = 0; i < 8; ++i) { out[i] = census[i]; if (reset) census[i] = 0; }
+}
+
 /* mc_interp_kernel.cu:187-200 */
 static f4 sdf_interp(const float p1[3], const float p2[3], float std1, float std2, float v1, float v2) {
     f4 o;
+    census[0]++;
+    if (fabsf(fabsf(0.0f - v1) - 1.0e-5f) < 1.0e-6f) census[4]++;
+    if (fabsf(fabsf(0.0f - v2) - 1.0e-5f) < 1.0e-6f) census[5]++;
+    if (fabsf(fabsf(v1 - v2) - 1.0e-5f) < 1.0e-6f) census[6]++;
+    if (fabsf(0.0f - v1) < 1.0e-5f) census[1]++;
+    else if (fabsf(0.0f - v2) < 1.0e-5f) census[2]++;
+    else if (fabsf(v1 - v2) < 1.0e-5f) census[3]++;
     if (fabsf(0.0f - v1) < 1.0e-5f) { o.x = p1[0]; o.y = p1[1]; o.z = p1[2]; o.w = std1; return o; }
     if (fabsf(0.0f - v2) < 1.0e-5f) { o.x = p2[0]; o.y = p2[1]; o.z = p2[2]; o.w = std2; return o; }
     if (fabsf(v1 - v2) < 1.0e-5f)   { o.x = p1[0]; o.y = p1[1]; o.z = p1[2]; o.w = std1; return o; }

@@ -295,8 +295,8 @@ def test_frame_descriptor_entry_point_bit_exact(gpu_model):
 
 
 def test_c3_full_size_invariants(gpu_model):
-    """BASELINE config C3 at full size (128^3 grid, 640x480 frames): no oracle run is affordable here, so pin size-independent
-    properties: slot <-> voxel bijection, conservation of the observation count, idempotence of extract, vertices inside their voxel,
+    """BASELINE config C3 at full size (128^3 grid, 640x480 frames): size-independent properties (the frame-by-frame comparison of the same
+    stream with the reference and the oracle is tests/test_gpu_long.py): slot <-> voxel bijection, conservation of the observation count, idempotence of extract, vertices inside their voxel,
     and bit-identity between an eager run and a hipGraph run (which walks the frame in 16x16 pixel tiles)."""
     from di_fusion_amd.stream import FusionStream
     scene, cfg = S.config_c3()

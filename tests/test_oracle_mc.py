@@ -105,3 +105,47 @@ def test_empty_inputs():
     n_xyz, indexer, vb, vbm, sdf, std = sphere_setup()
     tri, tid, tstd = O.marching_cubes_interp(indexer, vb[:0], vbm, sdf, std, 100, n_xyz, 1.0)
     assert tri.shape == (0, 3, 3) and tid.shape == (0,) and tstd.shape == (0, 3)
+
+
+def test_fma_contraction_bound(oracle_net):
+    """The one leg nothing can pin: the reference's marching cubes is a CUDA kernel, and nvcc's default `-fmad=true`
+    contracts its multiply-adds, which this oracle (`-ffp-contract=off`) does not.  Bound the effect: the same C source built with
+    `-ffp-contract=fast -mfma` against the oracle build, on the oracle's own cubes of seq_small (3 frames) and of BASELINE configs C2 and C3
+    (2 full 640x480 frames each): identical triangle counts and voxel ids, every vertex coordinate within 2 ulp of the other build's (grid
+    coordinates reach 64 / 128 voxel units at C2 / C3: 7.6e-6 / 1.5e-5 there), i.e. <= 1e-6 m in world units — a tenth of the 1e-5 m vertex bar
+    of the GPU tests —, std <= 1e-6: the un-runnable reference most likely sits well inside that bar.  And a census of
+    `sdf_interp`'s epsilon branches (mc_interp_kernel.cu:189-191) on those cubes: the edges whose tested value lies within 1e-6 of the 1e-5
+    epsilon are the only places where the contracted build could pick another branch; they are counted, and where one exists both builds
+    must still produce the same number of triangles."""
+    import os
+    import pytest
+    from di_fusion_amd import synthetic as syn
+    if "fma" not in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        pytest.skip("host CPU without FMA")
+    cases = {"seq_small": (syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6,) * 3, (1.6,) * 3, 0.4), syn.Intrinsic().scaled(0.125), 3, 20.0),
+             "seq_c2": (*syn.config_c2(), syn.Intrinsic(), 2, 0.5), "seq_c3": (*syn.config_c3(), syn.Intrinsic(), 2, 0.5)}
+    worst_v = worst_s = worst_ulp = worst_m = 0.0
+    total = {}
+    for name, (scene, cfg, intr, n_frames, deg) in cases.items():
+        m = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+        for f in range(n_frames):
+            xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg)
+            m.integrate_keyframe(xyz.numpy(), nrm.numpy())
+            a = m.extract_prepare(4)
+            args = (a["indexer"], a["valid_blocks"], a["vec_batch_mapping"], a["cube_sdf"], a["cube_std"], int(4e6), m.n_xyz, 0.15)
+            O.mc_census(reset=True)
+            t0, i0, s0 = O.marching_cubes_interp(*args)
+            cen = O.mc_census(reset=True)
+            t1, i1, s1 = O.marching_cubes_interp(*args, fma=True)
+            assert t0.shape[0] == t1.shape[0] > 0 and np.array_equal(i0, i1), (name, f, t0.shape, t1.shape)
+            dv, ds = float(np.abs(t0 - t1).max()), float(np.abs(s0 - s1).max())
+            ulp = float((np.abs(t0 - t1) / np.spacing(np.maximum(np.abs(t0), np.abs(t1)).astype(np.float32))).max())
+            worst_v, worst_s, worst_ulp, worst_m = max(worst_v, dv), max(worst_s, ds), max(worst_ulp, ulp), max(worst_m, dv * cfg.voxel_size)
+            for k, v in cen.items():
+                total[k] = total.get(k, 0) + v
+            print(f"  {name} frame {f}: {t0.shape[0]} triangles, contracted vs not: vertices {dv:.2e} voxel units = {ulp:.0f} ulp = {dv * cfg.voxel_size:.1e} m, std {ds:.2e}; census {cen}")
+    print(f"  worst: vertices {worst_v:.2e} voxel units, {worst_ulp:.0f} ulp, {worst_m:.1e} m; std {worst_s:.2e}; census over all cases {total}")
+    assert worst_ulp <= 2 and worst_m <= 1e-6 and worst_s <= 1e-6
+    # the epsilon branches are all but dead on real cubes: a handful of edges in 10^6 sit near an epsilon at all
+    near = total["near_eps_v1"] + total["near_eps_v2"] + total["near_eps_flat"]
+    assert total["edges"] > 100000 and near <= 1e-4 * total["edges"]
