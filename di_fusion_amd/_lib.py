@@ -131,6 +131,7 @@ SIGNATURES = {
     "dif_profile_read": (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
     "dif_profile_dump": (c_int64, [POINTER(c_int32), POINTER(c_float), c_int64, c_int32]),
     "dif_read_counters": (c_int32, [POINTER(DifMap), POINTER(c_int32), c_void_p]),
+    "dif_test_mc_grid_cap": (c_int32, [c_int32]),
 }
 
 _lib = None

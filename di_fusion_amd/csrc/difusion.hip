@@ -7,6 +7,7 @@
 // CPU build fuses (trilinear upsample) or where the order is ours to choose (MLP accumulation = the MFMA's fmaf chain).
 #include <cstring>
 #include <mutex>
+#include <atomic>
 #include <vector>
 #include <hip/hip_runtime.h>
 
@@ -905,6 +906,9 @@ static int voxel_decode_attributes() {
     return DIF_OK;
 }
 
+static std::atomic<int> g_mc_grid_cap{0};
+int dif_test_mc_grid_cap(int32_t n) { return g_mc_grid_cap.exchange(n > 0 ? n : 0); }
+
 static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int64_t max_voxels) {
     if (upload_tables() != DIF_OK) return DIF_ELAUNCH;
     const int r = a.R / 2, nc = (r + 1) * (r + 1) * (r + 1);
@@ -925,9 +929,10 @@ static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int6
     per_cu = per_cu < 1 ? 1 : per_cu > MC_WAVES_PER_SIMD ? MC_WAVES_PER_SIMD : per_cu;
     grid1 = per_cu * num_cus();
     if (need < grid1) grid1 = (int)(need < 1 ? 1 : need);
-    // test hook: DIF_MC_GRID=n caps the grid, so that a small map runs in ticket mode (more groups than workgroups) — the path that otherwise
-    // only a map with more than ~5,000 dirty voxels takes (tests/test_gpu_mesh_anchor.py)
-    if (const char* e = getenv("DIF_MC_GRID")) { const int n = atoi(e); if (n > 0 && n < grid1) grid1 = n; }
+    // test hook (dif_test_mc_grid_cap): caps the grid, so that a small map runs in ticket mode (more groups than workgroups) — the path that
+    // otherwise only a map with more than ~5,000 dirty voxels takes (tests/test_gpu_mesh_anchor.py).  An explicit call, not the environment:
+    // nothing a process inherits can change the launch shape of a production extract.
+    { const int n = g_mc_grid_cap.load(std::memory_order_relaxed); if (n > 0 && n < grid1) grid1 = n; }
     return DIF_OK;
 }
 

@@ -436,9 +436,12 @@ __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S,
                 float yn = normalize1(pw[1], g.by, g.vs);
                 float zn = normalize1(pw[2], g.bz, g.vs);
                 float ox = (o & 4) ? 0.5f : -0.5f, oy = (o & 2) ? 0.5f : -0.5f, oz = (o & 1) ? 0.5f : -0.5f;
-                float gx = fminf(fmaxf(ceilf(xn + ox) - 1.0f, 0.0f), (float)(g.nx - 1));
-                float gy = fminf(fmaxf(ceilf(yn + oy) - 1.0f, 0.0f), (float)(g.ny - 1));
-                float gz = fminf(fmaxf(ceilf(zn + oz) - 1.0f, 0.0f), (float)(g.nz - 1));
+                // (the clamp in integers — `ceilf(..) - 1` is integer-valued and, for the points of the list, inside the grid's range — with the
+                // bounds in scalar registers: as floats, (float)(n - 1) are loop-invariant VALU results that hipcc kept in three vector registers
+                // across the tile loop of the bf16-pipe kernel, over its 168-register budget: three scratch reloads per tile until round 5)
+                float gx = (float)clampi((int)(ceilf(xn + ox) - 1.0f), 0, g.nx - 1);
+                float gy = (float)clampi((int)(ceilf(yn + oy) - 1.0f), 0, g.ny - 1);
+                float gz = (float)clampi((int)(ceilf(zn + oz) - 1.0f), 0, g.nz - 1);
                 float rx = (xn - gx) - 0.5f, ry = (yn - gy) - 0.5f, rz = (zn - gz) - 0.5f;      // map.py:425
                 float nxv = nw[0], nyv = nw[1], nzv = nw[2];
                 t.x0 = half ? ry : rx;

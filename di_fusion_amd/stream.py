@@ -653,10 +653,12 @@ class FusionStreamGroup:
         self.device = a.device
         self._frames = (_lib.DifStreamFrame * len(streams))()
 
+    MIN_CAPACITY = 8192         # dif_extract_streams' dirty-set scan walks whole 256-slot blocks of maps with more than 4,096 slots
+
     def _equalise_capacity(self):
         """The batched launches are shaped by ONE capacity: a map that has grown pulls the others along (rare: the capacity covers three
         frames of worst-case allocations, see FusionStream.__init__)."""
-        cap = max(st.map._capacity for st in self.streams)
+        cap = max(self.MIN_CAPACITY, max(st.map._capacity for st in self.streams))
         for st in self.streams:
             if st.map._capacity != cap:
                 st._export_deferred_now(st._pending)
@@ -672,12 +674,16 @@ class FusionStreamGroup:
         with torch.cuda.device(self.device):
             begun = [st._direct_begin(i, d2h) for st, i in zip(self.streams, idx)]
             caps = {st.map._capacity for st in self.streams}
-            if len(caps) > 1:
+            if len(caps) > 1 or min(caps) < self.MIN_CAPACITY:
                 self._equalise_capacity()
                 for st in self.streams:
                     st._direct_prepare()                       # descriptors of re-allocated buffers
                 # (descriptors rebuilt by _direct_prepare are blank: the frame's stamp, notify word and output fields go in again)
                 begun = [(k, sl, st._direct_fill(k, export), export, out) for st, (k, sl, _, export, out) in zip(self.streams, begun)]
+            rows = {int(buf.max_voxels) for (_, _, buf, _, _) in begun}
+            if len(rows) > 1:
+                raise ValueError(f"the streams of a group need extract buffers of one size (rows per stream: {sorted(rows)}): give their maps the same "
+                                 "`extract_buffer_bytes`")
             for j, (st, (k, sl, buf, export, out)) in enumerate(zip(self.streams, begun)):
                 f, m = self._frames[j], st.map
                 f.map = ctypes.pointer(m._cmap)

@@ -296,8 +296,8 @@ typedef struct dif_extract_buffers {
                                      * a wave counts its voxel's triangles, learns its output offset by a decoupled look-back over groups of
                                      * four voxels and emits straight away (same canonical order).  A call with more groups than the launch has
                                      * workgroups (thousands of dirty voxels) hands the groups out through the ticket word at the end of this
-                                     * array.  Environment variable DIF_MC_GRID=n (a test hook, read at every call) caps that launch at n
-                                     * workgroups so that small maps take the ticket path too */
+                                     * array (dif_test_mc_grid_cap caps that launch, so that small maps take the ticket path
+                                     * in tests) */
     int32_t defer_export;           /* != 0 (with out_* and dif_map_t.pending_export): do not copy the new triangles to out_* now, leave a
                                      * dif_pending_export_t for the next dif_integrate_frame / dif_export_pending */
     /* Completion without stream events (an event record costs the queue ~5 us between two kernels; a frame has two):
@@ -445,6 +445,11 @@ int64_t dif_profile_dump(int32_t* which /* host */, float* ms /* host */, int64_
 
 /* Copy the counters to the host; the only synchronising call (hipStreamSynchronize on `stream`). */
 int dif_read_counters(const dif_map_t* map, int32_t* host_out /* [DIF_C_COUNT], host */, void* stream);
+
+/* TEST HOOK, not part of the reference's interface: caps the launch of the one-pass marching cubes (dif_extract / dif_extract_streams) at n workgroups
+ * (n <= 0: no cap, the default), so that a small map takes the ticket path that otherwise only a map with thousands of dirty voxels takes.  Process-wide;
+ * returns the previous cap.  (Until round 5 this was the environment variable DIF_MC_GRID, read at every call.) */
+int dif_test_mc_grid_cap(int32_t n);
 
 #ifdef __cplusplus
 }

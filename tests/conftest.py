@@ -52,3 +52,12 @@ def gpu_model_f32(raw_weights):
     """Same weights with the tiles on the f32-input MFMA (DIF_DECODER_PIPE=f32)."""
     from di_fusion_amd.network import utility as net_util
     return net_util.networks_from_arrays(raw_weights, x6=False)
+
+
+@pytest.fixture
+def mc_grid_cap():
+    """Cap the launch of the one-pass marching cubes (ticket mode on small maps) for one test: `mc_grid_cap(n)`; lifted again afterwards."""
+    from di_fusion_amd import _lib
+    lib = _lib.load()
+    yield lambda n: lib.dif_test_mc_grid_cap(int(n))
+    lib.dif_test_mc_grid_cap(0)

@@ -424,12 +424,12 @@ def test_get_sdf_gradient_vs_reference_autograd(name, pipe, gpu_model, gpu_model
 
 
 @pytest.mark.parametrize("resolution,fast,mc_grid", [(4, False, 0), (2, True, 0), (8, True, 0), (3, True, 0), (2, True, 3), (3, True, 5), (4, True, 2)])
-def test_other_resolutions_and_exact_decode(resolution, fast, mc_grid, gpu_model, oracle_net, monkeypatch):
+def test_other_resolutions_and_exact_decode(resolution, fast, mc_grid, gpu_model, oracle_net, mc_grid_cap):
     """extract_mesh(voxel_resolution, fast) away from the shipped default (4, True): same pipeline, checked against the oracle.
-    mc_grid > 0: the one-pass marching cubes capped at that many workgroups (DIF_MC_GRID), i.e. in ticket mode with parked groups."""
+    mc_grid > 0: the one-pass marching cubes capped at that many workgroups (dif_test_mc_grid_cap), i.e. in ticket mode with parked groups."""
     from oracle import difusion_oracle as O
     if mc_grid:
-        monkeypatch.setenv("DIF_MC_GRID", str(mc_grid))
+        mc_grid_cap(mc_grid)
     scene, cfg, intr = CASES["seq_small"]
     g = np.load(GOLDEN / "seq_small.npz")
     m = make_map(gpu_model, cfg)

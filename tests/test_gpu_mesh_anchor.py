@@ -147,14 +147,14 @@ def _sphere_stream(gpu_model, frames):
 
 
 @pytest.mark.parametrize("grid", [0, 7], ids=["group_per_workgroup", "ticket_mode"])
-def test_onepass_kernel_equals_flat_two_pass_kernels_on_the_extracts_own_cubes(gpu_model, grid, monkeypatch):
+def test_onepass_kernel_equals_flat_two_pass_kernels_on_the_extracts_own_cubes(gpu_model, grid, mc_grid_cap):
     """The stream's extract (one-pass marching cubes) and the flat HIP op (count pass, scan, emit pass) on the SAME decoded cubes, the same
     batch map and the same dirty list: identical triangles, ids and std — bit for bit (voxel units).  `ticket_mode`: the launch capped at
-    7 workgroups (DIF_MC_GRID), so the > 25 groups of a frame are claimed through the ticket counter — the path of a map with thousands of
+    7 workgroups (dif_test_mc_grid_cap), so the > 25 groups of a frame are claimed through the ticket counter — the path of a map with thousands of
     dirty voxels."""
     from di_fusion_amd.system import ext
     if grid:
-        monkeypatch.setenv("DIF_MC_GRID", str(grid))
+        mc_grid_cap(grid)
     st, scene, cfg = _sphere_stream(gpu_model, 3)
     for i in range(3):
         st.step(i, d2h="none")

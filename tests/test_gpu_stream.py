@@ -393,8 +393,8 @@ def test_stream_group_matches_single_streams(S, gpu_model):
         assert not torch.equal(solo[0][1]["indexer"], solo[1][1]["indexer"])
 
 
-def test_stream_group_marching_cubes_in_ticket_mode(gpu_model, monkeypatch):
-    """The grouped launch of the one-pass marching cubes capped at five workgroups per stream (DIF_MC_GRID): every stream's groups of four
+def test_stream_group_marching_cubes_in_ticket_mode(gpu_model, mc_grid_cap):
+    """The grouped launch of the one-pass marching cubes capped at five workgroups per stream (dif_test_mc_grid_cap): every stream's groups of four
     voxels are claimed through its ticket counter — the path of a map with thousands of dirty voxels — and the triangles still equal the
     streams stepped alone with a workgroup per group, bit for bit."""
     from di_fusion_amd.stream import FusionStream
@@ -404,7 +404,7 @@ def test_stream_group_marching_cubes_in_ticket_mode(gpu_model, monkeypatch):
     def make(j):
         return FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, N_FRAMES, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=None)
 
-    solo, grp, streams = _solo_and_group(gpu_model, make, 3, N_FRAMES, before_group=lambda: monkeypatch.setenv("DIF_MC_GRID", "5"))
+    solo, grp, streams = _solo_and_group(gpu_model, make, 3, N_FRAMES, before_group=lambda: mc_grid_cap(5))
     print("  dirty voxels of the last frame:", [st.map.last_counters["K"] for st in streams], "(ticket mode above 20)")
     for j in range(3):
         assert len(grp[j][0]) == N_FRAMES
@@ -449,6 +449,70 @@ def test_stream_group_survives_compaction_and_growth(gpu_model):
         for f, (a, b) in enumerate(zip(solo[j][0], got[j])):
             assert all(torch.equal(x, y) for x, y in zip(a, b)), f"stream {j} frame {f}"
         same(solo[j][1], snapshot(streams[j]))
+
+
+def test_stream_group_growth_after_every_slot_was_used_without_device_sync(gpu_model):
+    """a map that grows pulls the others of its group through a re-allocation BETWEEN `_direct_begin` and the launches — their slot
+    descriptors are rebuilt and must get the frame's stamp, notify word and output fields again (`FusionStream._direct_fill`).  With a stale
+    stamp of 0 the host would read a slot's previous counters and triangles at once.  Here the growth comes at frame 6, when all four slots
+    have been used (their stamp words hold old, non-zero stamps), and the host never drains the device between the group's frames."""
+    from di_fusion_amd.stream import FusionStream, FusionStreamGroup
+    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
+    intr = S_.Intrinsic().scaled(0.25)
+    F = 9
+
+    def make(j):
+        return FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, F, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=None)
+
+    solo = []
+    for j in range(2):
+        st = make(j)
+        per = [_eager(st, i) for i in range(F)]
+        solo.append((per, snapshot(st)))
+    streams = [make(j) for j in range(2)]
+    got = [[_eager(st, 0)] for st in streams]
+    grp = FusionStreamGroup(streams)
+    for i in range(1, F):
+        if i == 6:
+            with streams[0].map._state_lock:                    # stream 0 grows on its own; the group's step pulls stream 1 along
+                streams[0]._export_deferred_now(streams[0]._pending)
+                streams[0].map._alloc_state(2 * streams[0].map._capacity)
+        outs = grp.step(i, d2h="new")
+        for j, o in enumerate(outs):                            # (no torch.cuda.synchronize(): what comes back must be complete by itself)
+            if o is not None:
+                got[j].append(tuple(x.clone() for x in o))
+    for j, o in enumerate(grp.flush()):
+        got[j].append(tuple(x.clone() for x in o))
+    assert streams[0].map._capacity == streams[1].map._capacity == 2 * make(0).map._capacity
+    for j in range(2):
+        assert len(got[j]) == F
+        for f, (a, b) in enumerate(zip(solo[j][0], got[j])):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), f"stream {j} frame {f}"
+        same(solo[j][1], snapshot(streams[j]))
+
+
+def test_stream_group_rejects_maps_it_cannot_batch(gpu_model):
+    """`dif_extract_streams` needs capacity > 4096 and one extract-buffer size for all maps; the group says so instead of failing
+    with an opaque EINVAL at the first step."""
+    from di_fusion_amd.stream import FusionStream, FusionStreamGroup
+    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
+    intr = S_.Intrinsic().scaled(0.25)
+    small = [FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, 2, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=2048) for j in range(2)]
+    for st in small:
+        st.step(0, "new")
+    torch.cuda.synchronize()
+    grp = FusionStreamGroup(small)
+    grp.step(1, "new")                                          # the group grows such maps to the minimum instead of failing
+    grp.flush()
+    assert all(st.map._capacity >= 8192 for st in small)
+    a = FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, 2, deg_per_frame=6.0)
+    b = FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, 2, deg_per_frame=6.0, phase_deg=45.0)
+    b.map.extract_buffer_bytes = 1 << 28                        # -> fewer rows per extract buffer than stream a
+    for st in (a, b):
+        st.step(0, "new")
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="extract_buffer_bytes"):
+        FusionStreamGroup([a, b]).step(1, "new")
 
 
 def test_stream_group_c3_four_streams(gpu_model):

@@ -43,5 +43,8 @@ def run(repeats, verbose=True):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    if "--mc-grid-cap" in sys.argv:           # the one-pass marching cubes in ticket mode (test hook of the library)
+        from di_fusion_amd import _lib
+        _lib.load().dif_test_mc_grid_cap(int(sys.argv[sys.argv.index("--mc-grid-cap") + 1]))
     bad, c = run(n)
     print(f"{bad} of {n - 1} repeats differ from the first (B={c['B']} VH={c['VH']} M={c['M']})")

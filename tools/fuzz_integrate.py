@@ -1,7 +1,7 @@
 """Differential fuzzing of integrate + extract against the oracle on random small problems (grid size, voxel size, pruning on/off, point
 order, NaNs, out-of-bounds points, repeated frames).  Bit-exact integer state, latents within 2e-5, dirty / batch counts equal; the frame's new
 triangles against the oracle's marching cubes on the GPU's own cubes (ids and order exact, vertices within 1e-5) — in about half of the cases
-with the one-pass kernel capped at 1-5 workgroups (DIF_MC_GRID: ticket mode, parked groups); then random point queries (mask exact, values within 5e-5).
+with the one-pass kernel capped at 1-5 workgroups (dif_test_mc_grid_cap: ticket mode, parked groups); then random point queries (mask exact, values within 5e-5).
 Usage: python tools/fuzz_integrate.py [--cases 20] [--seed 0]      (GPU; a few seconds per case, the oracle is the slow side)"""
 import argparse
 import os
@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from di_fusion_amd import synthetic as syn                      # noqa: E402
+from di_fusion_amd import _lib, synthetic as syn                # noqa: E402
 from di_fusion_amd.network import utility as net_util            # noqa: E402
 from di_fusion_amd.system.map import DenseIndexedMap             # noqa: E402
 from oracle import difusion_oracle as O                          # noqa: E402
@@ -36,9 +36,9 @@ def run(cases: int, seed: int = 0):
         kind = rng.choice(["sphere", "plane", "blob"])
         mc_grid = int(rng.integers(1, 6)) if rng.random() < 0.5 else 0
         if mc_grid:
-            os.environ["DIF_MC_GRID"] = str(mc_grid)
+            _lib.load().dif_test_mc_grid_cap(mc_grid)
         else:
-            os.environ.pop("DIF_MC_GRID", None)
+            _lib.load().dif_test_mc_grid_cap(0)
         for frame in range(int(rng.integers(1, 4))):
             N = int(rng.integers(500, 20000))
             if kind == "sphere":
@@ -105,7 +105,7 @@ def run(cases: int, seed: int = 0):
         if oqm.any():
             assert np.abs(sdf.cpu().numpy() - osdf).max() < 5e-5 and np.abs(std.cpu().numpy() - ostd).max() < 5e-5, (case, "query values")
         print(f"case {case}: grid {n}^3 vs {vs} prune {prune} {kind} mc_grid {mc_grid}: n_occupied {m.n_occupied} triangles {0 if out is None else out[0].shape[0]} ok", flush=True)
-    os.environ.pop("DIF_MC_GRID", None)
+    _lib.load().dif_test_mc_grid_cap(0)
     print("fuzz ok")
 
 

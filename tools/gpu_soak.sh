@@ -9,5 +9,5 @@ for seed in ${SOAK_SEEDS:-101 102 103}; do
   timeout 900 python tools/fuzz_group.py --cases 25 --seed $seed > $out/group_$seed.log 2>&1; echo "group $seed rc=$? $(tail -1 $out/group_$seed.log)"
 done
 timeout 900 python tools/determinism_stress.py 60 > $out/determinism.log 2>&1; echo "determinism rc=$? $(tail -1 $out/determinism.log)"
-DIF_MC_GRID=3 timeout 900 python tools/determinism_stress.py 30 > $out/determinism_ticket.log 2>&1; echo "determinism (ticket mode) rc=$? $(tail -1 $out/determinism_ticket.log)"
+timeout 900 python tools/determinism_stress.py 30 --mc-grid-cap 3 > $out/determinism_ticket.log 2>&1; echo "determinism (ticket mode) rc=$? $(tail -1 $out/determinism_ticket.log)"
 timeout 900 python tools/stress_mc_ticket.py --n 128 --reps 2 > $out/mc_ticket_128.log 2>&1; echo "mc ticket 128 rc=$? $(tail -1 $out/mc_ticket_128.log)"
