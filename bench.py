@@ -67,6 +67,9 @@ def parse():
                     "their twelve launches (dif_integrate_frames + dif_extract_streams): `value` is then the aggregate over all world x S streams.  "
                     "0 (default): ONE stream per GPU is the measured configuration, and at N = 1 the aggregate rates for S = 2, 4, 8 are reported beside "
                     "it (config.frames_per_s_with_S_streams_per_gpu, roofline.by_streams)")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1], help="1 (default): ONE directly launched stream uses TWO hardware queues — frame i+1's integrate "
+                    "front end (unproject ... encoder) runs beside frame i's extract, ordered by device-side waits (FusionStream.enable_overlap; d2h dma / "
+                    "none); 0: every frame's twelve launches on one queue.  config.two_queues says what ran")
     ap.add_argument("--rccl-before-clock", type=int, default=0, choices=[0, 1], help="--mode c4 under torch.distributed: 0 (default) = the barriers around "
                     "the clock go over gloo and RCCL is brought up BEHIND the clock, for the exchange step (the global map merge); 1 = RCCL is the process group "
                     "from the start, alive during the timed region like in a deployment that merges maps periodically.  The line says which "
@@ -598,8 +601,11 @@ def main():
             cap0 = 1 << 16
             while cap0 < (2 * batch + 1) * 7 * (intr.width * intr.height // 17) + (1 << 16):
                 cap0 *= 2
-        return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise),
-                            initial_capacity=cap0)   # own arc of the orbit
+        st = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise),
+                          initial_capacity=cap0)   # own arc of the orbit
+        if a.overlap and a.direct and not a.graph and batch == 0 and a.d2h in ("dma", "none"):
+            st.enable_overlap()             # (stays off, and says so, when no second hardware queue is to be had)
+        return st
 
     S_main = int(a.streams_per_gpu)
     if a.d2h == "auto":
@@ -734,6 +740,11 @@ def main():
                                           else f"{world} independent subsequences (one map per GPU)"),
                           "streams_per_gpu": max(S_main, 1),
                           "d2h_per_frame": a.d2h,
+                          "d2h_engine": (None if a.d2h != "dma" else "sdma (hsa_amd_memory_async_copy, no copy kernel)" if stream._sdma else
+                                         "hipMemcpyAsync on a side stream (blit kernels)"),
+                          "two_queues": {"on": bool(stream.overlap), "queues_independent": stream.queues_independent,
+                                         "what": "frame i+1's integrate front end on a second hardware queue beside frame i's extract; fusion kernel and extract "
+                                                 "ordered by hipStreamWaitValue32 on words the kernels publish" if stream.overlap else "one queue"},
                           "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1, "launch": launch,
                           "avg_per_frame_rank0": {k: round(float(np.mean([s[k] for s in st])), 1)
                                                   for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},

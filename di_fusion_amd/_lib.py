@@ -15,7 +15,9 @@ LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "
 
 # counters (difusion.h)
 C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS, C_HALO_L, C_HALO_R, C_HALO_TICKET = range(23)
+C_SHADOW = 24
 C_STAMP = 31
+SYNC_FUSED, SYNC_EXTRACTED, SYNC_WORDS = 0, 32, 64       # dif_map_t.sync_words
 C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge"]
 PROF_COUNT = 8
@@ -35,7 +37,8 @@ class DifMap(Structure):
                 ("rec_dir", c_void_p), ("upd_list", c_void_p),
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
                 ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("dirty_tot", c_void_p),
-                ("halo_list", c_void_p), ("halo_list_cap", c_int32), ("pending_export", c_void_p)]
+                ("halo_list", c_void_p), ("halo_list_cap", c_int32), ("pending_export", c_void_p),
+                ("alloc_bits", c_void_p), ("alloc_tot", c_void_p), ("sync_words", c_void_p), ("frame_seq", c_int32)]
 
 
 class DifWeights(Structure):
@@ -132,6 +135,8 @@ SIGNATURES = {
     "dif_profile_dump": (c_int64, [POINTER(c_int32), POINTER(c_float), c_int64, c_int32]),
     "dif_read_counters": (c_int32, [POINTER(DifMap), POINTER(c_int32), c_void_p]),
     "dif_test_mc_grid_cap": (c_int32, [c_int32]),
+    "dif_queues_independent": (c_int32, [c_void_p, c_void_p]),
+    "dif_mesh_cache_export_sdma": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

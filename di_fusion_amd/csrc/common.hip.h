@@ -91,6 +91,21 @@ struct GridMarks {
     }
 };
 
+// ---- "this kernel is done", as a word another hardware queue waits for (hipStreamWaitValue32; dif_map_t.frame_seq) ---------------------
+// Every workgroup (of this map's share of the grid: gridDim.x) makes its stores visible to the device and takes a ticket; the last one returns
+// the ticket word to idle 0 and publishes `value`.  Costs a fence and one atomic per workgroup (grids of <= 256 here).
+__device__ __forceinline__ void publish_when_all_done(uint32_t* __restrict__ word, uint32_t* __restrict__ ticket, unsigned value) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---- boundary change lists of a spatially tiled map (dif_map_t.halo_list) ----------------------------------------------------------
 // Whoever allocates or fuses an OWNED voxel of the left / right boundary layers appends its slot; dif_export_halo_delta turns the lists
 // into the frame's halo messages.  list == nullptr: off (single map, or a caller that only uses whole-layer messages).

@@ -10,6 +10,9 @@
 #include <atomic>
 #include <vector>
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <dlfcn.h>
 
 #include "common.hip.h"
 #include "mlp.hip.h"
@@ -92,6 +95,24 @@ struct ProfScope {
 inline GridMarks grid_marks_of(const dif_map_t* map) {
     const int64_t nwords = ((int64_t)map->nx * map->ny * map->nz + 31) / 32;
     return GridMarks{map->grid_bits, map->grid_tot, counted_scan_per(nwords)};
+}
+
+// the allocation scan's bitmap: its own (dif_map_t.alloc_bits) or, without one, the bitmap it shares with the extract's neighbourhood marker
+inline uint32_t* alloc_bits_of(const dif_map_t* map) { return map->alloc_bits ? map->alloc_bits : map->grid_bits; }
+inline int32_t* alloc_tot_of(const dif_map_t* map) { return (map->alloc_bits && map->alloc_tot) ? map->alloc_tot : map->grid_tot; }
+inline GridMarks alloc_marks_of(const dif_map_t* map) {
+    const int64_t nwords = ((int64_t)map->nx * map->ny * map->nz + 31) / 32;
+    return GridMarks{alloc_bits_of(map), alloc_tot_of(map), counted_scan_per(nwords)};
+}
+
+// two hardware queues for one stream of frames (include/difusion.h: dif_map_t.frame_seq)
+inline bool overlapped(const dif_map_t* map) { return map->sync_words && map->frame_seq > 0; }
+inline bool overlap_ok(const dif_map_t* map) {
+    return map->alloc_bits && map->alloc_tot && map->dirty_tot && !map_is_tiled(map);
+}
+inline int wait_word(hipStream_t s, uint32_t* word, int32_t value) {
+    if (value <= 0) return DIF_OK;
+    return hipStreamWaitValue32(s, word, (uint32_t)value, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }
 
 inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096) {
@@ -406,7 +427,7 @@ struct FrameSource {            // integrate straight from a depth frame: the fi
 // pieces to the kernels by value, dif_integrate_frames collects the pieces of S maps into the kernels' argument arrays.
 struct IntegratePlan {
     UvcArgs uvc; PruneArgs prune; AllocFunctor alloc; const int* alloc_tot; GatherArgs gather; EncArgs enc; FuseArgs fuse;
-    int64_t grid; bool has_pending;
+    int64_t grid; bool has_pending; bool overlap;
 };
 
 static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
@@ -426,19 +447,25 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
     // a deferred triangle export of the previous extract rides with the three point passes of a streaming frame: nb_x leading workgroups each
     dif_pending_export_t* const pending = src ? (dif_pending_export_t*)map->pending_export : nullptr;
     P.grid = grid;
-    P.has_pending = pending != nullptr;
+    P.has_pending = pending != nullptr && !(src && overlapped(map));
     const ImageGeo im = src ? ImageGeo{src->H, src->W, src->fx, src->fy, src->cx, src->cy} : ImageGeo{};
     const PointSrc ps{xyz, normal, src ? ws.frame_copy : nullptr, im};
     P.uvc = UvcArgs{g, src ? src->frame : nullptr, const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C,
                     own_lo - map->halo, own_hi + map->halo, pending, src ? ws.frame_copy : nullptr};
-    P.prune = PruneArgs{g, (int)map->prune_min_vox_obs, ws.pt_lin, map->frame_count, map->indexer, unq_mask, grid_marks_of(map), C, pending};
-    P.alloc = AllocFunctor{map->grid_bits, map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
-    P.alloc_tot = map->grid_tot;                                   // k_prune_mark kept the block totals
+    // two queues: this frame's front end may run beside the previous frame's extract, which consumes the dirty flags and zeroes their block
+    // totals — the totals are then kept by the fusion kernel (behind that extract) instead of the encoder
+    const bool ov = src && overlapped(map);
+    if (ov && !overlap_ok(map)) return DIF_EINVAL;
+    P.overlap = ov;
+    P.prune = PruneArgs{g, (int)map->prune_min_vox_obs, ws.pt_lin, map->frame_count, map->indexer, unq_mask, alloc_marks_of(map), C, ov ? nullptr : pending};
+    P.alloc = AllocFunctor{alloc_bits_of(map), map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
+    P.alloc_tot = alloc_tot_of(map);                               // k_prune_mark kept the block totals
     P.gather = GatherArgs{g, map->encoder_count_th, ps, ws.pt_lin, unq_mask, map->frame_count, map->indexer, map->voxel_obs_count, ws.pair_list, C,
-                          map->capacity, map->grid_tot, own_lo, own_hi, pending};
-    P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, map->dirty_tot};
+                          map->capacity, alloc_tot_of(map), own_lo, own_hi, ov ? nullptr : pending};
+    P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, ov ? nullptr : map->dirty_tot};
     P.fuse = FuseArgs{ws.rec, ws.rec_next, map->rec_dir, map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->latent_vecs_pos,
-                      halo_lists_of(map), pending};
+                      halo_lists_of(map), ov ? nullptr : pending, ov ? map->dirty_tot : nullptr, ov ? map->sync_words : nullptr, ov ? map->frame_seq : 0};
+    if (ov) P.uvc.pending = nullptr;                               // (no deferred export rides with an overlapped frame: its extract has not run yet)
     return DIF_OK;
 }
 
@@ -491,6 +518,8 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
                                e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         DIF_CHECK_LAUNCH();
     }
+    // two queues: the fusion kernel writes what the previous frame's extract (other stream) reads — latents, counts, dirty flags
+    if (P.overlap && wait_word(s, map->sync_words + DIF_SYNC_EXTRACTED, map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, P.fuse);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
@@ -544,7 +573,7 @@ int dif_integrate_frames(const dif_stream_frame_t* st, int32_t S, const dif_weig
         fuse.s[j] = fuse.s[0];
     }
     hipStream_t s = (hipStream_t)stream_;
-    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK), nb_x = DIF_EXPORT_WGS;
+    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK), nb_x = overlapped(st[0].map) ? 0 : DIF_EXPORT_WGS;
     hipLaunchKernelGGL(k_unproject_voxel_count_batch, dim3(nb_pts + nb_x, S), dim3(DIF_BLOCK), 0, s, uvc, ImageGeo{H, W, fx, fy, cx, cy}, nb_x);
     hipLaunchKernelGGL(k_prune_mark_batch, dim3(nb_pts + nb_x, S), dim3(DIF_BLOCK), 0, s, prune, N, nb_x);
     DIF_CHECK_LAUNCH();
@@ -558,6 +587,10 @@ int dif_integrate_frames(const dif_stream_frame_t* st, int32_t S, const dif_weig
         if (x6) hipLaunchKernelGGL(k_encode_batch<true>, dim3(num_cus()), dim3(ENC_X6_THREADS), lds_bytes, s, enc, (int)S, (const float*)w->enc_x6_packed, N);
         else hipLaunchKernelGGL(k_encode_batch<false>, dim3(num_cus()), dim3(512), lds_bytes, s, enc, (int)S, w->enc_packed, N);
         DIF_CHECK_LAUNCH();
+    }
+    for (int j = 0; j < S; ++j) {
+        if (overlapped(st[j].map) != overlapped(st[0].map)) return DIF_EINVAL;
+        if (overlapped(st[j].map) && wait_word(s, st[j].map->sync_words + DIF_SYNC_EXTRACTED, st[j].map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
     }
     hipLaunchKernelGGL(k_fuse_batch, dim3(grid_for(st[0].map->capacity * 32, DIF_BLOCK, 256), S), dim3(DIF_BLOCK), 0, s, fuse);
     DIF_CHECK_LAUNCH();
@@ -883,11 +916,13 @@ static void mc_onepass_args(McArgs& a, const dif_map_t* map, const dif_extract_b
 
 static FinishArgs finish_args_of(const dif_map_t* map, const dif_extract_buffers_t* buf, bool fused_scan, bool onepass, bool exported, bool defer) {
     int32_t* const super_sum = buf->chunk_sum ? buf->chunk_sum + (buf->max_voxels + 255) / 256 : nullptr;
+    const bool ov = overlapped(map);
     return FinishArgs{buf->occ_slot, map->vbm, map->counters, buf->max_triangles, buf->cache_capacity, buf->cache_tri, buf->cache_id, buf->cache_std,
                       ExtractOut{buf->counters_out, buf->out_tri, buf->out_id, buf->out_std, buf->out_capacity, (exported || defer) ? 1 : 0,
                                  defer ? (dif_pending_export_t*)map->pending_export : nullptr, buf->stamp, defer ? buf->export_notify : nullptr},
                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
-                      onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr};
+                      onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr,
+                      ov ? map->sync_words : nullptr, ov ? map->frame_seq : 0};
 }
 
 static int voxel_decode_attributes() {
@@ -949,6 +984,10 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     Geo g = geo_of(map);
     int* C = map->counters;
+    // two queues: this extract sits on another stream than the frame's integrate and starts behind its fusion kernel
+    const bool ov = overlapped(map);
+    if (ov && (!overlap_ok(map) || no_cache || defer_export_of(map, buf))) return DIF_EINVAL;
+    if (ov && wait_word(s, map->sync_words + DIF_SYNC_FUSED, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
     const ExtractGeo e = extract_geo(resolution);
     const int r = e.r, R = e.R, l = e.l, R3 = e.R3;
     if (buf->max_voxels * (int64_t)R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
@@ -1127,6 +1166,13 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
     }
     hipStream_t s = (hipStream_t)stream_;
     const int64_t max_voxels = st[0].buf->max_voxels;
+    for (int j = 0; j < S; ++j) {          // two queues: behind every stream's fusion kernel
+        const dif_map_t* map = st[j].map;
+        if (overlapped(map) != overlapped(m0)) return DIF_EINVAL;
+        if (!overlapped(map)) continue;
+        if (!overlap_ok(map) || defer_export_of(map, st[j].buf)) return DIF_EINVAL;
+        if (wait_word(s, map->sync_words + DIF_SYNC_FUSED, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
+    }
     hipLaunchKernelGGL(k_dirty_scan_batch, dim3((int)(m0->capacity / DIF_BLOCK), S), dim3(DIF_BLOCK), 0, s, dirty);
     DIF_CHECK_LAUNCH();
     if (launch_counted_scan_batch(occ, S, (int)((grid + 31) / 32), s) != DIF_OK) return DIF_ELAUNCH;
@@ -1202,6 +1248,109 @@ int dif_mesh_cache_export_dma(const dif_extract_buffers_t* buf, int64_t lo, int6
     if (hipMemcpyAsync(out_id, (const int64_t*)buf->cache_id + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return DIF_ELAUNCH;
     if (hipMemcpyAsync(out_std, (const float*)buf->cache_std + lo * 3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) return DIF_ELAUNCH;
     return DIF_OK;
+}
+
+// ---- the export by the SDMA engines, through the HSA runtime the process already runs on (the one HIP sits on) --------------------------------
+struct HsaCopy {
+    bool tried = false, ok = false;
+    hsa_status_t (*init)() = nullptr;
+    hsa_status_t (*pointer_info)(const void*, hsa_amd_pointer_info_t*, void* (*)(size_t), uint32_t*, hsa_agent_t**) = nullptr;
+    hsa_status_t (*async_copy)(void*, hsa_agent_t, const void*, hsa_agent_t, size_t, uint32_t, const hsa_signal_t*, hsa_signal_t) = nullptr;
+    hsa_status_t (*signal_create)(hsa_signal_value_t, uint32_t, const hsa_agent_t*, hsa_signal_t*) = nullptr;
+    void (*signal_store)(hsa_signal_t, hsa_signal_value_t) = nullptr;
+    hsa_signal_value_t (*signal_wait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
+    hsa_signal_t sig{};
+    std::mutex mu;
+    bool load() {
+        if (tried) return ok;
+        tried = true;
+        // the runtime instance HIP uses: already in the process (global scope, or under one of its names) — never a second copy
+        void* h = nullptr;
+        auto sym = [&](const char* n) -> void* {
+            void* p = dlsym(RTLD_DEFAULT, n);
+            if (!p) {
+                if (!h) h = dlopen("libhsa-runtime64.so", RTLD_NOW | RTLD_NOLOAD);
+                if (!h) h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);
+                if (h) p = dlsym(h, n);
+            }
+            return p;
+        };
+        init = (decltype(init))sym("hsa_init");
+        pointer_info = (decltype(pointer_info))sym("hsa_amd_pointer_info");
+        async_copy = (decltype(async_copy))sym("hsa_amd_memory_async_copy");
+        signal_create = (decltype(signal_create))sym("hsa_signal_create");
+        signal_store = (decltype(signal_store))sym("hsa_signal_store_relaxed");
+        signal_wait = (decltype(signal_wait))sym("hsa_signal_wait_scacquire");
+        if (!init || !pointer_info || !async_copy || !signal_create || !signal_store || !signal_wait) return false;
+        if (init() != HSA_STATUS_SUCCESS) return false;                 // (reference-counted: the runtime is up already)
+        if (signal_create(0, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
+        ok = true;
+        return true;
+    }
+};
+static HsaCopy g_hsa;
+
+int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std) {
+    if (!buf || lo < 0 || n < 0 || lo + n > buf->cache_capacity || (n > 0 && (!out_tri || !out_id || !out_std))) return DIF_EINVAL;
+    if (n == 0) return DIF_OK;
+    std::lock_guard<std::mutex> lock(g_hsa.mu);
+    if (!g_hsa.load()) return DIF_ELAUNCH;
+    // who owns the two ends: asked of the runtime itself (no agent enumeration, no device-index mapping); memory this runtime instance does not
+    // know (another copy of the runtime in the process) shows up as an unknown pointer type and is refused
+    hsa_amd_pointer_info_t src{}, dst{};
+    src.size = sizeof(src); dst.size = sizeof(dst);
+    if (g_hsa.pointer_info(buf->cache_tri, &src, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || src.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return DIF_ELAUNCH;
+    if (g_hsa.pointer_info(out_tri, &dst, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || dst.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return DIF_ELAUNCH;
+    const hsa_agent_t gpu = src.agentOwner, cpu = dst.agentOwner;
+    g_hsa.signal_store(g_hsa.sig, 3);
+    const void* from[3] = {(const float*)buf->cache_tri + lo * 9, (const int64_t*)buf->cache_id + lo, (const float*)buf->cache_std + lo * 3};
+    void* to[3] = {out_tri, out_id, out_std};
+    const size_t bytes[3] = {(size_t)n * 9 * sizeof(float), (size_t)n * sizeof(int64_t), (size_t)n * 3 * sizeof(float)};
+    int issued = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (g_hsa.async_copy(to[k], cpu, from[k], gpu, bytes[k], 0, nullptr, g_hsa.sig) != HSA_STATUS_SUCCESS) break;
+        ++issued;
+    }
+    // wait for what was issued (each copy takes the signal down by one), at most ~2 s
+    const hsa_signal_value_t done_below = (hsa_signal_value_t)(3 - issued) + 1;
+    for (int spins = 0; spins < 2000; ++spins)
+        if (g_hsa.signal_wait(g_hsa.sig, HSA_SIGNAL_CONDITION_LT, done_below, 1000000 /* ~1 ms of the signal's clock */, HSA_WAIT_STATE_ACTIVE) < done_below)
+            return issued == 3 ? DIF_OK : DIF_ELAUNCH;
+    return DIF_ELAUNCH;
+}
+
+// ---- are two streams on different hardware queues? ----------------------------------------------------------------------------------------
+__global__ void k_gate_wait(const uint32_t* __restrict__ word, uint32_t value, uint32_t* __restrict__ gave_up) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 2000000ull) { *gave_up = 1u; return; }          // 20 ms of the 100 MHz clock
+    }
+}
+__global__ void k_gate_open(uint32_t* __restrict__ word, uint32_t value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int dif_queues_independent(void* stream_a, void* stream_b) {
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    if (a == b) return 0;
+    uint32_t* w = nullptr;
+    if (hipMalloc((void**)&w, 256) != hipSuccess) return DIF_ELAUNCH;
+    int result = DIF_ELAUNCH;
+    uint32_t host[2] = {0, 0};
+    if (hipMemsetAsync(w, 0, 256, a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess) {
+        // both directions: the waiter is enqueued first; on a shared queue it would sit in front of the kernel that releases it until it gives up
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, a, (const uint32_t*)w, 1u, w + 32);
+        hipLaunchKernelGGL(k_gate_open, dim3(1), dim3(64), 0, b, w, 1u);
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, b, (const uint32_t*)(w + 1), 1u, w + 33);
+        hipLaunchKernelGGL(k_gate_open, dim3(1), dim3(64), 0, a, w + 1, 1u);
+        if (hipGetLastError() == hipSuccess && hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+            hipMemcpy(host, w + 32, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess)
+            result = (host[0] == 0 && host[1] == 0) ? 1 : 0;
+    }
+    (void)hipFree(w);
+    return result;
 }
 
 int dif_mesh_cache_compact(const dif_map_t* map, const dif_extract_buffers_t* buf, float* out_tri, int64_t* out_id, float* out_std,
@@ -1304,14 +1453,14 @@ static int merge_impl(const dif_map_t* map, const MergeSrc& src, int32_t assign,
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     if (hipMemsetAsync(map->counters + DIF_C_ALLOC_NEW, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
     if (!map->grid_tot) return DIF_EINVAL;
-    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, src, (const int64_t*)map->indexer, grid_marks_of(map), grid);
+    hipLaunchKernelGGL(k_merge_mark, dim3(grid_for(n)), dim3(DIF_BLOCK), 0, s, src, (const int64_t*)map->indexer, alloc_marks_of(map), grid);
     DIF_CHECK_LAUNCH();
     // (voxels allocated by a merge are not noted in the boundary change lists: a map that merges foreign records into its own slab
     // refreshes its neighbours with whole-layer messages afterwards — the façade does)
-    AllocFunctor f{map->grid_bits, map->indexer, map->latent_vecs_pos, map->counters, map->capacity, HaloLists{}};
-    if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;
+    AllocFunctor f{alloc_bits_of(map), map->indexer, map->latent_vecs_pos, map->counters, map->capacity, HaloLists{}};
+    if (launch_counted_scan(f, (int)((grid + 31) / 32), alloc_tot_of(map), s) != DIF_OK) return DIF_ELAUNCH;
     hipLaunchKernelGGL(k_merge_apply, dim3(grid_for(n * 32, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, s, src, (const int64_t*)map->indexer,
-                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0, map->grid_tot, note);
+                       map->latent_vecs, map->voxel_obs_count, map->dirty, map->counters, grid, map->capacity, assign ? 1 : 0, alloc_tot_of(map), note);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                           const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
                                           uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, const HaloLists& hl,
-                                          dif_pending_export_t* __restrict__ pending) {
+                                          dif_pending_export_t* __restrict__ pending, int* __restrict__ dirty_tot, uint32_t* __restrict__ sync, int seq) {
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) {       // the point kernels' extra workgroups have done the copy (kernels ago: complete)
         pending->pending = 0;
         if (pending->notify) {              // tell the host without an event in the queue (dif_extract_buffers_t.export_notify)
@@ -607,24 +607,35 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
         __builtin_amdgcn_wave_barrier();
         if (f == 31) {                                       // after every lane of the group has read obs[s]
             obs[s] = w_old + (float)cnt;
+            // (two queues: the flag's block total is kept HERE, behind the previous frame's extract, which zeroes the totals — not by the encoder)
+            if (dirty_tot && !dirty[s]) atomicAdd(dirty_tot + (s >> 8), 1);
             dirty[s] = 1;                                    // map.py:452
             dir[0] = 0;
             dir[1] = 0;
             if (hl.list && s < first_new) hl.note(s, slot_lin[s]);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[DIF_C_ITEMS] = (counters[DIF_C_M] + 31) >> 5;   // encoder tiles of this frame
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int items = (counters[DIF_C_M] + 31) >> 5;                                                // encoder tiles of this frame
+        counters[DIF_C_ITEMS] = items;
+        if (sync) {         // this integrate's counters for its extract's snapshot: the next frame's front end rewrites the live words beside that extract
+            counters[DIF_C_SHADOW + 0] = counters[DIF_C_N_OCCUPIED]; counters[DIF_C_SHADOW + 1] = counters[DIF_C_ALLOC_NEW];
+            counters[DIF_C_SHADOW + 2] = counters[DIF_C_M]; counters[DIF_C_SHADOW + 3] = counters[DIF_C_C]; counters[DIF_C_SHADOW + 4] = items;
+        }
+    }
+    if (sync) publish_when_all_done(sync + DIF_SYNC_FUSED, sync + DIF_SYNC_FUSED_TICKET, (unsigned)seq);
 }
 
 struct FuseArgs {
     const long long* rec; const int* rec_next; int* rec_dir; const int* upd_list; float* latent; float* obs; uint8_t* dirty; int* counters;
     const int64_t* slot_lin; HaloLists hl; dif_pending_export_t* pending;
+    int* dirty_tot; uint32_t* sync; int seq;          // two queues (dif_map_t.frame_seq): block totals of the dirty flags, the words to publish, this frame's number
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(FuseArgs a) {
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.sync, a.seq);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse_batch(Batch<FuseArgs> b) {
     const FuseArgs& a = b.s[blockIdx.y];
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.sync, a.seq);
 }

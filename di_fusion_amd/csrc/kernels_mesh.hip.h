@@ -749,7 +749,8 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
                                                     int* __restrict__ counters, int64_t new_limit, int64_t capacity,
                                                     const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                     const float* __restrict__ log_std, const ExtractOut& out, int32_t* __restrict__ chunk_sum,
-                                                    int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket) {
+                                                    int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket,
+                                                    uint32_t* __restrict__ sync, int seq) {
     const int B = counters[DIF_C_B];
     if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
     {
@@ -780,6 +781,10 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
     if (blockIdx.x == 0 && threadIdx.x < 64) {      // wave 0: the call's counters with their final values, then the update itself
         const int lane = (int)threadIdx.x;
         int v = lane < DIF_C_COUNT ? counters[lane] : 0;
+        const int live = v;
+        // two queues: the next frame's front end may be rewriting N_OCCUPIED / ALLOC_NEW / M / C / ITEMS right now — this frame's values are the
+        // copies its fusion kernel left (lanes 0, 2, 3, 4, 5 <- DIF_C_SHADOW + 0..4)
+        if (sync && (lane == DIF_C_N_OCCUPIED || (lane >= DIF_C_ALLOC_NEW && lane <= DIF_C_ITEMS))) v = counters[DIF_C_SHADOW + (lane == DIF_C_N_OCCUPIED ? 0 : lane - DIF_C_ALLOC_NEW + 1)];
         if (lane == DIF_C_CACHE_T) v = (int)tot;
         if (lane == DIF_C_OVERFLOW && over) v = 5;
         if (out.counters_out && lane < DIF_C_STAMP) out.counters_out[lane] = v;
@@ -796,28 +801,32 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
             __threadfence_system();
             if (lane == 0) out.counters_out[DIF_C_STAMP] = out.stamp;
         }
-        if (lane == 0) {
+        if (lane == DIF_C_OVERFLOW) {
             // a flag that has just been handed to the caller with this snapshot is reported: cleared here, in stream order, so that the next
-            // call's snapshot neither repeats it nor loses a flag raised in between
-            if (out.counters_out) counters[DIF_C_OVERFLOW] = 0;
+            // call's snapshot neither repeats it nor loses a flag raised in between (compare-and-swap: with two queues the next frame's front end
+            // may raise one at this very moment — only the value that was reported is cleared)
+            if (out.counters_out) atomicCAS(counters + DIF_C_OVERFLOW, live, 0);
             else if (over) counters[DIF_C_OVERFLOW] = 5;
-            counters[DIF_C_CACHE_T] = (int)tot;
         }
+        if (lane == 0) counters[DIF_C_CACHE_T] = (int)tot;
     }
+    // two queues: the next frame's fusion kernel (other stream) may now overwrite what this extract read
+    if (sync) publish_when_all_done(sync + DIF_SYNC_EXTRACTED, sync + DIF_SYNC_EXTRACTED_TICKET, (unsigned)seq);
 }
 
 struct FinishArgs {
     const int32_t* occ_slot; int32_t* vbm; int* counters; int64_t new_limit, capacity; const float* log_tri; const int64_t* log_id; const float* log_std;
     ExtractOut out; int32_t* chunk_sum; int32_t* super_sum; int32_t* dirty_tot; int n_dirty_tot; uint32_t* mc_status; uint32_t* mc_ticket;
+    uint32_t* sync; int seq;
 };
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(FinishArgs a) {
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.sync, a.seq);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish_batch(Batch<FinishArgs> b) {
     const FinishArgs& a = b.s[blockIdx.y];
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.sync, a.seq);
 }
 
 struct TriScanFunctor {         // exclusive scan of the per-voxel triangle counts; on the mesh-cache path also the log bookkeeping

@@ -83,6 +83,58 @@ class FusionStream:
         self.keep_points = False
         self.backlog = []                   # outputs of a pending batch's earlier frames, when a frame-by-frame step had to complete it
         self.last_unq_mask = None           # eager / pipelined frames: the (H*W,) prune mask of the latest integrate (direct frames: `_d_mask`)
+        # step_direct on TWO hardware queues (`enable_overlap`): frame i+1's integrate front end (unproject ... encoder) runs on `_fe_stream` beside
+        # frame i's extract on the caller's stream; the fusion kernel of frame i+1 waits — on the device — for that extract, and the extract of a
+        # frame for its fusion kernel (dif_map_t.frame_seq / sync_words).  For d2h "dma" / "none" (an overlapped frame cannot carry the previous
+        # frame's deferred export: that extract has not run yet) on an untiled map.
+        self.overlap = False
+        self._fe_stream = None
+        self._fe_ptr = None
+        self._ov_active = False             # the frames in flight are overlapped ones (the two queues are coupled through the sync words)
+        self._ov_seq = 0
+        self.queues_independent = None      # what dif_queues_independent said about the two streams
+        self._sdma = None                   # None: untried; True / False: the SDMA export works / does not in this process
+
+    def enable_overlap(self, on: bool = True) -> bool:
+        """Two hardware queues for `step_direct`.  Returns whether the mode is on: it stays off (False) when no second stream on a hardware queue of
+        its own can be had (HIP shares a queue between streams once more than GPU_MAX_HW_QUEUES are alive) — the frames would be serialised
+        anyway and only pay for the device-side waits."""
+        if not on or self.tiling is not None:
+            self._ov_leave()
+            self.overlap = False
+            return False
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            main = _lib.stream_ptr()
+            tried = []
+            for _ in range(8):
+                fe = torch.cuda.Stream(device=self.device)
+                rc = int(lib.dif_queues_independent(main, ctypes.c_void_p(fe.cuda_stream)))
+                if rc == 1:
+                    self._fe_stream, self._fe_ptr, self.queues_independent, self.overlap = fe, ctypes.c_void_p(fe.cuda_stream), True, True
+                    return True
+                tried.append(fe)            # (kept alive until the search ends, so that the pool hands out another one)
+                if rc < 0:
+                    break
+            self.queues_independent = False
+            self.overlap = False
+            return False
+
+    def _ov_enter(self):
+        """First overlapped frame after anything else: the front-end stream starts behind everything the caller's stream holds, and the sync
+        words (and their tickets) start from zero."""
+        with torch.cuda.device(self.device):
+            self.map._sync_words.zero_()
+            self._ov_seq = 0
+            self._fe_stream.wait_stream(torch.cuda.current_stream())
+        self._ov_active = True
+
+    def _ov_leave(self):
+        """Before anything but an overlapped frame touches the map on the caller's stream: behind the front-end stream's last kernel."""
+        if self._ov_active:
+            with torch.cuda.device(self.device):
+                torch.cuda.current_stream().wait_stream(self._fe_stream)
+            self._ov_active = False
 
     def _pts(self):
         return (_lib.ptr(self.xyz), _lib.ptr(self.nrm)) if self.keep_points else (_lib.ptr(None), _lib.ptr(None))
@@ -95,6 +147,7 @@ class FusionStream:
         "full" copies the whole merged cache to the host like the reference's numpy cache."""
         intr = self.intr
         R, t = self.poses[i]
+        self._ov_leave()
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(self.depth[i]), _lib.ptr(self.ncam[i]), _lib.ptr(self.xyz), _lib.ptr(self.nrm),
                                                            intr.height, intr.width, intr.fx, intr.fy, intr.cx, intr.cy, R, t, _lib.stream_ptr()),
@@ -138,6 +191,7 @@ class FusionStream:
     def _enqueue_frame(self, i: int):
         intr = self.intr
         R, t = self.poses[i]
+        self._ov_leave()
         with torch.cuda.device(self.device):
             self._before_frame()
             _lib.check(_lib.load().dif_unproject_transform(_lib.ptr(self.depth[i]), _lib.ptr(self.ncam[i]), _lib.ptr(self.xyz), _lib.ptr(self.nrm),
@@ -210,6 +264,16 @@ class FusionStream:
             k = handle.get("dma_slot")
             if n and k is not None and n <= self.HOST_OUT_TRIANGLES:
                 sl = handle["host_slots"][k]
+                if self._sdma is not False:
+                    # by the SDMA engines themselves (HSA copy, three row ranges under one signal): no copy kernel on any queue; the call returns
+                    # when the rows have landed.  A process whose HSA runtime cannot be reached falls back to hipMemcpyAsync (blit kernels), once.
+                    rc = _lib.load().dif_mesh_cache_export_sdma(ctypes.byref(self.map._cache_struct()), tri.storage_offset() // 9, n, sl["out_ptr"][0],
+                                                                sl["out_ptr"][1], sl["out_ptr"][2])
+                    self._sdma = (rc == 0)
+                if self._sdma:
+                    hp = sl["out"]
+                    self.stats.append(dict(self.map.last_counters))
+                    return (hp[0][:n], hp[1][:n], hp[2][:n])
                 with torch.cuda.device(self.device):
                     with torch.cuda.stream(self._copy_stream):
                         _lib.check(_lib.load().dif_mesh_cache_export_dma(ctypes.byref(self.map._cache_struct()), tri.storage_offset() // 9, n, sl["out_ptr"][0],
@@ -247,6 +311,7 @@ class FusionStream:
 
     def flush_all(self, d2h: str = "new"):
         outs = self._finish_pending(d2h)
+        self._ov_leave()
         with torch.cuda.device(self.device):
             self._copy_stream.synchronize()
         return outs
@@ -391,9 +456,28 @@ class FusionStream:
         """One frame enqueued with two C calls (no graph), host one frame ahead; returns the previous frame's output like `step_pipelined`."""
         m = self.map
         with torch.cuda.device(self.device):
+            ov = self.overlap and d2h in ("dma", "none")
+            if not ov:
+                self._ov_leave()
             k, sl, buf, export, out = self._direct_begin(i, d2h)
             lib, w, sp = self._d_lib, self._d_w, _lib.stream_ptr()
             H, W, fx, fy, cx, cy = self._d_args
+            if ov:
+                # two queues: this frame's front end on `_fe_stream` (behind the previous frame's fusion kernel, beside its extract), its fusion kernel
+                # behind that extract, its extract — on the caller's stream — behind its fusion kernel: dif_map_t.frame_seq
+                if not self._ov_active:
+                    self._ov_enter()
+                self._ov_seq += 1
+                m._cmap.frame_seq = self._ov_seq
+                try:
+                    _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, *self._pts(),
+                                                       _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), self._fe_ptr), "dif_integrate_frame")
+                    self._direct_integrated()
+                    _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std), 0, 1, sp),
+                               "dif_extract")
+                finally:
+                    m._cmap.frame_seq = 0
+                return self._direct_end(k, sl, buf, export, d2h, out)
             _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, *self._pts(),
                                                _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
             self._direct_integrated()
@@ -470,6 +554,7 @@ class FusionStream:
         (the previous batch, a frame of one of the frame-by-frame paths, and anything an earlier call left in `backlog`), oldest first."""
         m = self.map
         self._no_async_meshing()
+        self._ov_leave()
         self._d2h_mode = d2h
         if self.tiling is not None:
             raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")
@@ -589,6 +674,7 @@ class FusionStream:
         into pinned memory and one graph launch)."""
         m = self.map
         self._no_async_meshing()
+        self._ov_leave()
         self._d2h_mode = d2h
         if self.tiling is not None:
             raise RuntimeError("the spatially tiled stream exchanges halos between kernels of a frame: step / step_pipelined only")

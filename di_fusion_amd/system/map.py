@@ -192,6 +192,11 @@ class DenseIndexedMap:
             self._frame_count = torch.zeros((self._grid,), device=device, dtype=torch.int32)
             self._grid_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._grid_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
+            # the allocation scan's own bitmap (dif_map_t.alloc_bits): the extract's neighbourhood marker keeps grid_bits, so a frame's integrate
+            # front end may run beside the previous frame's extract (two queues, FusionStream.overlap)
+            self._alloc_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
+            self._alloc_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
+            self._sync_words = torch.zeros((_lib.SYNC_WORDS,), device=device, dtype=torch.int32)     # dif_map_t.sync_words
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
             self._pending_export = torch.zeros((32,), device=device, dtype=torch.int32)        # dif_pending_export_t (72 bytes), idle all-zero
         self._capacity = 0
@@ -264,6 +269,10 @@ class DenseIndexedMap:
         hl = getattr(self, "_halo_list", None)
         m.halo_list = _lib.ptr(hl)
         m.halo_list_cap = 0 if hl is None else hl.size(1)
+        m.alloc_bits = _lib.ptr(self._alloc_bits)
+        m.alloc_tot = _lib.ptr(self._alloc_tot)
+        m.sync_words = _lib.ptr(self._sync_words)
+        m.frame_seq = 0                     # two queues off; FusionStream sets it per overlapped frame
         self._cmap = m
         self._recount_dirty()
 

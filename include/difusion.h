@@ -61,6 +61,8 @@ enum {
     DIF_C_HALO_L = 20,      /* entries appended to the LEFT / RIGHT boundary change list (dif_map_t.halo_list) since the last    */
     DIF_C_HALO_R = 21,      /* halo export; may exceed halo_list_cap (then the list is incomplete and the delta export says so)   */
     DIF_C_HALO_TICKET = 22, /* idle 0: workgroups of dif_export_halo_delta that are done                                          */
+    DIF_C_SHADOW = 24,      /* [24..28]: N_OCCUPIED, ALLOC_NEW, M, C, ITEMS of the latest COMPLETED integrate, left by its fusion kernel: what an extract's
+                             * snapshot reports for them while the next frame's front end is already rewriting the live words (dif_map_t.frame_seq)  */
     DIF_C_STAMP = 31,       /* snapshots handed to the caller only (dif_extract_buffers_t.counters_out): the extract's `stamp`, written LAST        */
     DIF_C_COUNT = 32
 };
@@ -109,7 +111,29 @@ typedef struct dif_map {
      * dif_integrate_frame on this map (a few extra workgroups beside the point pass): the PCIe transfer overlaps the next frame
      * instead of lengthening this one.  dif_export_pending does the same copy on its own (last frame of a stream, before a log compaction). */
     void* pending_export;
+    /* Optional: a second bitmap + block totals (shapes of grid_bits / grid_tot, idle 0) for the ALLOCATION scan of dif_integrate*, so that it
+     * shares nothing with the extract's neighbourhood marker (which keeps grid_bits / grid_tot).  NULL: grid_bits / grid_tot serve both, and a
+     * frame's integrate may then not run beside the previous frame's extract. */
+    uint32_t* alloc_bits;
+    int32_t* alloc_tot;
+    /* Two hardware queues for ONE stream of frames (DESIGN.md section 3 "two queues"): with `frame_seq` > 0 and `sync_words` set,
+     *   dif_integrate_frame(s) on stream A runs frame n's front end (unproject ... encoder) WITHOUT waiting for frame n-1's extract, waits —
+     *     on the device: hipStreamWaitValue32 — until sync_words[DIF_SYNC_EXTRACTED] >= frame_seq - 1, runs the fusion kernel, whose last
+     *     workgroup publishes sync_words[DIF_SYNC_FUSED] = frame_seq;
+     *   dif_extract / dif_extract_streams on stream B waits until sync_words[DIF_SYNC_FUSED] >= frame_seq, runs, and its last kernel's last
+     *     workgroup publishes sync_words[DIF_SYNC_EXTRACTED] = frame_seq.
+     * So frame n+1's front end (it follows frame n's fusion kernel on stream A) runs beside frame n's extract.  What makes that legal: slots
+     * that frame n+1 allocates are invisible to frame n's extract (observation count 0 => not confident, batch row -1 => missing:
+     * mc_interp_kernel.cu:17-24, map.py:628-631), the allocation bitmap is `alloc_bits`, the dirty-flag block totals are kept by the fusion
+     * kernel (behind the extract) instead of the encoder, and the counters of frame n's integrate that its extract hands to the caller are the
+     * copies the fusion kernel left in counters[DIF_C_SHADOW ..].  Requires alloc_bits, dirty_tot, no deferred export (pending_export idle),
+     * an untiled map, and that A and B really are different hardware queues (dif_queues_independent).  The caller advances frame_seq by one per
+     * frame, uses the same value for the frame's integrate and extract, and starts from words that hold frame_seq - 1.  frame_seq = 0: off. */
+    uint32_t* sync_words;           /* [DIF_SYNC_WORDS] device memory */
+    int32_t frame_seq;
 } dif_map_t;
+
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FUSED_TICKET = 16, DIF_SYNC_EXTRACTED = 32, DIF_SYNC_EXTRACTED_TICKET = 48, DIF_SYNC_WORDS = 64 };
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
 typedef struct dif_pending_export {
@@ -445,6 +469,18 @@ int64_t dif_profile_dump(int32_t* which /* host */, float* ms /* host */, int64_
 
 /* Copy the counters to the host; the only synchronising call (hipStreamSynchronize on `stream`). */
 int dif_read_counters(const dif_map_t* map, int32_t* host_out /* [DIF_C_COUNT], host */, void* stream);
+
+/* 1 if work on streams `a` and `b` really runs concurrently — they sit on different hardware queues —, 0 if not, negative on error: a kernel on `a`
+ * waits (bounded: ~20 ms) for a word that a kernel enqueued LATER on `b` writes.  HIP shares a hardware queue between streams once more than
+ * GPU_MAX_HW_QUEUES (default 4) are alive; a device-side wait (dif_map_t.frame_seq) between two streams that share one would never end.
+ * Synchronises both streams. */
+int dif_queues_independent(void* stream_a, void* stream_b);
+
+/* The same rows as dif_mesh_cache_export_dma, by the SDMA engines directly (hsa_amd_memory_async_copy: no copy kernel on any queue, nothing beside
+ * the frame's kernels): three copies under one completion signal, issued from the host NOW — the caller has seen the frame complete (its stamp) —
+ * and waited for (the call returns when the rows are in `out_*`, pinned host memory).  DIF_ELAUNCH when the HSA runtime of the process cannot be
+ * reached or refuses the copy (the caller then uses dif_mesh_cache_export_dma). */
+int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std);
 
 /* TEST HOOK, not part of the reference's interface: caps the launch of the one-pass marching cubes (dif_extract / dif_extract_streams) at n workgroups
  * (n <= 0: no cap, the default), so that a small map takes the ticket path that otherwise only a map with thousands of dirty voxels takes.  Process-wide;

@@ -102,12 +102,16 @@ def _new_worst():
     return dict(lat_ref=0.0, lat_oracle=0.0, cube_ref=0.0, cube_oracle=0.0, flips=0, gated=0)
 
 
-@pytest.mark.parametrize("name", ["seq_c3_long", "seq_c2_long"])
-def test_direct_dma_stream_vs_reference_frame_by_frame(name, gpu_model, oracle_net):
+@pytest.mark.parametrize("name,overlap", [("seq_c3_long", True), ("seq_c3_long", False), ("seq_c2_long", True)])
+def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model, oracle_net):
+    """overlap: the bench's default — frame i+1's integrate front end on a second hardware queue beside frame i's extract
+    (`FusionStream.enable_overlap`); False: every frame's twelve launches on one queue."""
     from oracle import difusion_oracle as O
     g = np.load(GOLDEN / f"{name}.npz")
     F = int(g["n_frames"])
     st, scene, cfg, phase = _make(gpu_model, name, F)
+    if overlap and not st.enable_overlap():
+        pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
     om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
     worst = _new_worst()
     per_frame, delivered = [], []
@@ -134,6 +138,8 @@ def test_direct_dma_stream_vs_reference_frame_by_frame(name, gpu_model, oracle_n
     del st
     torch.cuda.empty_cache()
     st, _, _, _ = _make(gpu_model, name, F)
+    if overlap:
+        assert st.enable_overlap()
     got = []
     for f in range(F):
         out = _drive(st, f, "dma")

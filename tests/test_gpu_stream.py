@@ -103,6 +103,52 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     same(outs["eager"], snapshot(st))
 
 
+@pytest.mark.parametrize("d2h", ["dma", "none"])
+def test_two_queue_frames_are_bit_identical(d2h, gpu_model):
+    """`enable_overlap`: frame i+1's integrate front end (unproject ... encoder) on a second hardware queue beside frame i's extract, its
+    fusion kernel behind that extract, every extract behind its frame's fusion kernel (device-side waits on words the kernels publish:
+    dif_map_t.frame_seq).  Every frame's triangles and the final map equal the eager single-queue run bit for bit — with new voxels
+    allocated on every frame (the slots frame i+1 allocates must stay invisible to frame i's extract), across a forced mesh-log compaction,
+    a capacity growth, an eager frame in the middle (leaves and re-enters the mode), and with the host never draining the device."""
+    st = make_stream(gpu_model)
+    F = N_FRAMES
+    per_frame = []
+    for i in range(F):
+        o = st.step(i, d2h="new")
+        torch.cuda.synchronize()
+        per_frame.append(tuple(x.clone() for x in o))
+    ref = snapshot(st)
+    for rep in range(3):
+        st = make_stream(gpu_model, initial_capacity=(1 << 13) if rep < 2 else None)
+        if not st.enable_overlap():
+            pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
+        got = []
+        st.step(0, d2h="new")
+        torch.cuda.synchronize()
+        got.append(per_frame[0])
+        for i in range(1, F):
+            if i == 3 and rep == 0:
+                st.map._gc_wanted = True                        # a mesh-log compaction with an overlapped frame in flight
+            if i == 4 and rep == 1:                             # an eager frame between overlapped ones
+                o = st.step_pipelined(i, d2h="new")
+            else:
+                o = st.step_direct(i, d2h=d2h)
+            if o is not None:
+                if d2h == "none" or (rep == 1 and i in (4, 5)):
+                    torch.cuda.synchronize()                    # ("none": device views of the log; around the eager frame: side-stream copies)
+                got.append(tuple(x.clone() for x in o))
+        o = st.flush(d2h)
+        torch.cuda.synchronize()
+        got.append(tuple(x.clone() for x in o))
+        assert len(got) == F
+        for f, (a, b) in enumerate(zip(per_frame[1:], got[1:])):
+            assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a, b)), f"rep {rep} frame {f + 1}"
+        same(ref, snapshot(st))
+        assert st.queues_independent is True
+        if rep == 0:
+            assert st.map._gc_epoch == 1
+
+
 @pytest.mark.parametrize("mix", ["direct", "direct+graph"])
 def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
     """`step_direct` with the stream's own capacity (room for the frames in flight, so the host never completes a frame early): a frame's new
