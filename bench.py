@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1], help="1 (default): ONE directly launched stream uses TWO hardware queues — frame i+1's integrate "
                     "front end (unproject ... encoder) runs beside frame i's extract, ordered by device-side waits (FusionStream.enable_overlap; d2h dma / "
                     "none); 0: every frame's twelve launches on one queue.  config.two_queues says what ran")
+    ap.add_argument("--group-d2h", default="dma", choices=["new", "dma"], help="how the secondary S-streams-per-GPU legs of a `--d2h dma` run deliver their triangles: "
+                    "dma (default since round 5: one SDMA call per stream and group frame, two queues) or new (carried by the next frame's point kernels, one queue)")
     ap.add_argument("--rccl-before-clock", type=int, default=0, choices=[0, 1], help="--mode c4 under torch.distributed: 0 (default) = the barriers around "
                     "the clock go over gloo and RCCL is brought up BEHIND the clock, for the exchange step (the global map merge); 1 = RCCL is the process group "
                     "from the start, alive during the timed region like in a deployment that merges maps periodically.  The line says which "
@@ -172,22 +174,28 @@ WORKLOADS = {"c1": "C1 32^3 grid 0.1 m, sphere", "c2": "C2 64^3 grid 0.1 m, room
              "c3": "C3 128^3 grid 0.05 m, ScanNet-shape 6 m room with boxes"}
 
 
-def prime_process(FusionStream, syn, model, intr, dev, d2h):
+def prime_process(FusionStream, syn, model, intr, dev, d2h, graphs=True, overlap=False):
     """One-time process costs (code-object load, kernel attributes, pinned-memory pools, graph machinery) are paid on a throwaway 32^3
-    map, so that they do not land in the timed region when the caller asks for little or no warmup.  Its allocator blocks are given
-    back: leaving them cached costs 9 % of throughput (buffer placement matters at 0.35 ms per frame)."""
+    map, so that they do not land in the timed region when the caller asks for little or no warmup.  Only the ways of driving a frame that
+    the run will use are primed (`graphs`: a hipGraph capture too), and the throwaway map's blocks stay in torch's caching allocator:
+    until round 5 they were returned to the driver (`torch.cuda.empty_cache()`: buffer placement was worth 9 % at 0.35 ms per frame), but a
+    process that has handed gigabytes back to the driver runs every later SDMA copy 6 times slower (hsa_amd_memory_async_copy of a frame's
+    rows 34 -> 223 us, measured with tools/exp_prime.py: any three primed frames followed by empty_cache; without the empty_cache, or
+    with the blocks kept, 34 us) — and with the blocks kept the rate is the same as without priming."""
     import gc
     s1, c1 = syn.config_c1()
     prime = FusionStream(model, s1, c1, intr, dev, 4, deg_per_frame=0.5)
+    if overlap:
+        prime.enable_overlap()
     prime.step(0, d2h)
     prime.step_pipelined(1, d2h)
-    prime.step_graph(2, d2h)
+    if graphs:
+        prime.step_graph(2, d2h)
     prime.step_direct(3, d2h)
     prime.flush(d2h)
     torch.cuda.synchronize()
     del prime
     gc.collect()
-    torch.cuda.empty_cache()
 
 
 def frame_runner(stream, a, d2h):
@@ -233,6 +241,8 @@ class GroupBench:
         from di_fusion_amd.stream import FusionStreamGroup
         self.streams, self.a, self.d2h, self.lib = streams, a, d2h, lib
         self.group = FusionStreamGroup(streams)
+        if getattr(a, "overlap", 0) and d2h in ("dma", "none"):
+            self.group.enable_overlap()         # the group's batched front ends of frame i+1 beside its batched extracts of frame i
 
     def run(self, i):
         a = self.a
@@ -303,7 +313,7 @@ def streams_leg(make_stream_j, S, a, n_frames, lib, pipe):
     import gc
     streams = [make_stream_j(j) for j in range(S)]
     aa = argparse.Namespace(**{**vars(a), "timed_from": None})
-    gb = GroupBench(streams, aa, "new" if a.d2h == "dma" else a.d2h, lib)       # (a group's frames carry their export themselves: 3 S copies per group frame cost the host more)
+    gb = GroupBench(streams, aa, a.group_d2h if a.d2h == "dma" else a.d2h, lib)
     dt, recs = timed_run(gb.run, gb.drain, aa, n_frames, lib, torch.cuda.synchronize)
     st = gb.frame_stats(a.warmup)
     timed_idx = [j for j in range(a.steps) if (a.warmup + j) >= 1 and ((a.warmup + j) % a.sample_every) == 0]
@@ -625,7 +635,7 @@ def main():
     else:
         stream = make_stream()
     if os.environ.get("DIF_BENCH_NO_PRIME") != "1":
-        prime_process(FusionStream, syn, model, syn.Intrinsic(), dev, a.d2h)
+        prime_process(FusionStream, syn, model, syn.Intrinsic(), dev, a.d2h, graphs=bool(a.graph or a.batch or not a.no_secondary), overlap=bool(stream.overlap))
 
     def barrier():
         torch.cuda.synchronize()

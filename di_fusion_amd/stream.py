@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import struct
+import time
 from typing import List, Optional
 
 import numpy as np
@@ -93,7 +94,8 @@ class FusionStream:
         self._ov_active = False             # the frames in flight are overlapped ones (the two queues are coupled through the sync words)
         self._ov_seq = 0
         self.queues_independent = None      # what dif_queues_independent said about the two streams
-        self._sdma = None                   # None: untried; True / False: the SDMA export works / does not in this process
+        self._sdma = None                   # None: untried; True / False: the SDMA export works / does not (or is slow) in this process
+        self._sdma_slow = 0
 
     def enable_overlap(self, on: bool = True) -> bool:
         """Two hardware queues for `step_direct`.  Returns whether the mode is on: it stays off (False) when no second stream on a hardware queue of
@@ -202,6 +204,7 @@ class FusionStream:
         return self.map.extract_mesh_enqueue(self.resolution, self.max_n_triangles, max_std=self.max_std)
 
     HOST_OUT_TRIANGLES = 1 << 18                                 # pinned staging per graph: 14 MB; larger updates fall back to _export_new
+    SDMA_SLOW_US = 150.0
 
     def _export_new(self, handle, tri, tid, tstd):
         """Eager frames (and oversized updates): one small kernel on a side stream writes the three arrays straight into pinned host
@@ -266,10 +269,18 @@ class FusionStream:
                 sl = handle["host_slots"][k]
                 if self._sdma is not False:
                     # by the SDMA engines themselves (HSA copy, three row ranges under one signal): no copy kernel on any queue; the call returns
-                    # when the rows have landed.  A process whose HSA runtime cannot be reached falls back to hipMemcpyAsync (blit kernels), once.
+                    # when the rows have landed.  A process whose HSA runtime cannot be reached falls back to hipMemcpyAsync (blit kernels), once —
+                    # and so does one in which the engines are slow: ~35 us for a steady-state frame's rows normally, but 6 times that in a process
+                    # that has returned gigabytes of device memory to the driver (torch.cuda.empty_cache(); bench.py:prime_process) — eight calls
+                    # in a row above SDMA_SLOW_US with fewer than 2^15 triangles each switch it off.
+                    t0 = time.perf_counter()
                     rc = _lib.load().dif_mesh_cache_export_sdma(ctypes.byref(self.map._cache_struct()), tri.storage_offset() // 9, n, sl["out_ptr"][0],
                                                                 sl["out_ptr"][1], sl["out_ptr"][2])
                     self._sdma = (rc == 0)
+                    if n < (1 << 15):
+                        self._sdma_slow = self._sdma_slow + 1 if (time.perf_counter() - t0) * 1e6 > self.SDMA_SLOW_US else 0
+                        if self._sdma_slow >= 8:
+                            self._sdma = False
                 if self._sdma:
                     hp = sl["out"]
                     self.stats.append(dict(self.map.last_counters))
@@ -398,6 +409,8 @@ class FusionStream:
         if m._gc_wanted:
             self._complete_batch_before_gc(d2h)
             self._export_deferred_now(self._pending)      # (the pending copy reads log positions that the compaction moves)
+            out = self._own_storage(out)
+            self.backlog = [self._own_storage(o) for o in self.backlog]
             m._cache_gc()
         self._direct_prepare()
         k = self._d_seq % self.DIRECT_SLOTS
@@ -571,6 +584,8 @@ class FusionStream:
             self._before_frame()
             if m._gc_wanted:
                 outs += self._finish_pending(d2h)
+                outs = [self._own_storage(o) for o in outs]
+                self.backlog = [self._own_storage(o) for o in self.backlog]
                 m._cache_gc()
             export = d2h == "new"
             self._batch_prepare(F, export)
@@ -590,6 +605,13 @@ class FusionStream:
         # whatever a log compaction above had to complete early went to `backlog`: it is older than everything in `outs`
         outs, self.backlog = self.backlog + outs, []
         return outs
+
+    @staticmethod
+    def _own_storage(o):
+        """An output handed back as DEVICE views of the mesh-cache log (d2h "none") gets storage of its own: a log compaction moves the rows the
+        views name.  (A frame completed early in the very call that then compacts the log — a map short of room — came back with rows of
+        other triangles until round 5.)"""
+        return o if (o is None or not o[0].is_cuda) else tuple(x.clone() for x in o)
 
     def _complete_batch_before_gc(self, d2h: str):
         """A compaction of the mesh-cache log moves entries: with ONE extract pending its triangles are simply the new log's tail, with a
@@ -694,6 +716,8 @@ class FusionStream:
             self._before_frame()
             if m._gc_wanted:
                 self._complete_batch_before_gc(d2h)
+                out = self._own_storage(out)
+                self.backlog = [self._own_storage(o) for o in self.backlog]
                 m._cache_gc()
             self._graph_export = (d2h == "new")
             if self._graphs is None or self._graph_sig != self._graph_signature():
@@ -738,6 +762,31 @@ class FusionStreamGroup:
         self.streams = list(streams)
         self.device = a.device
         self._frames = (_lib.DifStreamFrame * len(streams))()
+        self.overlap = False                # two hardware queues for the group's frames (enable_overlap)
+        self._ov_active = False
+        self._ov_seq = 0
+
+    def enable_overlap(self, on: bool = True) -> bool:
+        """The group's frames on two hardware queues, like `FusionStream.enable_overlap`: the S front ends of frame i+1 (one batched launch each)
+        beside the S extracts of frame i.  The front-end stream is stream 0's."""
+        self._ov_leave()
+        self.overlap = bool(on) and self.streams[0].enable_overlap(True)
+        return self.overlap
+
+    def _ov_enter(self):
+        with torch.cuda.device(self.device):
+            for st in self.streams:
+                st._ov_leave()
+                st.map._sync_words.zero_()
+            self._ov_seq = 0
+            self.streams[0]._fe_stream.wait_stream(torch.cuda.current_stream())
+        self._ov_active = True
+
+    def _ov_leave(self):
+        if self._ov_active:
+            with torch.cuda.device(self.device):
+                torch.cuda.current_stream().wait_stream(self.streams[0]._fe_stream)
+            self._ov_active = False
 
     MIN_CAPACITY = 8192         # dif_extract_streams' dirty-set scan walks whole 256-slot blocks of maps with more than 4,096 slots
 
@@ -780,11 +829,29 @@ class FusionStreamGroup:
                 f.buf = ctypes.pointer(buf)
             lib, w, sp = a._d_lib, a._d_w, _lib.stream_ptr()
             H, W, fx, fy, cx, cy = a._d_args
-            _lib.check(lib.dif_integrate_frames(self._frames, S, ctypes.byref(w), H, W, fx, fy, cx, cy, sp), "dif_integrate_frames")
-            for st in self.streams:
-                st._direct_integrated()
-            _lib.check(lib.dif_extract_streams(self._frames, S, ctypes.byref(w), int(a.resolution), float(a.max_std), 1, sp), "dif_extract_streams")
+            ov = self.overlap and d2h in ("dma", "none")
+            if ov:
+                if not self._ov_active:
+                    self._ov_enter()
+                self._ov_seq += 1
+                for st in self.streams:
+                    st.map._cmap.frame_seq = self._ov_seq
+                sp_fe = a._fe_ptr
+            else:
+                self._ov_leave()
+                sp_fe = sp
+            try:
+                _lib.check(lib.dif_integrate_frames(self._frames, S, ctypes.byref(w), H, W, fx, fy, cx, cy, sp_fe), "dif_integrate_frames")
+                for st in self.streams:
+                    st._direct_integrated()
+                _lib.check(lib.dif_extract_streams(self._frames, S, ctypes.byref(w), int(a.resolution), float(a.max_std), 1, sp), "dif_extract_streams")
+            finally:
+                if ov:
+                    for st in self.streams:
+                        st.map._cmap.frame_seq = 0
             return [st._direct_end(k, sl, buf, export, d2h, out) for st, (k, sl, buf, export, out) in zip(self.streams, begun)]
 
     def flush(self, d2h: str = "new"):
-        return [st.flush(d2h) for st in self.streams]
+        outs = [st.flush(d2h) for st in self.streams]
+        self._ov_leave()
+        return outs

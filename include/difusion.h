@@ -133,7 +133,10 @@ typedef struct dif_map {
     int32_t frame_seq;
 } dif_map_t;
 
-enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FUSED_TICKET = 16, DIF_SYNC_EXTRACTED = 32, DIF_SYNC_EXTRACTED_TICKET = 48, DIF_SYNC_WORDS = 64 };
+/* sync_words: the two published words and the tickets that elect the publishing workgroup, each on a 128-byte line of its own (nine ticket words per
+ * kernel: one per residue of the workgroup index modulo 8 — i.e. per XCD —, so that the same-address atomic chain is 32 long instead of 256, and one for
+ * the eight winners) */
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_EXTRACTED = 32, DIF_SYNC_FUSED_TICKET = 64, DIF_SYNC_EXTRACTED_TICKET = 384, DIF_SYNC_WORDS = 704 };
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
 typedef struct dif_pending_export {

@@ -439,6 +439,39 @@ def test_stream_group_matches_single_streams(S, gpu_model):
         assert not torch.equal(solo[0][1]["indexer"], solo[1][1]["indexer"])
 
 
+def test_stream_group_on_two_queues_matches_single_streams(gpu_model):
+    """`FusionStreamGroup.enable_overlap`: the batched front ends of frame i+1 beside the batched extracts of frame i (every map with its own
+    sync words), triangles delivered by the SDMA copy: per stream identical to the stream stepped alone, with no device drain between frames."""
+    from di_fusion_amd.stream import FusionStream, FusionStreamGroup
+    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
+    intr = S_.Intrinsic().scaled(0.25)
+    F, S = 8, 3
+
+    def make(j):
+        return FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, F, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=None)
+
+    solo = []
+    for j in range(S):
+        st = make(j)
+        solo.append(([_eager(st, i) for i in range(F)], snapshot(st)))
+    streams = [make(j) for j in range(S)]
+    got = [[_eager(st, 0)] for st in streams]
+    grp = FusionStreamGroup(streams)
+    if not grp.enable_overlap():
+        pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
+    for i in range(1, F):
+        for j, o in enumerate(grp.step(i, d2h="dma")):
+            if o is not None:
+                got[j].append(tuple(x.clone() for x in o))
+    for j, o in enumerate(grp.flush("dma")):
+        got[j].append(tuple(x.clone() for x in o))
+    for j in range(S):
+        assert len(got[j]) == F
+        for f, (a, b) in enumerate(zip(solo[j][0], got[j])):
+            assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a, b)), f"stream {j} frame {f}"
+        same(solo[j][1], snapshot(streams[j]))
+
+
 def test_stream_group_marching_cubes_in_ticket_mode(gpu_model, mc_grid_cap):
     """The grouped launch of the one-pass marching cubes capped at five workgroups per stream (dif_test_mc_grid_cap): every stream's groups of four
     voxels are claimed through its ticket counter — the path of a map with thousands of dirty voxels — and the triangles still equal the
