@@ -70,8 +70,12 @@ def parse():
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1], help="1 (default): ONE directly launched stream uses TWO hardware queues — frame i+1's integrate "
                     "front end (unproject ... encoder) runs beside frame i's extract, ordered by device-side waits (FusionStream.enable_overlap; d2h dma / "
                     "none); 0: every frame's twelve launches on one queue.  config.two_queues says what ran")
-    ap.add_argument("--group-d2h", default="dma", choices=["new", "dma"], help="how the secondary S-streams-per-GPU legs of a `--d2h dma` run deliver their triangles: "
-                    "dma (default since round 5: one SDMA call per stream and group frame, two queues) or new (carried by the next frame's point kernels, one queue)")
+    ap.add_argument("--group-d2h", default="new", choices=["new", "dma"], help="how the secondary S-streams-per-GPU legs of a `--d2h dma` run deliver their triangles: "
+                    "new (default: carried by the next group frame's point kernels) or dma (one SDMA call per stream and group frame: equal at S = 4, 6 % behind at "
+                    "S = 8 — the host)")
+    ap.add_argument("--host-depth", type=int, default=2, choices=[1, 2], help="directly launched frames: how many frames the host may have enqueued beyond the one "
+                    "it hands back.  1: frame i-1's triangles come back before frame i+1 is enqueued; 2 (default): frame i-2's — the host never waits for the "
+                    "frame in front of the one it enqueues, which is what keeps the second queue fed (config.host_pipeline_depth)")
     ap.add_argument("--rccl-before-clock", type=int, default=0, choices=[0, 1], help="--mode c4 under torch.distributed: 0 (default) = the barriers around "
                     "the clock go over gloo and RCCL is brought up BEHIND the clock, for the exchange step (the global map merge); 1 = RCCL is the process group "
                     "from the start, alive during the timed region like in a deployment that merges maps periodically.  The line says which "
@@ -241,8 +245,6 @@ class GroupBench:
         from di_fusion_amd.stream import FusionStreamGroup
         self.streams, self.a, self.d2h, self.lib = streams, a, d2h, lib
         self.group = FusionStreamGroup(streams)
-        if getattr(a, "overlap", 0) and d2h in ("dma", "none"):
-            self.group.enable_overlap()         # the group's batched front ends of frame i+1 beside its batched extracts of frame i
 
     def run(self, i):
         a = self.a
@@ -615,6 +617,8 @@ def main():
                           initial_capacity=cap0)   # own arc of the orbit
         if a.overlap and a.direct and not a.graph and batch == 0 and a.d2h in ("dma", "none"):
             st.enable_overlap()             # (stays off, and says so, when no second hardware queue is to be had)
+        if a.direct and not a.graph and batch == 0:
+            st.host_depth = a.host_depth
         return st
 
     S_main = int(a.streams_per_gpu)
@@ -755,7 +759,7 @@ def main():
                           "two_queues": {"on": bool(stream.overlap), "queues_independent": stream.queues_independent,
                                          "what": "frame i+1's integrate front end on a second hardware queue beside frame i's extract; fusion kernel and extract "
                                                  "ordered by hipStreamWaitValue32 on words the kernels publish" if stream.overlap else "one queue"},
-                          "host_pipeline_depth": 2 if (a.pipeline or a.graph) else 1, "launch": launch,
+                          "host_pipeline_depth": (1 + stream.host_depth) if (a.pipeline or a.graph) else 1, "launch": launch,
                           "avg_per_frame_rank0": {k: round(float(np.mean([s[k] for s in st])), 1)
                                                   for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,

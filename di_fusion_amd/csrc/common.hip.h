@@ -91,27 +91,6 @@ struct GridMarks {
     }
 };
 
-// ---- "this kernel is done", as a word another hardware queue waits for (hipStreamWaitValue32; dif_map_t.frame_seq) ---------------------
-// Every workgroup (of this map's share of the grid: gridDim.x) releases its stores to the device and takes a ticket; the last one publishes
-// `value`.  Two levels — a ticket word per residue of the workgroup index modulo 8, then one for the eight winners, every word on a cache
-// line of its own (tickets[32 * k]) — because same-address atomics retire one per ~12 ns: one word for 256 workgroups made the fusion kernel
-// 4.7 us longer, nine words make the chain 32 + 8 long.  The words return to idle 0.
-__device__ __forceinline__ void publish_when_all_done(uint32_t* __restrict__ word, uint32_t* __restrict__ tickets, unsigned value) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned x = blockIdx.x & 7u, n_x = (gridDim.x + 7u - x) >> 3, n_groups = gridDim.x < 8u ? gridDim.x : 8u;
-        // (release: this workgroup's stores are written back before its ticket counts; acquire: the winner's publication is ordered behind
-        // every increment it has seen)
-        if (__hip_atomic_fetch_add(tickets + 32u * x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == n_x - 1u) {
-            __hip_atomic_store(tickets + 32u * x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(tickets + 32u * 8u, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1u) {
-                __hip_atomic_store(tickets + 32u * 8u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
 // ---- boundary change lists of a spatially tiled map (dif_map_t.halo_list) ----------------------------------------------------------
 // Whoever allocates or fuses an OWNED voxel of the left / right boundary layers appends its slot; dif_export_halo_delta turns the lists
 // into the frame's halo messages.  list == nullptr: off (single map, or a caller that only uses whole-layer messages).

@@ -106,9 +106,9 @@ inline GridMarks alloc_marks_of(const dif_map_t* map) {
 }
 
 // two hardware queues for one stream of frames (include/difusion.h: dif_map_t.frame_seq)
-inline bool overlapped(const dif_map_t* map) { return map->sync_words && map->frame_seq > 0; }
+inline bool overlapped(const dif_map_t* map) { return map->sync_words && map->fuse_stream && map->frame_seq > 0; }
 inline bool overlap_ok(const dif_map_t* map) {
-    return map->alloc_bits && map->alloc_tot && map->dirty_tot && !map_is_tiled(map);
+    return map->alloc_bits && map->alloc_tot && map->dirty_tot && !map_is_tiled(map) && map->capacity > 4096 && map->capacity % DIF_BLOCK == 0;
 }
 inline int wait_word(hipStream_t s, uint32_t* word, int32_t value) {
     if (value <= 0) return DIF_OK;
@@ -391,6 +391,7 @@ struct IntegrateWs {
     long long* rec;         // [8N][32] run records, written sparsely at tile*32 + run rank (~3 per tile in a stream)
     int* block_tmp;         // [4096]
     dif_frame_t* frame_copy; // device copy of a streaming frame's descriptor (read by the kernels behind the first one)
+    uint8_t* chunk_any;     // [ceil(N / 256)] does the first kernel's workgroup (256 consecutive points) hold ANY point inside the map's slab + halo?
     int64_t total_bytes;
 };
 
@@ -400,12 +401,13 @@ static int carve_integrate(int64_t N, void* base, IntegrateWs& ws) {
     // 8N bounds the gathered rows (map.py:419-435), hence tiles * 32 and the run records: a run holds at least one row
     const size_t rows = (size_t)(8 * N + 32);
     size_t o_lin = take((size_t)N * 4), o_list = take(rows * 8), o_next = take(rows * 4), o_rec = take(rows * DIF_REC_WORDS * 8), o_tmp = take(4096 * 4),
-           o_frame = take(sizeof(dif_frame_t));
+           o_frame = take(sizeof(dif_frame_t)), o_any = take((size_t)((N + DIF_BLOCK - 1) / DIF_BLOCK));
     ws.total_bytes = (int64_t)off;
     if (base) {
         char* b = (char*)base;
         ws.pt_lin = (int*)(b + o_lin); ws.pair_list = (uint2*)(b + o_list); ws.rec_next = (int*)(b + o_next);
         ws.rec = (long long*)(b + o_rec); ws.block_tmp = (int*)(b + o_tmp); ws.frame_copy = (dif_frame_t*)(b + o_frame);
+        ws.chunk_any = (uint8_t*)(b + o_any);
     }
     return DIF_OK;
 }
@@ -450,21 +452,24 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
     P.has_pending = pending != nullptr && !(src && overlapped(map));
     const ImageGeo im = src ? ImageGeo{src->H, src->W, src->fx, src->fy, src->cx, src->cy} : ImageGeo{};
     const PointSrc ps{xyz, normal, src ? ws.frame_copy : nullptr, im};
+    // spatial tiling (C5): every rank is offered the whole frame, but most 256-point pieces of it hold no point near the rank's slab — the first
+    // kernel says which do, the second and third skip the others (per-slab point culling)
+    uint8_t* const cull = (src && map_is_tiled(map)) ? ws.chunk_any : nullptr;
     P.uvc = UvcArgs{g, src ? src->frame : nullptr, const_cast<float*>(xyz), const_cast<float*>(normal), ws.pt_lin, map->frame_count, C,
-                    own_lo - map->halo, own_hi + map->halo, pending, src ? ws.frame_copy : nullptr};
+                    own_lo - map->halo, own_hi + map->halo, pending, src ? ws.frame_copy : nullptr, cull};
     // two queues: this frame's front end may run beside the previous frame's extract, which consumes the dirty flags and zeroes their block
     // totals — the totals are then kept by the fusion kernel (behind that extract) instead of the encoder
     const bool ov = src && overlapped(map);
     if (ov && !overlap_ok(map)) return DIF_EINVAL;
     P.overlap = ov;
-    P.prune = PruneArgs{g, (int)map->prune_min_vox_obs, ws.pt_lin, map->frame_count, map->indexer, unq_mask, alloc_marks_of(map), C, ov ? nullptr : pending};
+    P.prune = PruneArgs{g, (int)map->prune_min_vox_obs, ws.pt_lin, map->frame_count, map->indexer, unq_mask, alloc_marks_of(map), C, ov ? nullptr : pending, cull};
     P.alloc = AllocFunctor{alloc_bits_of(map), map->indexer, map->latent_vecs_pos, C, map->capacity, halo_lists_of(map)};
     P.alloc_tot = alloc_tot_of(map);                               // k_prune_mark kept the block totals
     P.gather = GatherArgs{g, map->encoder_count_th, ps, ws.pt_lin, unq_mask, map->frame_count, map->indexer, map->voxel_obs_count, ws.pair_list, C,
-                          map->capacity, alloc_tot_of(map), own_lo, own_hi, ov ? nullptr : pending};
+                          map->capacity, alloc_tot_of(map), own_lo, own_hi, ov ? nullptr : pending, cull};
     P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, ov ? nullptr : map->dirty_tot};
     P.fuse = FuseArgs{ws.rec, ws.rec_next, map->rec_dir, map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->latent_vecs_pos,
-                      halo_lists_of(map), ov ? nullptr : pending, ov ? map->dirty_tot : nullptr, ov ? map->sync_words : nullptr, ov ? map->frame_seq : 0};
+                      halo_lists_of(map), ov ? nullptr : pending, ov ? map->dirty_tot : nullptr, ov};
     if (ov) P.uvc.pending = nullptr;                               // (no deferred export rides with an overlapped frame: its extract has not run yet)
     return DIF_OK;
 }
@@ -493,6 +498,8 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     hipStream_t s = (hipStream_t)stream_;
     const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK);
     const int nb_x = P.has_pending ? DIF_EXPORT_WGS : 0;
+    // two queues: the front end reads what the previous frame's fusion kernel (extracts' stream) wrote; that frame's extract says when it is done
+    if (P.overlap && wait_word(s, map->sync_words + DIF_SYNC_FUSED, map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
     // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
     if (src)
         hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, P.uvc, ImageGeo{src->H, src->W, src->fx, src->fy, src->cx, src->cy}, nb_x);
@@ -518,9 +525,15 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
                                e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         DIF_CHECK_LAUNCH();
     }
-    // two queues: the fusion kernel writes what the previous frame's extract (other stream) reads — latents, counts, dirty flags
-    if (P.overlap && wait_word(s, map->sync_words + DIF_SYNC_EXTRACTED, map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
-    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, P.fuse);
+    hipStream_t sf = s;
+    if (P.overlap) {
+        // two queues: the front end is done -> a word for the extracts' stream, where the fusion kernel goes: behind the previous frame's extract
+        // (it writes what that extract reads — latents, counts, dirty flags) and behind one wait for that word, which is normally long there
+        sf = (hipStream_t)map->fuse_stream;
+        hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, s, map->sync_words + DIF_SYNC_FRONT_DONE, (uint32_t)map->frame_seq);
+        if (wait_word(sf, map->sync_words + DIF_SYNC_FRONT_DONE, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, sf, P.fuse);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }
@@ -542,6 +555,7 @@ static bool batch_maps_ok(const dif_stream_frame_t* st, int S) {
     if (!st || S < 1 || S > DIF_MAX_STREAMS) return false;
     for (int j = 0; j < S; ++j) {
         const dif_map_t* m = st[j].map;
+        if (m && m->frame_seq != 0) return false;          // (two queues are for one stream per launch: S streams per launch fill the machine as they are)
         if (!m || map_is_tiled(m) || !m->dirty_tot || !m->grid_tot || !m->pending_export) return false;
         if (m->nx != st[0].map->nx || m->ny != st[0].map->ny || m->nz != st[0].map->nz || m->capacity != st[0].map->capacity) return false;
         for (int i = 0; i < j; ++i)
@@ -573,7 +587,7 @@ int dif_integrate_frames(const dif_stream_frame_t* st, int32_t S, const dif_weig
         fuse.s[j] = fuse.s[0];
     }
     hipStream_t s = (hipStream_t)stream_;
-    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK), nb_x = overlapped(st[0].map) ? 0 : DIF_EXPORT_WGS;
+    const int nb_pts = (int)((N + DIF_BLOCK - 1) / DIF_BLOCK), nb_x = DIF_EXPORT_WGS;
     hipLaunchKernelGGL(k_unproject_voxel_count_batch, dim3(nb_pts + nb_x, S), dim3(DIF_BLOCK), 0, s, uvc, ImageGeo{H, W, fx, fy, cx, cy}, nb_x);
     hipLaunchKernelGGL(k_prune_mark_batch, dim3(nb_pts + nb_x, S), dim3(DIF_BLOCK), 0, s, prune, N, nb_x);
     DIF_CHECK_LAUNCH();
@@ -587,10 +601,6 @@ int dif_integrate_frames(const dif_stream_frame_t* st, int32_t S, const dif_weig
         if (x6) hipLaunchKernelGGL(k_encode_batch<true>, dim3(num_cus()), dim3(ENC_X6_THREADS), lds_bytes, s, enc, (int)S, (const float*)w->enc_x6_packed, N);
         else hipLaunchKernelGGL(k_encode_batch<false>, dim3(num_cus()), dim3(512), lds_bytes, s, enc, (int)S, w->enc_packed, N);
         DIF_CHECK_LAUNCH();
-    }
-    for (int j = 0; j < S; ++j) {
-        if (overlapped(st[j].map) != overlapped(st[0].map)) return DIF_EINVAL;
-        if (overlapped(st[j].map) && wait_word(s, st[j].map->sync_words + DIF_SYNC_EXTRACTED, st[j].map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
     }
     hipLaunchKernelGGL(k_fuse_batch, dim3(grid_for(st[0].map->capacity * 32, DIF_BLOCK, 256), S), dim3(DIF_BLOCK), 0, s, fuse);
     DIF_CHECK_LAUNCH();
@@ -922,7 +932,7 @@ static FinishArgs finish_args_of(const dif_map_t* map, const dif_extract_buffers
                                  defer ? (dif_pending_export_t*)map->pending_export : nullptr, buf->stamp, defer ? buf->export_notify : nullptr},
                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
                       onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr,
-                      ov ? map->sync_words : nullptr, ov ? map->frame_seq : 0};
+                      ov};
 }
 
 static int voxel_decode_attributes() {
@@ -984,10 +994,10 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz;
     Geo g = geo_of(map);
     int* C = map->counters;
-    // two queues: this extract sits on another stream than the frame's integrate and starts behind its fusion kernel
+    // two queues: this extract follows the frame's fusion kernel on ITS stream (dif_map_t.fuse_stream); its first kernel tells the front-end
+    // stream that the fusion is done
     const bool ov = overlapped(map);
-    if (ov && (!overlap_ok(map) || no_cache || defer_export_of(map, buf))) return DIF_EINVAL;
-    if (ov && wait_word(s, map->sync_words + DIF_SYNC_FUSED, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
+    if (ov && (!overlap_ok(map) || no_cache || defer_export_of(map, buf) || s != (hipStream_t)map->fuse_stream)) return DIF_EINVAL;
     const ExtractGeo e = extract_geo(resolution);
     const int r = e.r, R = e.R, l = e.l, R3 = e.R3;
     if (buf->max_voxels * (int64_t)R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
@@ -1006,7 +1016,8 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             DirtyFunctor f{ds};
             // every writer of the flags kept the per-block totals (k_fuse; the host recomputes them after anything else): no counting pass
             if (map->dirty_tot && !no_cache && !tiled && map->capacity > 4096 && map->capacity % DIF_BLOCK == 0) {
-                hipLaunchKernelGGL(k_dirty_scan, dim3((int)(map->capacity / DIF_BLOCK)), dim3(DIF_BLOCK), 0, s, ds, n_slots, (const int*)map->dirty_tot);
+                hipLaunchKernelGGL(k_dirty_scan, dim3((int)(map->capacity / DIF_BLOCK)), dim3(DIF_BLOCK), 0, s, ds, n_slots, (const int*)map->dirty_tot,
+                                   ov ? map->sync_words + DIF_SYNC_FUSED : nullptr, (int)map->frame_seq);
                 DIF_CHECK_LAUNCH();
             } else if (map->dirty_tot && !no_cache && !tiled) {
                 if (launch_counted_scan_bounded(f, n_slots, map->capacity, map->dirty_tot, s) != DIF_OK) return DIF_ELAUNCH;
@@ -1166,13 +1177,6 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
     }
     hipStream_t s = (hipStream_t)stream_;
     const int64_t max_voxels = st[0].buf->max_voxels;
-    for (int j = 0; j < S; ++j) {          // two queues: behind every stream's fusion kernel
-        const dif_map_t* map = st[j].map;
-        if (overlapped(map) != overlapped(m0)) return DIF_EINVAL;
-        if (!overlapped(map)) continue;
-        if (!overlap_ok(map) || defer_export_of(map, st[j].buf)) return DIF_EINVAL;
-        if (wait_word(s, map->sync_words + DIF_SYNC_FUSED, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
-    }
     hipLaunchKernelGGL(k_dirty_scan_batch, dim3((int)(m0->capacity / DIF_BLOCK), S), dim3(DIF_BLOCK), 0, s, dirty);
     DIF_CHECK_LAUNCH();
     if (launch_counted_scan_batch(occ, S, (int)((grid + 31) / 32), s) != DIF_OK) return DIF_ELAUNCH;

@@ -105,8 +105,12 @@ struct DirtyFunctor {
 // were kept by whoever set the flags) with its memory chain started EARLY: a thread reads its flag without waiting for n_occupied (flags
 // beyond it are never set), and a dirty slot's position -> 7 neighbour look-ups -> 7 observation counts -> 7 bitmap words are requested
 // before the two block-wide sums of the prefix, not after them — nine dependent hops become six.
-__device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot) {
+__device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot,
+                                                uint32_t* __restrict__ fused_word, int seq) {
     __shared__ int smem[8];
+    // two queues: this kernel runs => the frame's fusion kernel, in front of it on this stream, has completed (and released its stores): say so
+    // to the other queue, where the next frame's front end waits for exactly that (dif_map_t.frame_seq)
+    if (fused_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fused_word, (uint32_t)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int s = (int)blockIdx.x * DIF_BLOCK + (int)threadIdx.x;           // grid covers the capacity (a multiple of DIF_BLOCK)
     const bool flag = a.dirty[s] != 0;
     if (!__syncthreads_or((int)flag) && blockIdx.x != 0) return;            // nothing dirty among this block's 256 slots (most blocks of a frame)
@@ -171,13 +175,17 @@ __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __
     }
 }
 
-__global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan(DirtySet a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot) {
-    dirty_scan_body(a, n_ptr, block_tot);
+__global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan(DirtySet a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot, uint32_t* __restrict__ fused_word, int seq) {
+    dirty_scan_body(a, n_ptr, block_tot, fused_word, seq);
 }
 struct DirtyScanArgs { DirtySet a; const int* n_ptr; const int* block_tot; };
 __global__ void __launch_bounds__(DIF_BLOCK) k_dirty_scan_batch(Batch<DirtyScanArgs> b) {
     const DirtyScanArgs& a = b.s[blockIdx.y];
-    dirty_scan_body(a.a, a.n_ptr, a.block_tot);
+    dirty_scan_body(a.a, a.n_ptr, a.block_tot, nullptr, 0);
+}
+// one wave: a word for another hardware queue's hipStreamWaitValue32 (everything in front of this kernel on its stream has completed)
+__global__ void k_publish_word(uint32_t* __restrict__ word, uint32_t value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm[slot] = b; clears the bitmap

@@ -78,7 +78,7 @@ __device__ __forceinline__ void unproject_voxel_count_body(const Geo& g, const d
                                                            float cx, float cy, float* __restrict__ xyz, float* __restrict__ nrm,
                                                            int* __restrict__ pt_lin, int* __restrict__ frame_count, int* __restrict__ counters,
                                                            int px_lo, int px_hi, const dif_pending_export_t* __restrict__ pending, int nb_x,
-                                                           dif_frame_t* __restrict__ frame_copy) {
+                                                           dif_frame_t* __restrict__ frame_copy, uint8_t* __restrict__ chunk_any) {
     // The first nb_x workgroups (dispatched first, so that the copy runs beside the whole point pass and not at its tail) carry out a third of
     // the previous extract's deferred triangle export; the other two thirds ride with the next two kernels.
     if ((int)blockIdx.x < nb_x) {
@@ -102,22 +102,27 @@ __device__ __forceinline__ void unproject_voxel_count_body(const Geo& g, const d
         }
     }
     voxel_count_point(g, in, p[0], p[1], p[2], i, pt_lin, frame_count, counters, px_lo, px_hi);
+    if (chunk_any) {        // spatial tiling: does this piece of the frame hold any point inside the slab + halo?  (what it wrote to pt_lin says so)
+        const int any = __syncthreads_or((int)(in && pt_lin[i] >= 0));
+        if (threadIdx.x == 0) chunk_any[(int)blockIdx.x - nb_x] = (uint8_t)(any != 0);
+    }
 }
 
 struct UvcArgs {            // per map; the image geometry is shared by the maps of a batched launch
     Geo g; const dif_frame_t* frame; float* xyz; float* nrm; int* pt_lin; int* frame_count; int* counters; int px_lo, px_hi;
     const dif_pending_export_t* pending;
     dif_frame_t* frame_copy;        // device copy of the descriptor for the later kernels of the frame (the caller's may sit in pinned host memory)
+    uint8_t* chunk_any;             // spatial tiling: per workgroup of this kernel, "holds a point inside the slab + halo" (NULL: not kept)
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count(UvcArgs a, ImageGeo im, int nb_x) {
     unproject_voxel_count_body(a.g, a.frame, im.H, im.W, im.fx, im.fy, im.cx, im.cy, a.xyz, a.nrm, a.pt_lin, a.frame_count, a.counters, a.px_lo, a.px_hi,
-                               a.pending, nb_x, a.frame_copy);
+                               a.pending, nb_x, a.frame_copy, a.chunk_any);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count_batch(Batch<UvcArgs> b, ImageGeo im, int nb_x) {
     const UvcArgs& a = b.s[blockIdx.y];
     unproject_voxel_count_body(a.g, a.frame, im.H, im.W, im.fx, im.fy, im.cx, im.cy, a.xyz, a.nrm, a.pt_lin, a.frame_count, a.counters, a.px_lo, a.px_hi,
-                               a.pending, nb_x, a.frame_copy);
+                               a.pending, nb_x, a.frame_copy, a.chunk_any);
 }
 
 // K2: prune mask + candidate voxels.  mask[i] = count(voxel of i) > prune_min_vox_obs (map.py:375).  A kept point whose
@@ -125,13 +130,18 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_unproject_voxel_count_batch(Batch
 __device__ __forceinline__ void prune_mark_body(const Geo& g, int prune_min, const int* __restrict__ pt_lin, int64_t N,
                                                 const int* __restrict__ frame_count, const int64_t* __restrict__ indexer,
                                                 uint8_t* __restrict__ unq_mask, const GridMarks& marks,
-                                                int* __restrict__ counters, const dif_pending_export_t* __restrict__ pending, int nb_x) {
+                                                int* __restrict__ counters, const dif_pending_export_t* __restrict__ pending, int nb_x,
+                                                const uint8_t* __restrict__ chunk_any) {
     if ((int)blockIdx.x < nb_x) {           // leading workgroups: the second third of a deferred triangle export
         export_pending_rows(pending, nb_x + (int)blockIdx.x, 3 * nb_x);
         return;
     }
     const uint32_t* bits = marks.bits;
     int64_t i = (int64_t)((int)blockIdx.x - nb_x) * blockDim.x + threadIdx.x;
+    if (chunk_any && !chunk_any[(int)blockIdx.x - nb_x]) {          // spatial tiling: no point of this piece lies near the slab — nothing is kept
+        if (i < N) unq_mask[i] = 0;
+        return;
+    }
     int lane = lane_id();
     int lin = (i < N) ? pt_lin[i] : -2;
     bool keep = false;
@@ -170,15 +180,15 @@ __device__ __forceinline__ void prune_mark_body(const Geo& g, int prune_min, con
 
 struct PruneArgs {
     Geo g; int prune_min; const int* pt_lin; const int* frame_count; const int64_t* indexer; uint8_t* unq_mask; GridMarks marks; int* counters;
-    const dif_pending_export_t* pending;
+    const dif_pending_export_t* pending; const uint8_t* chunk_any;
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark(PruneArgs a, int64_t N, int nb_x) {
-    prune_mark_body(a.g, a.prune_min, a.pt_lin, N, a.frame_count, a.indexer, a.unq_mask, a.marks, a.counters, a.pending, nb_x);
+    prune_mark_body(a.g, a.prune_min, a.pt_lin, N, a.frame_count, a.indexer, a.unq_mask, a.marks, a.counters, a.pending, nb_x, a.chunk_any);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_prune_mark_batch(Batch<PruneArgs> b, int64_t N, int nb_x) {
     const PruneArgs& a = b.s[blockIdx.y];
-    prune_mark_body(a.g, a.prune_min, a.pt_lin, N, a.frame_count, a.indexer, a.unq_mask, a.marks, a.counters, a.pending, nb_x);
+    prune_mark_body(a.g, a.prune_min, a.pt_lin, N, a.frame_count, a.indexer, a.unq_mask, a.marks, a.counters, a.pending, nb_x, a.chunk_any);
 }
 
 // K3: ordered compaction of the candidate bitmap -> slots n_occupied, n_occupied+1, ... in ASCENDING lin order
@@ -226,7 +236,7 @@ __device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, co
                                                   const int64_t* __restrict__ indexer, const float* __restrict__ obs,
                                                   uint2* __restrict__ pair_list, int* __restrict__ counters, int64_t capacity, int img_w,
                                                   int* __restrict__ grid_tot, int own_lo, int own_hi,
-                                                  const dif_pending_export_t* __restrict__ pending, int nb_x) {
+                                                  const dif_pending_export_t* __restrict__ pending, int nb_x, const uint8_t* __restrict__ chunk_any) {
     if ((int)blockIdx.x < nb_x) {           // leading workgroups: the last third of a deferred triangle export
         export_pending_rows(pending, 2 * nb_x + (int)blockIdx.x, 3 * nb_x);
         return;
@@ -254,6 +264,13 @@ __device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, co
         int n = counters[DIF_C_N_OCCUPIED] + counters[DIF_C_ALLOC_NEW];
         if (n > capacity) { n = (int)capacity; counters[DIF_C_OVERFLOW] = 1; }
         counters[DIF_C_N_OCCUPIED] = n;
+    }
+    // spatial tiling: a 16 x 16 pixel tile none of whose 16 row pieces holds a point near the slab has nothing to gather (and no frame count to
+    // restore: nothing of it was counted) — one byte per row piece instead of 5 bytes per pixel
+    if (chunk_any && img_w > 0) {
+        int flag = 0;
+        if (threadIdx.x < 16) flag = chunk_any[(i + (int64_t)threadIdx.x * img_w) >> 8];      // thread t: the piece that holds row t of the tile (pieces are 256 points)
+        if (!__syncthreads_or(flag)) return;
     }
     const int lin = (i < N) ? pt_lin[i] : -1;
     uint32_t key[8];
@@ -343,17 +360,17 @@ __device__ __forceinline__ void focus_gather_body(const Geo& g, float enc_th, co
 
 struct GatherArgs {
     Geo g; float enc_th; PointSrc src; const int* pt_lin; const uint8_t* unq_mask; int* frame_count; const int64_t* indexer; const float* obs;
-    uint2* pair_list; int* counters; int64_t capacity; int* grid_tot; int own_lo, own_hi; const dif_pending_export_t* pending;
+    uint2* pair_list; int* counters; int64_t capacity; int* grid_tot; int own_lo, own_hi; const dif_pending_export_t* pending; const uint8_t* chunk_any;
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather(GatherArgs a, int64_t N, int img_w, int nb_x) {
     focus_gather_body(a.g, a.enc_th, a.src, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
-                      a.own_lo, a.own_hi, a.pending, nb_x);
+                      a.own_lo, a.own_hi, a.pending, nb_x, a.chunk_any);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_focus_gather_batch(Batch<GatherArgs> b, int64_t N, int img_w, int nb_x) {
     const GatherArgs& a = b.s[blockIdx.y];
     focus_gather_body(a.g, a.enc_th, a.src, a.pt_lin, a.unq_mask, N, a.frame_count, a.indexer, a.obs, a.pair_list, a.counters, a.capacity, img_w, a.grid_tot,
-                      a.own_lo, a.own_hi, a.pending, nb_x);
+                      a.own_lo, a.own_hi, a.pending, nb_x, a.chunk_any);
 }
 
 // =================================================================================================================
@@ -563,7 +580,7 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                           const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
                                           uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, const HaloLists& hl,
-                                          dif_pending_export_t* __restrict__ pending, int* __restrict__ dirty_tot, uint32_t* __restrict__ sync, int seq) {
+                                          dif_pending_export_t* __restrict__ pending, int* __restrict__ dirty_tot, bool shadow) {
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) {       // the point kernels' extra workgroups have done the copy (kernels ago: complete)
         pending->pending = 0;
         if (pending->notify) {              // tell the host without an event in the queue (dif_extract_buffers_t.export_notify)
@@ -618,24 +635,23 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int items = (counters[DIF_C_M] + 31) >> 5;                                                // encoder tiles of this frame
         counters[DIF_C_ITEMS] = items;
-        if (sync) {         // this integrate's counters for its extract's snapshot: the next frame's front end rewrites the live words beside that extract
+        if (shadow) {       // this integrate's counters for its extract's snapshot: the next frame's front end rewrites the live words beside that extract
             counters[DIF_C_SHADOW + 0] = counters[DIF_C_N_OCCUPIED]; counters[DIF_C_SHADOW + 1] = counters[DIF_C_ALLOC_NEW];
             counters[DIF_C_SHADOW + 2] = counters[DIF_C_M]; counters[DIF_C_SHADOW + 3] = counters[DIF_C_C]; counters[DIF_C_SHADOW + 4] = items;
         }
     }
-    if (sync) publish_when_all_done(sync + DIF_SYNC_FUSED, sync + DIF_SYNC_FUSED_TICKET, (unsigned)seq);
 }
 
 struct FuseArgs {
     const long long* rec; const int* rec_next; int* rec_dir; const int* upd_list; float* latent; float* obs; uint8_t* dirty; int* counters;
     const int64_t* slot_lin; HaloLists hl; dif_pending_export_t* pending;
-    int* dirty_tot; uint32_t* sync; int seq;          // two queues (dif_map_t.frame_seq): block totals of the dirty flags, the words to publish, this frame's number
+    int* dirty_tot; bool shadow;      // two queues (dif_map_t.frame_seq): the fusion kernel keeps the block totals of the dirty flags and leaves the shadow counters
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(FuseArgs a) {
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.sync, a.seq);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.shadow);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse_batch(Batch<FuseArgs> b) {
     const FuseArgs& a = b.s[blockIdx.y];
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.sync, a.seq);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.shadow);
 }

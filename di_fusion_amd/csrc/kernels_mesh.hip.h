@@ -750,7 +750,7 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
                                                     const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                     const float* __restrict__ log_std, const ExtractOut& out, int32_t* __restrict__ chunk_sum,
                                                     int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket,
-                                                    uint32_t* __restrict__ sync, int seq) {
+                                                    bool shadow) {
     const int B = counters[DIF_C_B];
     if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
     {
@@ -784,7 +784,7 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
         const int live = v;
         // two queues: the next frame's front end may be rewriting N_OCCUPIED / ALLOC_NEW / M / C / ITEMS right now — this frame's values are the
         // copies its fusion kernel left (lanes 0, 2, 3, 4, 5 <- DIF_C_SHADOW + 0..4)
-        if (sync && (lane == DIF_C_N_OCCUPIED || (lane >= DIF_C_ALLOC_NEW && lane <= DIF_C_ITEMS))) v = counters[DIF_C_SHADOW + (lane == DIF_C_N_OCCUPIED ? 0 : lane - DIF_C_ALLOC_NEW + 1)];
+        if (shadow && (lane == DIF_C_N_OCCUPIED || (lane >= DIF_C_ALLOC_NEW && lane <= DIF_C_ITEMS))) v = counters[DIF_C_SHADOW + (lane == DIF_C_N_OCCUPIED ? 0 : lane - DIF_C_ALLOC_NEW + 1)];
         if (lane == DIF_C_CACHE_T) v = (int)tot;
         if (lane == DIF_C_OVERFLOW && over) v = 5;
         if (out.counters_out && lane < DIF_C_STAMP) out.counters_out[lane] = v;
@@ -810,23 +810,21 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
         }
         if (lane == 0) counters[DIF_C_CACHE_T] = (int)tot;
     }
-    // two queues: the next frame's fusion kernel (other stream) may now overwrite what this extract read
-    if (sync) publish_when_all_done(sync + DIF_SYNC_EXTRACTED, sync + DIF_SYNC_EXTRACTED_TICKET, (unsigned)seq);
 }
 
 struct FinishArgs {
     const int32_t* occ_slot; int32_t* vbm; int* counters; int64_t new_limit, capacity; const float* log_tri; const int64_t* log_id; const float* log_std;
     ExtractOut out; int32_t* chunk_sum; int32_t* super_sum; int32_t* dirty_tot; int n_dirty_tot; uint32_t* mc_status; uint32_t* mc_ticket;
-    uint32_t* sync; int seq;
+    bool shadow;            // two queues: N_OCCUPIED / ALLOC_NEW / M / C / ITEMS of the snapshot come from counters[DIF_C_SHADOW ..]
 };
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(FinishArgs a) {
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.sync, a.seq);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.shadow);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish_batch(Batch<FinishArgs> b) {
     const FinishArgs& a = b.s[blockIdx.y];
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.sync, a.seq);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.shadow);
 }
 
 struct TriScanFunctor {         // exclusive scan of the per-voxel triangle counts; on the mesh-cache path also the log bookkeeping

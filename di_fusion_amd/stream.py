@@ -85,10 +85,17 @@ class FusionStream:
         self.backlog = []                   # outputs of a pending batch's earlier frames, when a frame-by-frame step had to complete it
         self.last_unq_mask = None           # eager / pipelined frames: the (H*W,) prune mask of the latest integrate (direct frames: `_d_mask`)
         # step_direct on TWO hardware queues (`enable_overlap`): frame i+1's integrate front end (unproject ... encoder) runs on `_fe_stream` beside
-        # frame i's extract on the caller's stream; the fusion kernel of frame i+1 waits — on the device — for that extract, and the extract of a
-        # frame for its fusion kernel (dif_map_t.frame_seq / sync_words).  For d2h "dma" / "none" (an overlapped frame cannot carry the previous
-        # frame's deferred export: that extract has not run yet) on an untiled map.
+        # frame i's extract on the caller's stream, which carries fuse(i), extract(i), fuse(i+1), ... back to back: the front end waits — on the
+        # device — for a word frame i's extract publishes when its fusion kernel is done, the fusion kernel of frame i+1 for a word the front end
+        # publishes (dif_map_t.frame_seq / sync_words).  For d2h "dma" / "none" (an overlapped frame cannot carry the previous frame's deferred
+        # export: that extract has not run yet) on an untiled map.
         self.overlap = False
+        # step_direct: how many frames the host may have enqueued beyond the one it hands back.  1: step(i) returns frame i-1 (waits for it, exports
+        # it, returns) before frame i+1 is enqueued — with two queues frame i+1's front end then reaches the GPU ~70 us after frame i-1's extract
+        # ended, well into frame i's extract instead of at its start.  2: step(i) returns frame i-2, which is normally complete already: the host
+        # runs ahead, the front end of the next frame is always queued in time (flush() returns what is left, oldest first, through `backlog`).
+        self.host_depth = 1
+        self._pending_older = None
         self._fe_stream = None
         self._fe_ptr = None
         self._ov_active = False             # the frames in flight are overlapped ones (the two queues are coupled through the sync words)
@@ -316,8 +323,11 @@ class FusionStream:
         return out
 
     def flush(self, d2h: str = "new"):
-        """Complete what is pending; returns the last frame's output (`flush_all` returns every pending frame's)."""
+        """Complete what is pending; returns the last frame's output (`flush_all` returns every pending frame's; with host_depth 2 the frame
+        before the last goes to `backlog`)."""
         outs = self.flush_all(d2h)
+        if self.host_depth >= 2:
+            self.backlog += outs[:-1]
         return outs[-1] if outs else None
 
     def flush_all(self, d2h: str = "new"):
@@ -408,6 +418,9 @@ class FusionStream:
         self._before_frame()
         if m._gc_wanted:
             self._complete_batch_before_gc(d2h)
+            if self._pending_older is not None:           # (of two pending frames only the newer one's triangles are the compacted log's tail)
+                q, self._pending_older = self._pending_older, None
+                self.backlog.append(self._finish_frame(q, d2h))
             self._export_deferred_now(self._pending)      # (the pending copy reads log positions that the compaction moves)
             out = self._own_storage(out)
             self.backlog = [self._own_storage(o) for o in self.backlog]
@@ -458,6 +471,20 @@ class FusionStream:
                  host_out=(k if export else None), host_slots=self._d_slots, deferred=bool(buf.defer_export))
         if d2h == "dma":
             h["dma_slot"] = k
+        if self.host_depth >= 2 and (self._pending is None or (isinstance(self._pending, dict) and "stamp" in self._pending)):
+            # two frames in flight: hand back the older one (normally complete by now), keep the previous frame pending
+            if self._pending_older is not None:
+                p, self._pending_older = self._pending_older, None
+                done = self._finish_frame(p, d2h)
+                if out is not None:
+                    self.backlog.append(out)
+                out = done
+            self._pending_older, self._pending = self._pending, h
+            if self.backlog:                                  # (frames a safe point had to complete early are older than anything else: oldest first)
+                if out is not None:
+                    self.backlog.append(out)
+                out = self.backlog.pop(0)
+            return out
         done = self._finish_pending(d2h)                          # (a batch may be pending: its earlier frames go to `backlog`)
         if done:
             self.backlog += done[:-1]
@@ -482,6 +509,7 @@ class FusionStream:
                     self._ov_enter()
                 self._ov_seq += 1
                 m._cmap.frame_seq = self._ov_seq
+                m._cmap.fuse_stream = sp            # the fusion kernel goes to the extracts' stream (the caller's), behind the previous frame's extract
                 try:
                     _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, *self._pts(),
                                                        _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), self._fe_ptr), "dif_integrate_frame")
@@ -620,13 +648,17 @@ class FusionStream:
             self.backlog += self._finish_pending(d2h)
 
     def _finish_pending(self, d2h: str):
-        """Complete whatever is pending (one frame handle or a batch's list of them); returns the outputs, oldest first."""
+        """Complete whatever is pending (one frame handle or a batch's list of them; with host_depth 2 the frame before it first); returns the
+        outputs, oldest first."""
+        outs = []
+        if self._pending_older is not None:
+            q, self._pending_older = self._pending_older, None
+            outs.append(self._finish_frame(q, d2h))
         p, self._pending = self._pending, None
         if p is None:
-            return []
+            return outs
         if not isinstance(p, list):
-            return [self._finish_frame(p, d2h)]
-        outs = []
+            return outs + [self._finish_frame(p, d2h)]
         for h in p:
             out = self._finish_frame(h, d2h)
             if self._pin is not None and out[0].numel() and out[0].data_ptr() == self._pin[0].data_ptr():
@@ -762,31 +794,6 @@ class FusionStreamGroup:
         self.streams = list(streams)
         self.device = a.device
         self._frames = (_lib.DifStreamFrame * len(streams))()
-        self.overlap = False                # two hardware queues for the group's frames (enable_overlap)
-        self._ov_active = False
-        self._ov_seq = 0
-
-    def enable_overlap(self, on: bool = True) -> bool:
-        """The group's frames on two hardware queues, like `FusionStream.enable_overlap`: the S front ends of frame i+1 (one batched launch each)
-        beside the S extracts of frame i.  The front-end stream is stream 0's."""
-        self._ov_leave()
-        self.overlap = bool(on) and self.streams[0].enable_overlap(True)
-        return self.overlap
-
-    def _ov_enter(self):
-        with torch.cuda.device(self.device):
-            for st in self.streams:
-                st._ov_leave()
-                st.map._sync_words.zero_()
-            self._ov_seq = 0
-            self.streams[0]._fe_stream.wait_stream(torch.cuda.current_stream())
-        self._ov_active = True
-
-    def _ov_leave(self):
-        if self._ov_active:
-            with torch.cuda.device(self.device):
-                torch.cuda.current_stream().wait_stream(self.streams[0]._fe_stream)
-            self._ov_active = False
 
     MIN_CAPACITY = 8192         # dif_extract_streams' dirty-set scan walks whole 256-slot blocks of maps with more than 4,096 slots
 
@@ -829,29 +836,13 @@ class FusionStreamGroup:
                 f.buf = ctypes.pointer(buf)
             lib, w, sp = a._d_lib, a._d_w, _lib.stream_ptr()
             H, W, fx, fy, cx, cy = a._d_args
-            ov = self.overlap and d2h in ("dma", "none")
-            if ov:
-                if not self._ov_active:
-                    self._ov_enter()
-                self._ov_seq += 1
-                for st in self.streams:
-                    st.map._cmap.frame_seq = self._ov_seq
-                sp_fe = a._fe_ptr
-            else:
-                self._ov_leave()
-                sp_fe = sp
-            try:
-                _lib.check(lib.dif_integrate_frames(self._frames, S, ctypes.byref(w), H, W, fx, fy, cx, cy, sp_fe), "dif_integrate_frames")
-                for st in self.streams:
-                    st._direct_integrated()
-                _lib.check(lib.dif_extract_streams(self._frames, S, ctypes.byref(w), int(a.resolution), float(a.max_std), 1, sp), "dif_extract_streams")
-            finally:
-                if ov:
-                    for st in self.streams:
-                        st.map._cmap.frame_seq = 0
+            for st in self.streams:
+                st._ov_leave()                      # (S streams per launch fill the machine as they are: a group's frames stay on one queue)
+            _lib.check(lib.dif_integrate_frames(self._frames, S, ctypes.byref(w), H, W, fx, fy, cx, cy, sp), "dif_integrate_frames")
+            for st in self.streams:
+                st._direct_integrated()
+            _lib.check(lib.dif_extract_streams(self._frames, S, ctypes.byref(w), int(a.resolution), float(a.max_std), 1, sp), "dif_extract_streams")
             return [st._direct_end(k, sl, buf, export, d2h, out) for st, (k, sl, buf, export, out) in zip(self.streams, begun)]
 
     def flush(self, d2h: str = "new"):
-        outs = [st.flush(d2h) for st in self.streams]
-        self._ov_leave()
-        return outs
+        return [st.flush(d2h) for st in self.streams]

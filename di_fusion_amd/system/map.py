@@ -272,7 +272,8 @@ class DenseIndexedMap:
         m.alloc_bits = _lib.ptr(self._alloc_bits)
         m.alloc_tot = _lib.ptr(self._alloc_tot)
         m.sync_words = _lib.ptr(self._sync_words)
-        m.frame_seq = 0                     # two queues off; FusionStream sets it per overlapped frame
+        m.frame_seq = 0                     # two queues off; FusionStream sets it (and fuse_stream) per overlapped frame
+        m.fuse_stream = None
         self._cmap = m
         self._recount_dirty()
 

@@ -116,27 +116,27 @@ typedef struct dif_map {
      * frame's integrate may then not run beside the previous frame's extract. */
     uint32_t* alloc_bits;
     int32_t* alloc_tot;
-    /* Two hardware queues for ONE stream of frames (DESIGN.md section 3 "two queues"): with `frame_seq` > 0 and `sync_words` set,
-     *   dif_integrate_frame(s) on stream A runs frame n's front end (unproject ... encoder) WITHOUT waiting for frame n-1's extract, waits —
-     *     on the device: hipStreamWaitValue32 — until sync_words[DIF_SYNC_EXTRACTED] >= frame_seq - 1, runs the fusion kernel, whose last
-     *     workgroup publishes sync_words[DIF_SYNC_FUSED] = frame_seq;
-     *   dif_extract / dif_extract_streams on stream B waits until sync_words[DIF_SYNC_FUSED] >= frame_seq, runs, and its last kernel's last
-     *     workgroup publishes sync_words[DIF_SYNC_EXTRACTED] = frame_seq.
-     * So frame n+1's front end (it follows frame n's fusion kernel on stream A) runs beside frame n's extract.  What makes that legal: slots
-     * that frame n+1 allocates are invisible to frame n's extract (observation count 0 => not confident, batch row -1 => missing:
-     * mc_interp_kernel.cu:17-24, map.py:628-631), the allocation bitmap is `alloc_bits`, the dirty-flag block totals are kept by the fusion
-     * kernel (behind the extract) instead of the encoder, and the counters of frame n's integrate that its extract hands to the caller are the
-     * copies the fusion kernel left in counters[DIF_C_SHADOW ..].  Requires alloc_bits, dirty_tot, no deferred export (pending_export idle),
-     * an untiled map, and that A and B really are different hardware queues (dif_queues_independent).  The caller advances frame_seq by one per
-     * frame, uses the same value for the frame's integrate and extract, and starts from words that hold frame_seq - 1.  frame_seq = 0: off. */
+    /* Two hardware queues for ONE stream of frames (DESIGN.md section 3 "two queues"): with `frame_seq` > 0, `sync_words` and `fuse_stream` set,
+     *   dif_integrate_frame(s)(..., stream A) waits — on the device: hipStreamWaitValue32 — until sync_words[DIF_SYNC_FUSED] >= frame_seq - 1, runs
+     *     the frame's FRONT END on A (unproject ... encoder), publishes sync_words[DIF_SYNC_FRONT_DONE] = frame_seq behind it, and enqueues the
+     *     fusion kernel on `fuse_stream` (= stream B, the extracts' stream) behind a wait for that word;
+     *   dif_extract / dif_extract_streams on stream B publishes sync_words[DIF_SYNC_FUSED] = frame_seq from its first kernel (it starts when the
+     *     fusion kernel in front of it on B has completed).
+     * So stream B carries fuse(n), extract(n), fuse(n+1), ... back to back with ONE satisfied wait per frame in between, and frame n+1's front
+     * end runs on A beside frame n's extract.  What makes that legal: slots that frame n+1 allocates are invisible to frame n's extract
+     * (observation count 0 => not confident, batch row -1 => missing: mc_interp_kernel.cu:17-24, map.py:628-631), the allocation bitmap is
+     * `alloc_bits`, the dirty-flag block totals are kept by the fusion kernel (behind the extract) instead of the encoder, and the counters of
+     * frame n's integrate that its extract hands to the caller are the copies the fusion kernel left in counters[DIF_C_SHADOW ..].  Requires
+     * alloc_bits, dirty_tot, capacity > 4096 (a multiple of 256), no deferred export (pending_export idle), an untiled map.  On streams that share
+     * a hardware queue (dif_queues_independent) the frames are serialised in enqueue order — correct, nothing gained.  The caller advances
+     * frame_seq by one per frame, uses the same value for the frame's integrate and extract, and starts from words that hold frame_seq - 1.
+     * frame_seq = 0: off. */
     uint32_t* sync_words;           /* [DIF_SYNC_WORDS] device memory */
     int32_t frame_seq;
+    void* fuse_stream;              /* hipStream_t of the extracts: where an overlapped frame's fusion kernel goes */
 } dif_map_t;
 
-/* sync_words: the two published words and the tickets that elect the publishing workgroup, each on a 128-byte line of its own (nine ticket words per
- * kernel: one per residue of the workgroup index modulo 8 — i.e. per XCD —, so that the same-address atomic chain is 32 long instead of 256, and one for
- * the eight winners) */
-enum { DIF_SYNC_FUSED = 0, DIF_SYNC_EXTRACTED = 32, DIF_SYNC_FUSED_TICKET = 64, DIF_SYNC_EXTRACTED_TICKET = 384, DIF_SYNC_WORDS = 704 };
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_WORDS = 64 };      /* each word on a 128-byte line of its own */
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
 typedef struct dif_pending_export {

@@ -149,6 +149,47 @@ def test_two_queue_frames_are_bit_identical(d2h, gpu_model):
             assert st.map._gc_epoch == 1
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_host_two_frames_ahead_hands_back_the_same_frames(overlap, gpu_model):
+    """`host_depth = 2`: step_direct(i) returns frame i-2 (normally complete already), so the host never waits for the frame in front of the
+    one it enqueues — what lets the two-queue mode queue the next front end in time.  Same triangles, same order, same final map as the eager
+    run; a forced log compaction and a map short of room (every frame first completes what is pending) included."""
+    st = make_stream(gpu_model)
+    F = N_FRAMES
+    per_frame = []
+    for i in range(F):
+        o = st.step(i, d2h="new")
+        torch.cuda.synchronize()
+        per_frame.append(tuple(x.clone() for x in o))
+    ref = snapshot(st)
+    for rep, cap in enumerate([None, 1 << 13]):
+        for d2h in ("dma", "none"):
+            st = make_stream(gpu_model, initial_capacity=cap)
+            st.host_depth = 2
+            if overlap and not st.enable_overlap():
+                pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
+            got = [per_frame[0]]
+            st.step(0, d2h="new")
+            torch.cuda.synchronize()
+            for i in range(1, F):
+                if i == 4:
+                    st.map._gc_wanted = True
+                o = st.step_direct(i, d2h=d2h)
+                if o is not None:
+                    if d2h == "none":
+                        torch.cuda.synchronize()
+                    got.append(tuple(x.clone() for x in o))
+            rest = st.backlog + st.flush_all(d2h)
+            st.backlog = []
+            torch.cuda.synchronize()
+            got += [tuple(x.clone() for x in o) for o in rest]
+            assert len(got) == F, (rep, d2h, len(got))
+            for f, (a, b) in enumerate(zip(per_frame, got)):
+                assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a, b)), f"cap {cap} d2h {d2h} frame {f}"
+            same(ref, snapshot(st))
+            assert st.map._gc_epoch == 1
+
+
 @pytest.mark.parametrize("mix", ["direct", "direct+graph"])
 def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
     """`step_direct` with the stream's own capacity (room for the frames in flight, so the host never completes a frame early): a frame's new
@@ -437,39 +478,6 @@ def test_stream_group_matches_single_streams(S, gpu_model):
         same(solo[j][1], grp[j][1])
     if S > 1:       # the streams really are different subsequences
         assert not torch.equal(solo[0][1]["indexer"], solo[1][1]["indexer"])
-
-
-def test_stream_group_on_two_queues_matches_single_streams(gpu_model):
-    """`FusionStreamGroup.enable_overlap`: the batched front ends of frame i+1 beside the batched extracts of frame i (every map with its own
-    sync words), triangles delivered by the SDMA copy: per stream identical to the stream stepped alone, with no device drain between frames."""
-    from di_fusion_amd.stream import FusionStream, FusionStreamGroup
-    cfg = S_.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.2)
-    intr = S_.Intrinsic().scaled(0.25)
-    F, S = 8, 3
-
-    def make(j):
-        return FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, F, deg_per_frame=6.0, phase_deg=45.0 * j, initial_capacity=None)
-
-    solo = []
-    for j in range(S):
-        st = make(j)
-        solo.append(([_eager(st, i) for i in range(F)], snapshot(st)))
-    streams = [make(j) for j in range(S)]
-    got = [[_eager(st, 0)] for st in streams]
-    grp = FusionStreamGroup(streams)
-    if not grp.enable_overlap():
-        pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
-    for i in range(1, F):
-        for j, o in enumerate(grp.step(i, d2h="dma")):
-            if o is not None:
-                got[j].append(tuple(x.clone() for x in o))
-    for j, o in enumerate(grp.flush("dma")):
-        got[j].append(tuple(x.clone() for x in o))
-    for j in range(S):
-        assert len(got[j]) == F
-        for f, (a, b) in enumerate(zip(solo[j][0], got[j])):
-            assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a, b)), f"stream {j} frame {f}"
-        same(solo[j][1], snapshot(streams[j]))
 
 
 def test_stream_group_marching_cubes_in_ticket_mode(gpu_model, mc_grid_cap):
