@@ -106,7 +106,7 @@ inline GridMarks alloc_marks_of(const dif_map_t* map) {
 }
 
 // two hardware queues for one stream of frames (include/difusion.h: dif_map_t.frame_seq)
-inline bool overlapped(const dif_map_t* map) { return map->sync_words && map->fuse_stream && map->frame_seq > 0; }
+inline bool overlapped(const dif_map_t* map) { return map->sync_words && map->frame_seq > 0; }      // (fuse_stream may be the null stream: 0)
 inline bool overlap_ok(const dif_map_t* map) {
     return map->alloc_bits && map->alloc_tot && map->dirty_tot && !map_is_tiled(map) && map->capacity > 4096 && map->capacity % DIF_BLOCK == 0;
 }

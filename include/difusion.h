@@ -116,7 +116,8 @@ typedef struct dif_map {
      * frame's integrate may then not run beside the previous frame's extract. */
     uint32_t* alloc_bits;
     int32_t* alloc_tot;
-    /* Two hardware queues for ONE stream of frames (DESIGN.md section 3 "two queues"): with `frame_seq` > 0, `sync_words` and `fuse_stream` set,
+    /* Two hardware queues for ONE stream of frames (DESIGN.md section 3 "two queues"): with `frame_seq` > 0 and `sync_words` set (`fuse_stream`
+     * may be the null stream),
      *   dif_integrate_frame(s)(..., stream A) waits — on the device: hipStreamWaitValue32 — until sync_words[DIF_SYNC_FUSED] >= frame_seq - 1, runs
      *     the frame's FRONT END on A (unproject ... encoder), publishes sync_words[DIF_SYNC_FRONT_DONE] = frame_seq behind it, and enqueues the
      *     fusion kernel on `fuse_stream` (= stream B, the extracts' stream) behind a wait for that word;
