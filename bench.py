@@ -200,6 +200,8 @@ def prime_process(FusionStream, syn, model, intr, dev, d2h, graphs=True, overlap
     torch.cuda.synchronize()
     del prime
     gc.collect()
+    if os.environ.get("DIF_BENCH_PRIME_EMPTY_CACHE") == "1":        # (experiments: round 4's behaviour)
+        torch.cuda.empty_cache()
 
 
 def frame_runner(stream, a, d2h):
