@@ -73,9 +73,9 @@ def parse():
     ap.add_argument("--group-d2h", default="new", choices=["new", "dma"], help="how the secondary S-streams-per-GPU legs of a `--d2h dma` run deliver their triangles: "
                     "new (default: carried by the next group frame's point kernels) or dma (one SDMA call per stream and group frame: equal at S = 4, 6 % behind at "
                     "S = 8 — the host)")
-    ap.add_argument("--host-depth", type=int, default=2, choices=[1, 2], help="directly launched frames: how many frames the host may have enqueued beyond the one "
-                    "it hands back.  1: frame i-1's triangles come back before frame i+1 is enqueued; 2 (default): frame i-2's — the host never waits for the "
-                    "frame in front of the one it enqueues, which is what keeps the second queue fed (config.host_pipeline_depth)")
+    ap.add_argument("--host-depth", type=int, default=1, choices=[1, 2], help="directly launched frames: how many frames the host may have enqueued beyond the one "
+                    "it hands back.  1 (default): frame i-1's triangles come back before frame i+1 is enqueued; 2: frame i-2's — the host never waits for the "
+                    "frame in front of the one it enqueues (measured: the same rate, 6.6-6.9 k frames/s either way; config.host_pipeline_depth)")
     ap.add_argument("--rccl-before-clock", type=int, default=0, choices=[0, 1], help="--mode c4 under torch.distributed: 0 (default) = the barriers around "
                     "the clock go over gloo and RCCL is brought up BEHIND the clock, for the exchange step (the global map merge); 1 = RCCL is the process group "
                     "from the start, alive during the timed region like in a deployment that merges maps periodically.  The line says which "

@@ -474,6 +474,17 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
     return DIF_OK;
 }
 
+// workgroups (= CUs) of the encoder of an overlapped frame; DIF_OVERLAP_ENCODER_CUS (read once) for experiments
+static int overlap_encoder_cus() {
+    static const int n = [] {
+        const char* e = getenv("DIF_OVERLAP_ENCODER_CUS");
+        int v = e ? atoi(e) : 0;
+        if (v <= 0) v = num_cus();
+        return v < 1 ? 1 : (v > num_cus() ? num_cus() : v);
+    }();
+    return n;
+}
+
 static int encoder_attributes() {
     static bool attr_set[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
@@ -517,11 +528,16 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         if (encoder_attributes() != DIF_OK) return DIF_ELAUNCH;
         const EncArgs& e = P.enc;
         ProfScope prof(DIF_PROF_ENCODE, s);
+        // two queues: this encoder runs beside the previous frame's decode kernels, and neither shares a CU with the other (158 KB and 146-156 KB of
+        // LDS).  Measured (profiles/r05_experiments.md): confining the encoder to fewer CUs does not help — 256: 6,780 frames/s, 128: 7,120 / 6,900,
+        // 96: 6,370, 64: 5,990, 32: 4,930 (it becomes the critical path: 74 us on 64 CUs), and the decode kernels take their 43-45 us beside ANY of
+        // them — so it keeps all CUs.
+        const int enc_grid = P.overlap ? overlap_encoder_cus() : num_cus();
         if (x6)
-            hipLaunchKernelGGL(k_encode<true>, dim3(num_cus()), dim3(ENC_X6_THREADS), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
+            hipLaunchKernelGGL(k_encode<true>, dim3(enc_grid), dim3(ENC_X6_THREADS), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
                                e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         else
-            hipLaunchKernelGGL(k_encode<false>, dim3(num_cus()), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.src.xyz, e.src.normal, e.src.frame,
+            hipLaunchKernelGGL(k_encode<false>, dim3(enc_grid), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.src.xyz, e.src.normal, e.src.frame,
                                e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         DIF_CHECK_LAUNCH();
     }
