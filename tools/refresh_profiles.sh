@@ -8,8 +8,15 @@ timeout 600 $B > $O/bench_n1.json 2> $O/bench_n1.err
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- $B --no-cpu-baseline --no-secondary > $O/trace_bench.log 2>&1
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 200 > $O/kernel_stats.md 2>&1
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --after-nth k_prune_mark 160 --frames 50 > $O/kernel_stats_steady.md 2>&1
+python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --timeline k_prune_mark 150 > $O/timeline_overlap.txt 2>&1
+rm -rf $O/trace
+# ---- the same stream on ONE queue (--overlap 0): what the second queue buys ----
+timeout 600 $B --no-cpu-baseline --no-secondary --overlap 0 > $O/bench_n1_one_queue.json 2> $O/bench_n1_one_queue.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- $B --no-cpu-baseline --no-secondary --overlap 0 > $O/trace_bench_ov0.log 2>&1
+python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --after-nth k_prune_mark 160 --frames 50 > $O/kernel_stats_steady_one_queue.md 2>&1
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) --timeline k_prune_mark 150 > $O/timeline_direct.txt 2>&1
 rm -rf $O/trace
+timeout 300 $B --no-cpu-baseline --no-secondary --overlap 0 --steps 20 --warmup 5 > $O/bench_k20_one_queue.json 2> $O/bench_k20_one_queue.err
 # ---- the DRIVER's invocation: --steps 20 --warmup 5 (map-building transient) ----
 K20="--steps 20 --warmup 5 --no-cpu-baseline"
 timeout 300 $B $K20 > $O/bench_k20.json 2> $O/bench_k20.err
@@ -70,7 +77,8 @@ rm -rf $O/trace_lb8 $O/trace_t1
 timeout 300 $B --graph 1 --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
 timeout 300 $B --batch 5 --no-cpu-baseline --no-secondary > $O/bench_batch5.json 2> $O/bench_batch5.err
 for c in c1 c2; do timeout 300 $B --config $c --no-cpu-baseline --steps 50 > $O/bench_$c.json 2> $O/bench_$c.err; done
-DIF_FORCE_DIST=1 timeout 300 $B --no-cpu-baseline --steps 50 --no-secondary > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
+DIF_FORCE_DIST=1 timeout 300 $B --no-cpu-baseline --no-secondary > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
+DIF_FORCE_DIST=1 timeout 300 $B --no-cpu-baseline --no-secondary --rccl-before-clock 1 > $O/bench_rccl_1rank_before_clock.json 2> $O/bench_rccl_1rank_before_clock.err
 timeout 900 python tools/stress_full_occupancy.py --n 128 --reps 2 > $O/stress_full.json 2> $O/stress_full.err
 timeout 900 python tools/stress_integrate.py > $O/stress_integrate.json 2> $O/stress_integrate.err
 timeout 300 python tools/bench_cloud.py --cpu-sample 20000 > $O/bench_cloud.json 2> $O/bench_cloud.err
