@@ -758,6 +758,9 @@ def main():
                           "d2h_per_frame": a.d2h,
                           "d2h_engine": (None if a.d2h != "dma" else "sdma (hsa_amd_memory_async_copy, no copy kernel)" if stream._sdma else
                                          "hipMemcpyAsync on a side stream (blit kernels)"),
+                          "sdma_call_us": (None if not stream.sdma_us else {"calls": len(stream.sdma_us), "median": round(float(np.median([u for _, u in stream.sdma_us])), 1),
+                                                                               "p90": round(float(np.percentile([u for _, u in stream.sdma_us], 90)), 1),
+                                                                               "first_40": [(n, round(u)) for n, u in stream.sdma_us[:40]]}),
                           "two_queues": {"on": bool(stream.overlap), "queues_independent": stream.queues_independent,
                                          "what": "frame i+1's integrate front end on a second hardware queue beside frame i's extract; fusion kernel and extract "
                                                  "ordered by hipStreamWaitValue32 on words the kernels publish" if stream.overlap else "one queue"},

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <atomic>
+#include <chrono>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
@@ -1271,16 +1272,29 @@ int dif_mesh_cache_export_dma(const dif_extract_buffers_t* buf, int64_t lo, int6
 }
 
 // ---- the export by the SDMA engines, through the HSA runtime the process already runs on (the one HIP sits on) --------------------------------
+// Which engine: NOT the runtime's choice.  hsa_amd_memory_async_copy sends a device -> host copy to one of its two "preferred" engines, and that
+// engine turns slow — 139 us instead of 15 for 300 KB, for as long as the process lives — once the process has freed gigabytes of device memory
+// (tools/micro/sdma_engines.hip: engine 1 after hipFree of 8 GB; every other engine unchanged; this is what made the export 6x slower behind
+// torch.cuda.empty_cache()).  So the engines are timed here (one 256 KB copy each, three rounds, at the first export and again whenever four
+// exports in a row take more than 2.2 times what they should) and a frame's three row ranges go to the three fastest of the engines the runtime
+// does not prefer, one each.
 struct HsaCopy {
     bool tried = false, ok = false;
     hsa_status_t (*init)() = nullptr;
     hsa_status_t (*pointer_info)(const void*, hsa_amd_pointer_info_t*, void* (*)(size_t), uint32_t*, hsa_agent_t**) = nullptr;
     hsa_status_t (*async_copy)(void*, hsa_agent_t, const void*, hsa_agent_t, size_t, uint32_t, const hsa_signal_t*, hsa_signal_t) = nullptr;
+    hsa_status_t (*async_copy_on)(void*, hsa_agent_t, const void*, hsa_agent_t, size_t, uint32_t, const hsa_signal_t*, hsa_signal_t, hsa_amd_sdma_engine_id_t, bool) = nullptr;
+    hsa_status_t (*engine_status)(hsa_agent_t, hsa_agent_t, uint32_t*) = nullptr;
+    hsa_status_t (*preferred_engines)(hsa_agent_t, hsa_agent_t, uint32_t*) = nullptr;
     hsa_status_t (*signal_create)(hsa_signal_value_t, uint32_t, const hsa_agent_t*, hsa_signal_t*) = nullptr;
     void (*signal_store)(hsa_signal_t, hsa_signal_value_t) = nullptr;
     hsa_signal_value_t (*signal_wait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
-    hsa_signal_t sig{};
+    hsa_signal_t sig{}, sig3[3]{};
     std::mutex mu;
+    int engines[3] = {-1, -1, -1};      // the engines of the three row ranges (-1: let the runtime choose)
+    double engine_us = 0.0;             // what the calibration copy took on the fastest one (0: not calibrated yet; < 0: engines cannot be chosen here)
+    double us_per_byte = 0.0;           // ... and per byte beyond its fixed cost, for what a range of another size should take
+    int slow_calls = 0;
     bool load() {
         if (tried) return ok;
         tried = true;
@@ -1298,14 +1312,70 @@ struct HsaCopy {
         init = (decltype(init))sym("hsa_init");
         pointer_info = (decltype(pointer_info))sym("hsa_amd_pointer_info");
         async_copy = (decltype(async_copy))sym("hsa_amd_memory_async_copy");
+        async_copy_on = (decltype(async_copy_on))sym("hsa_amd_memory_async_copy_on_engine");        // (optional: older runtimes)
+        engine_status = (decltype(engine_status))sym("hsa_amd_memory_copy_engine_status");
+        preferred_engines = (decltype(preferred_engines))sym("hsa_amd_memory_get_preferred_copy_engine");
         signal_create = (decltype(signal_create))sym("hsa_signal_create");
         signal_store = (decltype(signal_store))sym("hsa_signal_store_relaxed");
         signal_wait = (decltype(signal_wait))sym("hsa_signal_wait_scacquire");
         if (!init || !pointer_info || !async_copy || !signal_create || !signal_store || !signal_wait) return false;
         if (init() != HSA_STATUS_SUCCESS) return false;                 // (reference-counted: the runtime is up already)
         if (signal_create(0, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
+        for (auto& q : sig3)
+            if (signal_create(0, 0, nullptr, &q) != HSA_STATUS_SUCCESS) return false;
         ok = true;
         return true;
+    }
+    // wait until signal q (set to 1 before its copy was issued) is down to 0; at most ~2 s
+    bool wait_one(hsa_signal_t q) {
+        for (int spins = 0; spins < 2000; ++spins)
+            if (signal_wait(q, HSA_SIGNAL_CONDITION_LT, 1, 1000000 /* ~1 ms of the signal's clock */, HSA_WAIT_STATE_ACTIVE) < 1) return true;
+        return false;
+    }
+    bool copy_on(int engine, void* dst, hsa_agent_t cpu, const void* src, hsa_agent_t gpu, size_t bytes, hsa_signal_t q) {
+        if (engine >= 0 && async_copy_on) return async_copy_on(dst, cpu, src, gpu, bytes, 0, nullptr, q, (hsa_amd_sdma_engine_id_t)(1u << engine), false) == HSA_STATUS_SUCCESS;
+        return async_copy(dst, cpu, src, gpu, bytes, 0, nullptr, q) == HSA_STATUS_SUCCESS;
+    }
+    // time a copy of `bytes` (src -> dst) on the candidate engines; keep the three fastest.  Candidates: the engines the runtime does NOT prefer for this
+    // direction, if at least two of them exist — its preferred ones carry the process's own copies and are the ones that turn slow — else all.
+    void calibrate(void* dst, hsa_agent_t cpu, const void* src, hsa_agent_t gpu, size_t bytes) {
+        engines[0] = engines[1] = engines[2] = -1;
+        engine_us = us_per_byte = 0.0;
+        slow_calls = 0;
+        uint32_t avail = 0, pref = 0;
+        if (!async_copy_on || !engine_status || engine_status(cpu, gpu, &avail) != HSA_STATUS_SUCCESS || !avail) return;
+        if (preferred_engines && preferred_engines(cpu, gpu, &pref) == HSA_STATUS_SUCCESS && __builtin_popcount(avail & ~pref) >= 2) avail &= ~pref;
+        double best[3] = {1e30, 1e30, 1e30}, small_us = 1e30;
+        for (int e = 0; e < 16; ++e) {
+            if (!(avail & (1u << e))) continue;
+            double t = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                signal_store(sig, 1);
+                const auto t0 = std::chrono::steady_clock::now();
+                if (!copy_on(e, dst, cpu, src, gpu, bytes, sig) || !wait_one(sig)) { t = 1e30; break; }
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                if (us < t) t = us;
+            }
+            for (int k = 0; k < 3; ++k)
+                if (t < best[k]) {
+                    for (int m = 2; m > k; --m) { best[m] = best[m - 1]; engines[m] = engines[m - 1]; }
+                    best[k] = t; engines[k] = e;
+                    break;
+                }
+        }
+        if (engines[0] < 0) return;
+        engine_us = best[0];
+        for (int k = 1; k < 3; ++k)
+            if (engines[k] < 0 || best[k] > 1.5 * best[0]) engines[k] = engines[k - 1];      // fewer than three fast ones: share
+        // the fixed cost of a copy on the fastest engine (4 KB), for the size model
+        for (int rep = 0; rep < 3; ++rep) {
+            signal_store(sig, 1);
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!copy_on(engines[0], dst, cpu, src, gpu, bytes < 4096 ? bytes : 4096, sig) || !wait_one(sig)) break;
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (us < small_us) small_us = us;
+        }
+        if (small_us < engine_us && bytes > 4096) us_per_byte = (engine_us - small_us) / (double)(bytes - 4096);
     }
 };
 static HsaCopy g_hsa;
@@ -1322,21 +1392,41 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
     if (g_hsa.pointer_info(buf->cache_tri, &src, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || src.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return DIF_ELAUNCH;
     if (g_hsa.pointer_info(out_tri, &dst, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || dst.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return DIF_ELAUNCH;
     const hsa_agent_t gpu = src.agentOwner, cpu = dst.agentOwner;
-    g_hsa.signal_store(g_hsa.sig, 3);
     const void* from[3] = {(const float*)buf->cache_tri + lo * 9, (const int64_t*)buf->cache_id + lo, (const float*)buf->cache_std + lo * 3};
     void* to[3] = {out_tri, out_id, out_std};
     const size_t bytes[3] = {(size_t)n * 9 * sizeof(float), (size_t)n * sizeof(int64_t), (size_t)n * 3 * sizeof(float)};
+    if (g_hsa.engines[0] < 0 && g_hsa.engine_us == 0.0) {
+        // (the calibration copies write rows of this very frame to where the real copy puts them again)
+        g_hsa.calibrate(out_tri, cpu, from[0], gpu, bytes[0] < (256u << 10) ? bytes[0] : (256u << 10));
+        if (g_hsa.engine_us == 0.0) g_hsa.engine_us = -1.0;              // engines cannot be chosen here: the runtime's choice, and no re-calibration
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     int issued = 0;
+    // (the 36-byte rows on the fastest engine, the two small ranges on the next two; a signal each, so that each range is timed)
     for (int k = 0; k < 3; ++k) {
-        if (g_hsa.async_copy(to[k], cpu, from[k], gpu, bytes[k], 0, nullptr, g_hsa.sig) != HSA_STATUS_SUCCESS) break;
+        g_hsa.signal_store(g_hsa.sig3[k], 1);
+        if (!g_hsa.copy_on(g_hsa.engines[k], to[k], cpu, from[k], gpu, bytes[k], g_hsa.sig3[k])) break;
         ++issued;
     }
-    // wait for what was issued (each copy takes the signal down by one), at most ~2 s
-    const hsa_signal_value_t done_below = (hsa_signal_value_t)(3 - issued) + 1;
-    for (int spins = 0; spins < 2000; ++spins)
-        if (g_hsa.signal_wait(g_hsa.sig, HSA_SIGNAL_CONDITION_LT, done_below, 1000000 /* ~1 ms of the signal's clock */, HSA_WAIT_STATE_ACTIVE) < done_below)
-            return issued == 3 ? DIF_OK : DIF_ELAUNCH;
-    return DIF_ELAUNCH;
+    bool landed = true, slow = false;
+    const int order[3] = {1, 2, 0};                                    // the small ranges land first
+    for (int j = 0; j < 3; ++j) {
+        const int k = order[j];
+        if (k >= issued) continue;
+        landed = g_hsa.wait_one(g_hsa.sig3[k]) && landed;
+        if (g_hsa.engine_us > 0.0) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            const double expect = g_hsa.engine_us + g_hsa.us_per_byte * (double)bytes[k] + 10.0;       // (+ the host's own time to issue three copies)
+            slow = slow || us > 2.2 * expect;
+        }
+    }
+    if (issued < 3 || !landed) return DIF_ELAUNCH;
+    // an engine that has turned slow (2.2 times what a range of that size should take, four exports in a row): look for better ones at the next call
+    if (g_hsa.engine_us > 0.0) {
+        g_hsa.slow_calls = slow ? g_hsa.slow_calls + 1 : 0;
+        if (g_hsa.slow_calls >= 4) { g_hsa.engines[0] = -1; g_hsa.engine_us = 0.0; }
+    }
+    return DIF_OK;
 }
 
 // ---- are two streams on different hardware queues? ----------------------------------------------------------------------------------------

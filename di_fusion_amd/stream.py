@@ -103,6 +103,7 @@ class FusionStream:
         self.queues_independent = None      # what dif_queues_independent said about the two streams
         self._sdma = None                   # None: untried; True / False: the SDMA export works / does not (or is slow) in this process
         self._sdma_slow = 0
+        self.sdma_us = []                   # (triangles, microseconds) of every SDMA export call
 
     def enable_overlap(self, on: bool = True) -> bool:
         """Two hardware queues for `step_direct`.  Returns whether the mode is on: it stays off (False) when no second stream on a hardware queue of
@@ -284,6 +285,7 @@ class FusionStream:
                     rc = _lib.load().dif_mesh_cache_export_sdma(ctypes.byref(self.map._cache_struct()), tri.storage_offset() // 9, n, sl["out_ptr"][0],
                                                                 sl["out_ptr"][1], sl["out_ptr"][2])
                     self._sdma = (rc == 0)
+                    self.sdma_us.append((int(n), (time.perf_counter() - t0) * 1e6))
                     if n < (1 << 15):
                         self._sdma_slow = self._sdma_slow + 1 if (time.perf_counter() - t0) * 1e6 > self.SDMA_SLOW_US else 0
                         if self._sdma_slow >= 8:

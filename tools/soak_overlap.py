@@ -1,0 +1,55 @@
+"""Soak of the two-queue mode: the C3 stream (F frames) stepped R times on two queues — without any device drain, d2h dma and none alternating,
+host depth 1 and 2 alternating — against ONE single-queue run: every frame's triangles and the final map bit for bit.  A race between a frame's
+front end and its predecessor's extract would show up as a differing frame sooner or later.
+Usage: python tools/soak_overlap.py [R=20] [F=40]"""
+import sys, time
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from di_fusion_amd import synthetic as S
+from di_fusion_amd.network import utility as net_util
+from di_fusion_amd.stream import FusionStream
+
+DEV = torch.device("cuda:0")
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+model = net_util.networks_from_arrays(net_util.load_weights_npz())
+scene, cfg = S.config_c3()
+
+
+def run(overlap, d2h, depth):
+    st = FusionStream(model, scene, cfg, S.Intrinsic(), DEV, F, deg_per_frame=0.5)
+    st.host_depth = depth
+    if overlap:
+        assert st.enable_overlap()
+    outs = []
+    for i in range(F):
+        o = (st.step_pipelined if i < 2 else st.step_direct)(i, d2h)
+        if o is not None:
+            if d2h == "none" or i <= 2:
+                torch.cuda.synchronize()
+            outs.append(tuple(x.clone().cpu() for x in o))
+    rest = st.backlog + st.flush_all(d2h)
+    st.backlog = []
+    torch.cuda.synchronize()
+    outs += [tuple(x.clone().cpu() for x in o) for o in rest]
+    n = st.map.n_occupied
+    final = (st.map.indexer.clone().cpu(), st.map.latent_vecs[:n].clone().cpu(), st.map.voxel_obs_count[:n].clone().cpu())
+    del st
+    return outs, final
+
+
+ref_outs, ref_final = run(False, "dma", 1)
+assert len(ref_outs) == F
+bad = 0
+t0 = time.time()
+for r in range(R):
+    d2h, depth = ("dma", "none")[r & 1], 1 + ((r >> 1) & 1)
+    outs, final = run(True, d2h, depth)
+    ok = len(outs) == F and all(all(torch.equal(x, y) for x, y in zip(a, b)) for a, b in zip(ref_outs, outs)) and all(torch.equal(x, y) for x, y in zip(ref_final, final))
+    if not ok:
+        bad += 1
+        first = next((f for f, (a, b) in enumerate(zip(ref_outs, outs)) if not all(torch.equal(x, y) for x, y in zip(a, b))), None)
+        print(f"repeat {r} (d2h {d2h}, host depth {depth}): DIFFERS (first differing frame: {first}, frames {len(outs)})", flush=True)
+print(f"two-queue soak: {R} runs of {F} C3 frames against the single-queue run: {bad} differ ({time.time() - t0:.0f} s)")
+sys.exit(1 if bad else 0)
