@@ -109,7 +109,8 @@ inline GridMarks alloc_marks_of(const dif_map_t* map) {
 // two hardware queues for one stream of frames (include/difusion.h: dif_map_t.frame_seq)
 inline bool overlapped(const dif_map_t* map) { return map->sync_words && map->frame_seq > 0; }      // (fuse_stream may be the null stream: 0)
 inline bool overlap_ok(const dif_map_t* map) {
-    return map->alloc_bits && map->alloc_tot && map->dirty_tot && !map_is_tiled(map) && map->capacity > 4096 && map->capacity % DIF_BLOCK == 0;
+    return map->alloc_bits && map->alloc_tot && map->dirty_tot && map->frame_counters && !map_is_tiled(map) && map->capacity > 4096 &&
+           map->capacity % DIF_BLOCK == 0;
 }
 inline int wait_word(hipStream_t s, uint32_t* word, int32_t value) {
     if (value <= 0) return DIF_OK;
@@ -470,7 +471,8 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
                           map->capacity, alloc_tot_of(map), own_lo, own_hi, ov ? nullptr : pending, cull};
     P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, ov ? nullptr : map->dirty_tot};
     P.fuse = FuseArgs{ws.rec, ws.rec_next, map->rec_dir, map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->latent_vecs_pos,
-                      halo_lists_of(map), ov ? nullptr : pending, ov ? map->dirty_tot : nullptr, ov};
+                      halo_lists_of(map), ov ? nullptr : pending, ov ? map->dirty_tot : nullptr, ov ? map->frame_counters : nullptr,
+                      ov ? map->sync_words + DIF_SYNC_DECODED : nullptr, ov ? map->frame_seq : 0};
     if (ov) P.uvc.pending = nullptr;                               // (no deferred export rides with an overlapped frame: its extract has not run yet)
     return DIF_OK;
 }
@@ -512,6 +514,8 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     const int nb_x = P.has_pending ? DIF_EXPORT_WGS : 0;
     // two queues: the front end reads what the previous frame's fusion kernel (extracts' stream) wrote; that frame's extract says when it is done
     if (P.overlap && wait_word(s, map->sync_words + DIF_SYNC_FUSED, map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
+    // ... and, with the mesh halves on a stream of their own, the one that used this frame's buffers two frames ago must have completed
+    if (P.overlap && map->mesh_wait > 0 && wait_word(s, map->sync_words + DIF_SYNC_MESHED, map->mesh_wait) != DIF_OK) return DIF_ELAUNCH;
     // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
     if (src)
         hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, P.uvc, ImageGeo{src->H, src->W, src->fx, src->fy, src->cx, src->cy}, nb_x);
@@ -949,7 +953,7 @@ static FinishArgs finish_args_of(const dif_map_t* map, const dif_extract_buffers
                                  defer ? (dif_pending_export_t*)map->pending_export : nullptr, buf->stamp, defer ? buf->export_notify : nullptr},
                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
                       onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr,
-                      ov};
+                      ov ? map->frame_counters : nullptr};
 }
 
 static int voxel_decode_attributes() {
@@ -998,6 +1002,9 @@ static int mc_onepass_setup(const McArgs& a, size_t& lds_bytes, int& grid1, int6
     return DIF_OK;
 }
 
+static int extract_mesh_part(const dif_map_t* map, const dif_extract_buffers_t* buf, const ExtractGeo& e, float max_std, int32_t no_cache,
+                             int32_t scale_vertices, hipStream_t s);
+
 static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                         float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     if (!map || !w || !buf || resolution < 1 || resolution > 8 || buf->max_voxels <= 0) return DIF_EINVAL;
@@ -1017,6 +1024,12 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     if (ov && (!overlap_ok(map) || no_cache || defer_export_of(map, buf) || s != (hipStream_t)map->fuse_stream)) return DIF_EINVAL;
     const ExtractGeo e = extract_geo(resolution);
     const int r = e.r, R = e.R, l = e.l, R3 = e.R3;
+    // two queues (and the split extract): only for the configuration a stream runs (fast decode on the bf16 pipe, one-pass marching cubes) — the
+    // refine pass is what leaves the frame's K, B, VH in its counter block
+    const bool split = ov && buf->split_mesh;
+    if (ov && !(fast && buf->chunk_sum && buf->mc_status && buf->max_voxels <= ((int64_t)1 << 24) && r * r * r <= 64 && buf->fold_table && w->dec_x6_packed &&
+                   w->dec_x6_packed_bytes == X6_BYTES && w->dec_fold_packed))
+        return DIF_EINVAL;
     if (buf->max_voxels * (int64_t)R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
     const double sample_a = e.sample_a, sample_b = e.sample_b;
 
@@ -1070,7 +1083,8 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             if (rblocks < 1) rblocks = 1;
             if (rblocks > num_cus()) rblocks = num_cus();
             ProfScope prof(DIF_PROF_DECODE_POINTS, s);
-            hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed);
+            hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed,
+                               ov ? SplitTail{map->frame_counters, (const int*)C, split ? map->grid_tot : nullptr} : SplitTail{nullptr, nullptr, nullptr});
             DIF_CHECK_LAUNCH();
             rc = DIF_OK;
         } else {
@@ -1103,8 +1117,22 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         rc = launch_decode(A, w, buf->max_voxels * (int64_t)((R3 + 31) / 32), s);
         if (rc != DIF_OK) return rc;
     }
-    // marching cubes (map.py:689-691)
+    if (split) return DIF_OK;       // marching cubes + finish: dif_extract_mesh, behind the next frame's integrate on the other stream
+    return extract_mesh_part(map, buf, e, max_std, no_cache, scale_vertices, s);
+}
+
+// marching cubes (map.py:689-691), mesh-cache bookkeeping, counter snapshot: the second half of an extract
+static int extract_mesh_part(const dif_map_t* map, const dif_extract_buffers_t* buf, const ExtractGeo& e, float max_std, int32_t no_cache,
+                             int32_t scale_vertices, hipStream_t s) {
+    int* C = map->counters;
+    const int r = e.r;
+    int rc;
     McArgs a = mc_args_of(map, buf, e, max_std, scale_vertices);
+    const bool split = overlapped(map) && buf->split_mesh;
+    if (split) {                    // the frame's own K (the live word may be the next frame's); the batch scan's totals were zeroed by the refine pass
+        a.K_ptr = map->frame_counters + DIF_FC_K;
+        a.grid_tot = nullptr;
+    }
     if (no_cache) {                                                                                               // map.py:614-616
         if (hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
         if (hipMemsetAsync(C + DIF_C_CACHE_DEAD, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
@@ -1240,6 +1268,22 @@ int dif_trace_read_encode(unsigned long long* out, int64_t n) {      // host cop
 int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, int32_t resolution, int32_t fast,
                 float max_std, int32_t no_cache, int32_t scale_vertices, void* stream_) {
     return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, stream_);
+}
+
+int dif_extract_mesh(const dif_map_t* map, const dif_extract_buffers_t* buf, int32_t resolution, float max_std, int32_t scale_vertices,
+                     int32_t wait_decoded, void* stream_) {
+    if (!map || !buf || resolution < 1 || resolution > 4 || buf->max_voxels <= 0 || !overlapped(map) || !overlap_ok(map) || !buf->split_mesh) return DIF_EINVAL;
+    if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_tri || !buf->cache_id || !buf->cache_std || !buf->cache_alive)
+        return DIF_EINVAL;
+    if (!map->tri_start || !map->tri_n || !buf->chunk_sum || !buf->mc_status || buf->max_voxels > ((int64_t)1 << 24) || defer_export_of(map, buf)) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    // behind the frame's decode kernels: the next frame's fusion kernel (extracts' stream) says when they are done
+    if (wait_decoded && wait_word(s, map->sync_words + DIF_SYNC_DECODED, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
+    const int rc = extract_mesh_part(map, buf, extract_geo(resolution), max_std, 0, scale_vertices, s);
+    if (rc != DIF_OK) return rc;
+    hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, s, map->sync_words + DIF_SYNC_MESHED, (uint32_t)map->frame_seq);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
 }
 
 int dif_export_pending(const dif_map_t* map, void* stream) {

@@ -472,7 +472,16 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
     }
 }
 
-__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
+// Split extract (dif_extract_buffers_t.split_mesh): the refine pass is the LAST kernel of a frame's decode half on the extracts' stream.  Its first
+// workgroup leaves K, B and VH in the frame's counter block (the next frame's kernels rewrite the live words before this frame's marching cubes
+// reads them) and returns the batch scan's block totals to idle 0 (the one-pass marching cubes does that otherwise).
+struct SplitTail { int* fc; const int* counters; int* grid_tot; };
+__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob, SplitTail t) {
+    if (t.fc && blockIdx.x == 0) {
+        if (threadIdx.x == 0) { t.fc[DIF_FC_K] = t.counters[DIF_C_K]; t.fc[DIF_FC_B] = t.counters[DIF_C_B]; t.fc[DIF_FC_VH] = t.counters[DIF_C_VH]; }
+        if (t.grid_tot)
+            for (int i = (int)threadIdx.x; i < 1024; i += (int)blockDim.x) t.grid_tot[i] = 0;
+    }
     const BatchN<DecodeArgs, 1> B{{A}};
     decode_refine_x6_body<1>(B, 1, wblob);
 }

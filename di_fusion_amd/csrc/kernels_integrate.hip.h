@@ -580,7 +580,10 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                           const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
                                           uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, const HaloLists& hl,
-                                          dif_pending_export_t* __restrict__ pending, int* __restrict__ dirty_tot, bool shadow) {
+                                          dif_pending_export_t* __restrict__ pending, int* __restrict__ dirty_tot, int* __restrict__ fc, uint32_t* __restrict__ decoded_word, int seq) {
+    // two queues: this kernel runs => everything in front of it on the extracts' stream — the previous frame's decode kernels — has completed: the
+    // word that frame's marching cubes (front-end stream) waits for
+    if (decoded_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(decoded_word, (uint32_t)(seq - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) {       // the point kernels' extra workgroups have done the copy (kernels ago: complete)
         pending->pending = 0;
         if (pending->notify) {              // tell the host without an event in the queue (dif_extract_buffers_t.export_notify)
@@ -635,9 +638,9 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int items = (counters[DIF_C_M] + 31) >> 5;                                                // encoder tiles of this frame
         counters[DIF_C_ITEMS] = items;
-        if (shadow) {       // this integrate's counters for its extract's snapshot: the next frame's front end rewrites the live words beside that extract
-            counters[DIF_C_SHADOW + 0] = counters[DIF_C_N_OCCUPIED]; counters[DIF_C_SHADOW + 1] = counters[DIF_C_ALLOC_NEW];
-            counters[DIF_C_SHADOW + 2] = counters[DIF_C_M]; counters[DIF_C_SHADOW + 3] = counters[DIF_C_C]; counters[DIF_C_SHADOW + 4] = items;
+        if (fc) {           // this integrate's counters for its extract's snapshot: the next frame's front end rewrites the live words beside that extract
+            fc[DIF_FC_SHADOW + 0] = counters[DIF_C_N_OCCUPIED]; fc[DIF_FC_SHADOW + 1] = counters[DIF_C_ALLOC_NEW];
+            fc[DIF_FC_SHADOW + 2] = counters[DIF_C_M]; fc[DIF_FC_SHADOW + 3] = counters[DIF_C_C]; fc[DIF_FC_SHADOW + 4] = items;
         }
     }
 }
@@ -645,13 +648,13 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
 struct FuseArgs {
     const long long* rec; const int* rec_next; int* rec_dir; const int* upd_list; float* latent; float* obs; uint8_t* dirty; int* counters;
     const int64_t* slot_lin; HaloLists hl; dif_pending_export_t* pending;
-    int* dirty_tot; bool shadow;      // two queues (dif_map_t.frame_seq): the fusion kernel keeps the block totals of the dirty flags and leaves the shadow counters
+    int* dirty_tot; int* fc; uint32_t* decoded_word; int seq;      // two queues (dif_map_t.frame_seq): block totals of the dirty flags, the frame's counter block, "the previous decode is done"
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(FuseArgs a) {
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.shadow);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.fc, a.decoded_word, a.seq);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse_batch(Batch<FuseArgs> b) {
     const FuseArgs& a = b.s[blockIdx.y];
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.shadow);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.fc, a.decoded_word, a.seq);
 }

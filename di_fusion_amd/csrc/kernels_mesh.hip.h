@@ -750,20 +750,22 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
                                                     const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                     const float* __restrict__ log_std, const ExtractOut& out, int32_t* __restrict__ chunk_sum,
                                                     int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket,
-                                                    bool shadow) {
-    const int B = counters[DIF_C_B];
+                                                    const int* __restrict__ fc) {
+    // (fc: an overlapped frame's own counter block — K, B, VH and the integrate's counters as this frame left them; the live words may be a frame ahead)
+    const int B = fc ? fc[DIF_FC_B] : counters[DIF_C_B];
+    const int Kd = fc ? fc[DIF_FC_K] : counters[DIF_C_K];
     if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
     {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((counters[DIF_C_K] + 3) >> 2); i += gridDim.x * blockDim.x) mc_status[i] = 0u;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((Kd + 3) >> 2); i += gridDim.x * blockDim.x) mc_status[i] = 0u;
         if (blockIdx.x == 0 && threadIdx.x == 0) *mc_ticket = 0u;
     }
     if (dirty_tot)                                  // every dirty flag has been consumed by this call: the block totals return to idle 0
         for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_dirty_tot; t += gridDim.x * blockDim.x) dirty_tot[t] = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
     if (chunk_sum)                                  // back to idle 0 (only the chunks this call's K dirty voxels could have touched)
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((counters[DIF_C_K] + 255) >> 8); i += gridDim.x * blockDim.x) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((Kd + 255) >> 8); i += gridDim.x * blockDim.x) {
             chunk_sum[i] = 0;
-            if (i < ((counters[DIF_C_K] + 65535) >> 16)) super_sum[i] = 0;
+            if (i < ((Kd + 65535) >> 16)) super_sum[i] = 0;
         }
     const int64_t kept = counters[DIF_C_CACHE_KEPT];
     int64_t n_new = counters[DIF_C_T];
@@ -782,9 +784,12 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
         const int lane = (int)threadIdx.x;
         int v = lane < DIF_C_COUNT ? counters[lane] : 0;
         const int live = v;
-        // two queues: the next frame's front end may be rewriting N_OCCUPIED / ALLOC_NEW / M / C / ITEMS right now — this frame's values are the
-        // copies its fusion kernel left (lanes 0, 2, 3, 4, 5 <- DIF_C_SHADOW + 0..4)
-        if (shadow && (lane == DIF_C_N_OCCUPIED || (lane >= DIF_C_ALLOC_NEW && lane <= DIF_C_ITEMS))) v = counters[DIF_C_SHADOW + (lane == DIF_C_N_OCCUPIED ? 0 : lane - DIF_C_ALLOC_NEW + 1)];
+        // two queues: the next frame's kernels may be rewriting N_OCCUPIED / ALLOC_NEW / M / C / ITEMS / K / B / VH right now — this frame's values are
+        // the copies its fusion kernel and its last decode kernel left in its own block
+        if (fc && (lane == DIF_C_N_OCCUPIED || (lane >= DIF_C_ALLOC_NEW && lane <= DIF_C_ITEMS))) v = fc[DIF_FC_SHADOW + (lane == DIF_C_N_OCCUPIED ? 0 : lane - DIF_C_ALLOC_NEW + 1)];
+        if (fc && lane == DIF_C_K) v = fc[DIF_FC_K];
+        if (fc && lane == DIF_C_B) v = fc[DIF_FC_B];
+        if (fc && lane == DIF_C_VH) v = fc[DIF_FC_VH];
         if (lane == DIF_C_CACHE_T) v = (int)tot;
         if (lane == DIF_C_OVERFLOW && over) v = 5;
         if (out.counters_out && lane < DIF_C_STAMP) out.counters_out[lane] = v;
@@ -815,16 +820,16 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
 struct FinishArgs {
     const int32_t* occ_slot; int32_t* vbm; int* counters; int64_t new_limit, capacity; const float* log_tri; const int64_t* log_id; const float* log_std;
     ExtractOut out; int32_t* chunk_sum; int32_t* super_sum; int32_t* dirty_tot; int n_dirty_tot; uint32_t* mc_status; uint32_t* mc_ticket;
-    bool shadow;            // two queues: N_OCCUPIED / ALLOC_NEW / M / C / ITEMS of the snapshot come from counters[DIF_C_SHADOW ..]
+    const int* fc;          // two queues: the frame's own counter block (dif_map_t.frame_counters) or NULL
 };
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(FinishArgs a) {
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.shadow);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish_batch(Batch<FinishArgs> b) {
     const FinishArgs& a = b.s[blockIdx.y];
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.shadow);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc);
 }
 
 struct TriScanFunctor {         // exclusive scan of the per-voxel triangle counts; on the mesh-cache path also the log bookkeeping

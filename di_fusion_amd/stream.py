@@ -98,8 +98,18 @@ class FusionStream:
         self._pending_older = None
         self._fe_stream = None
         self._fe_ptr = None
+        self._mesh_stream = None            # where the frames' mesh halves run (a third hardware queue, or the front end's)
+        self._mesh_ptr = None
         self._ov_active = False             # the frames in flight are overlapped ones (the two queues are coupled through the sync words)
         self._ov_seq = 0
+        # ... and the frame's marching cubes + finish kernel beside the NEXT frame's decode (dif_extract_buffers_t.split_mesh): the extracts' stream
+        # carries fuse, decode, fuse, decode, ...; frame n's mesh half is enqueued on the front-end stream behind frame n+1's integrate (whose fusion
+        # kernel tells it that frame n's decode is done).  Consecutive frames alternate between two sets of extract buffers, batch maps, dirty totals
+        # and counter blocks (slot parity).  Off by default: measured (profiles/r05_experiments.md 2) it is worth 2-3 % together with host_depth = 2
+        # (7,090-7,290 against 6,910-7,050 frames/s) and nothing without, for twice the per-voxel extract buffers.
+        self.split_mesh = False
+        self._mesh_pending = None           # (frame number, slot, stamp) of the frame whose mesh half is not enqueued yet
+        self.last_tensors = None            # the extract tensors of the frame enqueued last (tests)
         self.queues_independent = None      # what dif_queues_independent said about the two streams
         self._sdma = None                   # None: untried; True / False: the SDMA export works / does not (or is slow) in this process
         self._sdma_slow = 0
@@ -122,6 +132,15 @@ class FusionStream:
                 rc = int(lib.dif_queues_independent(main, ctypes.c_void_p(fe.cuda_stream)))
                 if rc == 1:
                     self._fe_stream, self._fe_ptr, self.queues_independent, self.overlap = fe, ctypes.c_void_p(fe.cuda_stream), True, True
+                    # a third queue for the frames' mesh halves (marching cubes + finish), independent of both; without one they share the front end's
+                    self._mesh_stream, self._mesh_ptr = fe, self._fe_ptr
+                    for _ in range(8):
+                        ms = torch.cuda.Stream(device=self.device)
+                        mp = ctypes.c_void_p(ms.cuda_stream)
+                        if int(lib.dif_queues_independent(main, mp)) == 1 and int(lib.dif_queues_independent(self._fe_ptr, mp)) == 1:
+                            self._mesh_stream, self._mesh_ptr = ms, mp
+                            break
+                        tried.append(ms)
                     return True
                 tried.append(fe)            # (kept alive until the search ends, so that the pool hands out another one)
                 if rc < 0:
@@ -137,14 +156,67 @@ class FusionStream:
             self.map._sync_words.zero_()
             self._ov_seq = 0
             self._fe_stream.wait_stream(torch.cuda.current_stream())
+            self._mesh_stream.wait_stream(torch.cuda.current_stream())
         self._ov_active = True
 
     def _ov_leave(self):
-        """Before anything but an overlapped frame touches the map on the caller's stream: behind the front-end stream's last kernel."""
+        """Before anything but an overlapped frame touches the map on the caller's stream: the pending mesh half, then behind the front-end stream's
+        last kernel."""
         if self._ov_active:
+            self._ov_drain_mesh()
             with torch.cuda.device(self.device):
                 torch.cuda.current_stream().wait_stream(self._fe_stream)
+                torch.cuda.current_stream().wait_stream(self._mesh_stream)
             self._ov_active = False
+
+    def _ov_frame_fields(self, seq: int, k: int, main_ptr):
+        """dif_map_t fields of overlapped frame `seq` in slot k: its number, the extracts' stream, and the arrays of its parity."""
+        m, cm, p = self.map, self.map._cmap, k & 1
+        cm.frame_seq = seq
+        cm.fuse_stream = main_ptr
+        cm.dirty_tot = _lib.ptr(m._dirty_tot_b if p else m._dirty_tot)
+        cm.vbm = _lib.ptr(m._vbm_b if p else m._vbm)
+        cm.frame_counters = ctypes.c_void_p(m._frame_counters.data_ptr() + p * _lib.FC_COUNT * 4)
+        # (mesh halves on a stream of their own: the front end of frame n waits for the mesh half of frame n-2, whose buffers frame n's decode reuses)
+        cm.mesh_wait = max(0, seq - 2) if (self.split_mesh and self._mesh_stream is not self._fe_stream) else 0
+
+    def _ov_restore_fields(self):
+        m, cm = self.map, self.map._cmap
+        cm.frame_seq = 0
+        cm.fuse_stream = None
+        cm.frame_counters = None
+        cm.mesh_wait = 0
+        cm.dirty_tot = _lib.ptr(m._dirty_tot)
+        cm.vbm = _lib.ptr(m._vbm)
+
+    def _enqueue_mesh(self, stream_ptr, main_ptr, wait: int):
+        """The mesh half (marching cubes + finish) of the frame in `_mesh_pending`, on `stream_ptr`."""
+        seq, k, _ = self._mesh_pending
+        self._mesh_pending = None
+        self._ov_frame_fields(seq, k, main_ptr)
+        try:
+            _lib.check(self._d_lib.dif_extract_mesh(ctypes.byref(self.map._cmap), ctypes.byref(self._d_bufs[k]), int(self.resolution), float(self.max_std), 1,
+                                                    int(wait), stream_ptr), "dif_extract_mesh")
+        finally:
+            self._ov_restore_fields()
+
+    def _ov_drain_mesh(self):
+        """A frame's mesh half that no later frame has carried onto the front-end stream yet (the last frame of a stream; before a safe point: log
+        compaction, growth, a wait for that frame's stamp): on the caller's stream, behind its decode kernels and behind the front-end stream's earlier
+        mesh halves (the log is appended to in frame order); later mesh halves on the mesh stream come behind it."""
+        if self._mesh_pending is None:
+            return
+        with torch.cuda.device(self.device):
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._mesh_stream)
+            sp = _lib.stream_ptr()
+            self._enqueue_mesh(sp, sp, 0)
+            self._mesh_stream.wait_stream(main)
+
+    def complete_frames(self):
+        """Everything of the frames enqueued so far is on the GPU's queues (a split frame's mesh half included): a device synchronisation then leaves
+        the map, the log and the counters in the state behind the last frame.  (Tests; the pipeline itself never needs it.)"""
+        self._ov_drain_mesh()
 
     def _pts(self):
         return (_lib.ptr(self.xyz), _lib.ptr(self.nrm)) if self.keep_points else (_lib.ptr(None), _lib.ptr(None))
@@ -191,6 +263,7 @@ class FusionStream:
         """The D2H of the previous frame's triangles (side stream) reads a region of the mesh-cache LOG that later frames only append
         behind, so the next frame does not wait for it — unless the log is about to be compacted."""
         if self.map._gc_wanted:
+            self._ov_drain_mesh()                         # (a pending mesh half appends to the log the compaction is about to move)
             self._complete_batch_before_gc(self._d2h_mode)
             self._export_deferred_now(self._pending)      # (the pending copy reads log positions that the compaction moves)
             if self._copy_done is not None:
@@ -247,6 +320,8 @@ class FusionStream:
                 handle["export_event"] = ev
 
     def _finish_frame(self, handle, d2h: str):
+        if self._mesh_pending is not None and isinstance(handle, dict) and handle.get("stamp") == self._mesh_pending[2]:
+            self._ov_drain_mesh()           # (its finish kernel, which stamps, is part of the mesh half)
         self._export_deferred_now(handle)
         tri, tid, tstd = self.map.extract_mesh_finish(handle)
         if handle.get("deferred"):
@@ -369,16 +444,21 @@ class FusionStream:
             self._d_seq = 0
             self._d_desc = [np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8).copy()
                             for i, (R, t) in enumerate(self.poses)]
-        sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES)
+        two_sets = bool(self.overlap and self.split_mesh and self.resolution <= 4)
+        sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES, two_sets)
         if self._d_sig != sig:                       # (re)build the per-slot buffer descriptors after a re-allocation
             # (a pending deferred export points into the mesh log: carry it out before anything below may re-allocate that log)
+            self._ov_drain_mesh()
             self._export_deferred_now(self._pending)
-            self._d_bufs = []
-            for sl in self._d_slots:
-                _, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=self._stream_extract_voxels())
+            self._d_bufs, self._d_tens = [], []
+            for k, sl in enumerate(self._d_slots):
+                # (split frames: the slots of odd index use the second set of per-voxel buffers — frame n's marching cubes reads its cubes while
+                # frame n+1's decode writes the other set's)
+                tens, buf = m._extract_buffers(self.resolution, self.max_n_triangles, max_vox=self._stream_extract_voxels(), second=bool(two_sets and (k & 1)))
                 buf.counters_out = _lib.ptr(sl["counters"])
                 self._d_bufs.append(buf)
-            self._d_sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES)
+                self._d_tens.append(tens)
+            self._d_sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES, two_sets)
             self._d_w = m.model.packed.weights_struct(dev)
             self._d_lib = _lib.load()
             self._d_args = (self.intr.height, self.intr.width, self.intr.fx, self.intr.fy, self.intr.cx, self.intr.cy)
@@ -412,10 +492,12 @@ class FusionStream:
         out = None
         if m._ws is None or m._xbuf is None or m._cache is None:
             raise RuntimeError("run at least one eager step before step_direct (buffers are sized there)")
-        if m._n_occ_ub + may_add > m._capacity and self._pending is not None:
-            done = self._finish_pending(d2h)                 # make the bound exact before deciding to grow
-            self.backlog += done[:-1]
-            out = done[-1]
+        if m._n_occ_ub + may_add > m._capacity:
+            self._ov_drain_mesh()                            # (a growth re-allocates the batch maps a pending mesh half reads)
+            if self._pending is not None:
+                done = self._finish_pending(d2h)             # make the bound exact before deciding to grow
+                self.backlog += done[:-1]
+                out = done[-1]
         m._ensure_capacity(may_add)
         self._before_frame()
         if m._gc_wanted:
@@ -456,6 +538,7 @@ class FusionStream:
         # marching cubes, a kernel before the stamp.)
         buf.stamp = self._stamp
         buf.export_notify = _lib.ptr(sl["notify"]) if buf.defer_export else None
+        buf.split_mesh = 0              # (set by the two-queue path of step_direct only)
         return buf
 
     def _direct_integrated(self):
@@ -510,17 +593,28 @@ class FusionStream:
                 if not self._ov_active:
                     self._ov_enter()
                 self._ov_seq += 1
-                m._cmap.frame_seq = self._ov_seq
-                m._cmap.fuse_stream = sp            # the fusion kernel goes to the extracts' stream (the caller's), behind the previous frame's extract
+                seq = self._ov_seq
+                split = bool(self.split_mesh and self.resolution <= 4)
+                buf.split_mesh = 1 if split else 0
+                self.last_tensors = self._d_tens[k]
                 try:
+                    # (the fusion kernel goes to the extracts' stream — the caller's —, behind the previous frame's decode)
+                    self._ov_frame_fields(seq, k, sp)
                     _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, *self._pts(),
                                                        _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), self._fe_ptr), "dif_integrate_frame")
                     self._direct_integrated()
+                    if self._mesh_pending is not None:      # the previous frame's marching cubes + finish: the mesh stream, behind this frame's fusion kernel
+                        self._enqueue_mesh(self._mesh_ptr, sp, 1)
+                        self._ov_frame_fields(seq, k, sp)
                     _lib.check(lib.dif_extract(ctypes.byref(m._cmap), ctypes.byref(w), ctypes.byref(buf), int(self.resolution), 1, float(self.max_std), 0, 1, sp),
                                "dif_extract")
+                    if split:
+                        self._mesh_pending = (seq, k, int(buf.stamp))
                 finally:
-                    m._cmap.frame_seq = 0
+                    self._ov_restore_fields()
                 return self._direct_end(k, sl, buf, export, d2h, out)
+            buf.split_mesh = 0
+            self.last_tensors = self._d_tens[k]
             _lib.check(lib.dif_integrate_frame(ctypes.byref(m._cmap), ctypes.byref(w), _lib.ptr(sl["frame"]), H, W, fx, fy, cx, cy, *self._pts(),
                                                _lib.ptr(self._d_mask), _lib.ptr(m._ws), m._ws.numel(), sp), "dif_integrate_frame")
             self._direct_integrated()

@@ -197,6 +197,7 @@ class DenseIndexedMap:
             self._alloc_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._alloc_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
             self._sync_words = torch.zeros((_lib.SYNC_WORDS,), device=device, dtype=torch.int32)     # dif_map_t.sync_words
+            self._frame_counters = torch.zeros((2, _lib.FC_COUNT), device=device, dtype=torch.int32)  # dif_map_t.frame_counters, one block per frame parity
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
             self._pending_export = torch.zeros((32,), device=device, dtype=torch.int32)        # dif_pending_export_t (72 bytes), idle all-zero
         self._capacity = 0
@@ -226,6 +227,10 @@ class DenseIndexedMap:
             tri_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_n = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             self._dirty_tot = torch.zeros(((capacity + 255) // 256,), dtype=torch.int32, device=dev)       # set dirty flags per 256 slots
+            # overlapped frames alternate between two batch maps and two sets of dirty-flag totals (frame n's marching cubes runs beside frame n+1's
+            # batch scan and fusion kernel: FusionStream, dif_extract_buffers_t.split_mesh); idle -1 / 0 like the first ones
+            self._vbm_b = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
+            self._dirty_tot_b = torch.zeros(((capacity + 255) // 256,), dtype=torch.int32, device=dev)
             if self._capacity > 0:
                 c = self._capacity
                 lat[:c] = self._latent
@@ -625,7 +630,21 @@ class DenseIndexedMap:
         o = self._cache_out
         return o[0][:n], o[1][:n], o[2][:n]
 
-    def _extract_buffers(self, resolution: int, max_n_triangles: int, max_vox: int = None):
+    def _extract_buffers(self, resolution: int, max_n_triangles: int, max_vox: int = None, second: bool = False):
+        """`second`: the other set of per-voxel buffers (same shapes), for the frames of odd parity of a stream whose marching cubes runs beside the
+        next frame's decode (FusionStream two queues, dif_extract_buffers_t.split_mesh); `max_vox` must be given."""
+        if second:
+            key = (resolution, int(max_vox))
+            if getattr(self, "_xbuf_b", None) is None or self._xbuf_b[0] != key:
+                self._xbuf_b = (key, {k: (torch.zeros_like(v) if k in ("chunk_sum", "mc_status") else torch.empty_like(v)) for k, v in self._xbuf[1].items()})
+                assert self._xbuf[0] == key, "the first set of extract buffers is sized first"
+            t = self._xbuf_b[1]
+            b = self._cache_struct()
+            b.max_voxels = int(max_vox)
+            b.max_triangles = int(max_n_triangles)
+            for k, v in t.items():
+                setattr(b, k, _lib.ptr(v))
+            return t, b
         R = 2 * resolution
         if max_vox is None:
             max_vox = _next_pow2(max(self._n_occ_ub, 1024))

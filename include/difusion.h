@@ -61,8 +61,6 @@ enum {
     DIF_C_HALO_L = 20,      /* entries appended to the LEFT / RIGHT boundary change list (dif_map_t.halo_list) since the last    */
     DIF_C_HALO_R = 21,      /* halo export; may exceed halo_list_cap (then the list is incomplete and the delta export says so)   */
     DIF_C_HALO_TICKET = 22, /* idle 0: workgroups of dif_export_halo_delta that are done                                          */
-    DIF_C_SHADOW = 24,      /* [24..28]: N_OCCUPIED, ALLOC_NEW, M, C, ITEMS of the latest COMPLETED integrate, left by its fusion kernel: what an extract's
-                             * snapshot reports for them while the next frame's front end is already rewriting the live words (dif_map_t.frame_seq)  */
     DIF_C_STAMP = 31,       /* snapshots handed to the caller only (dif_extract_buffers_t.counters_out): the extract's `stamp`, written LAST        */
     DIF_C_COUNT = 32
 };
@@ -135,9 +133,21 @@ typedef struct dif_map {
     uint32_t* sync_words;           /* [DIF_SYNC_WORDS] device memory */
     int32_t frame_seq;
     void* fuse_stream;              /* hipStream_t of the extracts: where an overlapped frame's fusion kernel goes */
+    /* Overlapped frames: int32[DIF_FC_COUNT] of THIS frame (the caller alternates between two blocks): the fusion kernel leaves the integrate's
+     * counters here ([DIF_FC_SHADOW ..]: N_OCCUPIED, ALLOC_NEW, M, C, ITEMS), the last decode kernel of the frame's extract K, B and VH — what the
+     * frame's marching cubes and its counter snapshot use while the next frame's kernels already rewrite the live words.  The same goes for `vbm`
+     * and `dirty_tot`: the caller passes frame n's extract (both halves) and integrate the arrays of parity n & 1. */
+    int32_t* frame_counters;
+    /* Split extracts on a stream of their own: > 0 = the front end of this frame first waits until sync_words[DIF_SYNC_MESHED] >= mesh_wait — the mesh
+     * half of frame_seq - 2 has completed, so the decode of this frame (which reuses that frame's buffers) cannot overtake it. */
+    int32_t mesh_wait;
 } dif_map_t;
 
-enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_WORDS = 64 };      /* each word on a 128-byte line of its own */
+/* sync_words (each on a 128-byte line of its own): frame n's fusion kernel has completed (written by the first kernel of its extract); frame n's front
+ * end has completed; frame n's decode kernels have completed (written by the fusion kernel of frame n + 1 as it starts — or by dif_extract_mesh's caller
+ * simply running that call on the extracts' stream) */
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_DECODED = 64, DIF_SYNC_MESHED = 96, DIF_SYNC_WORDS = 128 };     /* MESHED: frame n's mesh half has completed */
+enum { DIF_FC_K = 0, DIF_FC_B = 1, DIF_FC_VH = 2, DIF_FC_SHADOW = 4, DIF_FC_COUNT = 16 };
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
 typedef struct dif_pending_export {
@@ -337,6 +347,11 @@ typedef struct dif_extract_buffers {
      *                    dif_integrate_frame(s) that carried the deferred copy out (its point kernels copy, its fusion kernel notifies). */
     int32_t stamp;
     int32_t* export_notify;
+    /* Overlapped frames (dif_map_t.frame_seq) with the one-pass marching cubes: != 0 = dif_extract runs the DECODE half only (dirty set, batch,
+     * lattice + refine decode) and dif_extract_mesh — enqueued by the caller behind the NEXT frame's integrate, on the front-end stream — runs
+     * marching cubes and the finish kernel: the extracts' stream then carries fuse, decode, fuse, decode, ... and a frame's meshing runs beside the
+     * next frame's decode.  Needs extract buffers (and dif_map_t.vbm / dirty_tot / frame_counters) of alternating parity for consecutive frames. */
+    int32_t split_mesh;
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
@@ -473,6 +488,14 @@ int64_t dif_profile_dump(int32_t* which /* host */, float* ms /* host */, int64_
 
 /* Copy the counters to the host; the only synchronising call (hipStreamSynchronize on `stream`). */
 int dif_read_counters(const dif_map_t* map, int32_t* host_out /* [DIF_C_COUNT], host */, void* stream);
+
+/* The mesh half of a split extract (dif_extract_buffers_t.split_mesh): one-pass marching cubes + the finish kernel (counter snapshot, stamp) of the
+ * frame whose decode half dif_extract enqueued with the same map fields and buffers.  wait_decoded != 0: first wait, on the device, until
+ * sync_words[DIF_SYNC_DECODED] >= frame_seq (the next frame's fusion kernel says so as it starts: enqueue this call BEHIND that frame's
+ * dif_integrate_frame); 0: the call runs on the extracts' stream itself, behind the decode kernels (the last frame of a stream).  Either way a one-wave
+ * kernel behind the finish kernel publishes sync_words[DIF_SYNC_MESHED] = frame_seq (dif_map_t.mesh_wait). */
+int dif_extract_mesh(const dif_map_t* map, const dif_extract_buffers_t* buf, int32_t resolution, float max_std, int32_t scale_vertices,
+                     int32_t wait_decoded, void* stream);
 
 /* 1 if work on streams `a` and `b` really runs concurrently — they sit on different hardware queues —, 0 if not, negative on error: a kernel on `a`
  * waits (bounded: ~20 ms) for a word that a kernel enqueued LATER on `b` writes.  HIP shares a hardware queue between streams once more than

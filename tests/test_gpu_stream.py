@@ -103,8 +103,9 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     same(outs["eager"], snapshot(st))
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("d2h", ["dma", "none"])
-def test_two_queue_frames_are_bit_identical(d2h, gpu_model):
+def test_two_queue_frames_are_bit_identical(d2h, split, gpu_model):
     """`enable_overlap`: frame i+1's integrate front end (unproject ... encoder) on a second hardware queue beside frame i's extract, its
     fusion kernel behind that extract, every extract behind its frame's fusion kernel (device-side waits on words the kernels publish:
     dif_map_t.frame_seq).  Every frame's triangles and the final map equal the eager single-queue run bit for bit — with new voxels
@@ -120,6 +121,7 @@ def test_two_queue_frames_are_bit_identical(d2h, gpu_model):
     ref = snapshot(st)
     for rep in range(3):
         st = make_stream(gpu_model, initial_capacity=(1 << 13) if rep < 2 else None)
+        st.split_mesh = split               # (True: the frame's marching cubes + finish on a third queue beside the next frame's decode)
         if not st.enable_overlap():
             pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
         got = []
@@ -166,6 +168,7 @@ def test_host_two_frames_ahead_hands_back_the_same_frames(overlap, gpu_model):
         for d2h in ("dma", "none"):
             st = make_stream(gpu_model, initial_capacity=cap)
             st.host_depth = 2
+            st.split_mesh = bool(overlap)       # (the combination the split extract is meant for)
             if overlap and not st.enable_overlap():
                 pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
             got = [per_frame[0]]

@@ -17,8 +17,10 @@ F = 140
 lib = _lib.load()
 
 
-def run(d2h, sdma, ov):
+def run(d2h, sdma, ov, depth=1, split=True):
     st = FusionStream(model, scene, cfg, S.Intrinsic(), DEV, F, deg_per_frame=0.5)
+    st.host_depth = depth
+    st.split_mesh = split
     if ov:
         assert st.enable_overlap()
     if not sdma:
@@ -45,11 +47,12 @@ def run(d2h, sdma, ov):
     st.flush(d2h); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (F - 20)
     stream_mod._lib.spin_until = orig_wait; mp._lib.spin_until = orig_wait
-    print(f"d2h={d2h:5s} sdma={int(sdma)} two_queues={int(ov)}: {dt * 1e6:7.1f} us/frame; completing the previous frame {np.mean(t_fin) * 1e6:6.1f} us "
+    print(f"d2h={d2h:5s} sdma={int(sdma)} two_queues={int(ov)} depth={depth} split={int(split)}: {dt * 1e6:7.1f} us/frame; completing the previous frame {np.mean(t_fin) * 1e6:6.1f} us "
           f"(of which waiting for its stamp {np.sum(t_spin) / len(t_fin) * 1e6:6.1f}); enqueue + the rest {dt * 1e6 - np.mean(t_fin) * 1e6:6.1f} us", flush=True)
 
 
-for ov in (0, 1):
-    run("none", False, ov)
-    run("dma", False, ov)
-    run("dma", True, ov)
+run("dma", True, 0)
+for depth in (1, 2):
+    for split in (False, True):
+        run("dma", True, 1, depth, split)
+        run("none", True, 1, depth, split)

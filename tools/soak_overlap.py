@@ -1,5 +1,5 @@
 """Soak of the two-queue mode: the C3 stream (F frames) stepped R times on two queues — without any device drain, d2h dma and none alternating,
-host depth 1 and 2 alternating — against ONE single-queue run: every frame's triangles and the final map bit for bit.  A race between a frame's
+host depth 1 and 2 alternating, the mesh half on the extracts' queue or on a third one, the host's steps delayed by random 0-100 / 0-300 us in two runs of three — against ONE single-queue run: every frame's triangles and the final map bit for bit.  A race between a frame's
 front end and its predecessor's extract would show up as a differing frame sooner or later.
 Usage: python tools/soak_overlap.py [R=20] [F=40]"""
 import sys, time
@@ -17,13 +17,22 @@ model = net_util.networks_from_arrays(net_util.load_weights_npz())
 scene, cfg = S.config_c3()
 
 
-def run(overlap, d2h, depth):
+import random
+
+
+def run(overlap, d2h, depth, jitter=0.0, seed=0, split=False):
     st = FusionStream(model, scene, cfg, S.Intrinsic(), DEV, F, deg_per_frame=0.5)
     st.host_depth = depth
+    st.split_mesh = split
     if overlap:
         assert st.enable_overlap()
     outs = []
+    rng = random.Random(seed)
     for i in range(F):
+        if jitter > 0.0 and i > 2:                       # (moves the front end's start against the previous frame's extract: other interleavings)
+            t_end = time.perf_counter() + rng.random() * jitter
+            while time.perf_counter() < t_end:
+                pass
         o = (st.step_pipelined if i < 2 else st.step_direct)(i, d2h)
         if o is not None:
             if d2h == "none" or i <= 2:
@@ -45,7 +54,7 @@ bad = 0
 t0 = time.time()
 for r in range(R):
     d2h, depth = ("dma", "none")[r & 1], 1 + ((r >> 1) & 1)
-    outs, final = run(True, d2h, depth)
+    outs, final = run(True, d2h, depth, jitter=(0.0, 100e-6, 300e-6)[r % 3], seed=r, split=bool((r >> 2) & 1))
     ok = len(outs) == F and all(all(torch.equal(x, y) for x, y in zip(a, b)) for a, b in zip(ref_outs, outs)) and all(torch.equal(x, y) for x, y in zip(ref_final, final))
     if not ok:
         bad += 1
