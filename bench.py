@@ -337,17 +337,19 @@ def streams_leg(make_stream_j, S, a, n_frames, lib, pipe):
     return rate, ({k: blk[k] for k in keep if k in blk} if blk else None)
 
 
-def secondary_rate(make_stream, a, n_frames, d2h, batch):
+def secondary_rate(make_stream, a, n_frames, d2h, batch, variant=None):
     """Secondary figures (N=1 only, reported next to `value`, never instead of it): the same stream (i) without the per-frame hand-over
     of the new triangles to pinned host memory — the difference is PCIe traffic, not kernels — and (ii) with 5 frames per captured
     hipGraph, for callers that know their poses ahead (no kernel boundaries inside a graph, one launch gap per 5 frames).  Best of two
     passes over fresh streams: these 40 ms measurements are informational, and a single host or driver stall (seen in about one run in
     ten on shared boxes) would otherwise decide them."""
-    return max(_secondary_pass(make_stream, a, n_frames, d2h, batch) for _ in range(2))
+    return max(_secondary_pass(make_stream, a, n_frames, d2h, batch, variant) for _ in range(2))
 
 
-def _secondary_pass(make_stream, a, n_frames, d2h, batch):
+def _secondary_pass(make_stream, a, n_frames, d2h, batch, variant=None):
     s2 = make_stream(batch)
+    if variant == "split_d2" and s2.overlap:        # the frame's marching cubes on a third queue beside the next frame's decode, the host two frames ahead
+        s2.split_mesh, s2.host_depth = True, 2
     run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30, "timed_from": None, "batch": batch}), d2h)
     for i in range(a.warmup):
         run2(i)
@@ -689,12 +691,14 @@ def main():
         tt = torch.tensor([dt], device=("cpu" if clock_over_gloo else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    hbm_resident = batched = None
+    hbm_resident = batched = split_d2 = None
     # (secondary figures need a run long enough to amortise their own one-time costs — a fresh stream's buffer growth, graph captures)
     if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled and a.steps >= 100 and gb is None:
         hbm_resident = secondary_rate(make_stream, a, n_frames, "none", 0)
         if a.batch == 0 and a.direct and not a.graph:        # (a per-frame-graph run would mix two sets of captured graphs on one stream)
             batched = secondary_rate(make_stream, a, n_frames, "new" if a.d2h == "dma" else a.d2h, 5)
+            if stream.overlap and not (stream.split_mesh and stream.host_depth >= 2):
+                split_d2 = secondary_rate(make_stream, a, n_frames, a.d2h, 0, "split_d2")
     # S independent subsequences per GPU sharing their launches: aggregate frames/s and the MFMA kernels' roofline at S = 2, 4, 8
     by_streams = {}
     if world == 1 and not a.no_secondary and not tiled and gb is None and a.direct and not a.graph and a.batch == 0 and a.warmup + a.steps >= 2:
@@ -773,6 +777,7 @@ def main():
                                                   for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
                           "frames_per_s_with_5_frames_per_hipgraph": batched,
+                          "frames_per_s_with_the_mesh_half_on_a_third_queue_and_the_host_two_frames_ahead": split_d2,
                           "frames_per_s_with_S_streams_per_gpu": ({str(S): v[0] for S, v in by_streams.items()} if by_streams else None),
                           "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
                           "global_map_merge_after_the_clock": merge_info,

@@ -5,6 +5,7 @@
 // Every float expression whose rounding is observable in voxel ids or lattice coordinates is written with the
 // reference's operation order and compiled without FMA contraction; fmaf() is used only where the reference's own
 // CPU build fuses (trilinear upsample) or where the order is ours to choose (MLP accumulation = the MFMA's fmaf chain).
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <atomic>
@@ -1334,11 +1335,14 @@ struct HsaCopy {
     void (*signal_store)(hsa_signal_t, hsa_signal_value_t) = nullptr;
     hsa_signal_value_t (*signal_wait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
     hsa_signal_t sig{}, sig3[3]{};
+    void* cal_dev = nullptr; void* cal_host = nullptr;      // 256 KB each, allocated once: what the engines are timed on (a caller's first export may be tiny,
+    static constexpr size_t CAL_BYTES = 256u << 10;         // and an engine that has turned slow is only slow for copies beyond 64 KB)
     std::mutex mu;
     int engines[3] = {-1, -1, -1};      // the engines of the three row ranges (-1: let the runtime choose)
     double engine_us = 0.0;             // what the calibration copy took on the fastest one (0: not calibrated yet; < 0: engines cannot be chosen here)
     double us_per_byte = 0.0;           // ... and per byte beyond its fixed cost, for what a range of another size should take
     int slow_calls = 0;
+    double ratio_min = 0.0;             // the best (measured / modelled) time of an export since the calibration
     bool load() {
         if (tried) return ok;
         tried = true;
@@ -1367,6 +1371,7 @@ struct HsaCopy {
         if (signal_create(0, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
         for (auto& q : sig3)
             if (signal_create(0, 0, nullptr, &q) != HSA_STATUS_SUCCESS) return false;
+        if (hipMalloc(&cal_dev, CAL_BYTES) != hipSuccess || hipHostMalloc(&cal_host, CAL_BYTES, hipHostMallocDefault) != hipSuccess) { cal_dev = cal_host = nullptr; (void)hipGetLastError(); }
         ok = true;
         return true;
     }
@@ -1386,6 +1391,7 @@ struct HsaCopy {
         engines[0] = engines[1] = engines[2] = -1;
         engine_us = us_per_byte = 0.0;
         slow_calls = 0;
+        ratio_min = 0.0;
         uint32_t avail = 0, pref = 0;
         if (!async_copy_on || !engine_status || engine_status(cpu, gpu, &avail) != HSA_STATUS_SUCCESS || !avail) return;
         if (preferred_engines && preferred_engines(cpu, gpu, &pref) == HSA_STATUS_SUCCESS && __builtin_popcount(avail & ~pref) >= 2) avail &= ~pref;
@@ -1393,7 +1399,7 @@ struct HsaCopy {
         for (int e = 0; e < 16; ++e) {
             if (!(avail & (1u << e))) continue;
             double t = 1e30;
-            for (int rep = 0; rep < 3; ++rep) {
+            for (int rep = 0; rep < 2; ++rep) {                   // (sixteen engines x 15-60 us: a calibration is ~1 ms — rare, but it may fall into a caller's frame)
                 signal_store(sig, 1);
                 const auto t0 = std::chrono::steady_clock::now();
                 if (!copy_on(e, dst, cpu, src, gpu, bytes, sig) || !wait_one(sig)) { t = 1e30; break; }
@@ -1420,6 +1426,10 @@ struct HsaCopy {
             if (us < small_us) small_us = us;
         }
         if (small_us < engine_us && bytes > 4096) us_per_byte = (engine_us - small_us) / (double)(bytes - 4096);
+        static const bool debug = getenv("DIF_SDMA_DEBUG") != nullptr;
+        if (debug)
+            fprintf(stderr, "dif sdma: calibrated on %zu bytes: engines %d %d %d, best %.1f %.1f %.1f us, 4 KB %.1f us, %.2e us/B\n", bytes, engines[0], engines[1], engines[2],
+                    best[0], best[1], best[2], small_us, us_per_byte);
     }
 };
 static HsaCopy g_hsa;
@@ -1440,8 +1450,7 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
     void* to[3] = {out_tri, out_id, out_std};
     const size_t bytes[3] = {(size_t)n * 9 * sizeof(float), (size_t)n * sizeof(int64_t), (size_t)n * 3 * sizeof(float)};
     if (g_hsa.engines[0] < 0 && g_hsa.engine_us == 0.0) {
-        // (the calibration copies write rows of this very frame to where the real copy puts them again)
-        g_hsa.calibrate(out_tri, cpu, from[0], gpu, bytes[0] < (256u << 10) ? bytes[0] : (256u << 10));
+        if (g_hsa.cal_dev) g_hsa.calibrate(g_hsa.cal_host, cpu, g_hsa.cal_dev, gpu, HsaCopy::CAL_BYTES);      // (the library's own 256 KB pair: same two agents)
         if (g_hsa.engine_us == 0.0) g_hsa.engine_us = -1.0;              // engines cannot be chosen here: the runtime's choice, and no re-calibration
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -1452,22 +1461,25 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
         if (!g_hsa.copy_on(g_hsa.engines[k], to[k], cpu, from[k], gpu, bytes[k], g_hsa.sig3[k])) break;
         ++issued;
     }
-    bool landed = true, slow = false;
-    const int order[3] = {1, 2, 0};                                    // the small ranges land first
-    for (int j = 0; j < 3; ++j) {
-        const int k = order[j];
-        if (k >= issued) continue;
-        landed = g_hsa.wait_one(g_hsa.sig3[k]) && landed;
-        if (g_hsa.engine_us > 0.0) {
-            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-            const double expect = g_hsa.engine_us + g_hsa.us_per_byte * (double)bytes[k] + 10.0;       // (+ the host's own time to issue three copies)
-            slow = slow || us > 2.2 * expect;
-        }
-    }
+    bool landed = true;
+    for (int k = 0; k < issued; ++k) landed = g_hsa.wait_one(g_hsa.sig3[k]) && landed;
     if (issued < 3 || !landed) return DIF_ELAUNCH;
-    // an engine that has turned slow (2.2 times what a range of that size should take, four exports in a row): look for better ones at the next call
+    // an engine that has turned slow: the whole export took more than 2.2 times what ALL its bytes would take on the fastest engine alone (the three
+    // ranges share the link: the large exports of a map-building transient must not look slow), four exports in a row — look for better engines at
+    // the next call
     if (g_hsa.engine_us > 0.0) {
-        g_hsa.slow_calls = slow ? g_hsa.slow_calls + 1 : 0;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        const double expect = g_hsa.engine_us + g_hsa.us_per_byte * (double)(bytes[0] + bytes[1] + bytes[2]) + 10.0;      // (+ the host's own time to issue three copies)
+        // ... or 2.5 times the best it has done against that model since the calibration (three engines in parallel do a steady-state frame's rows in
+        // about half the model's time: an engine that takes 60 us instead of 17 stays inside 2.2 x the model)
+        const double ratio = us / expect;
+        g_hsa.ratio_min = (g_hsa.ratio_min == 0.0 || ratio < g_hsa.ratio_min) ? ratio : g_hsa.ratio_min * 1.002;
+        const bool slow_now = us > 2.2 * expect || ratio > 2.5 * g_hsa.ratio_min;
+        g_hsa.slow_calls = slow_now ? g_hsa.slow_calls + 1 : 0;
+        static const bool debug = getenv("DIF_SDMA_DEBUG") != nullptr;
+        if (debug && slow_now)
+            fprintf(stderr, "dif sdma: slow export %d: n=%lld %.1f us, expected %.1f (engine %.1f us + %.2e us/B), engines %d %d %d\n", g_hsa.slow_calls, (long long)n, us,
+                    expect, g_hsa.engine_us, g_hsa.us_per_byte, g_hsa.engines[0], g_hsa.engines[1], g_hsa.engines[2]);
         if (g_hsa.slow_calls >= 4) { g_hsa.engines[0] = -1; g_hsa.engine_us = 0.0; }
     }
     return DIF_OK;

@@ -2,7 +2,7 @@
 host depth 1 and 2 alternating, the mesh half on the extracts' queue or on a third one, the host's steps delayed by random 0-100 / 0-300 us in two runs of three — against ONE single-queue run: every frame's triangles and the final map bit for bit.  A race between a frame's
 front end and its predecessor's extract would show up as a differing frame sooner or later.
 Usage: python tools/soak_overlap.py [R=20] [F=40]"""
-import sys, time
+import gc, sys, time
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -45,6 +45,7 @@ def run(overlap, d2h, depth, jitter=0.0, seed=0, split=False):
     n = st.map.n_occupied
     final = (st.map.indexer.clone().cpu(), st.map.latent_vecs[:n].clone().cpu(), st.map.voxel_obs_count[:n].clone().cpu())
     del st
+    gc.collect()                                         # (a stream's map and mesh cache refer to each other: 4-8 GB of extract buffers per run otherwise pile up)
     return outs, final
 
 
