@@ -73,6 +73,12 @@ class DifStreamFrame(Structure):
 
 
 # name -> (restype, argtypes); mirrors include/difusion.h one to one (tests/test_abi.py checks the symbol list)
+class DifSdfHg(ctypes.Structure):
+    """include/difusion.h: dif_sdf_hg_t"""
+    _fields_ = [("T_cur", c_float * 12), ("T_delta", c_float * 12), ("last_Rt", c_float * 9), ("robust_kernel", c_int32), ("robust_k", c_float),
+                ("no_grad", c_int32)]
+
+
 SIGNATURES = {
     "dif_version": (c_int32, []),
     "dif_build_id": (ctypes.c_char_p, []),
@@ -138,6 +144,9 @@ SIGNATURES = {
     "dif_test_mc_grid_cap": (c_int32, [c_int32]),
     "dif_queues_independent": (c_int32, [c_void_p, c_void_p]),
     "dif_mesh_cache_export_sdma": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "dif_sdf_hg_workspace_bytes": (c_int64, [c_int64]),
+    "dif_sdf_hg": (c_int32, [POINTER(DifMap), POINTER(DifWeights), c_void_p, c_int64, POINTER(DifSdfHg), c_void_p, c_int64, c_void_p, c_void_p,
+                             c_int64, c_void_p]),
 }
 
 _lib = None

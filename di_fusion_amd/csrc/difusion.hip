@@ -134,6 +134,7 @@ inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096)
 #include "kernels_mesh.hip.h"
 #include "kernels_cloud.hip.h"
 #include "kernels_optimize.hip.h"
+#include "kernels_track.hip.h"
 
 }  // namespace
 
@@ -1583,6 +1584,57 @@ int dif_query_grad_gather(const float* grad, const float* g_sdf, const int32_t* 
     if (N < 0 || (N > 0 && (!grad || !g_sdf || !scratch || !out))) return DIF_EINVAL;
     if (N == 0) return DIF_OK;
     hipLaunchKernelGGL(k_query_grad_gather, dim3(grid_for(N * 3, DIF_BLOCK, 2048)), dim3(DIF_BLOCK), 0, (hipStream_t)stream, grad, g_sdf, scratch + 4096, N, out);
+    DIF_CHECK_LAUNCH();
+    return DIF_OK;
+}
+
+// ---- f1: the tracker's SDF term (tracker.py:174-218) ----------------------------------------------------------------
+namespace {
+struct HgLayout { int64_t cur, sdf, std_, grad, sel, scratch, mask, partial, ticket, total; };
+inline int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
+inline HgLayout hg_layout(int64_t N) {
+    HgLayout L;
+    int64_t o = 0;
+    L.cur = o;     o = up256(o + N * 12);
+    L.sdf = o;     o = up256(o + N * 4);
+    L.std_ = o;    o = up256(o + N * 4);
+    L.grad = o;    o = up256(o + N * 12);
+    L.sel = o;     o = up256(o + N * 4);
+    L.scratch = o; o = up256(o + (N + 4096) * 4);
+    L.mask = o;    o = up256(o + N);
+    L.partial = o; o = up256(o + (int64_t)HG_BLOCKS * HG_TERMS * 8);
+    L.ticket = o;  o = up256(o + 4);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+int64_t dif_sdf_hg_workspace_bytes(int64_t N) { return N < 0 ? 0 : hg_layout(N).total; }
+
+int dif_sdf_hg(const dif_map_t* map, const dif_weights_t* w, const float* obs_xyz, int64_t N, const dif_sdf_hg_t* args, void* ws, int64_t ws_bytes,
+               double* out, double* out_host, int64_t seq, void* stream_) {
+    if (!map || !w || !args || !out || N < 0 || N >= ((int64_t)1 << 31)) return DIF_EINVAL;
+    if (args->robust_kernel < 0 || args->robust_kernel > 2) return DIF_EINVAL;
+    const HgLayout L = hg_layout(N);
+    if (!ws || ws_bytes < L.total || ((uintptr_t)ws & 255) != 0 || (N > 0 && !obs_xyz)) return DIF_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    char* b = (char*)ws;
+    float* cur = (float*)(b + L.cur);
+    int* ticket = (int*)(b + L.ticket);
+    HgArgs a;
+    for (int i = 0; i < 12; ++i) { a.Tc[i] = args->T_cur[i]; a.Td[i] = args->T_delta[i]; }
+    for (int i = 0; i < 9; ++i) a.Lt[i] = args->last_Rt[i];
+    a.robust = args->robust_kernel; a.k = args->robust_k; a.no_grad = args->no_grad ? 1 : 0;
+    hipLaunchKernelGGL(k_hg_transform, dim3(grid_for(N, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, obs_xyz, N, a, cur, ticket);
+    DIF_CHECK_LAUNCH();
+    int rc = dif_query_select(map, cur, N, (uint8_t*)(b + L.mask), (int32_t*)(b + L.sel), (int32_t*)(b + L.scratch), nullptr, 0, stream_);
+    if (rc != DIF_OK) return rc;
+    float* grad = a.no_grad ? nullptr : (float*)(b + L.grad);
+    rc = dif_query_decode(map, w, cur, N, (const int32_t*)(b + L.sel), (float*)(b + L.sdf), (float*)(b + L.std_), grad, stream_);
+    if (rc != DIF_OK) return rc;
+    hipLaunchKernelGGL(k_sdf_hg_reduce, dim3(grid_for(N, 2 * DIF_BLOCK, HG_BLOCKS)), dim3(DIF_BLOCK), 0, s, (const int*)(map->counters + DIF_C_QUERY_M), (const int32_t*)(b + L.sel),
+                       obs_xyz, (const float*)(b + L.sdf), (const float*)(b + L.std_), (const float*)grad, a, (double*)(b + L.partial), ticket, out,
+                       out_host, seq);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

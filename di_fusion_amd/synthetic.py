@@ -176,6 +176,16 @@ def frame_points(scene: Scene, i: int, intr: Intrinsic, device=torch.device("cpu
     return xyz.contiguous(), nrm.contiguous()
 
 
+def frame_cloud_camera(scene: Scene, i: int, intr: Intrinsic, device=torch.device("cpu"), orbit_radius: float = 0.3,
+                       deg_per_frame: float = 0.5, phase_deg: float = 0.0):
+    """Camera-space points of frame i (NaN pixels removed, row-major pixel order) and the frame's camera-to-world pose (R, t) float64: what
+    the tracker is handed as `obs_xyz` (reference `system/tracker.py:220`) and the pose it is asked to find."""
+    R, t = orbit_pose(i, orbit_radius, deg_per_frame, phase_deg)
+    depth, _ = render_frame(scene, R, t, intr, device)
+    pc = unproject_reference_order(depth, intr).reshape(-1, 3)
+    return pc[~torch.isnan(pc[:, 0])].contiguous(), R, t
+
+
 def transform_points(p: torch.Tensor, R: torch.Tensor, t: Optional[torch.Tensor]) -> torch.Tensor:
     """p @ R^T (+ t) with an explicit, unfused float32 op order ((r0*x + r1*y) + r2*z) + t — the order the
     HIP kernel `dif_unproject_transform` uses — so CPU and GPU agree bit-for-bit.  (The reference does this

@@ -437,6 +437,30 @@ int dif_query_grad_scatter(const float* grad, const float* g_sdf, const int32_t*
  * its scratch (scratch[4096 + i] = row of point i among the valid ones, -1 = invalid).  `scratch`: the array that call was given, untouched since. */
 int dif_query_grad_gather(const float* grad, const float* g_sdf, const int32_t* scratch, int64_t N, float* out, void* stream);
 
+/* ---- f1: the SDF term of the tracker's Gauss-Newton step in one call (tracker.py:174-218, SDFTracker.compute_sdf_Hg) ---------------------------
+ * obs_xyz (N,3): the frame's points in CAMERA space (tracker.py:220 obs_xyz).  Per call:
+ *   cur = (last_pose . cur_delta_pose) @ obs (tracker.py:181; float32 [R | t] rows as Isometry.torch_matrices gives them, motion_util.py:322-327),
+ *   get_sdf(cur) with d sdf / d cur (map.py:559-579, tracker.py:184-192), residual s = sdf / std,
+ *   J = [d @ last_R^T | (cur_delta_pose @ obs) x (d @ last_R^T)] with d = grad(sdf) / std (tracker.py:193-199),
+ *   robust weights (tracker.py:58-72: 1 = "huber", 2 = "tukey", 0 = none), and the sums scaled by 1 / M (tracker.py:209-218).
+ * out (device, 44 doubles): H row-major [0,36), g [36,42), sum_error [42], M [43].  M = 0 -> all zero (the reference divides by zero there).
+ * out_host (optional, pinned host memory the device can write, 45 x 8 bytes): the same 44 doubles, then `seq` as int64 behind a system-scope
+ * fence — a host that polls word 44 for its sequence number has the numbers without a copy or a stream synchronisation.
+ * no_grad != 0: only sum_error and M (the loop's last evaluation, tracker.py:239), through the value-only decoder.
+ * ws: dif_sdf_hg_workspace_bytes(N) bytes of device memory, 256-byte aligned, private to the call's stream while it runs.
+ * The sums are accumulated in double in a fixed order: the same inputs give the same bits. */
+typedef struct dif_sdf_hg_t {
+    float T_cur[12];        /* last_pose . cur_delta_pose: rows of [R | t]                         */
+    float T_delta[12];      /* cur_delta_pose                                                      */
+    float last_Rt[9];       /* last_pose.q.rotation_matrix.T, row-major (tracker.py:196 `Lt`)      */
+    int32_t robust_kernel;  /* 0 none, 1 huber, 2 tukey                                            */
+    float robust_k;
+    int32_t no_grad;
+} dif_sdf_hg_t;
+int64_t dif_sdf_hg_workspace_bytes(int64_t N);
+int dif_sdf_hg(const dif_map_t* map, const dif_weights_t* w, const float* obs_xyz, int64_t N, const dif_sdf_hg_t* args, void* ws, int64_t ws_bytes,
+               double* out, double* out_host, int64_t seq, void* stream);
+
 /* ---- multi-GPU map merge (no reference counterpart) ----------------------------------- */
 /* Pack the allocated voxels whose x index lies in [x_lo, x_hi) as 32-word records, in slot order:
  *   lin int32 | flags int32 (bit 0 = dirty) | w f32 | payload f32[29],  payload = w*z (raw == 0: additive merge) or z itself (raw != 0: exact copy).

@@ -14,6 +14,10 @@ Stubs injected before import:
     vector for everything up to marching cubes)
   * `torch.cuda.Stream/stream/synchronize` — no-ops (`map.py:232,625-626`)
   * `np.product` — removed in NumPy 2 (`map.py:201,407`)
+  * (tracker fixtures only, `--only track`) `pyquaternion` — the image has none: a `Quaternion` that keeps the rotation as a 3x3 matrix in
+    float64 (`rotation_matrix`, `inverse`, `rotate`, `*`), enough for `utils/motion_util.Isometry` to run as written; the rest of
+    `system.ext` the tracker imports (CUDA image / point-cloud kernels) as names that are never called; `Tensor.cuda()` = identity
+    (`tracker.py:196`)
 
 Usage:  python tests/golden/make_golden.py            (writes *.npz next to this file)
 """
@@ -419,6 +423,144 @@ def long_sequences(model, which):
         long_sequence(model, "seq_c2_long", scene, cfg, syn.Intrinsic(), n_frames=16, deg_per_frame=0.5)
 
 
+# ---- the tracker's SDF term (tracker.py:174-283) ---------------------------------------------------------------------
+def _import_reference_tracker():
+    pq = types.ModuleType("pyquaternion")
+
+    class Quaternion:
+        """Rotation kept as a matrix (see the module docstring)."""
+
+        def __init__(self, *a, matrix=None, degrees=None, axis=None, **k):
+            assert not a and not k
+            if matrix is not None:
+                u, _, vt = np.linalg.svd(np.asarray(matrix, dtype=np.float64)[:3, :3])       # the nearest rotation, as a unit quaternion would be
+                self.m = u @ vt
+            elif degrees is not None:
+                ax = np.asarray(axis, dtype=np.float64)
+                ax = ax / np.linalg.norm(ax)
+                th = np.radians(degrees)
+                K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                self.m = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+            else:
+                self.m = np.eye(3)
+
+        rotation_matrix = property(lambda self: self.m)
+        inverse = property(lambda self: Quaternion(matrix=self.m.T))
+
+        def rotate(self, v):
+            return self.m @ np.asarray(v)
+
+        def __mul__(self, other):
+            return Quaternion(matrix=self.m @ other.m)
+
+    pq.Quaternion = Quaternion
+    sys.modules["pyquaternion"] = pq
+    for name in ("unproject_depth", "remove_radius_outlier", "estimate_normals", "rgb_odometry", "gradient_xy"):
+        setattr(_ext, name, None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from system import tracker as ref_tracker
+    from utils.motion_util import Isometry
+    return ref_tracker, Isometry, Quaternion
+
+
+def tracker_fixture(model, name, scene, cfg, intr_map, intr_obs, n_map_frames, deg_per_frame, cases, iter_config, init_deg=None, obs_frame=None,
+                    obs_phase_deg=0.0):
+    """The reference's map after `n_map_frames` frames, then its tracker's SDF term for frame `n_map_frames` of the same orbit: the numbers
+    `SDFTracker.compute_sdf_Hg` returns for each (delta pose, robust kernel) of `cases`, and `SDFTracker.gauss_newton` over `iter_config`
+    ('sdf' terms only) from the previous frame's pose — every call it makes to compute_sdf_Hg recorded."""
+    import argparse
+    ref_tracker, Isometry, Quaternion = _import_reference_tracker()
+    m = ref_map.DenseIndexedMap(model, cfg.namespace(), 29, torch.device("cpu"))
+    out = dict(n_map_frames=np.int64(n_map_frames), deg_per_frame=np.float64(deg_per_frame))
+    for f in range(n_map_frames):
+        xyz, nrm = syn.frame_points(scene, f, intr_map, deg_per_frame=deg_per_frame)
+        out[f"f{f}_xyz_sha"] = sha(xyz.numpy())
+        m.integrate_keyframe(xyz, nrm)
+    out["n_occupied"] = np.int64(int(m.n_occupied))
+    out["latent_vecs"] = m.latent_vecs[:int(m.n_occupied)].numpy().copy()
+    out["latent_pos"] = m.latent_vecs_pos[:int(m.n_occupied)].numpy().copy()
+    out["voxel_obs_count"] = m.voxel_obs_count[:int(m.n_occupied)].numpy().copy()
+    obs_frame = n_map_frames if obs_frame is None else obs_frame
+    out["obs_frame"], out["obs_phase_deg"] = np.int64(obs_frame), np.float64(obs_phase_deg)
+    obs, R_gt, t_gt = syn.frame_cloud_camera(scene, obs_frame, intr_obs, deg_per_frame=deg_per_frame, phase_deg=obs_phase_deg)
+    R_last, t_last = syn.orbit_pose(n_map_frames - 1, deg_per_frame=deg_per_frame)
+    out["obs_sha"] = sha(obs.numpy())
+    out["obs_n"] = np.int64(obs.size(0))
+    out["last_R"], out["last_t"], out["gt_R"], out["gt_t"] = R_last, t_last, R_gt, t_gt
+    last_pose = Isometry(q=Quaternion(matrix=R_last), t=t_last)
+
+    def tracker(kernel, k, iters):
+        a = argparse.Namespace(sdf=dict(robust_kernel=kernel, robust_k=k, subsample=0.5),
+                               rgb=dict(weight=500.0, robust_kernel=None, robust_k=0.01, min_grad_scale=0.0, max_depth_delta=0.2), iter_config=iters)
+        t = ref_tracker.SDFTracker(m, a)
+        t.all_pd_pose = [last_pose]
+        return t
+
+    for i, (xi, kernel, k) in enumerate(cases):
+        delta = Isometry.from_twist(np.asarray(xi, dtype=np.float64))
+        t = tracker(kernel, k, [])
+        H, g, e = t.compute_sdf_Hg(0, last_pose, delta, obs.clone(), False)
+        _, _, e2 = t.compute_sdf_Hg(-1, last_pose, delta, obs.clone(), True)
+        assert e2 == e
+        cur = (last_pose.dot(delta)) @ obs
+        with torch.no_grad():
+            _, _, mask = m.get_sdf(cur)
+        out[f"case{i}_xi"] = np.asarray(xi, dtype=np.float64)
+        out[f"case{i}_kernel"] = np.array(str(kernel))
+        out[f"case{i}_k"] = np.float64(k)
+        out[f"case{i}_delta_R"], out[f"case{i}_delta_t"] = delta.q.rotation_matrix.copy(), delta.t.copy()
+        out[f"case{i}_H"], out[f"case{i}_g"], out[f"case{i}_e"], out[f"case{i}_M"] = H, g, np.float64(e), np.int64(int(mask.sum()))
+        out[f"case{i}_mask_sha"] = sha(mask.numpy())
+        print(f"{name} case {i}: kernel {kernel} k {k} M {int(mask.sum())} / {obs.size(0)} e {e:.6f} |H| {np.abs(H).max():.4f} |g| {np.abs(g).max():.5f}")
+
+    # the loop: from the previous frame's pose (tracker.py:121-122: `lspeed` = identity), or from a pose `init_deg` of yaw further off
+    t = tracker("huber", 5.0, iter_config)
+    calls = []
+    orig = t.compute_sdf_Hg
+
+    def recording(n_iter, last_pose_, cur_delta_pose, obs_xyz, no_grad=False):
+        r = orig(n_iter, last_pose_, cur_delta_pose, obs_xyz, no_grad)
+        calls.append((n_iter, cur_delta_pose.q.rotation_matrix.copy(), cur_delta_pose.t.copy(), r))
+        return r
+
+    t.compute_sdf_Hg = recording
+    init = last_pose
+    if init_deg is not None:
+        th = np.radians(init_deg)
+        init = last_pose.dot(Isometry(q=Quaternion(matrix=np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]]))))
+    out["gn_init_R"], out["gn_init_t"] = init.q.rotation_matrix.copy(), init.t.copy()
+    final = t.gauss_newton(init, None, None, None, obs.clone(), None)
+    out["gn_iter_config"] = np.array(json.dumps(iter_config))
+    out["gn_n_calls"] = np.int64(len(calls))
+    for j, (n_iter, dR, dt, (H, g, e)) in enumerate(calls):
+        out[f"gn{j}_iter"], out[f"gn{j}_delta_R"], out[f"gn{j}_delta_t"], out[f"gn{j}_e"] = np.int64(n_iter), dR, dt, np.float64(e)
+        if H is not None:
+            out[f"gn{j}_H"], out[f"gn{j}_g"] = H, g
+    out["gn_final_R"], out["gn_final_t"] = final.q.rotation_matrix.copy(), final.t.copy()
+    err_t = np.linalg.norm(final.t - t_gt)
+    err_R = np.degrees(np.arccos(np.clip((np.trace(final.q.rotation_matrix.T @ R_gt) - 1) / 2, -1, 1)))
+    e0 = calls[0][3][2]
+    print(f"{name} gauss_newton: {len(calls)} calls, energy {e0:.6f} -> {calls[-1][3][2]:.6f}, final pose off the true one by {err_t * 1000:.2f} mm / {err_R:.4f} deg")
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"{name}: saved ({(HERE / f'{name}.npz').stat().st_size / 1e6:.2f} MB)")
+
+
+def tracker_fixtures(model):
+    cases = [((0, 0, 0, 0, 0, 0), "huber", 5.0),
+             ((0.01, -0.004, 0.006, 0.004, -0.008, 0.003), "huber", 5.0),
+             ((0.01, -0.004, 0.006, 0.004, -0.008, 0.003), "huber", 0.5),
+             ((-0.006, 0.003, 0.002, -0.002, 0.005, 0.001), "tukey", 1.5),
+             ((0.002, 0.001, -0.003, 0.001, 0.002, -0.001), None, 0.0)]
+    iters = [{"n": 10, "type": [["sdf"]]}, {"n": 5, "type": [["sdf"]]}]
+    # S: seq_room16's scene and map (16^3 grid of 0.4 m voxels, four 160 x 120 frames 15 degrees apart), a 160 x 120 cloud seen one degree
+    # further along the orbit than the last frame
+    tracker_fixture(model, "track_small", syn.default_room(), syn.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.4),
+                    syn.Intrinsic().scaled(0.25), syn.Intrinsic().scaled(0.25), 4, 15.0, cases, iters, init_deg=None, obs_frame=3, obs_phase_deg=1.0)
+    # C2 of BASELINE.json (64^3 grid, 0.1 m voxels, room scene), two 640x480 frames in the map, the tracker's 320x240 cloud of frame 2
+    scene, cfg = syn.config_c2()
+    tracker_fixture(model, "track_c2", scene, cfg, syn.Intrinsic(), syn.Intrinsic().scaled(0.5), 2, 0.5, cases, iters, init_deg=0.4)
+
+
 def main():
     model, hyper = load_reference_model()
     if "--map-only" in sys.argv:
@@ -430,6 +572,8 @@ def main():
         long_sequences(model, which)
         if "seq_optim" in which:
             optimize_sequence(model)
+        if "track" in which:
+            tracker_fixtures(model)
         if "grads" in which:
             add_gradient_probes(model, "seq_small", syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.4),
                                 syn.Intrinsic().scaled(0.125), 3, 20.0)

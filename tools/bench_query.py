@@ -1,10 +1,14 @@
 """Times DenseIndexedMap.get_sdf on the C3 room map: values only and values + analytic d sdf / d xyz (what one
-Gauss-Newton iteration of the tracker asks for, reference tracker.py:174-218).  Usage: python tools/bench_query.py [--frames 30]"""
+Gauss-Newton iteration of the tracker asks for, reference tracker.py:174-218), and one whole iteration of the SDF term: the reference's op
+sequence on torch tensors against the one-call `dif_sdf_hg` (host wall clock: every iteration ends with H and g on the host).
+Usage: python tools/bench_query.py [--frames 30]"""
 import argparse
 import json
 import sys
+import time
 from pathlib import Path
 
+import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -25,6 +29,44 @@ def timed(fn, reps=20):
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
+
+
+def wall(fn, reps=50):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def reference_iteration(m, obs, last, delta, k=5.0):
+    """tracker.py:174-218 as the reference writes it (huber), on this map: get_sdf with autograd, the Jacobian and the sums as torch ops,
+    H / g / energy to the host."""
+    cur = (last.dot(delta)) @ obs
+    cur.requires_grad_(True)
+    sdf, std, mask = m.get_sdf(cur)
+    s = sdf / std.detach()
+    (d,) = torch.autograd.grad(s, [cur], grad_outputs=torch.ones_like(s), retain_graph=False, create_graph=False)
+    d = d[mask]
+    s = s.detach()
+    c = (delta @ obs)[mask]
+    Lt = torch.from_numpy(last.R.astype(np.float32).T).to(obs.device)
+    Lai = torch.mm(d, Lt)
+    J = torch.cat([Lai, torch.linalg.cross(c, Lai)], dim=-1)
+    w = torch.ones_like(s)
+    sa = torch.abs(s)
+    big = sa > k
+    w[big] = k / sa[big]
+    wf = s * w
+    JW = J * w.unsqueeze(1)
+    scale = 1.0 / wf.size(0)
+    e = (s * wf).sum().item() * scale
+    H = torch.einsum("na,nb->nab", JW, J).sum(0) * scale
+    g = (J * wf.unsqueeze(1)).sum(0) * scale
+    return H.cpu().numpy().astype(float), g.cpu().numpy().astype(float), float(e)
 
 
 def main():
@@ -63,6 +105,20 @@ def main():
         out[name] = {"points": int(q.shape[0]), "valid_points": m, "values_ms": round(t_val, 4), "values_and_gradient_ms": round(t_grad, 4),
                      "values_and_gradient_without_autograd_engine_ms": round(t_direct, 4),
                      "values_algorithmic_tflops": round(m * DEC_FLOP_PER_ROW / (t_val * 1e-3) / 1e12, 2)}
+    # one Gauss-Newton iteration of the SDF term, the tracker's 320 x 240 cloud of the middle frame against the map, from the previous frame's pose
+    from di_fusion_amd.system.tracker import Pose, sdf_hg
+    f = a.frames // 2
+    obs, R, t = syn.frame_cloud_camera(scene, f, syn.Intrinsic().scaled(0.5), device=dev)
+    last, delta = Pose(*syn.orbit_pose(f - 1)), Pose()
+    Hr, gr, er = reference_iteration(st.map, obs, last, delta)
+    H, g, e, M = sdf_hg(st.map, obs, last, delta, "huber", 5.0)
+    assert np.abs(H - Hr).max() < 1e-4 * np.abs(Hr).max() and abs(e - er) < 1e-5 * max(1.0, er)
+    out["gauss_newton_iteration 320x240"] = {
+        "points": int(obs.size(0)), "valid_points": M,
+        "reference_op_sequence_ms": round(wall(lambda: reference_iteration(st.map, obs, last, delta)), 4),
+        "one_call_ms": round(wall(lambda: sdf_hg(st.map, obs, last, delta, "huber", 5.0)), 4),
+        "one_call_no_grad_ms": round(wall(lambda: sdf_hg(st.map, obs, last, delta, "huber", 5.0, no_grad=True)), 4),
+        "clock": "host wall clock per iteration, H / g / energy on the host at the end of each"}
     print(json.dumps(out))
 
 
