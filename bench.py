@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--split-mesh", type=int, default=0, choices=[0, 1], help="with --overlap 1: frame n's marching cubes + finish kernel on a third queue beside frame "
                     "n+1's decode (the extracts' queue then carries fuse, decode, fuse, decode, ...; two sets of per-voxel extract buffers).  Off by default: "
                     "+2-3 %% together with --host-depth 2, nothing without")
+    ap.add_argument("--scan-ahead", type=int, default=0, choices=[0, 1], help="with --overlap 1: the frame's two extract scans (dirty-set compaction + neighbourhood "
+                    "marker, batch scan) in its front end, before its fusion kernel (dif_map_t.scan_ahead): the extracts' queue carries fuse, lattice decode, "
+                    "refine, marching cubes, finish only (two sets of per-voxel extract buffers).  Off by default: the same rate (profiles/r05_experiments.md 2)")
     ap.add_argument("--rccl-before-clock", type=int, default=0, choices=[0, 1], help="--mode c4 under torch.distributed: 0 (default) = the barriers around "
                     "the clock go over gloo and RCCL is brought up BEHIND the clock, for the exchange step (the global map merge); 1 = RCCL is the process group "
                     "from the start, alive during the timed region like in a deployment that merges maps periodically.  The line says which "
@@ -624,6 +627,7 @@ def main():
                           initial_capacity=cap0)   # own arc of the orbit
         if a.overlap and a.direct and not a.graph and batch == 0 and a.d2h in ("dma", "none"):
             st.split_mesh = bool(a.split_mesh)
+            st.scan_ahead = bool(a.scan_ahead)
             st.enable_overlap()             # (stays off, and says so, when no second hardware queue is to be had)
         if a.direct and not a.graph and batch == 0:
             st.host_depth = a.host_depth
@@ -770,6 +774,7 @@ def main():
                                                                                "p90": round(float(np.percentile([u for _, u in stream.sdma_us], 90)), 1),
                                                                                "first_40": [(n, round(u)) for n, u in stream.sdma_us[:40]]}),
                           "two_queues": {"on": bool(stream.overlap), "queues_independent": stream.queues_independent, "mesh_half_on_a_third_queue": bool(stream.overlap and stream.split_mesh),
+                                         "extract_scans_in_the_front_end": bool(stream.overlap and stream.scan_ahead),
                                          "what": "frame i+1's integrate front end on a second hardware queue beside frame i's extract; fusion kernel and extract "
                                                  "ordered by hipStreamWaitValue32 on words the kernels publish" if stream.overlap else "one queue"},
                           "host_pipeline_depth": (1 + stream.host_depth) if (a.pipeline or a.graph) else 1, "launch": launch,

@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "
 C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS, C_HALO_L, C_HALO_R, C_HALO_TICKET = range(23)
 C_STAMP = 31
 SYNC_FUSED, SYNC_FRONT_DONE, SYNC_DECODED, SYNC_MESHED, SYNC_WORDS = 0, 32, 64, 96, 128      # dif_map_t.sync_words
-FC_COUNT = 16                                            # dif_map_t.frame_counters
+FC_COUNT = 32                                            # dif_map_t.frame_counters
 C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge"]
 PROF_COUNT = 8
@@ -38,7 +38,8 @@ class DifMap(Structure):
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
                 ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("dirty_tot", c_void_p),
                 ("halo_list", c_void_p), ("halo_list_cap", c_int32), ("pending_export", c_void_p),
-                ("alloc_bits", c_void_p), ("alloc_tot", c_void_p), ("sync_words", c_void_p), ("frame_seq", c_int32), ("fuse_stream", c_void_p), ("frame_counters", c_void_p), ("mesh_wait", c_int32)]
+                ("alloc_bits", c_void_p), ("alloc_tot", c_void_p), ("sync_words", c_void_p), ("frame_seq", c_int32), ("fuse_stream", c_void_p), ("frame_counters", c_void_p), ("mesh_wait", c_int32),
+                ("front_stream", c_void_p), ("pend_cnt", c_void_p), ("scan_ahead", c_int32)]
 
 
 class DifWeights(Structure):

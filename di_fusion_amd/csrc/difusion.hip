@@ -113,6 +113,9 @@ inline bool overlap_ok(const dif_map_t* map) {
     return map->alloc_bits && map->alloc_tot && map->dirty_tot && map->frame_counters && !map_is_tiled(map) && map->capacity > 4096 &&
            map->capacity % DIF_BLOCK == 0;
 }
+// the scans of an overlapped frame's extract in its front end (include/difusion.h: dif_map_t.scan_ahead)
+inline bool scan_ahead(const dif_map_t* map) { return overlapped(map) && map->scan_ahead != 0; }
+inline bool scan_ahead_ok(const dif_map_t* map) { return map->pend_cnt != nullptr && map->frame_counters != nullptr; }
 inline int wait_word(hipStream_t s, uint32_t* word, int32_t value) {
     if (value <= 0) return DIF_OK;
     return hipStreamWaitValue32(s, word, (uint32_t)value, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
@@ -433,7 +436,7 @@ struct FrameSource {            // integrate straight from a depth frame: the fi
 // pieces to the kernels by value, dif_integrate_frames collects the pieces of S maps into the kernels' argument arrays.
 struct IntegratePlan {
     UvcArgs uvc; PruneArgs prune; AllocFunctor alloc; const int* alloc_tot; GatherArgs gather; EncArgs enc; FuseArgs fuse;
-    int64_t grid; bool has_pending; bool overlap;
+    int64_t grid; bool has_pending; bool overlap; bool scan_ahead;
 };
 
 static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
@@ -471,10 +474,15 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
     P.alloc_tot = alloc_tot_of(map);                               // k_prune_mark kept the block totals
     P.gather = GatherArgs{g, map->encoder_count_th, ps, ws.pt_lin, unq_mask, map->frame_count, map->indexer, map->voxel_obs_count, ws.pair_list, C,
                           map->capacity, alloc_tot_of(map), own_lo, own_hi, ov ? nullptr : pending, cull};
-    P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, ov ? nullptr : map->dirty_tot};
+    // ... unless the frame's scans run in its front end too (scan_ahead): then flags, totals and the slots' pending counts are the encoder's again
+    const bool sa = ov && scan_ahead(map);
+    if (sa && !scan_ahead_ok(map)) return DIF_EINVAL;
+    P.scan_ahead = sa;
+    P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, (ov && !sa) ? nullptr : map->dirty_tot,
+                    sa ? map->pend_cnt : nullptr};
     P.fuse = FuseArgs{ws.rec, ws.rec_next, map->rec_dir, map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->latent_vecs_pos,
-                      halo_lists_of(map), ov ? nullptr : pending, ov ? map->dirty_tot : nullptr, ov ? map->frame_counters : nullptr,
-                      ov ? map->sync_words + DIF_SYNC_DECODED : nullptr, ov ? map->frame_seq : 0};
+                      halo_lists_of(map), ov ? nullptr : pending, (ov && !sa) ? map->dirty_tot : nullptr, ov ? map->frame_counters : nullptr,
+                      ov ? map->sync_words + DIF_SYNC_DECODED : nullptr, ov ? map->frame_seq : 0, sa ? map->pend_cnt : nullptr};
     if (ov) P.uvc.pending = nullptr;                               // (no deferred export rides with an overlapped frame: its extract has not run yet)
     return DIF_OK;
 }
@@ -542,10 +550,10 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         const int enc_grid = P.overlap ? overlap_encoder_cus() : num_cus();
         if (x6)
             hipLaunchKernelGGL(k_encode<true>, dim3(enc_grid), dim3(ENC_X6_THREADS), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
-                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
+                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot, e.pend);
         else
             hipLaunchKernelGGL(k_encode<false>, dim3(enc_grid), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.src.xyz, e.src.normal, e.src.frame,
-                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
+                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot, e.pend);
         DIF_CHECK_LAUNCH();
     }
     hipStream_t sf = s;
@@ -553,7 +561,8 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         // two queues: the front end is done -> a word for the extracts' stream, where the fusion kernel goes: behind the previous frame's extract
         // (it writes what that extract reads — latents, counts, dirty flags) and behind one wait for that word, which is normally long there
         sf = (hipStream_t)map->fuse_stream;
-        hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, s, map->sync_words + DIF_SYNC_FRONT_DONE, (uint32_t)map->frame_seq);
+        // (scan-ahead: the front end goes on into the frame's dif_extract, which runs the two scans on this stream and publishes the word behind them)
+        if (!P.scan_ahead) hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, s, map->sync_words + DIF_SYNC_FRONT_DONE, (uint32_t)map->frame_seq);
         if (wait_word(sf, map->sync_words + DIF_SYNC_FRONT_DONE, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, sf, P.fuse);
@@ -895,13 +904,17 @@ static DirtySet dirty_set_of(const dif_map_t* map, const dif_extract_buffers_t* 
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz, plane = (int64_t)map->ny * map->nz;
     const bool tiled = map_is_tiled(map);
     const int64_t own_lo = tiled ? map->own_x_lo * plane : 0, own_hi = tiled ? map->own_x_hi * plane : grid;
+    const bool sa = scan_ahead(map);
     return DirtySet{map->dirty, map->latent_vecs_pos, buf->valid_blocks, map->counters, no_cache, buf->max_voxels, geo_of(map), map->ignore_count_th,
-                    map->indexer, map->voxel_obs_count, grid_marks_of(map), own_lo, own_hi, tiled};
+                    map->indexer, map->voxel_obs_count, grid_marks_of(map), own_lo, own_hi, tiled,
+                    sa ? map->pend_cnt : nullptr, sa ? map->frame_counters + DIF_FC_XC : nullptr};
 }
 
 static VoxelDecodeArgs voxel_decode_args_of(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, const ExtractGeo& e, bool fold) {
     VoxelDecodeArgs V = {};
-    V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std; V.counters = map->counters;
+    V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std;
+    V.counters = scan_ahead(map) ? map->frame_counters + DIF_FC_XC : map->counters;          // B, VH of the frame
+    if (scan_ahead(map)) { V.fused_word = map->sync_words + DIF_SYNC_FUSED; V.seq = map->frame_seq; }
     V.refine_list = buf->refine_list; V.R = e.R;
     V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
     V.low.res = e.l; V.low.a = (float)e.sample_a; V.low.vsize = (e.l > 1) ? (float)((e.sample_b - e.sample_a) / (e.l - 1)) : 0.0f;
@@ -910,7 +923,7 @@ static VoxelDecodeArgs voxel_decode_args_of(const dif_map_t* map, const dif_weig
 
 static DecodeArgs refine_args_of(const dif_map_t* map, const dif_extract_buffers_t* buf, const ExtractGeo& e, bool fold) {
     DecodeArgs Rf = {};
-    Rf.mode = 1; Rf.n_ptr = map->counters + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
+    Rf.mode = 1; Rf.n_ptr = (scan_ahead(map) ? map->frame_counters + DIF_FC_XC : map->counters) + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
     Rf.lat.res = e.R; Rf.lat.a = (float)e.sample_a; Rf.lat.vsize = (float)((e.sample_b - e.sample_a) / (e.R - 1));
     Rf.fold_table = fold ? buf->fold_table : nullptr;
     Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
@@ -955,7 +968,7 @@ static FinishArgs finish_args_of(const dif_map_t* map, const dif_extract_buffers
                                  defer ? (dif_pending_export_t*)map->pending_export : nullptr, buf->stamp, defer ? buf->export_notify : nullptr},
                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
                       onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr,
-                      ov ? map->frame_counters : nullptr};
+                      ov ? map->frame_counters : nullptr, scan_ahead(map) ? 1 : 0};
 }
 
 static int voxel_decode_attributes() {
@@ -1029,6 +1042,12 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     // two queues (and the split extract): only for the configuration a stream runs (fast decode on the bf16 pipe, one-pass marching cubes) — the
     // refine pass is what leaves the frame's K, B, VH in its counter block
     const bool split = ov && buf->split_mesh;
+    // scan-ahead: the two scans below run on the FRONT-END stream, before the frame's fusion kernel (dif_map_t.scan_ahead), into the frame's own
+    // counter block; the word the fusion kernel waits for follows them
+    const bool sa = ov && scan_ahead(map);
+    if (sa && (!scan_ahead_ok(map) || !map->front_stream || (hipStream_t)map->front_stream == s)) return DIF_EINVAL;
+    hipStream_t ss = sa ? (hipStream_t)map->front_stream : s;
+    int* const XC = sa ? map->frame_counters + DIF_FC_XC : nullptr;
     if (ov && !(fast && buf->chunk_sum && buf->mc_status && buf->max_voxels <= ((int64_t)1 << 24) && r * r * r <= 64 && buf->fold_table && w->dec_x6_packed &&
                    w->dec_x6_packed_bytes == X6_BYTES && w->dec_fold_packed))
         return DIF_EINVAL;
@@ -1039,7 +1058,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         const DirtySet ds = dirty_set_of(map, buf, no_cache);
         const bool tiled = ds.tiled;
         if (tiled) {
-            hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th, map->dirty,
+            hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, ss, g, map->ignore_count_th, map->dirty,
                                (const int64_t*)map->latent_vecs_pos, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, bits,
                                n_slots, ds.own_lin_lo, ds.own_lin_hi);
             DIF_CHECK_LAUNCH();
@@ -1048,18 +1067,23 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             DirtyFunctor f{ds};
             // every writer of the flags kept the per-block totals (k_fuse; the host recomputes them after anything else): no counting pass
             if (map->dirty_tot && !no_cache && !tiled && map->capacity > 4096 && map->capacity % DIF_BLOCK == 0) {
-                hipLaunchKernelGGL(k_dirty_scan, dim3((int)(map->capacity / DIF_BLOCK)), dim3(DIF_BLOCK), 0, s, ds, n_slots, (const int*)map->dirty_tot,
-                                   ov ? map->sync_words + DIF_SYNC_FUSED : nullptr, (int)map->frame_seq);
+                hipLaunchKernelGGL(k_dirty_scan, dim3((int)(map->capacity / DIF_BLOCK)), dim3(DIF_BLOCK), 0, ss, ds, n_slots, (const int*)map->dirty_tot,
+                                   (ov && !sa) ? map->sync_words + DIF_SYNC_FUSED : nullptr, (int)map->frame_seq);
                 DIF_CHECK_LAUNCH();
+            } else if (sa) {
+                return DIF_EINVAL;          // (overlap_ok() admits only maps that take the launch above)
             } else if (map->dirty_tot && !no_cache && !tiled) {
                 if (launch_counted_scan_bounded(f, n_slots, map->capacity, map->dirty_tot, s) != DIF_OK) return DIF_ELAUNCH;
             } else if (launch_scan(f, n_slots, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
         }
     }
     {
-        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
-        if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // the markers kept the block totals
-
+        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels, XC};
+        if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, ss) != DIF_OK) return DIF_ELAUNCH;      // the markers kept the block totals
+    }
+    if (sa) {   // the front end of the frame ends here: its fusion kernel (dif_integrate_frame left it on `s` behind a wait for this word) may go
+        hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, ss, map->sync_words + DIF_SYNC_FRONT_DONE, (uint32_t)map->frame_seq);
+        DIF_CHECK_LAUNCH();
     }
     int rc;
     if (fast && l * l * l <= VD_MAX_L3 && R * R <= VD_MAX_R2) {
@@ -1086,7 +1110,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             if (rblocks > num_cus()) rblocks = num_cus();
             ProfScope prof(DIF_PROF_DECODE_POINTS, s);
             hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed,
-                               ov ? SplitTail{map->frame_counters, (const int*)C, split ? map->grid_tot : nullptr} : SplitTail{nullptr, nullptr, nullptr});
+                               ov ? SplitTail{map->frame_counters, sa ? (const int*)XC : (const int*)C, split ? map->grid_tot : nullptr} : SplitTail{nullptr, nullptr, nullptr});
             DIF_CHECK_LAUNCH();
             rc = DIF_OK;
         } else {
@@ -1131,10 +1155,8 @@ static int extract_mesh_part(const dif_map_t* map, const dif_extract_buffers_t* 
     int rc;
     McArgs a = mc_args_of(map, buf, e, max_std, scale_vertices);
     const bool split = overlapped(map) && buf->split_mesh;
-    if (split) {                    // the frame's own K (the live word may be the next frame's); the batch scan's totals were zeroed by the refine pass
-        a.K_ptr = map->frame_counters + DIF_FC_K;
-        a.grid_tot = nullptr;
-    }
+    if (split || scan_ahead(map)) a.K_ptr = map->frame_counters + DIF_FC_K;      // the frame's own K (the live word may be the next frame's)
+    if (split) a.grid_tot = nullptr;                                              // the batch scan's totals were zeroed by the refine pass
     if (no_cache) {                                                                                               // map.py:614-616
         if (hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
         if (hipMemsetAsync(C + DIF_C_CACHE_DEAD, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
@@ -1209,7 +1231,7 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
             return DIF_EINVAL;
         if (!map->tri_start || !map->tri_n || !buf->fold_table || !buf->chunk_sum || !buf->mc_status || buf->max_voxels > ((int64_t)1 << 24)) return DIF_EINVAL;
         dirty.s[j] = DirtyScanArgs{dirty_set_of(map, buf, 0), map->counters + DIF_C_N_OCCUPIED, map->dirty_tot};
-        occ.f[j] = OccFunctor{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, map->counters, buf->max_voxels};
+        occ.f[j] = OccFunctor{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, map->counters, buf->max_voxels, nullptr};
         occ.tot[j] = map->grid_tot;
         vd.s[j] = voxel_decode_args_of(map, w, buf, e, true);
         rf.s[j] = refine_args_of(map, buf, e, true);

@@ -6,7 +6,7 @@
 // =================================================================================================================
 // set the bitmap bits of the confident voxels among `lin` and its 6 allocated neighbours (map.py:628-631)
 __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float ignore_th, const int64_t* __restrict__ indexer,
-                                                    const float* __restrict__ obs, const GridMarks& marks) {
+                                                    const float* __restrict__ obs, const GridMarks& marks, const int32_t* __restrict__ pend = nullptr) {
     const uint32_t* bits = marks.bits;
     int ix, iy, iz;
     unlinearize(g, lin, ix, iy, iz);
@@ -24,7 +24,7 @@ __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float
     for (int c = 0; c < 7; ++c) slot[c] = indexer[cand[c]];
     float w[7];
 #pragma unroll
-    for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? obs[slot[c]] : ignore_th;
+    for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? obs[slot[c]] + (pend ? (float)pend[slot[c]] : 0.0f) : ignore_th;      // (scan-ahead: DirtySet.pend)
     uint32_t word[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) word[c] = (w[c] > ignore_th) ? bits[cand[c] >> 5] : 0xFFFFFFFFu;
@@ -74,6 +74,11 @@ struct DirtySet {
     GridMarks bits;
     int64_t own_lin_lo, own_lin_hi;     // only owned voxels are meshed (spatial tiling); the whole grid by default
     bool tiled;
+    // scan-ahead (dif_map_t.scan_ahead): the scan runs BEFORE the frame's fusion kernel — a voxel's observation count is obs + pend (the points the
+    // encoder has just counted for it; exact: integers below 2^24, the sum the fusion kernel writes) — and K goes to the frame's own counter block
+    const int32_t* pend;
+    int* xc;
+    __device__ __forceinline__ int* k_block() const { return xc ? xc : counters; }
     __device__ __forceinline__ bool owned(int s) const {
         if (!tiled) return true;
         const int64_t p = pos[s];
@@ -93,11 +98,11 @@ struct DirtyFunctor {
         if (offset >= a.max_voxels) return;
         const int lin = (int)a.pos[s];
         a.valid_blocks[offset] = lin;
-        mark_confident_nbhd(a.g, lin, a.ignore_th, a.indexer, a.obs, a.bits);
+        mark_confident_nbhd(a.g, lin, a.ignore_th, a.indexer, a.obs, a.bits, a.pend);
     }
     __device__ void finish(int total) const {
         if (total > a.max_voxels) { total = (int)a.max_voxels; a.counters[DIF_C_OVERFLOW] = 2; }
-        a.counters[DIF_C_K] = total;
+        a.k_block()[DIF_C_K] = total;
     }
 };
 
@@ -143,7 +148,7 @@ __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __
         for (int c = 0; c < 7; ++c) slot[c] = a.indexer[cand[c]];
         float w[7];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? a.obs[slot[c]] : a.ignore_th;
+        for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? a.obs[slot[c]] + (a.pend ? (float)a.pend[slot[c]] : 0.0f) : a.ignore_th;
 #pragma unroll
         for (int c = 0; c < 7; ++c) word[c] = (w[c] > a.ignore_th) ? marks.bits[cand[c] >> 5] : 0xFFFFFFFFu;
     }
@@ -171,7 +176,7 @@ __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int t = total;
         if (t > a.max_voxels) { t = (int)a.max_voxels; a.counters[DIF_C_OVERFLOW] = 2; }
-        a.counters[DIF_C_K] = t;
+        a.k_block()[DIF_C_K] = t;
     }
 }
 
@@ -195,6 +200,7 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
     int32_t* vbm;
     int* counters;
     int64_t max_voxels;
+    int* xc;                // scan-ahead: B, VH, WORK of the frame's own counter block (NULL: the live words)
     __device__ int count(int w) const { return __popc(bits[w]); }
     __device__ void emit(int w, int offset) const {
         uint32_t word = bits[w];
@@ -212,9 +218,10 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
     }
     __device__ void finish(int total) const {
         if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 3; }
-        counters[DIF_C_B] = total;
-        counters[DIF_C_VH] = 0;
-        counters[DIF_C_WORK] = 0;
+        int* c = xc ? xc : counters;
+        c[DIF_C_B] = total;
+        c[DIF_C_VH] = 0;
+        c[DIF_C_WORK] = 0;
     }
 };
 
@@ -582,6 +589,8 @@ struct VoxelDecodeArgs {
     int* counters;
     const float* fold_w;            // packing.py:pack_decoder_fold, or NULL (latent carried through the MFMAs)
     float* fold_table;              // [batch voxel][256] out, for the refine pass
+    uint32_t* fused_word;           // scan-ahead: this is the first kernel behind the frame's fusion kernel on its stream: it says so (DIF_SYNC_FUSED)
+    int seq;
 };
 
 #define VD_MAX_L3 64
@@ -738,6 +747,7 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
 
 template <bool X6>
 __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
+    if (A.fused_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.fused_word, (uint32_t)A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const BatchN<VoxelDecodeArgs, 1> B{{A}};
     decode_voxels_body<X6, 1>(B, 1, wblob);
 }

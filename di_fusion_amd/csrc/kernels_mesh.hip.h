@@ -750,7 +750,7 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
                                                     const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                     const float* __restrict__ log_std, const ExtractOut& out, int32_t* __restrict__ chunk_sum,
                                                     int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket,
-                                                    const int* __restrict__ fc) {
+                                                    const int* __restrict__ fc, int live_kbvh = 0) {
     // (fc: an overlapped frame's own counter block — K, B, VH and the integrate's counters as this frame left them; the live words may be a frame ahead)
     const int B = fc ? fc[DIF_FC_B] : counters[DIF_C_B];
     const int Kd = fc ? fc[DIF_FC_K] : counters[DIF_C_K];
@@ -816,6 +816,9 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
             else if (over) counters[DIF_C_OVERFLOW] = 5;
         }
         if (lane == 0) counters[DIF_C_CACHE_T] = (int)tot;
+        // scan-ahead frames count K, B, VH in their own block only: the live words follow here, so that whoever reads the map's counters after
+        // the stream (dif_read_counters) finds the last frame's values (no other kernel writes or reads these three in that mode)
+        if (live_kbvh && fc && (lane == DIF_C_K || lane == DIF_C_B || lane == DIF_C_VH)) counters[lane] = v;
     }
 }
 
@@ -823,15 +826,16 @@ struct FinishArgs {
     const int32_t* occ_slot; int32_t* vbm; int* counters; int64_t new_limit, capacity; const float* log_tri; const int64_t* log_id; const float* log_std;
     ExtractOut out; int32_t* chunk_sum; int32_t* super_sum; int32_t* dirty_tot; int n_dirty_tot; uint32_t* mc_status; uint32_t* mc_ticket;
     const int* fc;          // two queues: the frame's own counter block (dif_map_t.frame_counters) or NULL
+    int live_kbvh;          // scan-ahead: K, B, VH also into the live counters
 };
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(FinishArgs a) {
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc, a.live_kbvh);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish_batch(Batch<FinishArgs> b) {
     const FinishArgs& a = b.s[blockIdx.y];
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc, a.live_kbvh);
 }
 
 struct TriScanFunctor {         // exclusive scan of the per-voxel triangle counts; on the mesh-cache path also the log bookkeeping

@@ -108,6 +108,12 @@ class FusionStream:
         # and counter blocks (slot parity).  Off by default: measured (profiles/r05_experiments.md 2) it is worth 2-3 % together with host_depth = 2
         # (7,090-7,290 against 6,910-7,050 frames/s) and nothing without, for twice the per-voxel extract buffers.
         self.split_mesh = False
+        # ... and the frame's two extract scans (dirty-set compaction + neighbourhood marker, batch scan: two latency-bound launches, ~19 us) in its
+        # FRONT END, before its fusion kernel (dif_map_t.scan_ahead): what a frame's extract decodes follows from what its encoder updated — the
+        # extracts' stream then carries fuse, lattice decode, refine, marching cubes, finish only.  Needs the two buffer sets as well.  Off by default:
+        # bit-identical, and measured (profiles/r05_experiments.md 2) 6,900-7,090 frames/s against 6,940-6,970 without, whatever the host depth — the
+        # frame's ~170 us of launches take ~140 us on two queues however they are arranged.
+        self.scan_ahead = False
         self._mesh_pending = None           # (frame number, slot, stamp) of the frame whose mesh half is not enqueued yet
         self.last_tensors = None            # the extract tensors of the frame enqueued last (tests)
         self.queues_independent = None      # what dif_queues_independent said about the two streams
@@ -179,6 +185,11 @@ class FusionStream:
         cm.frame_counters = ctypes.c_void_p(m._frame_counters.data_ptr() + p * _lib.FC_COUNT * 4)
         # (mesh halves on a stream of their own: the front end of frame n waits for the mesh half of frame n-2, whose buffers frame n's decode reuses)
         cm.mesh_wait = max(0, seq - 2) if (self.split_mesh and self._mesh_stream is not self._fe_stream) else 0
+        sa = bool(self.scan_ahead and self.resolution <= 4)
+        cm.scan_ahead = 1 if sa else 0
+        cm.front_stream = self._fe_ptr
+        if sa:
+            cm.grid_tot = _lib.ptr(m._grid_tot_b if p else m._grid_tot)
 
     def _ov_restore_fields(self):
         m, cm = self.map, self.map._cmap
@@ -186,6 +197,9 @@ class FusionStream:
         cm.fuse_stream = None
         cm.frame_counters = None
         cm.mesh_wait = 0
+        cm.scan_ahead = 0
+        cm.front_stream = None
+        cm.grid_tot = _lib.ptr(m._grid_tot)
         cm.dirty_tot = _lib.ptr(m._dirty_tot)
         cm.vbm = _lib.ptr(m._vbm)
 
@@ -444,7 +458,7 @@ class FusionStream:
             self._d_seq = 0
             self._d_desc = [np.frombuffer(struct.pack("<QQ12f", self.depth[i].data_ptr(), self.ncam[i].data_ptr(), *R, *t), dtype=np.uint8).copy()
                             for i, (R, t) in enumerate(self.poses)]
-        two_sets = bool(self.overlap and self.split_mesh and self.resolution <= 4)
+        two_sets = bool(self.overlap and (self.split_mesh or self.scan_ahead) and self.resolution <= 4)
         sig = (m._capacity, m._ws.data_ptr(), m._xbuf[0], m._cache[0].data_ptr(), self.HOST_OUT_TRIANGLES, two_sets)
         if self._d_sig != sig:                       # (re)build the per-slot buffer descriptors after a re-allocation
             # (a pending deferred export points into the mesh log: carry it out before anything below may re-allocate that log)

@@ -196,6 +196,7 @@ class DenseIndexedMap:
             # front end may run beside the previous frame's extract (two queues, FusionStream.overlap)
             self._alloc_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._alloc_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
+            self._grid_tot_b = torch.zeros((1024,), device=device, dtype=torch.int32)                 # the marker's block totals of the frames of odd parity (scan-ahead)
             self._sync_words = torch.zeros((_lib.SYNC_WORDS,), device=device, dtype=torch.int32)     # dif_map_t.sync_words
             self._frame_counters = torch.zeros((2, _lib.FC_COUNT), device=device, dtype=torch.int32)  # dif_map_t.frame_counters, one block per frame parity
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
@@ -231,6 +232,8 @@ class DenseIndexedMap:
             # batch scan and fusion kernel: FusionStream, dif_extract_buffers_t.split_mesh); idle -1 / 0 like the first ones
             self._vbm_b = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
             self._dirty_tot_b = torch.zeros(((capacity + 255) // 256,), dtype=torch.int32, device=dev)
+            # points the encoder has counted for a slot and the fusion kernel has not yet added (dif_map_t.pend_cnt): zero outside a frame
+            self._pend_cnt = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             if self._capacity > 0:
                 c = self._capacity
                 lat[:c] = self._latent
@@ -279,6 +282,9 @@ class DenseIndexedMap:
         m.sync_words = _lib.ptr(self._sync_words)
         m.frame_seq = 0                     # two queues off; FusionStream sets it (and fuse_stream) per overlapped frame
         m.fuse_stream = None
+        m.front_stream = None
+        m.pend_cnt = _lib.ptr(self._pend_cnt)
+        m.scan_ahead = 0
         self._cmap = m
         self._recount_dirty()
 

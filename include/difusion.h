@@ -141,13 +141,26 @@ typedef struct dif_map {
     /* Split extracts on a stream of their own: > 0 = the front end of this frame first waits until sync_words[DIF_SYNC_MESHED] >= mesh_wait — the mesh
      * half of frame_seq - 2 has completed, so the decode of this frame (which reuses that frame's buffers) cannot overtake it. */
     int32_t mesh_wait;
+    /* The scans of an overlapped frame's extract in its FRONT END (`scan_ahead` != 0, with frame_seq > 0): what frame n's extract decodes is known
+     * before its fusion kernel has run — the voxels its encoder updated, and which of them and of their neighbours are confident once the frame's
+     * points are counted in — so the dirty-set compaction + neighbourhood marker and the batch scan (map.py:627-631), two latency-bound launches of
+     * ~19 us, leave the extracts' stream: dif_integrate_frame's encoder sets the dirty flags and their block totals itself and adds every run's
+     * length to `pend_cnt[slot]` (int32 per slot, idle 0; the fusion kernel returns it to 0), and does NOT publish DIF_SYNC_FRONT_DONE;
+     * dif_extract runs the two scans on `front_stream` — counting a voxel as observed `voxel_obs_count + pend_cnt` times, the value the fusion
+     * kernel is about to write —, publishes DIF_SYNC_FRONT_DONE behind them, and its first decode kernel (on `fuse_stream`) publishes
+     * DIF_SYNC_FUSED.  K, B, VH live in the frame's counter block from the start ([DIF_FC_XC + DIF_C_K ...]).  The extracts' stream then carries
+     * fuse, lattice decode, refine, marching cubes, finish.  The caller alternates `grid_tot` by frame parity too (like vbm / dirty_tot / the
+     * extract buffers): frame n's marching cubes returns its block totals to idle while frame n + 1's marker already counts into the other set. */
+    void* front_stream;             /* hipStream_t of the front ends (the stream dif_integrate_frame is called on) */
+    int32_t* pend_cnt;
+    int32_t scan_ahead;
 } dif_map_t;
 
 /* sync_words (each on a 128-byte line of its own): frame n's fusion kernel has completed (written by the first kernel of its extract); frame n's front
  * end has completed; frame n's decode kernels have completed (written by the fusion kernel of frame n + 1 as it starts — or by dif_extract_mesh's caller
  * simply running that call on the extracts' stream) */
 enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_DECODED = 64, DIF_SYNC_MESHED = 96, DIF_SYNC_WORDS = 128 };     /* MESHED: frame n's mesh half has completed */
-enum { DIF_FC_K = 0, DIF_FC_B = 1, DIF_FC_VH = 2, DIF_FC_SHADOW = 4, DIF_FC_COUNT = 16 };
+enum { DIF_FC_K = 0, DIF_FC_B = 1, DIF_FC_VH = 2, DIF_FC_SHADOW = 4, DIF_FC_XC = 16, DIF_FC_COUNT = 32 };    /* [DIF_FC_XC + DIF_C_*]: K, B, VH, WORK of a scan-ahead frame */
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
 typedef struct dif_pending_export {

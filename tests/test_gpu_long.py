@@ -102,16 +102,18 @@ def _new_worst():
     return dict(lat_ref=0.0, lat_oracle=0.0, cube_ref=0.0, cube_oracle=0.0, flips=0, gated=0)
 
 
-@pytest.mark.parametrize("name,overlap", [("seq_c3_long", True), ("seq_c3_long", False), ("seq_c3_long", "split"), ("seq_c2_long", True)])
+@pytest.mark.parametrize("name,overlap", [("seq_c3_long", True), ("seq_c3_long", False), ("seq_c3_long", "split"), ("seq_c3_long", "scan"), ("seq_c2_long", True)])
 def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model, oracle_net):
     """overlap: the bench's default — frame i+1's integrate front end on a second hardware queue beside frame i's extract
-    (`FusionStream.enable_overlap`); "split": also the frame's marching cubes on a third queue beside the next frame's decode; False: every
+    (`FusionStream.enable_overlap`); "split": also the frame's marching cubes on a third queue beside the next frame's decode; "scan": the frame's
+    two extract scans in its front end, before its fusion kernel (`scan_ahead`); False: every
     frame's twelve launches on one queue."""
     from oracle import difusion_oracle as O
     g = np.load(GOLDEN / f"{name}.npz")
     F = int(g["n_frames"])
     st, scene, cfg, phase = _make(gpu_model, name, F)
     st.split_mesh = overlap == "split"
+    st.scan_ahead = overlap == "scan"
     if overlap and not st.enable_overlap():
         pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
     om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
@@ -142,6 +144,7 @@ def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model,
     torch.cuda.empty_cache()
     st, _, _, _ = _make(gpu_model, name, F)
     st.split_mesh = overlap == "split"
+    st.scan_ahead = overlap == "scan"
     if overlap:
         assert st.enable_overlap()
     got = []

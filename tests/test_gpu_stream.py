@@ -103,7 +103,7 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     same(outs["eager"], snapshot(st))
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "scan", "split+scan"])
 @pytest.mark.parametrize("d2h", ["dma", "none"])
 def test_two_queue_frames_are_bit_identical(d2h, split, gpu_model):
     """`enable_overlap`: frame i+1's integrate front end (unproject ... encoder) on a second hardware queue beside frame i's extract, its
@@ -121,7 +121,8 @@ def test_two_queue_frames_are_bit_identical(d2h, split, gpu_model):
     ref = snapshot(st)
     for rep in range(3):
         st = make_stream(gpu_model, initial_capacity=(1 << 13) if rep < 2 else None)
-        st.split_mesh = split               # (True: the frame's marching cubes + finish on a third queue beside the next frame's decode)
+        st.split_mesh = split in (True, "split+scan")       # (the frame's marching cubes + finish on a third queue beside the next frame's decode)
+        st.scan_ahead = split in ("scan", "split+scan")     # (the frame's two extract scans in its front end, before its fusion kernel)
         if not st.enable_overlap():
             pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
         got = []
@@ -169,6 +170,7 @@ def test_host_two_frames_ahead_hands_back_the_same_frames(overlap, gpu_model):
             st = make_stream(gpu_model, initial_capacity=cap)
             st.host_depth = 2
             st.split_mesh = bool(overlap)       # (the combination the split extract is meant for)
+            st.scan_ahead = bool(overlap and rep == 1)
             if overlap and not st.enable_overlap():
                 pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
             got = [per_frame[0]]

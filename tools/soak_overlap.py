@@ -20,10 +20,11 @@ scene, cfg = S.config_c3()
 import random
 
 
-def run(overlap, d2h, depth, jitter=0.0, seed=0, split=False):
+def run(overlap, d2h, depth, jitter=0.0, seed=0, split=False, scan=False):
     st = FusionStream(model, scene, cfg, S.Intrinsic(), DEV, F, deg_per_frame=0.5)
     st.host_depth = depth
     st.split_mesh = split
+    st.scan_ahead = scan                                 # (the frame's extract scans in its front end, before its fusion kernel)
     if overlap:
         assert st.enable_overlap()
     outs = []
@@ -55,7 +56,7 @@ bad = 0
 t0 = time.time()
 for r in range(R):
     d2h, depth = ("dma", "none")[r & 1], 1 + ((r >> 1) & 1)
-    outs, final = run(True, d2h, depth, jitter=(0.0, 100e-6, 300e-6)[r % 3], seed=r, split=bool((r >> 2) & 1))
+    outs, final = run(True, d2h, depth, jitter=(0.0, 100e-6, 300e-6)[r % 3], seed=r, split=bool((r >> 2) & 1), scan=bool((r >> 3) & 1))
     ok = len(outs) == F and all(all(torch.equal(x, y) for x, y in zip(a, b)) for a, b in zip(ref_outs, outs)) and all(torch.equal(x, y) for x, y in zip(ref_final, final))
     if not ok:
         bad += 1
