@@ -805,7 +805,7 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
             *out.defer = d;
         }
         if (out.counters_out) {                      // the stamp goes out behind the snapshot: whoever sees it has all of it
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // vmcnt(0)
             if (lane == 0) __hip_atomic_store(out.counters_out + DIF_C_STAMP, out.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (lane == DIF_C_OVERFLOW) {
@@ -899,7 +899,7 @@ struct QueryFunctor {
         counters[DIF_C_QUERY_M] = total;
         if (count_out) {                         // M first, the sequence number behind a system-scope fence: a host that polls for its seq has M
             __hip_atomic_store(count_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): M has been acknowledged (a system-scope fence costs ~4 us of L2 write-back here)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // vmcnt(0): M has been acknowledged (a system-scope fence costs ~4 us of L2 write-back here)
             __hip_atomic_store(count_out + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

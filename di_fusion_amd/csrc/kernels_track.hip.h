@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_sdf_hg_reduce(const int* __restri
         __hip_atomic_store(partial + (int64_t)blockIdx.x * HG_TERMS + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     static_assert(HG_TERMS <= 64, "the partial sums and the ticket must come from one wave");
-    if (threadIdx.x < 64) __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // vmcnt(0)
     if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!last) return;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_sdf_hg_reduce(const int* __restri
         out[e] = v;
         if (out_host) {                          // written through to the host and acknowledged ...
             __hip_atomic_store(out_host + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();
