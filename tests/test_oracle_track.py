@@ -93,3 +93,28 @@ def test_gauss_newton_follows_the_references_iterations(name, oracle_net):
         if H is not None:
             close(H, g[f"gn{j}_H"], f"{name} evaluation {j} H", rel=2e-3)
     assert np.abs(R - g["gn_final_R"]).max() < 1e-5 and np.abs(t - g["gn_final_t"]).max() < 1e-5
+
+
+def test_pose_matches_the_references_isometry():
+    """`di_fusion_amd.system.tracker.Pose` (host arithmetic only: runs without a GPU) against what the reference's `Isometry` produced for the
+    fixtures: `from_twist` for the five cases, and the loop's pose updates `from_twist(xi) . delta` re-derived from consecutive evaluations."""
+    from di_fusion_amd.system.tracker import Pose
+    g = np.load(GOLDEN / "track_c2.npz")
+    for i in range(n_cases(g)):
+        p = Pose.from_twist(g[f"case{i}_xi"])
+        assert np.abs(p.R - g[f"case{i}_delta_R"]).max() < 1e-12 and np.abs(p.t - g[f"case{i}_delta_t"]).max() < 1e-12
+        assert np.abs(p.R @ p.R.T - np.eye(3)).max() < 1e-12
+        q = p.inv().dot(p)
+        assert np.abs(q.R - np.eye(3)).max() < 1e-12 and np.abs(q.t).max() < 1e-12
+    assert np.abs(Pose.from_twist(np.zeros(6)).matrix - np.eye(4)).max() == 0.0
+    tiny = Pose.from_twist([1e-3, 0, 0, 1e-10, 0, 0])                    # the first-order branch (|phi| ~ 0)
+    assert np.abs(tiny.R - np.eye(3)).max() < 2e-10 and abs(tiny.t[0] - 1e-3) < 1e-12
+    # the loop: delta_{j+1} = from_twist(solve(H_j, -g_j)) . delta_j whenever evaluation j was accepted and had derivatives
+    for j in range(int(g["gn_n_calls"]) - 1):
+        if f"gn{j}_H" not in g or int(g[f"gn{j + 1}_iter"]) != int(g[f"gn{j}_iter"]) + 1:
+            continue
+        step = Pose.from_twist(np.linalg.solve(g[f"gn{j}_H"], -g[f"gn{j}_g"])).dot(Pose(g[f"gn{j}_delta_R"], g[f"gn{j}_delta_t"]))
+        assert np.abs(step.R - g[f"gn{j + 1}_delta_R"]).max() < 1e-10 and np.abs(step.t - g[f"gn{j + 1}_delta_t"]).max() < 1e-10
+    x = np.random.default_rng(0).standard_normal((5, 3))
+    last = Pose(g["last_R"], g["last_t"])
+    assert np.abs((last @ x) - (x @ last.R.T + last.t)).max() == 0.0
