@@ -736,6 +736,7 @@ int dif_optimize_latents(const dif_map_t* map, const dif_weights_t* w, const flo
 static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t tiles_upper, hipStream_t s) {
     if (!w || !w->dec_packed || w->dec_packed_floats != DEC_FLOATS) return DIF_EINVAL;
     const bool grad = A.out_grad != nullptr;
+    const bool dense = A.mode == 4;          // (the dense query of dif_sdf_hg: instantiations of their own, kernels_extract.hip.h)
     if (grad && (!w->dec_bwd_packed || w->dec_bwd_packed_floats != DECB_FLOATS)) return DIF_EINVAL;
     const size_t lds_bytes = (size_t)DEC_LDS_FLOATS * 4;
     static bool attr_set[64] = {};
@@ -743,6 +744,8 @@ static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t ti
     if (dev < 64 && !attr_set[dev]) {
         if (hipFuncSetAttribute((const void*)k_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
         if (hipFuncSetAttribute((const void*)k_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DIF_ELAUNCH;
         attr_set[dev] = true;
     }
     int64_t blocks = (tiles_upper + 7) / 8;
@@ -752,10 +755,12 @@ static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t ti
     if (!grad && A.mode != 1 && w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES && w->dec_x6u_packed && w->dec_x6u_packed_bytes == X6U_BYTES) {
         static bool attr_set6[64] = {};                      // forward-only rows on the bf16 matrix pipe
         if (dev < 64 && !attr_set6[dev]) {
-            if (hipFuncSetAttribute((const void*)k_decode_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)k_decode_x6<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)k_decode_x6<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
             attr_set6[dev] = true;
         }
-        hipLaunchKernelGGL(k_decode_x6, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed, (const float*)w->dec_x6u_packed);
+        if (dense) hipLaunchKernelGGL(k_decode_x6<true>, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed, (const float*)w->dec_x6u_packed);
+        else hipLaunchKernelGGL(k_decode_x6<false>, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed, (const float*)w->dec_x6u_packed);
         DIF_CHECK_LAUNCH();
         return DIF_OK;
     }
@@ -764,13 +769,16 @@ static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t ti
         static bool attr_set7[64] = {};                      // values + input gradient on the bf16 matrix pipe
         if (dev < 64 && !attr_set7[dev]) {
             if (hipFuncSetAttribute((const void*)k_decode_grad_x6<GRAD_X6_PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+            if (hipFuncSetAttribute((const void*)k_decode_grad_x6<GRAD_X6_PF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
             attr_set7[dev] = true;
         }
         blocks = (tiles_upper + GRAD_X6_THREADS / 64 - 1) / (GRAD_X6_THREADS / 64);
         if (blocks < 1) blocks = 1;
         if (blocks > num_cus()) blocks = num_cus();
-        hipLaunchKernelGGL(k_decode_grad_x6<GRAD_X6_PF>, dim3((int)blocks), dim3(GRAD_X6_THREADS), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed,
-                           (const float*)w->dec_x6u_packed, (const float*)w->dec_x6b_packed);
+        if (dense) hipLaunchKernelGGL((k_decode_grad_x6<GRAD_X6_PF, true>), dim3((int)blocks), dim3(GRAD_X6_THREADS), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed,
+                                      (const float*)w->dec_x6u_packed, (const float*)w->dec_x6b_packed);
+        else hipLaunchKernelGGL(k_decode_grad_x6<GRAD_X6_PF>, dim3((int)blocks), dim3(GRAD_X6_THREADS), (size_t)X6_LDS_BYTES, s, A, (const float*)w->dec_x6_packed,
+                                (const float*)w->dec_x6u_packed, (const float*)w->dec_x6b_packed);
         DIF_CHECK_LAUNCH();
         return DIF_OK;
     }
@@ -780,7 +788,10 @@ static int launch_decode(const DecodeArgs& A, const dif_weights_t* w, int64_t ti
         blocks = (tiles_upper + 3) / 4;
         if (blocks < 1) blocks = 1;
         if (blocks > num_cus()) blocks = num_cus();
-        hipLaunchKernelGGL(k_decode<true>, dim3((int)blocks), dim3(256), lds_bytes, s, B, w->dec_packed);
+        if (dense) hipLaunchKernelGGL((k_decode<true, true>), dim3((int)blocks), dim3(256), lds_bytes, s, B, w->dec_packed);
+        else hipLaunchKernelGGL(k_decode<true>, dim3((int)blocks), dim3(256), lds_bytes, s, B, w->dec_packed);
+    } else if (dense) {
+        hipLaunchKernelGGL((k_decode<false, true>), dim3((int)blocks), dim3(512), lds_bytes, s, A, w->dec_packed);
     } else {
         hipLaunchKernelGGL(k_decode<false>, dim3((int)blocks), dim3(512), lds_bytes, s, A, w->dec_packed);
     }
@@ -1612,18 +1623,14 @@ int dif_query_grad_gather(const float* grad, const float* g_sdf, const int32_t* 
 
 // ---- f1: the tracker's SDF term (tracker.py:174-218) ----------------------------------------------------------------
 namespace {
-struct HgLayout { int64_t cur, sdf, std_, grad, sel, scratch, mask, partial, ticket, total; };
+struct HgLayout { int64_t sdf, std_, grad, partial, ticket, total; };
 inline int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 inline HgLayout hg_layout(int64_t N) {
     HgLayout L;
     int64_t o = 0;
-    L.cur = o;     o = up256(o + N * 12);
     L.sdf = o;     o = up256(o + N * 4);
     L.std_ = o;    o = up256(o + N * 4);
     L.grad = o;    o = up256(o + N * 12);
-    L.sel = o;     o = up256(o + N * 4);
-    L.scratch = o; o = up256(o + (N + 4096) * 4);
-    L.mask = o;    o = up256(o + N);
     L.partial = o; o = up256(o + (int64_t)HG_BLOCKS * HG_TERMS * 8);
     L.ticket = o;  o = up256(o + 4);
     L.total = o;
@@ -1641,22 +1648,27 @@ int dif_sdf_hg(const dif_map_t* map, const dif_weights_t* w, const float* obs_xy
     if (!ws || ws_bytes < L.total || ((uintptr_t)ws & 255) != 0 || (N > 0 && !obs_xyz)) return DIF_EINVAL;
     hipStream_t s = (hipStream_t)stream_;
     char* b = (char*)ws;
-    float* cur = (float*)(b + L.cur);
     int* ticket = (int*)(b + L.ticket);
     HgArgs a;
     for (int i = 0; i < 12; ++i) { a.Tc[i] = args->T_cur[i]; a.Td[i] = args->T_delta[i]; }
     for (int i = 0; i < 9; ++i) a.Lt[i] = args->last_Rt[i];
     a.robust = args->robust_kernel; a.k = args->robust_k; a.no_grad = args->no_grad ? 1 : 0;
-    hipLaunchKernelGGL(k_hg_transform, dim3(grid_for(N, DIF_BLOCK, 1024)), dim3(DIF_BLOCK), 0, s, obs_xyz, N, a, cur, ticket);
-    DIF_CHECK_LAUNCH();
-    int rc = dif_query_select(map, cur, N, (uint8_t*)(b + L.mask), (int32_t*)(b + L.sel), (int32_t*)(b + L.scratch), nullptr, 0, stream_);
-    if (rc != DIF_OK) return rc;
     float* grad = a.no_grad ? nullptr : (float*)(b + L.grad);
-    rc = dif_query_decode(map, w, cur, N, (const int32_t*)(b + L.sel), (float*)(b + L.sdf), (float*)(b + L.std_), grad, stream_);
-    if (rc != DIF_OK) return rc;
-    hipLaunchKernelGGL(k_sdf_hg_reduce, dim3(grid_for(N, 2 * DIF_BLOCK, HG_BLOCKS)), dim3(DIF_BLOCK), 0, s, (const int*)(map->counters + DIF_C_QUERY_M), (const int32_t*)(b + L.sel),
-                       obs_xyz, (const float*)(b + L.sdf), (const float*)(b + L.std_), (const float*)grad, a, (double*)(b + L.partial), ticket, out,
-                       out_host, seq);
+    if (N > 0) {
+        // the decoder over ALL points of the posed cloud: pose, validity test (map.py:565-572) and latent look-up in its row fetch, std = 0 for the
+        // points that are not valid — no transform kernel, no compaction; the kernel also returns the reduction's ticket to 0
+        DecodeArgs A = {};
+        A.mode = 4; A.n_ptr = nullptr; A.n_static = N; A.latent = map->latent_vecs; A.xyz = obs_xyz; A.indexer = map->indexer; A.geo = geo_of(map);
+        A.out_sdf = (float*)(b + L.sdf); A.out_std = (float*)(b + L.std_); A.sign = 1.0f; A.lat.res = 1;
+        A.out_grad = grad; A.grad_scale = 1.0f / map->voxel_size;
+        A.obs = map->voxel_obs_count; A.ignore_th = map->ignore_count_th;
+        for (int i = 0; i < 12; ++i) A.pose[i] = args->T_cur[i];
+        A.zero_word = ticket;
+        const int rc = launch_decode(A, w, (N + 31) / 32, s);
+        if (rc != DIF_OK) return rc;
+    } else if (hipMemsetAsync(ticket, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
+    hipLaunchKernelGGL(k_sdf_hg_reduce, dim3(grid_for(N, 2 * DIF_BLOCK, HG_BLOCKS)), dim3(DIF_BLOCK), 0, s, (int)N, obs_xyz, (const float*)(b + L.sdf),
+                       (const float*)(b + L.std_), (const float*)grad, a, (double*)(b + L.partial), ticket, out, out_host, seq);
     DIF_CHECK_LAUNCH();
     return DIF_OK;
 }

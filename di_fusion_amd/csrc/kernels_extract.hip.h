@@ -234,7 +234,9 @@ struct Lattice {            // get_samples(res, a, b) - 0.5 (utility.py:129-149,
     __device__ __forceinline__ float coord(int i) const { return ((float)i * vsize + a) - 0.5f; }
 };
 
-// decode mode: 0 = lattice (rows are (voxel b, sample s)), 1 = refine list, 2 = explicit rows, 3 = map point query
+// decode mode: 0 = lattice (rows are (voxel b, sample s)), 1 = refine list, 2 = explicit rows, 3 = map point query (compacted list of valid points),
+// 4 = map point query over ALL points of a posed cloud (dif_sdf_hg): row i = point i, transformed by `pose` and tested for validity here (map.py:565-572);
+//     rows that are not valid get out_std = 0 (a valid std is >= 0.05) and nothing else
 struct DecodeArgs {
     int mode;
     const int* n_ptr;               // device row / voxel count (modes 0,1,3), or NULL
@@ -254,17 +256,29 @@ struct DecodeArgs {
     const float* wbwd;              // GRAD kernels: transposed-layer blob
     float grad_scale;               // 1 / voxel_size (mode 3), 1 (mode 2)
     const float* fold_table;        // mode 1, optional: [batch voxel][256] constants written by k_decode_voxels (decoder_tile_folded)
+    const float* obs;               // mode 4: voxel_obs_count
+    float ignore_th;                // mode 4
+    float pose[12];                 // mode 4: rows of [R | t] applied to xyz first (x R^T + t, unfused, left to right)
+    int* zero_word;                 // optional: a word the launch returns to 0 before anything else (the ticket of the kernel behind it)
 };
+
+// x' = x R^T + t the way `other @ th_R.t() + th_t` (utils/motion_util.py:324-327) rounds it in float32: 3-term dot product left to right, then + t
+__device__ __forceinline__ float pose_row(const float* T, int j, float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, T[4 * j]), __fmul_rn(y, T[4 * j + 1])), __fmul_rn(z, T[4 * j + 2])), T[4 * j + 3]);
+}
 
 // Row of a decode tile: which sample lane `col` of tile `tile` works on, where its result goes, and its input fragment
 // xin[t] = x0[2t + half] with x0 = [latent 29 | xyz 3] (the natural k order of layer 0 and of the skip input).
 struct DecodeRow { bool live; int64_t out_idx; float px, py, pz; };
+// DENSE: the instantiation for mode 4 only (and the others without it): the dense query's pose, counts and threshold are twelve more kernel arguments
+// held in scalar registers, which the general kernels do not have to spare (k_decode_x6 spilled seven vector registers with both in one body).
+template <bool DENSE = false>
 __device__ __forceinline__ DecodeRow decode_row_input(const DecodeArgs& A, int64_t tile, int col, int half, int res3, int tiles_per_voxel, int64_t n_rows,
                                                       f16v& xin) {
     DecodeRow R{false, 0, 0.f, 0.f, 0.f};
     const float* lat_row = nullptr;
     const float* row32 = nullptr;
-    if (A.mode == 0) {
+    if (!DENSE && A.mode == 0) {
         const int64_t b = tile / tiles_per_voxel;
         const int s = (int)(tile - b * tiles_per_voxel) * 32 + col;
         R.live = s < res3;
@@ -274,7 +288,7 @@ __device__ __forceinline__ DecodeRow decode_row_input(const DecodeArgs& A, int64
             lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
             R.out_idx = b * res3 + s;
         }
-    } else if (A.mode == 1) {
+    } else if (!DENSE && A.mode == 1) {
         const int64_t row = tile * 32 + col;
         R.live = row < n_rows;
         if (R.live) {
@@ -284,10 +298,28 @@ __device__ __forceinline__ DecodeRow decode_row_input(const DecodeArgs& A, int64
             lat_row = A.latent + (int64_t)A.occ_slot[b] * L;
             R.out_idx = e;
         }
-    } else if (A.mode == 2) {
+    } else if (!DENSE && A.mode == 2) {
         const int64_t row = tile * 32 + col;
         R.live = row < n_rows;
         if (R.live) { row32 = A.rows + row * 32; R.out_idx = row; }
+    } else if (DENSE) {
+        const int64_t row = tile * 32 + col;
+        if (row < n_rows) {
+            const float x = A.xyz[row * 3 + 0], y = A.xyz[row * 3 + 1], z = A.xyz[row * 3 + 2];
+            float xn, yn, zn; int ix, iy, iz;
+            bool ok = voxel_of(A.geo, pose_row(A.pose, 0, x, y, z), pose_row(A.pose, 1, x, y, z), pose_row(A.pose, 2, x, y, z), xn, yn, zn, ix, iy, iz);
+            int64_t slot = -1;
+            if (ok) {
+                slot = A.indexer[linearize(A.geo, ix, iy, iz)];
+                ok = slot >= 0 && A.obs[slot] > A.ignore_th;                                              // map.py:568-572
+            }
+            R.live = ok;
+            R.out_idx = row;
+            if (ok) {
+                R.px = (xn - (float)ix) - 0.5f; R.py = (yn - (float)iy) - 0.5f; R.pz = (zn - (float)iz) - 0.5f;      // map.py:575
+                lat_row = A.latent + slot * L;
+            } else if (half == 1) A.out_std[row] = 0.0f;
+        }
     } else {
         const int64_t row = tile * 32 + col;
         R.live = row < n_rows;
@@ -315,9 +347,10 @@ __device__ __forceinline__ DecodeRow decode_row_input(const DecodeArgs& A, int64
 }
 
 // GRAD: 256 threads = one wave per SIMD with the full 512-register budget (forward + reverse chain keep ~300 values live)
-template <bool GRAD>
+template <bool GRAD, bool DENSE = false>
 __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(DecodeArgs A, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (DENSE && A.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_word = 0;
     stage_weights(lds, wblob, DEC_LDS_FLOATS);
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, DEC_FLOATS);
     const __amdgpu_buffer_rsrc_t wbwd = make_rsrc(GRAD ? A.wbwd : wblob, GRAD ? DECB_FLOATS : DEC_FLOATS);
@@ -337,7 +370,7 @@ __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(Decod
     }
     for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
         f16v xin;
-        const DecodeRow R = decode_row_input(A, tile, col, half, res3, tiles_per_voxel, n_rows, xin);
+        const DecodeRow R = decode_row_input<DENSE>(A, tile, col, half, res3, tiles_per_voxel, n_rows, xin);
         const bool live = R.live;
         const int64_t out_idx = R.out_idx;
         const float px = R.px, py = R.py, pz = R.pz;
@@ -365,8 +398,10 @@ __global__ void __launch_bounds__(GRAD ? 256 : 512, GRAD ? 1 : 2) k_decode(Decod
 
 // Modes 0 (lattice, every sample), 2 (explicit rows) and 3 (map point query, values only) on the bf16 matrix pipe: the row set-up of
 // k_decode, the tile of decoder_tile_x6.  wblob = packing.py:pack_decoder_x6, wu = pack_decoder_x6u.
+template <bool DENSE = false>
 __global__ void __launch_bounds__(512, 1) k_decode_x6(DecodeArgs A, const float* __restrict__ wblob, const float* __restrict__ wu) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (DENSE && A.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_word = 0;
     stage_weights(lds, wblob, X6_LDS_BYTES / 4);
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
     const __amdgpu_buffer_rsrc_t wun = make_rsrc(wu, X6U_BYTES / 4);
@@ -385,7 +420,7 @@ __global__ void __launch_bounds__(512, 1) k_decode_x6(DecodeArgs A, const float*
     }
     for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
         f16v xin;
-        const DecodeRow R = decode_row_input(A, tile, col, half, res3, tiles_per_voxel, n_rows, xin);
+        const DecodeRow R = decode_row_input<DENSE>(A, tile, col, half, res3, tiles_per_voxel, n_rows, xin);
         const bool live = R.live;
         const int64_t out_idx = R.out_idx;
         float sdf, sd;
@@ -402,10 +437,11 @@ __global__ void __launch_bounds__(512, 1) k_decode_x6(DecodeArgs A, const float*
 #endif
 // Values AND d sdf / d xyz (modes 2, 3) on the bf16 matrix pipe: decoder_tile_grad_x6.  One wave per SIMD with the 512-register budget,
 // like k_decode<true>; wb = packing.py:pack_decoder_x6_backward.
-template <int PF>
+template <int PF, bool DENSE = false>
 __global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArgs A, const float* __restrict__ wblob, const float* __restrict__ wu,
                                                           const float* __restrict__ wb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (DENSE && A.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_word = 0;
     stage_weights(lds, wblob, X6_LDS_BYTES / 4);
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
     const __amdgpu_buffer_rsrc_t wun = make_rsrc(wu, X6U_BYTES / 4);
@@ -418,7 +454,7 @@ __global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArg
     const int64_t n_tiles = (n_rows + 31) / 32;
     for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
         f16v xin;
-        const DecodeRow R = decode_row_input(A, tile, col, half, res3, 1, n_rows, xin);
+        const DecodeRow R = decode_row_input<DENSE>(A, tile, col, half, res3, 1, n_rows, xin);
         float sdf, sd, gx, gy, gz;
         decoder_tile_grad_x6<PF>(lds, wfwd, wun, wbw, xin, lane, sdf, sd, gx, gy, gz);
         if (R.live) {

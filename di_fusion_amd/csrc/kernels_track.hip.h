@@ -7,8 +7,9 @@
 //   w = robust(s) ; Wf = s w ; JW = J w                 tracker.py:203-207, 58-72
 //   H = sum JW (x) J / M ; g = sum J Wf / M ; e = sum s Wf / M        tracker.py:209-218
 //
-// What the reference spreads over ~25 torch launches, the autograd engine and three host round trips per iteration is one small kernel
-// before and one behind the two query launches; the 44 numbers come back through pinned host memory.
+// What the reference spreads over ~25 torch launches, the autograd engine and three host round trips per iteration is TWO launches: the decoder
+// kernel over all N points of the cloud (DecodeArgs mode 4: pose, validity test and latent look-up in its row fetch; invalid rows get std = 0) and
+// the reduction below; the 44 numbers come back through pinned host memory.
 #pragma once
 
 struct HgArgs {
@@ -20,40 +21,27 @@ struct HgArgs {
     int no_grad;
 };
 
-#define HG_TERMS 28      /* 21 (upper triangle of H) + 6 (g) + 1 (e) */
+#define HG_TERMS 29      /* 21 (upper triangle of H) + 6 (g) + 1 (e) + 1 (the number of valid points) */
 #define HG_BLOCKS 256     /* most workgroups the reduction is launched with (rows of the partial-sum buffer) */
-
-// x' = x R^T + t the way `other @ th_R.t() + th_t` rounds it in float32: a 3-term dot product accumulated left to right, then the translation
-__device__ __forceinline__ float hg_row(const float* T, int j, float x, float y, float z) {
-    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, T[4 * j]), __fmul_rn(y, T[4 * j + 1])), __fmul_rn(z, T[4 * j + 2])), T[4 * j + 3]);
-}
-
-__global__ void __launch_bounds__(DIF_BLOCK) k_hg_transform(const float* __restrict__ obs, int64_t N, HgArgs a, float* __restrict__ cur, int* ticket) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const float x = obs[i * 3], y = obs[i * 3 + 1], z = obs[i * 3 + 2];
-        cur[i * 3 + 0] = hg_row(a.Tc, 0, x, y, z);
-        cur[i * 3 + 1] = hg_row(a.Tc, 1, x, y, z);
-        cur[i * 3 + 2] = hg_row(a.Tc, 2, x, y, z);
-    }
-}
 
 struct HgPoint {
     float sd, sf, g0, g1, g2, x, y, z;
-    __device__ __forceinline__ void load(int m, const int32_t* __restrict__ sel, const float* __restrict__ obs, const float* __restrict__ sdf,
-                                         const float* __restrict__ std_, const float* __restrict__ grad, int no_grad) {
-        sd = std_[m]; sf = sdf[m];
+    // row i of the decoder's outputs = point i of the cloud; sd == 0: not a valid point (the decoder kernel's mark)
+    __device__ __forceinline__ void load(int i, const float* __restrict__ obs, const float* __restrict__ sdf, const float* __restrict__ std_,
+                                         const float* __restrict__ grad, int no_grad) {
+        sd = std_[i]; sf = sdf[i];
         g0 = g1 = g2 = x = y = z = 0.0f;
         if (!no_grad) {
-            const int64_t p = sel[m];
-            g0 = grad[(int64_t)m * 3]; g1 = grad[(int64_t)m * 3 + 1]; g2 = grad[(int64_t)m * 3 + 2];
-            x = obs[p * 3]; y = obs[p * 3 + 1]; z = obs[p * 3 + 2];
+            g0 = grad[(int64_t)i * 3]; g1 = grad[(int64_t)i * 3 + 1]; g2 = grad[(int64_t)i * 3 + 2];
+            x = obs[(int64_t)i * 3]; y = obs[(int64_t)i * 3 + 1]; z = obs[(int64_t)i * 3 + 2];
         }
     }
 };
 
 __device__ __forceinline__ void hg_accumulate(double* acc, const HgArgs& a, const HgPoint& q) {
     const float sd = q.sd;
+    if (sd == 0.0f) return;
+    acc[28] += 1.0;
     const float s = q.sf / sd;
     float w = 1.0f;
     if (a.robust == 1) {
@@ -73,7 +61,7 @@ __device__ __forceinline__ void hg_accumulate(double* acc, const HgArgs& a, cons
     float J[6];
 #pragma unroll
     for (int j = 0; j < 3; ++j) J[j] = (d0 * a.Lt[j] + d1 * a.Lt[3 + j]) + d2 * a.Lt[6 + j];
-    const float c0 = hg_row(a.Td, 0, q.x, q.y, q.z), c1 = hg_row(a.Td, 1, q.x, q.y, q.z), c2 = hg_row(a.Td, 2, q.x, q.y, q.z);
+    const float c0 = pose_row(a.Td, 0, q.x, q.y, q.z), c1 = pose_row(a.Td, 1, q.x, q.y, q.z), c2 = pose_row(a.Td, 2, q.x, q.y, q.z);
     J[3] = c1 * J[2] - c2 * J[1];
     J[4] = c2 * J[0] - c0 * J[2];
     J[5] = c0 * J[1] - c1 * J[0];
@@ -90,23 +78,21 @@ __device__ __forceinline__ void hg_accumulate(double* acc, const HgArgs& a, cons
 
 // Fixed reduction tree (thread: grid-stride order; 16-lane row; workgroup: rows in order; grid: workgroups in order, summed by whichever workgroup
 // arrives last): the same inputs give the same 44 numbers, whatever the order the workgroups run in.
-__global__ void __launch_bounds__(DIF_BLOCK) k_sdf_hg_reduce(const int* __restrict__ n_ptr, const int32_t* __restrict__ sel, const float* __restrict__ obs,
-                                                           const float* __restrict__ sdf, const float* __restrict__ std_, const float* __restrict__ grad,
-                                                           HgArgs a, double* partial, int* ticket, double* out, double* out_host, int64_t seq) {
+__global__ void __launch_bounds__(DIF_BLOCK) k_sdf_hg_reduce(int N, const float* __restrict__ obs, const float* __restrict__ sdf, const float* __restrict__ std_,
+                                                           const float* __restrict__ grad, HgArgs a, double* partial, int* ticket, double* out,
+                                                           double* out_host, int64_t seq) {
     __shared__ double red[DIF_BLOCK / 16][HG_TERMS];
     __shared__ int last;
-    const int M = *n_ptr;
     double acc[HG_TERMS];
 #pragma unroll
     for (int t = 0; t < HG_TERMS; ++t) acc[t] = 0.0;
-    // two points per thread and trip, their loads issued together: the inputs were written by other XCDs a moment ago (L2 misses), and the
-    // chain sel -> obs makes two dependent levels of them
+    // two points per thread and trip, their loads issued together (the decoder's outputs were written by other XCDs a moment ago: L2 misses)
     const int stride = (int)(gridDim.x * blockDim.x);
-    for (int m = (int)(blockIdx.x * blockDim.x + threadIdx.x); m < M; m += 2 * stride) {
-        const int m1 = m + stride < M ? m + stride : m;
+    for (int m = (int)(blockIdx.x * blockDim.x + threadIdx.x); m < N; m += 2 * stride) {
+        const int m1 = m + stride < N ? m + stride : m;
         HgPoint p0, p1;
-        p0.load(m, sel, obs, sdf, std_, grad, a.no_grad);
-        p1.load(m1, sel, obs, sdf, std_, grad, a.no_grad);
+        p0.load(m, obs, sdf, std_, grad, a.no_grad);
+        p1.load(m1, obs, sdf, std_, grad, a.no_grad);
         hg_accumulate(acc, a, p0);
         if (m1 != m) hg_accumulate(acc, a, p1);
     }
@@ -161,9 +147,10 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_sdf_hg_reduce(const int* __restri
     if (threadIdx.x < HG_TERMS) {
         double v = 0.0;
         for (int q = 0; q < DIF_BLOCK / 32; ++q) v += fin[q][threadIdx.x];
-        tot[threadIdx.x] = M > 0 ? v / (double)M : 0.0;
+        tot[threadIdx.x] = v;
     }
     __syncthreads();
+    const double Mv = tot[28];                   // the number of valid points; the sums are scaled by 1 / M (tracker.py:209-218)
     if (threadIdx.x < 44) {
         double v;
         const int e = (int)threadIdx.x;
@@ -173,7 +160,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_sdf_hg_reduce(const int* __restri
             v = tot[r * 6 - r * (r - 1) / 2 + (c - r)];
         } else if (e < 42) v = tot[21 + (e - 36)];
         else if (e == 42) v = tot[27];
-        else v = (double)M;
+        else v = Mv;
+        if (e < 43) v = Mv > 0.0 ? v / Mv : 0.0;
         out[e] = v;
         if (out_host) {                          // written through to the host and acknowledged ...
             __hip_atomic_store(out_host + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

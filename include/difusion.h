@@ -460,7 +460,8 @@ int dif_query_grad_gather(const float* grad, const float* g_sdf, const int32_t* 
  * out_host (optional, pinned host memory the device can write, 45 x 8 bytes): the same 44 doubles, then `seq` as int64 behind a system-scope
  * fence — a host that polls word 44 for its sequence number has the numbers without a copy or a stream synchronisation.
  * no_grad != 0: only sum_error and M (the loop's last evaluation, tracker.py:239), through the value-only decoder.
- * ws: dif_sdf_hg_workspace_bytes(N) bytes of device memory, 256-byte aligned, private to the call's stream while it runs.
+ * Two launches: the decoder kernel over all N points (pose, validity test and latent look-up in its row fetch; invalid points are marked, not
+ * compacted) and the reduction.  ws: dif_sdf_hg_workspace_bytes(N) bytes of device memory, 256-byte aligned, private to the call's stream while it runs.
  * The sums are accumulated in double in a fixed order: the same inputs give the same bits. */
 typedef struct dif_sdf_hg_t {
     float T_cur[12];        /* last_pose . cur_delta_pose: rows of [R | t]                         */
