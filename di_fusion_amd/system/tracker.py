@@ -2,9 +2,10 @@
 
 Reference: `pytorch/system/tracker.py`.  Its `compute_sdf_Hg` (tracker.py:174-218) is what calls `map.get_sdf` once per Gauss-Newton
 iteration — tens of times per frame, where the map is integrated once in twenty frames — and spreads the rest of the iteration over ~25
-torch launches, the autograd engine and three device -> host round trips.  Here the whole term is ONE C call (`dif_sdf_hg`: transform,
-validity mask + compaction, decoder with its analytic input gradient, Jacobian, robust weights, the 6x6 / 6 / 1 sums in double in a fixed
-order) and the 44 numbers come back through pinned host memory, without a copy and without a stream synchronisation.
+torch launches, the autograd engine and three device -> host round trips.  Here the whole term is ONE C call of two launches (`dif_sdf_hg`:
+the decoder kernel over all points of the posed cloud — pose, validity test, latent look-up, values and analytic input gradient —, then
+Jacobian, robust weights and the 6x6 / 6 / 1 sums in double in a fixed order) and the 44 numbers come back through pinned host memory,
+without a copy and without a stream synchronisation.
 
 What is here: `Pose` (the part of `utils.motion_util.Isometry` the loop needs, on plain rotation matrices: pyquaternion is not a
 dependency), `SDFTracker` with `compute_sdf_Hg`, `gauss_newton`, `track_camera` (the point-cloud preparation of tracker.py:87-118 on the HIP

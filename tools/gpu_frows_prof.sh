@@ -12,7 +12,7 @@ for name in query cloud frows; do
   timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/w_$name -o w -- $cmd > $out/pmc_w_$name.log 2>&1
   python tools/frows_summary.py $(find $out/t_$name -name "*.db" | head -1) --mfma $(find $out/m_$name -name "*counter_collection.csv" | head -1) \
      --fetch $(find $out/f_$name -name "*counter_collection.csv" | head -1) --write $(find $out/w_$name -name "*counter_collection.csv" | head -1) \
-     --only k_decode_grad,k_decode_x6,k_optim,k_cloud,k_depth_frontend,k_pbf,k_query,k_sdf_hg,k_hg_transform,QueryFunctor,OptimGather,OptimUnique,CloudStart,BoxRank > $out/kernel_stats_$name.md 2>&1
+     --only k_decode_grad,k_decode_x6,k_optim,k_cloud,k_depth_frontend,k_pbf,k_query,k_sdf_hg,QueryFunctor,OptimGather,OptimUnique,CloudStart,BoxRank > $out/kernel_stats_$name.md 2>&1
   rm -rf $out/t_$name $out/m_$name $out/f_$name $out/w_$name
   cat $out/bench_$name.json; echo; cat $out/kernel_stats_$name.md
 done
