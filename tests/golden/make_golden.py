@@ -545,6 +545,33 @@ def tracker_fixture(model, name, scene, cfg, intr_map, intr_obs, n_map_frames, d
     print(f"{name}: saved ({(HERE / f'{name}.npz').stat().st_size / 1e6:.2f} MB)")
 
 
+def box_filter_fixture():
+    """The reference's own `point_box_filter` (system/tracker.py:13-23, plain torch) on the tracker's half-resolution cloud of the room stream —
+    with `torch_scatter.scatter_mean` (not in this image) as an index_add_ / count stand-in: sums in float64, then float32 like scatter_mean's
+    result.  Inputs by hash (synthetic frame 3 at 320 x 240), outputs stored."""
+    ref_tracker, _, _ = _import_reference_tracker()
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_mean(src, index, dim=0):
+        n = int(index.max()) + 1
+        out = torch.zeros((n, src.size(1)), dtype=torch.float64)
+        out.index_add_(0, index, src.double())
+        cnt = torch.zeros((n,), dtype=torch.float64)
+        cnt.index_add_(0, index, torch.ones_like(index, dtype=torch.float64))
+        return (out / cnt[:, None]).float()
+
+    ts.scatter_mean = scatter_mean
+    sys.modules["torch_scatter"] = ts
+    xyz, nrm = syn.frame_points(syn.default_room(), 3, syn.Intrinsic().scaled(0.5))
+    out = dict(xyz_sha=np.array(sha(xyz.numpy())), nrm_sha=np.array(sha(nrm.numpy())), n=np.int64(xyz.size(0)))
+    for vs in (0.02, 0.05):
+        fp, fn = ref_tracker.point_box_filter(xyz, nrm, vs)
+        out[f"vs{int(vs * 100)}_points"], out[f"vs{int(vs * 100)}_normals"] = fp.numpy(), fn.numpy()
+        print(f"box_filter: voxel {vs}: {xyz.size(0)} points -> {fp.size(0)} boxes")
+    np.savez_compressed(HERE / "box_filter.npz", **out)
+    print(f"box_filter: saved ({(HERE / 'box_filter.npz').stat().st_size / 1e6:.2f} MB)")
+
+
 def tracker_fixtures(model):
     cases = [((0, 0, 0, 0, 0, 0), "huber", 5.0),
              ((0.01, -0.004, 0.006, 0.004, -0.008, 0.003), "huber", 5.0),
@@ -574,6 +601,8 @@ def main():
             optimize_sequence(model)
         if "track" in which:
             tracker_fixtures(model)
+        if "box_filter" in which:
+            box_filter_fixture()
         if "grads" in which:
             add_gradient_probes(model, "seq_small", syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.4),
                                 syn.Intrinsic().scaled(0.125), 3, 20.0)

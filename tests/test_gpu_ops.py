@@ -178,6 +178,22 @@ def test_point_box_filter_vs_oracle():
         ext.point_box_filter(xyz.to(DEV), nrm.to(DEV), 0.02, max_cells=1 << 12)
 
 
+def test_point_box_filter_vs_the_references_own():
+    """The HIP operator against what the REFERENCE's `point_box_filter` (system/tracker.py:13-23, plain torch) returned for the same cloud
+    (tests/golden/box_filter.npz): the same boxes in the same order, means within float32 rounding, at the tracker's 2 cm and at 5 cm."""
+    from di_fusion_amd.system import ext
+    from di_fusion_amd import synthetic as syn
+    from tests.conftest import GOLDEN
+    g = np.load(GOLDEN / "box_filter.npz")
+    xyz, nrm = syn.frame_points(syn.default_room(), 3, syn.Intrinsic().scaled(0.5))
+    assert xyz.size(0) == int(g["n"])
+    for vs in (0.02, 0.05):
+        fp, fn = ext.point_box_filter(xyz.to(DEV), nrm.to(DEV), vs)
+        wp, wn = g[f"vs{int(vs * 100)}_points"], g[f"vs{int(vs * 100)}_normals"]
+        assert tuple(fp.shape) == wp.shape
+        assert np.abs(fp.cpu().numpy() - wp).max() < 2e-6 and np.abs(fn.cpu().numpy() - wn).max() < 2e-6
+
+
 def test_depth_frontend_equals_the_three_kernel_composition():
     """8f-2: filter_depth -> unproject_depth -> compute_normal_weight fused into one LDS-tiled pass, at full resolution (640x480 and a
     size that is not a multiple of the tile), on a noisy frame with NaN holes, zeros and depth discontinuities: bit-identical to the
