@@ -50,19 +50,13 @@ def parse():
                     "itself (device copies of the size that would go over xGMI): export / merge kernels and message sizes land in the timed region")
     ap.add_argument("--halo", default="delta", choices=["delta", "full"], help="--mode tiled: bounded delta halo messages (default) or whole boundary layers")
     ap.add_argument("--noise", type=int, default=0)
-    ap.add_argument("--d2h", default="auto", choices=["auto", "none", "new", "dma", "full"], help="what leaves the GPU each frame.  new / dma: the frame's new triangles, to pinned host memory, written by kernels (the next frame's first ones carry them) / by the copy engine beside the next frame's kernels; auto (default): dma for one directly launched stream per GPU, new for stream groups, graphs and the tiled mode")
-    ap.add_argument("--pipeline", type=int, default=1, help="1: enqueue frame i before completing frame i-1 on the host (no GPU idle at frame boundaries)")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the frame's launches from a captured hipGraph (every --sample-every-th frame runs "
-                    "eagerly with HIP events around the MFMA kernels); 0 (default): launch them directly, two C calls per frame, HIP events on every "
-                    "--sample-every-th frame — equally fast in steady state (a graph has no kernel boundaries but ~33 us between consecutive launches), and "
-                    "no re-capture when a buffer grows")
+    ap.add_argument("--d2h", default="auto", choices=["auto", "none", "new", "dma", "full"], help="what leaves the GPU each frame.  new / dma: the frame's new triangles, to pinned host memory, written by kernels (the next frame's first ones carry them) / by the copy engine beside the next frame's kernels; auto (default): dma for one directly launched stream per GPU, new for stream groups and the tiled mode")
+    ap.add_argument("--pipeline", type=int, default=1, help="1 (default): direct launches (two C calls per frame), the host one frame ahead of the GPU, HIP events on "
+                    "every --sample-every-th frame; 0: the façade's own synchronous calls, frame by frame")
     ap.add_argument("--sample-every", type=int, default=8)
     ap.add_argument("--mlp-pipe", choices=["bf16x6", "f32"], default=None,
                     help="matrix pipe of the MLP tiles: bf16x6 (default; fp32 products as six exact bf16 slice products) or f32 (f32-input MFMA); "
                          "same as the DIF_DECODER_PIPE environment variable")
-    ap.add_argument("--batch", type=int, default=0, help="F > 0: between the sampled frames, F consecutive frames go into ONE captured hipGraph "
-                    "(no kernel boundaries inside, one ~33 us launch gap per F frames); for streams whose poses are known ahead; F = sample-every - 1 "
-                    "fills the space between two sampled frames")
     ap.add_argument("--streams-per-gpu", type=int, default=0, help="S >= 1: every rank fuses S independent subsequences (S private maps) whose frames share "
                     "their twelve launches (dif_integrate_frames + dif_extract_streams): `value` is then the aggregate over all world x S streams.  "
                     "0 (default): ONE stream per GPU is the measured configuration, and at N = 1 the aggregate rates for S = 2, 4, 8 are reported beside "
@@ -73,15 +67,6 @@ def parse():
     ap.add_argument("--group-d2h", default="new", choices=["new", "dma"], help="how the secondary S-streams-per-GPU legs of a `--d2h dma` run deliver their triangles: "
                     "new (default: carried by the next group frame's point kernels) or dma (one SDMA call per stream and group frame: equal at S = 4, 6 % behind at "
                     "S = 8 — the host)")
-    ap.add_argument("--host-depth", type=int, default=1, choices=[1, 2], help="directly launched frames: how many frames the host may have enqueued beyond the one "
-                    "it hands back.  1 (default): frame i-1's triangles come back before frame i+1 is enqueued; 2: frame i-2's — the host never waits for the "
-                    "frame in front of the one it enqueues (measured: the same rate, 6.6-6.9 k frames/s either way; config.host_pipeline_depth)")
-    ap.add_argument("--split-mesh", type=int, default=0, choices=[0, 1], help="with --overlap 1: frame n's marching cubes + finish kernel on a third queue beside frame "
-                    "n+1's decode (the extracts' queue then carries fuse, decode, fuse, decode, ...; two sets of per-voxel extract buffers).  Off by default: "
-                    "+2-3 %% together with --host-depth 2, nothing without")
-    ap.add_argument("--scan-ahead", type=int, default=0, choices=[0, 1], help="with --overlap 1: the frame's two extract scans (dirty-set compaction + neighbourhood "
-                    "marker, batch scan) in its front end, before its fusion kernel (dif_map_t.scan_ahead): the extracts' queue carries fuse, lattice decode, "
-                    "refine, marching cubes, finish only (two sets of per-voxel extract buffers).  Off by default: the same rate (profiles/r05_experiments.md 2)")
     ap.add_argument("--rccl-before-clock", type=int, default=0, choices=[0, 1], help="--mode c4 under torch.distributed: 0 (default) = the barriers around "
                     "the clock go over gloo and RCCL is brought up BEHIND the clock, for the exchange step (the global map merge); 1 = RCCL is the process group "
                     "from the start, alive during the timed region like in a deployment that merges maps periodically.  The line says which "
@@ -184,10 +169,9 @@ WORKLOADS = {"c1": "C1 32^3 grid 0.1 m, sphere", "c2": "C2 64^3 grid 0.1 m, room
              "c3": "C3 128^3 grid 0.05 m, ScanNet-shape 6 m room with boxes"}
 
 
-def prime_process(FusionStream, syn, model, intr, dev, d2h, graphs=True, overlap=False):
-    """One-time process costs (code-object load, kernel attributes, pinned-memory pools, graph machinery) are paid on a throwaway 32^3
-    map, so that they do not land in the timed region when the caller asks for little or no warmup.  Only the ways of driving a frame that
-    the run will use are primed (`graphs`: a hipGraph capture too), and the throwaway map's blocks stay in torch's caching allocator:
+def prime_process(FusionStream, syn, model, intr, dev, d2h, overlap=False):
+    """One-time process costs (code-object load, kernel attributes, pinned-memory pools) are paid on a throwaway 32^3
+    map, so that they do not land in the timed region when the caller asks for little or no warmup.  The throwaway map's blocks stay in torch's caching allocator:
     until round 5 they were returned to the driver (`torch.cuda.empty_cache()`: buffer placement was worth 9 % at 0.35 ms per frame), but a
     process that has handed gigabytes back to the driver runs every later SDMA copy 6 times slower (hsa_amd_memory_async_copy of a frame's
     rows 34 -> 223 us, measured with tools/exp_prime.py: any three primed frames followed by empty_cache; without the empty_cache, or
@@ -199,8 +183,7 @@ def prime_process(FusionStream, syn, model, intr, dev, d2h, graphs=True, overlap
         prime.enable_overlap()
     prime.step(0, d2h)
     prime.step_pipelined(1, d2h)
-    if graphs:
-        prime.step_graph(2, d2h)
+    prime.step_direct(2, d2h)
     prime.step_direct(3, d2h)
     prime.flush(d2h)
     torch.cuda.synchronize()
@@ -213,21 +196,12 @@ def prime_process(FusionStream, syn, model, intr, dev, d2h, graphs=True, overlap
 def frame_runner(stream, a, d2h):
     """(run(i), drain()) for the chosen way of driving a frame."""
     lib = None
-    skip_until = 0
 
     def run(i):
-        nonlocal lib, skip_until
-        if i < skip_until:                                  # part of a batch that is already enqueued
-            return None
-        if i < 2 or not (a.graph or a.direct) or (stream.tiling is not None and not a.direct):
-            return stream.step_pipelined(i, d2h) if (a.pipeline or a.graph) else stream.step(i, d2h)
+        nonlocal lib
+        if i < 2 or not a.direct:
+            return stream.step_pipelined(i, d2h) if a.pipeline else stream.step(i, d2h)
         sampled = (i % a.sample_every) == 0
-        F = a.batch
-        if F > 0 and not sampled and i + F <= a.n_frames and not (i < a.warmup < i + F) and all(((i + j) % a.sample_every) != 0 for j in range(F)):
-            skip_until = i + F
-            return stream.step_batch(i, F, d2h)             # F frames, one graph launch
-        if a.graph and not sampled:
-            return stream.step_graph(i, d2h)
         # direct launches (two C calls); on the sampled frames of the timed region with HIP events around the MFMA / marching-cubes kernels
         timed = sampled and a.timed_from is not None and i >= a.timed_from
         if timed:
@@ -241,7 +215,7 @@ def frame_runner(stream, a, d2h):
         return out
 
     def drain():
-        stream.flush_all(d2h)
+        stream.flush(d2h)
     return run, drain
 
 
@@ -269,7 +243,7 @@ class GroupBench:
 
     def drain(self):
         for st in self.streams:
-            st.flush_all(self.d2h)
+            st.flush(self.d2h)
 
     def frame_stats(self, first):
         """Counters per frame from frame `first` on, summed over the streams (rows per LAUNCH)."""
@@ -340,20 +314,17 @@ def streams_leg(make_stream_j, S, a, n_frames, lib, pipe):
     return rate, ({k: blk[k] for k in keep if k in blk} if blk else None)
 
 
-def secondary_rate(make_stream, a, n_frames, d2h, batch, variant=None):
-    """Secondary figures (N=1 only, reported next to `value`, never instead of it): the same stream (i) without the per-frame hand-over
-    of the new triangles to pinned host memory — the difference is PCIe traffic, not kernels — and (ii) with 5 frames per captured
-    hipGraph, for callers that know their poses ahead (no kernel boundaries inside a graph, one launch gap per 5 frames).  Best of two
+def secondary_rate(make_stream, a, n_frames, d2h):
+    """Secondary figure (N=1 only, reported next to `value`, never instead of it): the same stream without the per-frame hand-over
+    of the new triangles to pinned host memory — the difference is PCIe traffic, not kernels.  Best of two
     passes over fresh streams: these 40 ms measurements are informational, and a single host or driver stall (seen in about one run in
     ten on shared boxes) would otherwise decide them."""
-    return max(_secondary_pass(make_stream, a, n_frames, d2h, batch, variant) for _ in range(2))
+    return max(_secondary_pass(make_stream, a, n_frames, d2h) for _ in range(2))
 
 
-def _secondary_pass(make_stream, a, n_frames, d2h, batch, variant=None):
-    s2 = make_stream(batch)
-    if variant == "split_d2" and s2.overlap:        # the frame's marching cubes on a third queue beside the next frame's decode, the host two frames ahead
-        s2.split_mesh, s2.host_depth = True, 2
-    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30, "timed_from": None, "batch": batch}), d2h)
+def _secondary_pass(make_stream, a, n_frames, d2h):
+    s2 = make_stream()
+    run2, drain2 = frame_runner(s2, argparse.Namespace(**{**vars(a), "sample_every": 1 << 30, "timed_from": None}), d2h)
     for i in range(a.warmup):
         run2(i)
     drain2()
@@ -604,39 +575,24 @@ def main():
     model = net_util.networks_from_arrays(net_util.load_weights_npz(), x6=(None if a.mlp_pipe is None else a.mlp_pipe == "bf16x6"))
     pipe = "bf16x6" if model.packed.x6 else "f32"
     n_frames = a.warmup + a.steps
-    if tiled:
-        a.graph = a.batch = 0               # the halo exchange sits between the kernels of a frame: direct launches, host one frame ahead
     a.direct = bool(a.pipeline)
     a.timed_from = None
     a.n_frames = n_frames
 
-    def make_stream(batch=None):
-        batch = a.batch if batch is None else batch
+    def make_stream():
         if tiled:           # every rank renders the same stream and owns one x-slab of the grid
             tiling = (a.loopback // 2, a.loopback, None) if a.loopback > 1 else (rank, world, None)
             return FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, noise=bool(a.noise),
                                 tiling=tiling, halo_mode=a.halo, halo_loopback=a.loopback > 1)
-        # (a batch of F frames needs room for the worst-case allocations of two batches in flight: sized up front instead of growing in the clock;
-        # frame-by-frame streams size themselves: FusionStream's default)
-        cap0 = None
-        if batch > 0:
-            cap0 = 1 << 16
-            while cap0 < (2 * batch + 1) * 7 * (intr.width * intr.height // 17) + (1 << 16):
-                cap0 *= 2
-        st = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise),
-                          initial_capacity=cap0)   # own arc of the orbit
-        if a.overlap and a.direct and not a.graph and batch == 0 and a.d2h in ("dma", "none"):
-            st.split_mesh = bool(a.split_mesh)
-            st.scan_ahead = bool(a.scan_ahead)
+        st = FusionStream(model, scene, cfg, intr, dev, n_frames, deg_per_frame=0.5, phase_deg=rank * 45.0, noise=bool(a.noise))   # own arc of the orbit
+        if a.overlap and a.direct and a.d2h in ("dma", "none"):
             st.enable_overlap()             # (stays off, and says so, when no second hardware queue is to be had)
-        if a.direct and not a.graph and batch == 0:
-            st.host_depth = a.host_depth
         return st
 
     S_main = int(a.streams_per_gpu)
     if a.d2h == "auto":
-        a.d2h = "dma" if (a.direct and not a.graph and a.batch == 0 and S_main <= 1 and not tiled) else "new"
-    if S_main < 0 or S_main > _lib.MAX_STREAMS or (S_main >= 1 and (tiled or a.graph or a.batch)):
+        a.d2h = "dma" if (a.direct and S_main <= 1 and not tiled) else "new"
+    if S_main < 0 or S_main > _lib.MAX_STREAMS or (S_main >= 1 and tiled):
         raise SystemExit(f"bench.py --streams-per-gpu: 0..{_lib.MAX_STREAMS}, with --mode c4 and direct launches")
 
     def make_stream_j(j, S):
@@ -651,7 +607,7 @@ def main():
     else:
         stream = make_stream()
     if os.environ.get("DIF_BENCH_NO_PRIME") != "1":
-        prime_process(FusionStream, syn, model, syn.Intrinsic(), dev, a.d2h, graphs=bool(a.graph or a.batch or not a.no_secondary), overlap=bool(stream.overlap))
+        prime_process(FusionStream, syn, model, syn.Intrinsic(), dev, a.d2h, overlap=bool(stream.overlap))
 
     def barrier():
         torch.cuda.synchronize()
@@ -663,11 +619,6 @@ def main():
     for i in range(a.warmup):
         run(i)
     drain()
-    if a.graph and a.warmup >= 1 and stream._graphs is None:
-        torch.cuda.synchronize()
-        with torch.cuda.device(dev):
-            stream._graph_export = (a.d2h == "new")
-            stream._capture_graphs()            # a short warmup never reached the first replay: capture outside the clock
     stats_base = len(stream.stats)
     cap = 1 << 16
     p_which, p_ms = (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)()
@@ -675,7 +626,7 @@ def main():
     lib.dif_profile_enable(1)               # (fills the library's event pool outside the clock)
     lib.dif_profile_enable(0)
     a.timed_from = a.warmup
-    if not (a.graph or a.direct):
+    if not a.direct:
         lib.dif_profile_enable(1)           # (otherwise the runner switches it on for the sampled frames only)
     gc.collect()
     gc.disable()            # a generation-2 collection in the middle of a 70 ms timed region shows up as a 20 % outlier
@@ -695,17 +646,13 @@ def main():
         tt = torch.tensor([dt], device=("cpu" if clock_over_gloo else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    hbm_resident = batched = split_d2 = None
-    # (secondary figures need a run long enough to amortise their own one-time costs — a fresh stream's buffer growth, graph captures)
+    hbm_resident = None
+    # (secondary figures need a run long enough to amortise their own one-time costs — a fresh stream's buffer growth)
     if world == 1 and a.d2h != "none" and not a.no_secondary and not tiled and a.steps >= 100 and gb is None:
-        hbm_resident = secondary_rate(make_stream, a, n_frames, "none", 0)
-        if a.batch == 0 and a.direct and not a.graph:        # (a per-frame-graph run would mix two sets of captured graphs on one stream)
-            batched = secondary_rate(make_stream, a, n_frames, "new" if a.d2h == "dma" else a.d2h, 5)
-            if stream.overlap and not (stream.split_mesh and stream.host_depth >= 2):
-                split_d2 = secondary_rate(make_stream, a, n_frames, a.d2h, 0, "split_d2")
+        hbm_resident = secondary_rate(make_stream, a, n_frames, "none")
     # S independent subsequences per GPU sharing their launches: aggregate frames/s and the MFMA kernels' roofline at S = 2, 4, 8
     by_streams = {}
-    if world == 1 and not a.no_secondary and not tiled and gb is None and a.direct and not a.graph and a.batch == 0 and a.warmup + a.steps >= 2:
+    if world == 1 and not a.no_secondary and not tiled and gb is None and a.direct and a.warmup + a.steps >= 2:
         for S in (2, 4, 8):
             try:
                 by_streams[S] = streams_leg(lambda j, S=S: make_stream_j(j, S), S, a, n_frames, lib, pipe)
@@ -720,8 +667,8 @@ def main():
     out = None
     if rank == 0:
         st = gb.frame_stats(stats_base) if gb is not None else stream.stats[stats_base:]
-        # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones under hipGraph replay
-        sampled_only = bool(a.graph or a.direct)
+        # frames whose kernels were bracketed by HIP events: all of them when eager, the sampled ones of a directly launched run
+        sampled_only = bool(a.direct)
         if gb is not None:
             timed_idx = [j for j in range(a.steps) if (a.warmup + j) >= 1 and ((a.warmup + j) % a.sample_every) == 0]
         else:
@@ -738,10 +685,7 @@ def main():
         launch = (f"direct launches, two C calls per frame of ALL {S_main} streams of the rank (dif_integrate_frames + dif_extract_streams: blockIdx.y = stream in "
                   f"the point / scan / fusion / marching-cubes kernels, concatenated tile ranges in the persistent MLP kernels), host one frame ahead, HIP events "
                   f"on 1 frame in {a.sample_every}" if gb is not None else
-                  "eager, host one frame ahead" if not sampled_only else
-                  f"{a.batch} frames per captured hipGraph between the sampled frames; 1 frame in {a.sample_every} launched directly with HIP events "
-                  "(roofline sample)" if a.batch > 0 else
-                  f"hipGraph replay; 1 frame in {a.sample_every} launched directly with HIP events (roofline sample)" if a.graph else
+                  "eager, frame by frame" if not sampled_only else
                   f"direct launches (two C calls per frame), host one frame ahead, HIP events on 1 frame in {a.sample_every} (roofline sample)")
         pixels = intr.width * intr.height
         value = (a.steps if tiled else world * max(S_main, 1) * a.steps) / dt       # tiled: ONE stream, however many GPUs work on it
@@ -768,23 +712,22 @@ def main():
                                           else f"{world} independent subsequences (one map per GPU)"),
                           "streams_per_gpu": max(S_main, 1),
                           "d2h_per_frame": a.d2h,
-                          "d2h_engine": (None if a.d2h != "dma" else "sdma (hsa_amd_memory_async_copy, no copy kernel)" if stream._sdma else
+                          "d2h_engine": (None if a.d2h != "dma" else "sdma (hsa_amd_memory_async_copy, no copy kernel)" if stream.sdma else
                                          "hipMemcpyAsync on a side stream (blit kernels)"),
                           "sdma_call_us": (None if not stream.sdma_us else {"calls": len(stream.sdma_us), "median": round(float(np.median([u for _, u in stream.sdma_us])), 1),
                                                                                "p90": round(float(np.percentile([u for _, u in stream.sdma_us], 90)), 1),
                                                                                "first_40": [(n, round(u)) for n, u in stream.sdma_us[:40]]}),
-                          "two_queues": {"on": bool(stream.overlap), "queues_independent": stream.queues_independent, "mesh_half_on_a_third_queue": bool(stream.overlap and stream.split_mesh),
-                                         "extract_scans_in_the_front_end": bool(stream.overlap and stream.scan_ahead),
+                          "two_queues": {"on": bool(stream.overlap), "queues_independent": stream.queues_independent,
                                          "what": "frame i+1's integrate front end on a second hardware queue beside frame i's extract; fusion kernel and extract "
                                                  "ordered by hipStreamWaitValue32 on words the kernels publish" if stream.overlap else "one queue"},
-                          "host_pipeline_depth": (1 + stream.host_depth) if (a.pipeline or a.graph) else 1, "launch": launch,
+                          "host_pipeline_depth": 2 if a.pipeline else 1, "launch": launch,
                           "avg_per_frame_rank0": {k: round(float(np.mean([s[k] for s in st])), 1)
                                                   for k in ("M", "C", "K", "B", "VH", "T", "n_occupied", "cache_T")},
                           "frames_per_s_with_mesh_left_in_hbm": hbm_resident,
-                          "frames_per_s_with_5_frames_per_hipgraph": batched,
-                          "frames_per_s_with_the_mesh_half_on_a_third_queue_and_the_host_two_frames_ahead": split_d2,
                           "frames_per_s_with_S_streams_per_gpu": ({str(S): v[0] for S, v in by_streams.items()} if by_streams else None),
-                          "graph_captures": stream.n_captures, "mesh_log_compactions": stream.map._gc_epoch,
+                          "mesh_log_compactions": stream.map._gc_epoch,
+                          "extract_buffers": {"rows": int(stream.map._xbuf[0][1]) if stream.map._xbuf else None, "deferred_extracts": int(stream.map.n_deferred),
+                                              "bytes": int(sum(t.numel() * t.element_size() for t in stream.map._xbuf[1].values())) if stream.map._xbuf else None},
                           "global_map_merge_after_the_clock": merge_info,
                           "halo_exchange": halo_summary(stream, a)},
                "roofline": roofline_block(per_frame, [st[j] for j in timed_idx], pipe, short_run=(a.steps <= 30), streams=max(S_main, 1))}

@@ -14,9 +14,9 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "libdifusion.so"    # DIF_LIB: instrumented builds (tools/)
 
 # counters (difusion.h)
-C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS, C_HALO_L, C_HALO_R, C_HALO_TICKET = range(23)
+C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS, C_HALO_L, C_HALO_R, C_HALO_TICKET, C_DEFERRED, C_DEC_TICKET, C_DEC_DONE = range(26)
 C_STAMP = 31
-SYNC_FUSED, SYNC_FRONT_DONE, SYNC_DECODED, SYNC_MESHED, SYNC_WORDS = 0, 32, 64, 96, 128      # dif_map_t.sync_words
+SYNC_FUSED, SYNC_FRONT_DONE, SYNC_WORDS = 0, 32, 64      # dif_map_t.sync_words
 FC_COUNT = 32                                            # dif_map_t.frame_counters
 C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge"]
@@ -38,8 +38,7 @@ class DifMap(Structure):
                 ("tri_start", c_void_p), ("tri_n", c_void_p),
                 ("own_x_lo", c_int32), ("own_x_hi", c_int32), ("halo", c_int32), ("dirty_tot", c_void_p),
                 ("halo_list", c_void_p), ("halo_list_cap", c_int32), ("pending_export", c_void_p),
-                ("alloc_bits", c_void_p), ("alloc_tot", c_void_p), ("sync_words", c_void_p), ("frame_seq", c_int32), ("fuse_stream", c_void_p), ("frame_counters", c_void_p), ("mesh_wait", c_int32),
-                ("front_stream", c_void_p), ("pend_cnt", c_void_p), ("scan_ahead", c_int32)]
+                ("alloc_bits", c_void_p), ("alloc_tot", c_void_p), ("sync_words", c_void_p), ("frame_seq", c_int32), ("fuse_stream", c_void_p), ("frame_counters", c_void_p)]
 
 
 class DifWeights(Structure):
@@ -61,7 +60,7 @@ class DifExtractBuffers(Structure):
                 ("cache_tri", c_void_p), ("cache_id", c_void_p), ("cache_std", c_void_p), ("cache_alive", c_void_p),
                 ("counters_out", c_void_p), ("out_tri", c_void_p), ("out_id", c_void_p), ("out_std", c_void_p), ("out_capacity", c_int64),
                 ("chunk_sum", c_void_p), ("fold_table", c_void_p), ("mc_status", c_void_p), ("defer_export", c_int32),
-                ("stamp", c_int32), ("export_notify", c_void_p), ("split_mesh", c_int32)]
+                ("stamp", c_int32), ("export_notify", c_void_p)]
 
 
 MAX_STREAMS = 8          # DIF_MAX_STREAMS
@@ -113,7 +112,6 @@ SIGNATURES = {
                               c_int32, c_int32, c_void_p]),
     "dif_integrate_frames": (c_int32, [POINTER(DifStreamFrame), c_int32, POINTER(DifWeights), c_int32, c_int32, c_float, c_float, c_float, c_float,
                                        c_void_p]),
-    "dif_extract_mesh": (c_int32, [POINTER(DifMap), POINTER(DifExtractBuffers), c_int32, c_float, c_int32, c_int32, c_void_p]),
     "dif_extract_streams": (c_int32, [POINTER(DifStreamFrame), c_int32, POINTER(DifWeights), c_int32, c_float, c_int32, c_void_p]),
     "dif_export_pending": (c_int32, [POINTER(DifMap), c_void_p]),
     "dif_mesh_cache_export": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -143,6 +141,8 @@ SIGNATURES = {
     "dif_profile_dump": (c_int64, [POINTER(c_int32), POINTER(c_float), c_int64, c_int32]),
     "dif_read_counters": (c_int32, [POINTER(DifMap), POINTER(c_int32), c_void_p]),
     "dif_test_mc_grid_cap": (c_int32, [c_int32]),
+    "dif_test_sdma_mode": (c_int32, [c_int32]),
+    "dif_sdma_info": (c_int32, [POINTER(c_int32)]),
     "dif_queues_independent": (c_int32, [c_void_p, c_void_p]),
     "dif_mesh_cache_export_sdma": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "dif_sdf_hg_workspace_bytes": (c_int64, [c_int64]),

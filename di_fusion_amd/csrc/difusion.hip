@@ -113,9 +113,6 @@ inline bool overlap_ok(const dif_map_t* map) {
     return map->alloc_bits && map->alloc_tot && map->dirty_tot && map->frame_counters && !map_is_tiled(map) && map->capacity > 4096 &&
            map->capacity % DIF_BLOCK == 0;
 }
-// the scans of an overlapped frame's extract in its front end (include/difusion.h: dif_map_t.scan_ahead)
-inline bool scan_ahead(const dif_map_t* map) { return overlapped(map) && map->scan_ahead != 0; }
-inline bool scan_ahead_ok(const dif_map_t* map) { return map->pend_cnt != nullptr && map->frame_counters != nullptr; }
 inline int wait_word(hipStream_t s, uint32_t* word, int32_t value) {
     if (value <= 0) return DIF_OK;
     return hipStreamWaitValue32(s, word, (uint32_t)value, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
@@ -436,7 +433,7 @@ struct FrameSource {            // integrate straight from a depth frame: the fi
 // pieces to the kernels by value, dif_integrate_frames collects the pieces of S maps into the kernels' argument arrays.
 struct IntegratePlan {
     UvcArgs uvc; PruneArgs prune; AllocFunctor alloc; const int* alloc_tot; GatherArgs gather; EncArgs enc; FuseArgs fuse;
-    int64_t grid; bool has_pending; bool overlap; bool scan_ahead;
+    int64_t grid; bool has_pending; bool overlap;
 };
 
 static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const float* xyz, const float* normal, int64_t N, uint8_t* unq_mask,
@@ -474,15 +471,9 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
     P.alloc_tot = alloc_tot_of(map);                               // k_prune_mark kept the block totals
     P.gather = GatherArgs{g, map->encoder_count_th, ps, ws.pt_lin, unq_mask, map->frame_count, map->indexer, map->voxel_obs_count, ws.pair_list, C,
                           map->capacity, alloc_tot_of(map), own_lo, own_hi, ov ? nullptr : pending, cull};
-    // ... unless the frame's scans run in its front end too (scan_ahead): then flags, totals and the slots' pending counts are the encoder's again
-    const bool sa = ov && scan_ahead(map);
-    if (sa && !scan_ahead_ok(map)) return DIF_EINVAL;
-    P.scan_ahead = sa;
-    P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, (ov && !sa) ? nullptr : map->dirty_tot,
-                    sa ? map->pend_cnt : nullptr};
+    P.enc = EncArgs{g, ps, ws.pair_list, map->rec_dir, ws.rec_next, ws.rec, map->upd_list, C, map->dirty, ov ? nullptr : map->dirty_tot};
     P.fuse = FuseArgs{ws.rec, ws.rec_next, map->rec_dir, map->upd_list, map->latent_vecs, map->voxel_obs_count, map->dirty, C, map->latent_vecs_pos,
-                      halo_lists_of(map), ov ? nullptr : pending, (ov && !sa) ? map->dirty_tot : nullptr, ov ? map->frame_counters : nullptr,
-                      ov ? map->sync_words + DIF_SYNC_DECODED : nullptr, ov ? map->frame_seq : 0, sa ? map->pend_cnt : nullptr};
+                      halo_lists_of(map), ov ? nullptr : pending, ov ? map->dirty_tot : nullptr, ov ? map->frame_counters : nullptr};
     if (ov) P.uvc.pending = nullptr;                               // (no deferred export rides with an overlapped frame: its extract has not run yet)
     return DIF_OK;
 }
@@ -524,8 +515,6 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
     const int nb_x = P.has_pending ? DIF_EXPORT_WGS : 0;
     // two queues: the front end reads what the previous frame's fusion kernel (extracts' stream) wrote; that frame's extract says when it is done
     if (P.overlap && wait_word(s, map->sync_words + DIF_SYNC_FUSED, map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
-    // ... and, with the mesh halves on a stream of their own, the one that used this frame's buffers two frames ago must have completed
-    if (P.overlap && map->mesh_wait > 0 && wait_word(s, map->sync_words + DIF_SYNC_MESHED, map->mesh_wait) != DIF_OK) return DIF_ELAUNCH;
     // k_voxel_count also zeroes the per-call counters (ALLOC_NEW, M, C, ITEMS): every kernel that writes them runs later
     if (src)
         hipLaunchKernelGGL(k_unproject_voxel_count, dim3(nb_pts + nb_x), dim3(DIF_BLOCK), 0, s, P.uvc, ImageGeo{src->H, src->W, src->fx, src->fy, src->cx, src->cy}, nb_x);
@@ -550,10 +539,10 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         const int enc_grid = P.overlap ? overlap_encoder_cus() : num_cus();
         if (x6)
             hipLaunchKernelGGL(k_encode<true>, dim3(enc_grid), dim3(ENC_X6_THREADS), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
-                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot, e.pend);
+                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         else
             hipLaunchKernelGGL(k_encode<false>, dim3(enc_grid), dim3(512), lds_bytes, s, e.g, w->enc_packed, e.src.xyz, e.src.normal, e.src.frame,
-                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot, e.pend);
+                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         DIF_CHECK_LAUNCH();
     }
     hipStream_t sf = s;
@@ -561,8 +550,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         // two queues: the front end is done -> a word for the extracts' stream, where the fusion kernel goes: behind the previous frame's extract
         // (it writes what that extract reads — latents, counts, dirty flags) and behind one wait for that word, which is normally long there
         sf = (hipStream_t)map->fuse_stream;
-        // (scan-ahead: the front end goes on into the frame's dif_extract, which runs the two scans on this stream and publishes the word behind them)
-        if (!P.scan_ahead) hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, s, map->sync_words + DIF_SYNC_FRONT_DONE, (uint32_t)map->frame_seq);
+        hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, s, map->sync_words + DIF_SYNC_FRONT_DONE, (uint32_t)map->frame_seq);
         if (wait_word(sf, map->sync_words + DIF_SYNC_FRONT_DONE, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
     }
     hipLaunchKernelGGL(k_fuse, dim3(grid_for(map->capacity * 32, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, sf, P.fuse);
@@ -915,17 +903,14 @@ static DirtySet dirty_set_of(const dif_map_t* map, const dif_extract_buffers_t* 
     const int64_t grid = (int64_t)map->nx * map->ny * map->nz, plane = (int64_t)map->ny * map->nz;
     const bool tiled = map_is_tiled(map);
     const int64_t own_lo = tiled ? map->own_x_lo * plane : 0, own_hi = tiled ? map->own_x_hi * plane : grid;
-    const bool sa = scan_ahead(map);
     return DirtySet{map->dirty, map->latent_vecs_pos, buf->valid_blocks, map->counters, no_cache, buf->max_voxels, geo_of(map), map->ignore_count_th,
-                    map->indexer, map->voxel_obs_count, grid_marks_of(map), own_lo, own_hi, tiled,
-                    sa ? map->pend_cnt : nullptr, sa ? map->frame_counters + DIF_FC_XC : nullptr};
+                    map->indexer, map->voxel_obs_count, grid_marks_of(map), own_lo, own_hi, tiled};
 }
 
 static VoxelDecodeArgs voxel_decode_args_of(const dif_map_t* map, const dif_weights_t* w, const dif_extract_buffers_t* buf, const ExtractGeo& e, bool fold) {
     VoxelDecodeArgs V = {};
     V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std;
-    V.counters = scan_ahead(map) ? map->frame_counters + DIF_FC_XC : map->counters;          // B, VH of the frame
-    if (scan_ahead(map)) { V.fused_word = map->sync_words + DIF_SYNC_FUSED; V.seq = map->frame_seq; }
+    V.counters = map->counters;          // B, VH of the frame
     V.refine_list = buf->refine_list; V.R = e.R;
     V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
     V.low.res = e.l; V.low.a = (float)e.sample_a; V.low.vsize = (e.l > 1) ? (float)((e.sample_b - e.sample_a) / (e.l - 1)) : 0.0f;
@@ -934,7 +919,7 @@ static VoxelDecodeArgs voxel_decode_args_of(const dif_map_t* map, const dif_weig
 
 static DecodeArgs refine_args_of(const dif_map_t* map, const dif_extract_buffers_t* buf, const ExtractGeo& e, bool fold) {
     DecodeArgs Rf = {};
-    Rf.mode = 1; Rf.n_ptr = (scan_ahead(map) ? map->frame_counters + DIF_FC_XC : map->counters) + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
+    Rf.mode = 1; Rf.n_ptr = map->counters + DIF_C_VH; Rf.occ_slot = buf->occ_slot; Rf.latent = map->latent_vecs; Rf.list = buf->refine_list;
     Rf.lat.res = e.R; Rf.lat.a = (float)e.sample_a; Rf.lat.vsize = (float)((e.sample_b - e.sample_a) / (e.R - 1));
     Rf.fold_table = fold ? buf->fold_table : nullptr;
     Rf.out_sdf = buf->cube_sdf; Rf.out_std = buf->cube_std; Rf.sign = -1.0f;
@@ -979,7 +964,7 @@ static FinishArgs finish_args_of(const dif_map_t* map, const dif_extract_buffers
                                  defer ? (dif_pending_export_t*)map->pending_export : nullptr, buf->stamp, defer ? buf->export_notify : nullptr},
                       (fused_scan && !onepass) ? buf->chunk_sum : nullptr, super_sum, map->dirty_tot, (int)((map->capacity + DIF_BLOCK - 1) / DIF_BLOCK),
                       onepass ? buf->mc_status : nullptr, onepass ? buf->mc_status + (buf->max_voxels + 3) / 4 : nullptr,
-                      ov ? map->frame_counters : nullptr, scan_ahead(map) ? 1 : 0};
+                      ov ? map->frame_counters : nullptr};
 }
 
 static int voxel_decode_attributes() {
@@ -1050,18 +1035,6 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     if (ov && (!overlap_ok(map) || no_cache || defer_export_of(map, buf) || s != (hipStream_t)map->fuse_stream)) return DIF_EINVAL;
     const ExtractGeo e = extract_geo(resolution);
     const int r = e.r, R = e.R, l = e.l, R3 = e.R3;
-    // two queues (and the split extract): only for the configuration a stream runs (fast decode on the bf16 pipe, one-pass marching cubes) — the
-    // refine pass is what leaves the frame's K, B, VH in its counter block
-    const bool split = ov && buf->split_mesh;
-    // scan-ahead: the two scans below run on the FRONT-END stream, before the frame's fusion kernel (dif_map_t.scan_ahead), into the frame's own
-    // counter block; the word the fusion kernel waits for follows them
-    const bool sa = ov && scan_ahead(map);
-    if (sa && (!scan_ahead_ok(map) || !map->front_stream || (hipStream_t)map->front_stream == s)) return DIF_EINVAL;
-    hipStream_t ss = sa ? (hipStream_t)map->front_stream : s;
-    int* const XC = sa ? map->frame_counters + DIF_FC_XC : nullptr;
-    if (ov && !(fast && buf->chunk_sum && buf->mc_status && buf->max_voxels <= ((int64_t)1 << 24) && r * r * r <= 64 && buf->fold_table && w->dec_x6_packed &&
-                   w->dec_x6_packed_bytes == X6_BYTES && w->dec_fold_packed))
-        return DIF_EINVAL;
     if (buf->max_voxels * (int64_t)R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
     const double sample_a = e.sample_a, sample_b = e.sample_b;
 
@@ -1069,7 +1042,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         const DirtySet ds = dirty_set_of(map, buf, no_cache);
         const bool tiled = ds.tiled;
         if (tiled) {
-            hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, ss, g, map->ignore_count_th, map->dirty,
+            hipLaunchKernelGGL(k_mark_halo_dirty, dim3(grid_for(map->capacity, DIF_BLOCK, 256)), dim3(DIF_BLOCK), 0, s, g, map->ignore_count_th, map->dirty,
                                (const int64_t*)map->latent_vecs_pos, (const int64_t*)map->indexer, (const float*)map->voxel_obs_count, bits,
                                n_slots, ds.own_lin_lo, ds.own_lin_hi);
             DIF_CHECK_LAUNCH();
@@ -1078,23 +1051,19 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             DirtyFunctor f{ds};
             // every writer of the flags kept the per-block totals (k_fuse; the host recomputes them after anything else): no counting pass
             if (map->dirty_tot && !no_cache && !tiled && map->capacity > 4096 && map->capacity % DIF_BLOCK == 0) {
-                hipLaunchKernelGGL(k_dirty_scan, dim3((int)(map->capacity / DIF_BLOCK)), dim3(DIF_BLOCK), 0, ss, ds, n_slots, (const int*)map->dirty_tot,
-                                   (ov && !sa) ? map->sync_words + DIF_SYNC_FUSED : nullptr, (int)map->frame_seq);
+                hipLaunchKernelGGL(k_dirty_scan, dim3((int)(map->capacity / DIF_BLOCK)), dim3(DIF_BLOCK), 0, s, ds, n_slots, (const int*)map->dirty_tot,
+                                   ov ? map->sync_words + DIF_SYNC_FUSED : nullptr, (int)map->frame_seq);
                 DIF_CHECK_LAUNCH();
-            } else if (sa) {
-                return DIF_EINVAL;          // (overlap_ok() admits only maps that take the launch above)
+            } else if (ov) {
+                return DIF_EINVAL;          // (overlap_ok() admits only maps that take the launch above: it publishes DIF_SYNC_FUSED)
             } else if (map->dirty_tot && !no_cache && !tiled) {
                 if (launch_counted_scan_bounded(f, n_slots, map->capacity, map->dirty_tot, s) != DIF_OK) return DIF_ELAUNCH;
             } else if (launch_scan(f, n_slots, 0, map->capacity, buf->block_tmp, s) != DIF_OK) return DIF_ELAUNCH;
         }
     }
     {
-        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels, XC};
-        if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, ss) != DIF_OK) return DIF_ELAUNCH;      // the markers kept the block totals
-    }
-    if (sa) {   // the front end of the frame ends here: its fusion kernel (dif_integrate_frame left it on `s` behind a wait for this word) may go
-        hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, ss, map->sync_words + DIF_SYNC_FRONT_DONE, (uint32_t)map->frame_seq);
-        DIF_CHECK_LAUNCH();
+        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
+        if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // the markers kept the block totals
     }
     int rc;
     if (fast && l * l * l <= VD_MAX_L3 && R * R <= VD_MAX_R2) {
@@ -1120,8 +1089,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             if (rblocks < 1) rblocks = 1;
             if (rblocks > num_cus()) rblocks = num_cus();
             ProfScope prof(DIF_PROF_DECODE_POINTS, s);
-            hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed,
-                               ov ? SplitTail{map->frame_counters, sa ? (const int*)XC : (const int*)C, split ? map->grid_tot : nullptr} : SplitTail{nullptr, nullptr, nullptr});
+            hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed);
             DIF_CHECK_LAUNCH();
             rc = DIF_OK;
         } else {
@@ -1154,7 +1122,6 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         rc = launch_decode(A, w, buf->max_voxels * (int64_t)((R3 + 31) / 32), s);
         if (rc != DIF_OK) return rc;
     }
-    if (split) return DIF_OK;       // marching cubes + finish: dif_extract_mesh, behind the next frame's integrate on the other stream
     return extract_mesh_part(map, buf, e, max_std, no_cache, scale_vertices, s);
 }
 
@@ -1165,9 +1132,6 @@ static int extract_mesh_part(const dif_map_t* map, const dif_extract_buffers_t* 
     const int r = e.r;
     int rc;
     McArgs a = mc_args_of(map, buf, e, max_std, scale_vertices);
-    const bool split = overlapped(map) && buf->split_mesh;
-    if (split || scan_ahead(map)) a.K_ptr = map->frame_counters + DIF_FC_K;      // the frame's own K (the live word may be the next frame's)
-    if (split) a.grid_tot = nullptr;                                              // the batch scan's totals were zeroed by the refine pass
     if (no_cache) {                                                                                               // map.py:614-616
         if (hipMemsetAsync(C + DIF_C_CACHE_T, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
         if (hipMemsetAsync(C + DIF_C_CACHE_DEAD, 0, sizeof(int), s) != hipSuccess) return DIF_ELAUNCH;
@@ -1242,7 +1206,7 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
             return DIF_EINVAL;
         if (!map->tri_start || !map->tri_n || !buf->fold_table || !buf->chunk_sum || !buf->mc_status || buf->max_voxels > ((int64_t)1 << 24)) return DIF_EINVAL;
         dirty.s[j] = DirtyScanArgs{dirty_set_of(map, buf, 0), map->counters + DIF_C_N_OCCUPIED, map->dirty_tot};
-        occ.f[j] = OccFunctor{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, map->counters, buf->max_voxels, nullptr};
+        occ.f[j] = OccFunctor{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, map->counters, buf->max_voxels};
         occ.tot[j] = map->grid_tot;
         vd.s[j] = voxel_decode_args_of(map, w, buf, e, true);
         rf.s[j] = refine_args_of(map, buf, e, true);
@@ -1305,22 +1269,6 @@ int dif_extract(const dif_map_t* map, const dif_weights_t* w, const dif_extract_
     return extract_impl(map, w, buf, resolution, fast, max_std, no_cache, scale_vertices, stream_);
 }
 
-int dif_extract_mesh(const dif_map_t* map, const dif_extract_buffers_t* buf, int32_t resolution, float max_std, int32_t scale_vertices,
-                     int32_t wait_decoded, void* stream_) {
-    if (!map || !buf || resolution < 1 || resolution > 4 || buf->max_voxels <= 0 || !overlapped(map) || !overlap_ok(map) || !buf->split_mesh) return DIF_EINVAL;
-    if (buf->cache_capacity <= 0 || buf->cache_capacity >= ((int64_t)1 << 31) || !buf->cache_tri || !buf->cache_id || !buf->cache_std || !buf->cache_alive)
-        return DIF_EINVAL;
-    if (!map->tri_start || !map->tri_n || !buf->chunk_sum || !buf->mc_status || buf->max_voxels > ((int64_t)1 << 24) || defer_export_of(map, buf)) return DIF_EINVAL;
-    hipStream_t s = (hipStream_t)stream_;
-    // behind the frame's decode kernels: the next frame's fusion kernel (extracts' stream) says when they are done
-    if (wait_decoded && wait_word(s, map->sync_words + DIF_SYNC_DECODED, map->frame_seq) != DIF_OK) return DIF_ELAUNCH;
-    const int rc = extract_mesh_part(map, buf, extract_geo(resolution), max_std, 0, scale_vertices, s);
-    if (rc != DIF_OK) return rc;
-    hipLaunchKernelGGL(k_publish_word, dim3(1), dim3(64), 0, s, map->sync_words + DIF_SYNC_MESHED, (uint32_t)map->frame_seq);
-    DIF_CHECK_LAUNCH();
-    return DIF_OK;
-}
-
 int dif_export_pending(const dif_map_t* map, void* stream) {
     if (!map) return DIF_EINVAL;
     if (!map->pending_export) return DIF_OK;
@@ -1377,6 +1325,8 @@ struct HsaCopy {
     double us_per_byte = 0.0;           // ... and per byte beyond its fixed cost, for what a range of another size should take
     int slow_calls = 0;
     double ratio_min = 0.0;             // the best (measured / modelled) time of an export since the calibration
+    int calibrations = 0, exports = 0;  // (dif_sdma_info)
+    int runtime_version = 0;            // hipRuntimeGetVersion of the process
     bool load() {
         if (tried) return ok;
         tried = true;
@@ -1405,14 +1355,18 @@ struct HsaCopy {
         if (signal_create(0, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
         for (auto& q : sig3)
             if (signal_create(0, 0, nullptr, &q) != HSA_STATUS_SUCCESS) return false;
+        (void)hipRuntimeGetVersion(&runtime_version);
         if (hipMalloc(&cal_dev, CAL_BYTES) != hipSuccess || hipHostMalloc(&cal_host, CAL_BYTES, hipHostMallocDefault) != hipSuccess) { cal_dev = cal_host = nullptr; (void)hipGetLastError(); }
         ok = true;
         return true;
     }
-    // wait until signal q (set to 1 before its copy was issued) is down to 0; at most ~2 s
+    // wait until signal q (set to 1 before its copy was issued) is down to 0; at most ~2 s.  Exactly 0: the runtime sets the completion signal
+    // NEGATIVE when an async copy fails — the rows did not land, and the caller must take the fallback
     bool wait_one(hsa_signal_t q) {
-        for (int spins = 0; spins < 2000; ++spins)
-            if (signal_wait(q, HSA_SIGNAL_CONDITION_LT, 1, 1000000 /* ~1 ms of the signal's clock */, HSA_WAIT_STATE_ACTIVE) < 1) return true;
+        for (int spins = 0; spins < 2000; ++spins) {
+            const hsa_signal_value_t v = signal_wait(q, HSA_SIGNAL_CONDITION_LT, 1, 1000000 /* ~1 ms of the signal's clock */, HSA_WAIT_STATE_ACTIVE);
+            if (v < 1) return v == 0;
+        }
         return false;
     }
     bool copy_on(int engine, void* dst, hsa_agent_t cpu, const void* src, hsa_agent_t gpu, size_t bytes, hsa_signal_t q) {
@@ -1426,6 +1380,7 @@ struct HsaCopy {
         engine_us = us_per_byte = 0.0;
         slow_calls = 0;
         ratio_min = 0.0;
+        ++calibrations;
         uint32_t avail = 0, pref = 0;
         if (!async_copy_on || !engine_status || engine_status(cpu, gpu, &avail) != HSA_STATUS_SUCCESS || !avail) return;
         if (preferred_engines && preferred_engines(cpu, gpu, &pref) == HSA_STATUS_SUCCESS && __builtin_popcount(avail & ~pref) >= 2) avail &= ~pref;
@@ -1468,11 +1423,33 @@ struct HsaCopy {
 };
 static HsaCopy g_hsa;
 
+// The engine SELECTION (explicit engine ids, the calibration, the "has an engine turned slow?" model) leans on how ONE build of the runtime numbers and
+// schedules its SDMA engines (profiles/r05_experiments.md 3): it is used only under the HIP runtime it was validated with — like VALIDATED_HIPCC for
+// the compiler (di_fusion_amd/_build.py) — or when DIF_SDMA_ANY_RUNTIME=1 says the tests (tests/test_gpu_handoff.py) have passed with another one.
+// Under any other runtime the copies still go through hsa_amd_memory_async_copy, on the engines the runtime picks.
+#define DIF_VALIDATED_HIP_RUNTIME 70051831      /* hipRuntimeGetVersion of torch 2.10.0+rocm7.0's bundled runtime */
+static std::atomic<int> g_sdma_mode{0};
+int dif_test_sdma_mode(int32_t mode) { return g_sdma_mode.exchange(mode); }
+int dif_sdma_info(int32_t* out) {
+    if (!out) return DIF_EINVAL;
+    std::lock_guard<std::mutex> lock(g_hsa.mu);
+    out[0] = g_hsa.ok ? 1 : 0; out[1] = g_hsa.runtime_version; out[2] = DIF_VALIDATED_HIP_RUNTIME; out[3] = g_hsa.calibrations; out[4] = g_hsa.exports;
+    out[5] = g_hsa.engines[0]; out[6] = g_hsa.engines[1]; out[7] = g_hsa.engines[2];
+    return DIF_OK;
+}
+
 int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int64_t n, float* out_tri, int64_t* out_id, float* out_std) {
     if (!buf || lo < 0 || n < 0 || lo + n > buf->cache_capacity || (n > 0 && (!out_tri || !out_id || !out_std))) return DIF_EINVAL;
     if (n == 0) return DIF_OK;
+    const int mode = g_sdma_mode.load(std::memory_order_relaxed);      // test hook (dif_test_sdma_mode)
+    if (mode == 2) return DIF_ELAUNCH;                                   // "the runtime cannot be reached": the caller's fallback
     std::lock_guard<std::mutex> lock(g_hsa.mu);
     if (!g_hsa.load()) return DIF_ELAUNCH;
+    static const bool any_runtime = [] { const char* e = getenv("DIF_SDMA_ANY_RUNTIME"); return e && atoi(e) != 0; }();
+    const bool choose = mode != 1 && (g_hsa.runtime_version == DIF_VALIDATED_HIP_RUNTIME || any_runtime);
+    static bool unchosen = false;                                        // (under g_hsa.mu)
+    if (!choose) { g_hsa.engines[0] = g_hsa.engines[1] = g_hsa.engines[2] = -1; g_hsa.engine_us = -1.0; unchosen = true; }      // the runtime's engines, no model
+    else if (unchosen) { g_hsa.engine_us = 0.0; unchosen = false; }      // (back from a forced mode 1: time the engines again)
     // who owns the two ends: asked of the runtime itself (no agent enumeration, no device-index mapping); memory this runtime instance does not
     // know (another copy of the runtime in the process) shows up as an unknown pointer type and is refused
     hsa_amd_pointer_info_t src{}, dst{};
@@ -1498,6 +1475,7 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
     bool landed = true;
     for (int k = 0; k < issued; ++k) landed = g_hsa.wait_one(g_hsa.sig3[k]) && landed;
     if (issued < 3 || !landed) return DIF_ELAUNCH;
+    ++g_hsa.exports;
     // an engine that has turned slow: the whole export took more than 2.2 times what ALL its bytes would take on the fastest engine alone (the three
     // ranges share the link: the large exports of a map-building transient must not look slow), four exports in a row — look for better engines at
     // the next call
@@ -1508,7 +1486,7 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
         // about half the model's time: an engine that takes 60 us instead of 17 stays inside 2.2 x the model)
         const double ratio = us / expect;
         g_hsa.ratio_min = (g_hsa.ratio_min == 0.0 || ratio < g_hsa.ratio_min) ? ratio : g_hsa.ratio_min * 1.002;
-        const bool slow_now = us > 2.2 * expect || ratio > 2.5 * g_hsa.ratio_min;
+        const bool slow_now = mode == 3 || us > 2.2 * expect || ratio > 2.5 * g_hsa.ratio_min;      // (mode 3: every export counts as slow -> re-calibration)
         g_hsa.slow_calls = slow_now ? g_hsa.slow_calls + 1 : 0;
         static const bool debug = getenv("DIF_SDMA_DEBUG") != nullptr;
         if (debug && slow_now)

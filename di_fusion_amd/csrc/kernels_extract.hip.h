@@ -6,7 +6,7 @@
 // =================================================================================================================
 // set the bitmap bits of the confident voxels among `lin` and its 6 allocated neighbours (map.py:628-631)
 __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float ignore_th, const int64_t* __restrict__ indexer,
-                                                    const float* __restrict__ obs, const GridMarks& marks, const int32_t* __restrict__ pend = nullptr) {
+                                                    const float* __restrict__ obs, const GridMarks& marks) {
     const uint32_t* bits = marks.bits;
     int ix, iy, iz;
     unlinearize(g, lin, ix, iy, iz);
@@ -24,7 +24,7 @@ __device__ __forceinline__ void mark_confident_nbhd(const Geo& g, int lin, float
     for (int c = 0; c < 7; ++c) slot[c] = indexer[cand[c]];
     float w[7];
 #pragma unroll
-    for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? obs[slot[c]] + (pend ? (float)pend[slot[c]] : 0.0f) : ignore_th;      // (scan-ahead: DirtySet.pend)
+    for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? obs[slot[c]] : ignore_th;
     uint32_t word[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) word[c] = (w[c] > ignore_th) ? bits[cand[c] >> 5] : 0xFFFFFFFFu;
@@ -74,11 +74,6 @@ struct DirtySet {
     GridMarks bits;
     int64_t own_lin_lo, own_lin_hi;     // only owned voxels are meshed (spatial tiling); the whole grid by default
     bool tiled;
-    // scan-ahead (dif_map_t.scan_ahead): the scan runs BEFORE the frame's fusion kernel — a voxel's observation count is obs + pend (the points the
-    // encoder has just counted for it; exact: integers below 2^24, the sum the fusion kernel writes) — and K goes to the frame's own counter block
-    const int32_t* pend;
-    int* xc;
-    __device__ __forceinline__ int* k_block() const { return xc ? xc : counters; }
     __device__ __forceinline__ bool owned(int s) const {
         if (!tiled) return true;
         const int64_t p = pos[s];
@@ -98,11 +93,12 @@ struct DirtyFunctor {
         if (offset >= a.max_voxels) return;
         const int lin = (int)a.pos[s];
         a.valid_blocks[offset] = lin;
-        mark_confident_nbhd(a.g, lin, a.ignore_th, a.indexer, a.obs, a.bits, a.pend);
+        mark_confident_nbhd(a.g, lin, a.ignore_th, a.indexer, a.obs, a.bits);
     }
     __device__ void finish(int total) const {
         if (total > a.max_voxels) { total = (int)a.max_voxels; a.counters[DIF_C_OVERFLOW] = 2; }
-        a.k_block()[DIF_C_K] = total;
+        a.counters[DIF_C_K] = total;
+        a.counters[DIF_C_DEFERRED] = 0;
     }
 };
 
@@ -110,6 +106,12 @@ struct DirtyFunctor {
 // were kept by whoever set the flags) with its memory chain started EARLY: a thread reads its flag without waiting for n_occupied (flags
 // beyond it are never set), and a dirty slot's position -> 7 neighbour look-ups -> 7 observation counts -> 7 bitmap words are requested
 // before the two block-wide sums of the prefix, not after them — nine dependent hops become six.
+// DEFERRAL instead of overflow: the per-voxel extract buffers of a stream are sized by the high-water mark of what its frames decoded, not by the
+// map's capacity (7.7 KB per row).  A frame decodes B <= min(7 K, n_occupied) voxels (the dirty voxels and their confident 6-neighbours); when that
+// bound exceeds the rows there are, every workgroup leaves the launch BEFORE it has changed anything — flags, block totals and bitmap untouched —,
+// K = 0 goes to the counters and the bound to counters[DIF_C_DEFERRED]: the frame's extract then finds nothing to do, the caller (which sees the
+// word with the frame's snapshot) grows its buffers, and the next extract meshes the accumulated dirty set — the mesh a voxel ends up with is the
+// same, one or two frames later (include/difusion.h).
 __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __restrict__ n_ptr, const int* __restrict__ block_tot,
                                                 uint32_t* __restrict__ fused_word, int seq) {
     __shared__ int smem[8];
@@ -120,7 +122,7 @@ __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __
     const bool flag = a.dirty[s] != 0;
     if (!__syncthreads_or((int)flag) && blockIdx.x != 0) return;            // nothing dirty among this block's 256 slots (most blocks of a frame)
     int before = 0, all = 0;
-    const int n_blk = blockIdx.x == 0 ? (int)gridDim.x : (int)blockIdx.x;  // block 0 also reports the grand total
+    const int n_blk = (int)gridDim.x;                                      // every block needs the grand total (deferral), block 0 reports it
     for (int b = (int)threadIdx.x; b < n_blk; b += DIF_BLOCK) {
         const int t = block_tot[b];
         all += t;
@@ -148,7 +150,7 @@ __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __
         for (int c = 0; c < 7; ++c) slot[c] = a.indexer[cand[c]];
         float w[7];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? a.obs[slot[c]] + (a.pend ? (float)a.pend[slot[c]] : 0.0f) : a.ignore_th;
+        for (int c = 0; c < 7; ++c) w[c] = slot[c] >= 0 ? a.obs[slot[c]] : a.ignore_th;
 #pragma unroll
         for (int c = 0; c < 7; ++c) word[c] = (w[c] > a.ignore_th) ? marks.bits[cand[c] >> 5] : 0xFFFFFFFFu;
     }
@@ -156,6 +158,13 @@ __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __
     const bool mine = flag && s < n;
     int offset = block_sum(before, smem);
     const int total = block_sum(all, smem);
+    {
+        const int64_t need = min((int64_t)7 * total, (int64_t)n);          // map.py:628-631: the batch is a subset of the dirty voxels' 7-neighbourhoods
+        if (need > a.max_voxels) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { a.counters[DIF_C_K] = 0; a.counters[DIF_C_DEFERRED] = (int)need; }
+            return;
+        }
+    }
     int chunk_total;
     const int ex = block_excl_scan(mine ? 1 : 0, smem, chunk_total);
     if (mine) {
@@ -176,7 +185,8 @@ __device__ __forceinline__ void dirty_scan_body(const DirtySet& a, const int* __
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int t = total;
         if (t > a.max_voxels) { t = (int)a.max_voxels; a.counters[DIF_C_OVERFLOW] = 2; }
-        a.k_block()[DIF_C_K] = t;
+        a.counters[DIF_C_K] = t;
+        a.counters[DIF_C_DEFERRED] = 0;
     }
 }
 
@@ -200,7 +210,6 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
     int32_t* vbm;
     int* counters;
     int64_t max_voxels;
-    int* xc;                // scan-ahead: B, VH, WORK of the frame's own counter block (NULL: the live words)
     __device__ int count(int w) const { return __popc(bits[w]); }
     __device__ void emit(int w, int offset) const {
         uint32_t word = bits[w];
@@ -218,10 +227,9 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
     }
     __device__ void finish(int total) const {
         if (total > max_voxels) { total = (int)max_voxels; counters[DIF_C_OVERFLOW] = 3; }
-        int* c = xc ? xc : counters;
-        c[DIF_C_B] = total;
-        c[DIF_C_VH] = 0;
-        c[DIF_C_WORK] = 0;
+        counters[DIF_C_B] = total;
+        counters[DIF_C_VH] = 0;
+        counters[DIF_C_WORK] = 0;
     }
 };
 
@@ -515,16 +523,7 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
     }
 }
 
-// Split extract (dif_extract_buffers_t.split_mesh): the refine pass is the LAST kernel of a frame's decode half on the extracts' stream.  Its first
-// workgroup leaves K, B and VH in the frame's counter block (the next frame's kernels rewrite the live words before this frame's marching cubes
-// reads them) and returns the batch scan's block totals to idle 0 (the one-pass marching cubes does that otherwise).
-struct SplitTail { int* fc; const int* counters; int* grid_tot; };
-__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob, SplitTail t) {
-    if (t.fc && blockIdx.x == 0) {
-        if (threadIdx.x == 0) { t.fc[DIF_FC_K] = t.counters[DIF_C_K]; t.fc[DIF_FC_B] = t.counters[DIF_C_B]; t.fc[DIF_FC_VH] = t.counters[DIF_C_VH]; }
-        if (t.grid_tot)
-            for (int i = (int)threadIdx.x; i < 1024; i += (int)blockDim.x) t.grid_tot[i] = 0;
-    }
+__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
     const BatchN<DecodeArgs, 1> B{{A}};
     decode_refine_x6_body<1>(B, 1, wblob);
 }
@@ -625,8 +624,6 @@ struct VoxelDecodeArgs {
     int* counters;
     const float* fold_w;            // packing.py:pack_decoder_fold, or NULL (latent carried through the MFMAs)
     float* fold_table;              // [batch voxel][256] out, for the refine pass
-    uint32_t* fused_word;           // scan-ahead: this is the first kernel behind the frame's fusion kernel on its stream: it says so (DIF_SYNC_FUSED)
-    int seq;
 };
 
 #define VD_MAX_L3 64
@@ -783,7 +780,6 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
 
 template <bool X6>
 __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_decode_voxels(VoxelDecodeArgs A, const float* __restrict__ wblob) {
-    if (A.fused_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.fused_word, (uint32_t)A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const BatchN<VoxelDecodeArgs, 1> B{{A}};
     decode_voxels_body<X6, 1>(B, 1, wblob);
 }

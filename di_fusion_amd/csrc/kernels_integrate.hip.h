@@ -406,7 +406,6 @@ __device__ unsigned long long g_en_trace[4096 * 8];       // (up to 16 waves x 2
 struct EncArgs {
     Geo g; PointSrc src; const uint2* pair_list; int* rec_dir; int* rec_next; long long* rec; int* upd_list; int* counters;
     uint8_t* dirty; int* dirty_tot;
-    int32_t* pend;              // scan-ahead (dif_map_t.scan_ahead): the encoder sets the dirty flags itself and adds each run's length to pend[slot]
 };
 #ifndef ENC_X6_THREADS
 #define ENC_X6_THREADS 768        /* twelve waves per CU: 3,072 tile slots on the chip */
@@ -520,10 +519,7 @@ __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S,
                 // k_fuse will set the slot's dirty flag: if it is not set yet, count it into the total of its 256-slot block here (extract's
                 // ordered compaction of the dirty set then needs no counting pass) — one lane per updated slot and frame, off k_fuse's tail
                 if (a.dirty_tot && !a.dirty[key]) atomicAdd(a.dirty_tot + (key >> 8), 1);
-                if (a.pend) a.dirty[key] = 1;                                               // (scan-ahead: the flag itself too; map.py:452)
             }
-            // scan-ahead: the run's points into the slot's pending count (the lanes of a live run tail's run are all live: rows ascend)
-            if (a.pend) atomicAdd(a.pend + key, col - my_head + 1);
         }
         EN_STAMP(4);
     }
@@ -535,8 +531,8 @@ template <bool X6>
 __global__ void __launch_bounds__(X6 ? ENC_X6_THREADS : 512, X6 ? 1 : 2)
 k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, const dif_frame_t* __restrict__ frame,
          ImageGeo im, int64_t N, const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
-         int* __restrict__ upd_list, int* __restrict__ counters, uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot, int32_t* __restrict__ pend) {
-    const BatchN<EncArgs, 1> B{{EncArgs{g, PointSrc{xyz, normal, frame, im}, pair_list, rec_dir, rec_next, rec, upd_list, counters, dirty, dirty_tot, pend}}};
+         int* __restrict__ upd_list, int* __restrict__ counters, uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
+    const BatchN<EncArgs, 1> B{{EncArgs{g, PointSrc{xyz, normal, frame, im}, pair_list, rec_dir, rec_next, rec, upd_list, counters, dirty, dirty_tot}}};
     encode_body<X6, 1>(B, 1, wblob, N);
 }
 
@@ -584,11 +580,7 @@ __global__ void __launch_bounds__(512, X6 ? 1 : 2) k_encode_rows(const float* __
 __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, const int* __restrict__ rec_next, int* __restrict__ rec_dir,
                                           const int* __restrict__ upd_list, float* __restrict__ latent, float* __restrict__ obs,
                                           uint8_t* __restrict__ dirty, int* __restrict__ counters, const int64_t* __restrict__ slot_lin, const HaloLists& hl,
-                                          dif_pending_export_t* __restrict__ pending, int* __restrict__ dirty_tot, int* __restrict__ fc, uint32_t* __restrict__ decoded_word, int seq,
-                                          int32_t* __restrict__ pend) {
-    // two queues: this kernel runs => everything in front of it on the extracts' stream — the previous frame's decode kernels — has completed: the
-    // word that frame's marching cubes (front-end stream) waits for
-    if (decoded_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(decoded_word, (uint32_t)(seq - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                          dif_pending_export_t* __restrict__ pending, int* __restrict__ dirty_tot, int* __restrict__ fc) {
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) {       // the point kernels' extra workgroups have done the copy (kernels ago: complete)
         pending->pending = 0;
         if (pending->notify) {              // tell the host without an event in the queue (dif_extract_buffers_t.export_notify)
@@ -633,11 +625,8 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
         if (f == 31) {                                       // after every lane of the group has read obs[s]
             obs[s] = w_old + (float)cnt;
             // (two queues: the flag's block total is kept HERE, behind the previous frame's extract, which zeroes the totals — not by the encoder)
-            if (pend) pend[s] = 0;                           // scan-ahead: the encoder flagged the slot, the scans have run: the pending count returns to idle
-            else {
-                if (dirty_tot && !dirty[s]) atomicAdd(dirty_tot + (s >> 8), 1);
-                dirty[s] = 1;                                // map.py:452
-            }
+            if (dirty_tot && !dirty[s]) atomicAdd(dirty_tot + (s >> 8), 1);
+            dirty[s] = 1;                                    // map.py:452
             dir[0] = 0;
             dir[1] = 0;
             if (hl.list && s < first_new) hl.note(s, slot_lin[s]);
@@ -656,14 +645,13 @@ __device__ __forceinline__ void fuse_body(const long long* __restrict__ rec, con
 struct FuseArgs {
     const long long* rec; const int* rec_next; int* rec_dir; const int* upd_list; float* latent; float* obs; uint8_t* dirty; int* counters;
     const int64_t* slot_lin; HaloLists hl; dif_pending_export_t* pending;
-    int* dirty_tot; int* fc; uint32_t* decoded_word; int seq;      // two queues (dif_map_t.frame_seq): block totals of the dirty flags, the frame's counter block, "the previous decode is done"
-    int32_t* pend;              // scan-ahead: the slots' pending counts, returned to idle 0 here (the dirty flags were set by the encoder)
+    int* dirty_tot; int* fc;      // two queues (dif_map_t.frame_seq): block totals of the dirty flags, the frame's counter block
 };
 
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse(FuseArgs a) {
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.fc, a.decoded_word, a.seq, a.pend);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.fc);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_fuse_batch(Batch<FuseArgs> b) {
     const FuseArgs& a = b.s[blockIdx.y];
-    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.fc, a.decoded_word, a.seq, a.pend);
+    fuse_body(a.rec, a.rec_next, a.rec_dir, a.upd_list, a.latent, a.obs, a.dirty, a.counters, a.slot_lin, a.hl, a.pending, a.dirty_tot, a.fc);
 }

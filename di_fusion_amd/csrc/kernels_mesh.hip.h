@@ -750,16 +750,18 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
                                                     const float* __restrict__ log_tri, const int64_t* __restrict__ log_id,
                                                     const float* __restrict__ log_std, const ExtractOut& out, int32_t* __restrict__ chunk_sum,
                                                     int32_t* __restrict__ super_sum, int32_t* __restrict__ dirty_tot, int n_dirty_tot, uint32_t* __restrict__ mc_status, uint32_t* __restrict__ mc_ticket,
-                                                    const int* __restrict__ fc, int live_kbvh = 0) {
-    // (fc: an overlapped frame's own counter block — K, B, VH and the integrate's counters as this frame left them; the live words may be a frame ahead)
-    const int B = fc ? fc[DIF_FC_B] : counters[DIF_C_B];
-    const int Kd = fc ? fc[DIF_FC_K] : counters[DIF_C_K];
+                                                    const int* __restrict__ fc) {
+    // (fc: an overlapped frame's own counter block — the integrate's counters as this frame's fusion kernel left them; the live words may be a frame
+    // ahead.  K, B, VH are written by the extracts' own stream only: the live words are this frame's)
+    const int B = counters[DIF_C_B];
+    const int Kd = counters[DIF_C_K];
     if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
     {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((Kd + 3) >> 2); i += gridDim.x * blockDim.x) mc_status[i] = 0u;
         if (blockIdx.x == 0 && threadIdx.x == 0) *mc_ticket = 0u;
     }
-    if (dirty_tot)                                  // every dirty flag has been consumed by this call: the block totals return to idle 0
+    // every dirty flag has been consumed by this call: the block totals return to idle 0 (a DEFERRED extract consumed none: k_dirty_scan)
+    if (dirty_tot && counters[DIF_C_DEFERRED] == 0)
         for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_dirty_tot; t += gridDim.x * blockDim.x) dirty_tot[t] = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) vbm[occ_slot[i]] = -1;
     if (chunk_sum)                                  // back to idle 0 (only the chunks this call's K dirty voxels could have touched)
@@ -784,12 +786,9 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
         const int lane = (int)threadIdx.x;
         int v = lane < DIF_C_COUNT ? counters[lane] : 0;
         const int live = v;
-        // two queues: the next frame's kernels may be rewriting N_OCCUPIED / ALLOC_NEW / M / C / ITEMS / K / B / VH right now — this frame's values are
-        // the copies its fusion kernel and its last decode kernel left in its own block
+        // two queues: the next frame's front end may be rewriting N_OCCUPIED / ALLOC_NEW / M / C / ITEMS right now — this frame's values are the copies
+        // its fusion kernel left in its own block
         if (fc && (lane == DIF_C_N_OCCUPIED || (lane >= DIF_C_ALLOC_NEW && lane <= DIF_C_ITEMS))) v = fc[DIF_FC_SHADOW + (lane == DIF_C_N_OCCUPIED ? 0 : lane - DIF_C_ALLOC_NEW + 1)];
-        if (fc && lane == DIF_C_K) v = fc[DIF_FC_K];
-        if (fc && lane == DIF_C_B) v = fc[DIF_FC_B];
-        if (fc && lane == DIF_C_VH) v = fc[DIF_FC_VH];
         if (lane == DIF_C_CACHE_T) v = (int)tot;
         if (lane == DIF_C_OVERFLOW && over) v = 5;
         // (the snapshot and its stamp go to pinned host memory as write-through stores of ONE wave, the stamp after the snapshot's stores have been
@@ -816,9 +815,6 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
             else if (over) counters[DIF_C_OVERFLOW] = 5;
         }
         if (lane == 0) counters[DIF_C_CACHE_T] = (int)tot;
-        // scan-ahead frames count K, B, VH in their own block only: the live words follow here, so that whoever reads the map's counters after
-        // the stream (dif_read_counters) finds the last frame's values (no other kernel writes or reads these three in that mode)
-        if (live_kbvh && fc && (lane == DIF_C_K || lane == DIF_C_B || lane == DIF_C_VH)) counters[lane] = v;
     }
 }
 
@@ -826,16 +822,15 @@ struct FinishArgs {
     const int32_t* occ_slot; int32_t* vbm; int* counters; int64_t new_limit, capacity; const float* log_tri; const int64_t* log_id; const float* log_std;
     ExtractOut out; int32_t* chunk_sum; int32_t* super_sum; int32_t* dirty_tot; int n_dirty_tot; uint32_t* mc_status; uint32_t* mc_ticket;
     const int* fc;          // two queues: the frame's own counter block (dif_map_t.frame_counters) or NULL
-    int live_kbvh;          // scan-ahead: K, B, VH also into the live counters
 };
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish(FinishArgs a) {
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc, a.live_kbvh);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc);
 }
 __global__ void __launch_bounds__(DIF_BLOCK) k_extract_finish_batch(Batch<FinishArgs> b) {
     const FinishArgs& a = b.s[blockIdx.y];
     extract_finish_body(a.occ_slot, a.vbm, a.counters, a.new_limit, a.capacity, a.log_tri, a.log_id, a.log_std, a.out, a.chunk_sum, a.super_sum, a.dirty_tot,
-                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc, a.live_kbvh);
+                        a.n_dirty_tot, a.mc_status, a.mc_ticket, a.fc);
 }
 
 struct TriScanFunctor {         // exclusive scan of the per-voxel triangle counts; on the mesh-cache path also the log bookkeeping

@@ -179,7 +179,10 @@ class DenseIndexedMap:
         self.optimize_noise = None          # optional (k,) tensor of N(0,1) samples for the optimiser's perturbations (default: torch.randn)
         self.optimize_losses = None         # device float[64]: likelihood loss before each Adam step of the last optimisation
         self._cache_call_limit = 0          # max_n_triangles of the latest extract (what one more call may append to the log)
-        self.extract_buffer_bytes = 8 << 30 # upper bound for the per-voxel extract buffers sized ahead of the occupancy (see _extract_buffers)
+        self.extract_buffer_bytes = 8 << 30 # upper bound for the per-voxel extract buffers (see _extract_rows)
+        self._extract_high_water = 0        # most voxels any extract of this map has decoded or meshed (max over frames of B, K)
+        self._extract_rows_wanted = 0       # rows the last DEFERRED extract would have needed (counters[DIF_C_DEFERRED]); 0 = none deferred
+        self.n_deferred = 0                 # extracts that deferred themselves (their dirty set was meshed by a later one)
         self._query_ws = None               # get_sdf: scan scratch + pinned count slots
         self._halo_list = None              # spatial tiling: boundary change lists (dif_map_t.halo_list)
         self._halo_lists_stale = True       # the lists do not cover every change since the last halo export: whole-layer messages next
@@ -196,9 +199,8 @@ class DenseIndexedMap:
             # front end may run beside the previous frame's extract (two queues, FusionStream.overlap)
             self._alloc_bits = torch.zeros(((self._grid + 31) // 32,), device=device, dtype=torch.int32)
             self._alloc_tot = torch.zeros((1024,), device=device, dtype=torch.int32)
-            self._grid_tot_b = torch.zeros((1024,), device=device, dtype=torch.int32)                 # the marker's block totals of the frames of odd parity (scan-ahead)
             self._sync_words = torch.zeros((_lib.SYNC_WORDS,), device=device, dtype=torch.int32)     # dif_map_t.sync_words
-            self._frame_counters = torch.zeros((2, _lib.FC_COUNT), device=device, dtype=torch.int32)  # dif_map_t.frame_counters, one block per frame parity
+            self._frame_counters = torch.zeros((_lib.FC_COUNT,), device=device, dtype=torch.int32)    # dif_map_t.frame_counters
             self._counters = torch.zeros((_lib.C_COUNT,), device=device, dtype=torch.int32)
             self._pending_export = torch.zeros((32,), device=device, dtype=torch.int32)        # dif_pending_export_t (72 bytes), idle all-zero
         self._capacity = 0
@@ -228,12 +230,6 @@ class DenseIndexedMap:
             tri_start = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             tri_n = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             self._dirty_tot = torch.zeros(((capacity + 255) // 256,), dtype=torch.int32, device=dev)       # set dirty flags per 256 slots
-            # overlapped frames alternate between two batch maps and two sets of dirty-flag totals (frame n's marching cubes runs beside frame n+1's
-            # batch scan and fusion kernel: FusionStream, dif_extract_buffers_t.split_mesh); idle -1 / 0 like the first ones
-            self._vbm_b = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
-            self._dirty_tot_b = torch.zeros(((capacity + 255) // 256,), dtype=torch.int32, device=dev)
-            # points the encoder has counted for a slot and the fusion kernel has not yet added (dif_map_t.pend_cnt): zero outside a frame
-            self._pend_cnt = torch.zeros((capacity,), dtype=torch.int32, device=dev)
             if self._capacity > 0:
                 c = self._capacity
                 lat[:c] = self._latent
@@ -282,9 +278,7 @@ class DenseIndexedMap:
         m.sync_words = _lib.ptr(self._sync_words)
         m.frame_seq = 0                     # two queues off; FusionStream sets it (and fuse_stream) per overlapped frame
         m.fuse_stream = None
-        m.front_stream = None
-        m.pend_cnt = _lib.ptr(self._pend_cnt)
-        m.scan_ahead = 0
+        m.frame_counters = None
         self._cmap = m
         self._recount_dirty()
 
@@ -319,7 +313,8 @@ class DenseIndexedMap:
                                   items=c[_lib.C_ITEMS], K=c[_lib.C_K], B=c[_lib.C_B], VH=c[_lib.C_VH], T=c[_lib.C_T],
                                   query_M=c[_lib.C_QUERY_M], opt_rows=c[_lib.C_OPT_ROWS], opt_voxels=c[_lib.C_OPT_VOXELS],
                                   cache_T=c[_lib.C_CACHE_T], cache_kept=c[_lib.C_CACHE_KEPT],
-                                  cache_dead=c[_lib.C_CACHE_DEAD], cache_live=c[_lib.C_CACHE_LIVE])
+                                  cache_dead=c[_lib.C_CACHE_DEAD], cache_live=c[_lib.C_CACHE_LIVE], deferred=c[_lib.C_DEFERRED])
+        self._extract_high_water = max(self._extract_high_water, c[_lib.C_B], c[_lib.C_K])
         return self.last_counters
 
     def _read_counters(self):
@@ -636,33 +631,38 @@ class DenseIndexedMap:
         o = self._cache_out
         return o[0][:n], o[1][:n], o[2][:n]
 
-    def _extract_buffers(self, resolution: int, max_n_triangles: int, max_vox: int = None, second: bool = False):
-        """`second`: the other set of per-voxel buffers (same shapes), for the frames of odd parity of a stream whose marching cubes runs beside the
-        next frame's decode (FusionStream two queues, dif_extract_buffers_t.split_mesh); `max_vox` must be given."""
-        if second:
-            key = (resolution, int(max_vox))
-            if getattr(self, "_xbuf_b", None) is None or self._xbuf_b[0] != key:
-                self._xbuf_b = (key, {k: (torch.zeros_like(v) if k in ("chunk_sum", "mc_status") else torch.empty_like(v)) for k, v in self._xbuf[1].items()})
-                assert self._xbuf[0] == key, "the first set of extract buffers is sized first"
-            t = self._xbuf_b[1]
-            b = self._cache_struct()
-            b.max_voxels = int(max_vox)
-            b.max_triangles = int(max_n_triangles)
-            for k, v in t.items():
-                setattr(b, k, _lib.ptr(v))
-            return t, b
+    MIN_EXTRACT_ROWS = 1 << 15
+
+    def _extract_rows(self, resolution: int, no_cache: bool = False) -> int:
+        """Rows of the per-voxel extract buffers (~7.7 KB per row at resolution 4).
+        A streaming map (untiled, more than 4,096 slots, not `no_cache`) cannot overflow them: an extract whose dirty set could need more rows
+        than there are DEFERS itself on the device (`k_dirty_scan`, counters[DIF_C_DEFERRED]: nothing changed, dirty set kept), the host sees
+        the rows it wanted with that frame's counters, grows the buffers here, and the next extract meshes the accumulated dirty set.  Such maps
+        get four times the high-water mark of what a frame has decoded so far (at least MIN_EXTRACT_ROWS) — not the map's CAPACITY, which was
+        4 GB for the 524,288-slot map of a 640x480 stream that decodes 1-13 k voxels per frame.  Every other map keeps rows for its whole
+        occupancy bound (there the device can only flag an overflow).  Never shrinks (pointers stay stable), never exceeds the capacity."""
+        R = 2 * resolution
+        per_voxel = (R ** 3) * 12 + (resolution ** 3) * 8 + 1024 + 64
+        if not no_cache and not self._tiled and self._capacity > 4096:
+            rows = _next_pow2(max(self.MIN_EXTRACT_ROWS, 4 * self._extract_high_water, 2 * self._extract_rows_wanted))
+            while rows > 4096 and rows * per_voxel > self.extract_buffer_bytes:
+                rows //= 2
+        else:
+            rows = _next_pow2(max(self._n_occ_ub, 1024))
+            # Room to grow: four times the occupancy bound, at most the map's capacity and at most `extract_buffer_bytes` — re-allocating
+            # ~8 KB per voxel every time the occupancy crosses a power of two costs tens of milliseconds in the middle of a stream
+            roomy = min(self._capacity, 4 * rows)
+            if roomy * per_voxel <= self.extract_buffer_bytes:
+                rows = max(rows, roomy)
+        rows = min(rows, _next_pow2(self._capacity))
+        if self._xbuf is not None and self._xbuf[0][0] == resolution:
+            rows = max(rows, self._xbuf[0][1])
+        return rows
+
+    def _extract_buffers(self, resolution: int, max_n_triangles: int, max_vox: int = None, no_cache: bool = False):
         R = 2 * resolution
         if max_vox is None:
-            max_vox = _next_pow2(max(self._n_occ_ub, 1024))
-            # Room to grow: four times the occupancy bound, at most the map's capacity and at most `extract_buffer_bytes` (8 GB unless the
-            # caller sets it) — re-allocating ~8 KB per voxel every time the occupancy crosses a power of two costs tens of milliseconds in
-            # the middle of a stream, while sizing for the capacity of a nearly empty map would tie up gigabytes for nothing.
-            per_voxel = (R ** 3) * 12 + (resolution ** 3) * 8 + 1024 + 64
-            roomy = min(self._capacity, 4 * max_vox)
-            if roomy * per_voxel <= self.extract_buffer_bytes:
-                max_vox = max(max_vox, roomy)
-            if self._xbuf is not None and self._xbuf[0][0] == resolution and self._xbuf[0][1] >= max_vox:
-                max_vox = self._xbuf[0][1]                      # never shrink: keeps pointers stable
+            max_vox = self._extract_rows(resolution, no_cache)
         key = (resolution, max_vox)
         if self._xbuf is None or self._xbuf[0] != key:
             dev = self.device
@@ -705,7 +705,7 @@ class DenseIndexedMap:
             # which was enqueued completely under the same lock (the reference drains the device instead, map.py:625).
             if self._integrate_done is not None:
                 torch.cuda.current_stream().wait_event(self._integrate_done)
-            tens, buf = self._extract_buffers(voxel_resolution, max_n_triangles)
+            tens, buf = self._extract_buffers(voxel_resolution, max_n_triangles, no_cache=no_cache)
             w = self.model.packed.weights_struct(self.device)
             _lib.check(lib.dif_extract(ctypes.byref(self._cmap), ctypes.byref(w), ctypes.byref(buf), int(voxel_resolution), 1 if fast else 0,
                                        float(max_std), 1 if no_cache else 0, 1, _lib.stream_ptr()), "dif_extract")
@@ -728,6 +728,9 @@ class DenseIndexedMap:
         else:
             handle["event"].synchronize()
         c = self._publish_counters(handle["counters"].tolist(), handle["add_total"])
+        if c["deferred"] > 0:               # the extract found its buffers too small and changed nothing: the next one runs with more rows
+            self._extract_rows_wanted = max(self._extract_rows_wanted, int(c["deferred"]))
+            self.n_deferred += 1
         if c["T"] >= handle["max_n_triangles"]:
             logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {handle['max_n_triangles']}")
         if c["K"] > 0:
@@ -751,6 +754,8 @@ class DenseIndexedMap:
         vertices_flatten_id (T,) i64, vertices_std (T,3) f32) as numpy (`to_host`) or as device views; None while the cache is
         empty and nothing was dirty."""
         self.extract_mesh_finish(self.extract_mesh_enqueue(voxel_resolution, max_n_triangles, fast, max_std, no_cache))
+        while self.last_counters["deferred"] > 0:      # grow-and-retry: this call hands the whole dirty set's mesh back (map.py:624-714)
+            self.extract_mesh_finish(self.extract_mesh_enqueue(voxel_resolution, max_n_triangles, fast, max_std, no_cache))
         if not self._cache_any:
             return None
         if not to_host:

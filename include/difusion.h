@@ -61,6 +61,11 @@ enum {
     DIF_C_HALO_L = 20,      /* entries appended to the LEFT / RIGHT boundary change list (dif_map_t.halo_list) since the last    */
     DIF_C_HALO_R = 21,      /* halo export; may exceed halo_list_cap (then the list is incomplete and the delta export says so)   */
     DIF_C_HALO_TICKET = 22, /* idle 0: workgroups of dif_export_halo_delta that are done                                          */
+    DIF_C_DEFERRED = 23,    /* 0, or the rows the per-voxel extract buffers would have needed when the last streaming extract (dirty_tot set, untiled,
+                             * capacity > 4096) found them too small for min(7 K, n_occupied) voxels: that extract then changed NOTHING (dirty set kept,
+                             * K = B = T = 0) — the caller grows dif_extract_buffers_t.max_voxels and the next extract meshes the accumulated dirty set */
+    DIF_C_DEC_TICKET = 24,  /* idle 0: the persistent decoder's claim counter and its count of completed lattice groups (returned to 0 by the     */
+    DIF_C_DEC_DONE = 25,    /* batch scan in front of it)                                                                                        */
     DIF_C_STAMP = 31,       /* snapshots handed to the caller only (dif_extract_buffers_t.counters_out): the extract's `stamp`, written LAST        */
     DIF_C_COUNT = 32
 };
@@ -126,41 +131,24 @@ typedef struct dif_map {
      * (observation count 0 => not confident, batch row -1 => missing: mc_interp_kernel.cu:17-24, map.py:628-631), the allocation bitmap is
      * `alloc_bits`, the dirty-flag block totals are kept by the fusion kernel (behind the extract) instead of the encoder, and the counters of
      * frame n's integrate that its extract hands to the caller are the copies the fusion kernel left in counters[DIF_C_SHADOW ..].  Requires
-     * alloc_bits, dirty_tot, capacity > 4096 (a multiple of 256), no deferred export (pending_export idle), an untiled map.  On streams that share
-     * a hardware queue (dif_queues_independent) the frames are serialised in enqueue order — correct, nothing gained.  The caller advances
+     * alloc_bits, dirty_tot, frame_counters, capacity > 4096 (a multiple of 256), no deferred export (pending_export idle), an untiled map.  On
+     * streams that share a hardware queue (dif_queues_independent) the packets serialise in enqueue order and every wait's producer was enqueued
+     * first — correct, nothing gained.  The caller advances
      * frame_seq by one per frame, uses the same value for the frame's integrate and extract, and starts from words that hold frame_seq - 1.
      * frame_seq = 0: off. */
     uint32_t* sync_words;           /* [DIF_SYNC_WORDS] device memory */
     int32_t frame_seq;
     void* fuse_stream;              /* hipStream_t of the extracts: where an overlapped frame's fusion kernel goes */
     /* Overlapped frames: int32[DIF_FC_COUNT] of THIS frame (the caller alternates between two blocks): the fusion kernel leaves the integrate's
-     * counters here ([DIF_FC_SHADOW ..]: N_OCCUPIED, ALLOC_NEW, M, C, ITEMS), the last decode kernel of the frame's extract K, B and VH — what the
-     * frame's marching cubes and its counter snapshot use while the next frame's kernels already rewrite the live words.  The same goes for `vbm`
-     * and `dirty_tot`: the caller passes frame n's extract (both halves) and integrate the arrays of parity n & 1. */
+     * counters here ([DIF_FC_SHADOW ..]: N_OCCUPIED, ALLOC_NEW, M, C, ITEMS) — what the frame's counter snapshot reports while the next frame's
+     * front end already rewrites the live words.  (K, B, VH are written on the extracts' stream only: the live words are the frame's.) */
     int32_t* frame_counters;
-    /* Split extracts on a stream of their own: > 0 = the front end of this frame first waits until sync_words[DIF_SYNC_MESHED] >= mesh_wait — the mesh
-     * half of frame_seq - 2 has completed, so the decode of this frame (which reuses that frame's buffers) cannot overtake it. */
-    int32_t mesh_wait;
-    /* The scans of an overlapped frame's extract in its FRONT END (`scan_ahead` != 0, with frame_seq > 0): what frame n's extract decodes is known
-     * before its fusion kernel has run — the voxels its encoder updated, and which of them and of their neighbours are confident once the frame's
-     * points are counted in — so the dirty-set compaction + neighbourhood marker and the batch scan (map.py:627-631), two latency-bound launches of
-     * ~19 us, leave the extracts' stream: dif_integrate_frame's encoder sets the dirty flags and their block totals itself and adds every run's
-     * length to `pend_cnt[slot]` (int32 per slot, idle 0; the fusion kernel returns it to 0), and does NOT publish DIF_SYNC_FRONT_DONE;
-     * dif_extract runs the two scans on `front_stream` — counting a voxel as observed `voxel_obs_count + pend_cnt` times, the value the fusion
-     * kernel is about to write —, publishes DIF_SYNC_FRONT_DONE behind them, and its first decode kernel (on `fuse_stream`) publishes
-     * DIF_SYNC_FUSED.  K, B, VH live in the frame's counter block from the start ([DIF_FC_XC + DIF_C_K ...]).  The extracts' stream then carries
-     * fuse, lattice decode, refine, marching cubes, finish.  The caller alternates `grid_tot` by frame parity too (like vbm / dirty_tot / the
-     * extract buffers): frame n's marching cubes returns its block totals to idle while frame n + 1's marker already counts into the other set. */
-    void* front_stream;             /* hipStream_t of the front ends (the stream dif_integrate_frame is called on) */
-    int32_t* pend_cnt;
-    int32_t scan_ahead;
 } dif_map_t;
 
 /* sync_words (each on a 128-byte line of its own): frame n's fusion kernel has completed (written by the first kernel of its extract); frame n's front
- * end has completed; frame n's decode kernels have completed (written by the fusion kernel of frame n + 1 as it starts — or by dif_extract_mesh's caller
- * simply running that call on the extracts' stream) */
-enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_DECODED = 64, DIF_SYNC_MESHED = 96, DIF_SYNC_WORDS = 128 };     /* MESHED: frame n's mesh half has completed */
-enum { DIF_FC_K = 0, DIF_FC_B = 1, DIF_FC_VH = 2, DIF_FC_SHADOW = 4, DIF_FC_XC = 16, DIF_FC_COUNT = 32 };    /* [DIF_FC_XC + DIF_C_*]: K, B, VH, WORK of a scan-ahead frame */
+ * end has completed */
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_WORDS = 64 };
+enum { DIF_FC_SHADOW = 4, DIF_FC_COUNT = 32 };
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
 typedef struct dif_pending_export {
@@ -360,11 +348,6 @@ typedef struct dif_extract_buffers {
      *                    dif_integrate_frame(s) that carried the deferred copy out (its point kernels copy, its fusion kernel notifies). */
     int32_t stamp;
     int32_t* export_notify;
-    /* Overlapped frames (dif_map_t.frame_seq) with the one-pass marching cubes: != 0 = dif_extract runs the DECODE half only (dirty set, batch,
-     * lattice + refine decode) and dif_extract_mesh — enqueued by the caller behind the NEXT frame's integrate, on the front-end stream — runs
-     * marching cubes and the finish kernel: the extracts' stream then carries fuse, decode, fuse, decode, ... and a frame's meshing runs beside the
-     * next frame's decode.  Needs extract buffers (and dif_map_t.vbm / dirty_tot / frame_counters) of alternating parity for consecutive frames. */
-    int32_t split_mesh;
 } dif_extract_buffers_t;
 
 /* resolution r (map.py:581 voxel_resolution; lattice R=2r), fast!=0: two-level decode (low lattice l=r, trilinear x2,
@@ -527,14 +510,6 @@ int64_t dif_profile_dump(int32_t* which /* host */, float* ms /* host */, int64_
 /* Copy the counters to the host; the only synchronising call (hipStreamSynchronize on `stream`). */
 int dif_read_counters(const dif_map_t* map, int32_t* host_out /* [DIF_C_COUNT], host */, void* stream);
 
-/* The mesh half of a split extract (dif_extract_buffers_t.split_mesh): one-pass marching cubes + the finish kernel (counter snapshot, stamp) of the
- * frame whose decode half dif_extract enqueued with the same map fields and buffers.  wait_decoded != 0: first wait, on the device, until
- * sync_words[DIF_SYNC_DECODED] >= frame_seq (the next frame's fusion kernel says so as it starts: enqueue this call BEHIND that frame's
- * dif_integrate_frame); 0: the call runs on the extracts' stream itself, behind the decode kernels (the last frame of a stream).  Either way a one-wave
- * kernel behind the finish kernel publishes sync_words[DIF_SYNC_MESHED] = frame_seq (dif_map_t.mesh_wait). */
-int dif_extract_mesh(const dif_map_t* map, const dif_extract_buffers_t* buf, int32_t resolution, float max_std, int32_t scale_vertices,
-                     int32_t wait_decoded, void* stream);
-
 /* 1 if work on streams `a` and `b` really runs concurrently — they sit on different hardware queues —, 0 if not, negative on error: a kernel on `a`
  * waits (bounded: ~20 ms) for a word that a kernel enqueued LATER on `b` writes.  HIP shares a hardware queue between streams once more than
  * GPU_MAX_HW_QUEUES (default 4) are alive; a device-side wait (dif_map_t.frame_seq) between two streams that share one would never end.
@@ -551,6 +526,13 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
  * (n <= 0: no cap, the default), so that a small map takes the ticket path that otherwise only a map with thousands of dirty voxels takes.  Process-wide;
  * returns the previous cap.  (Until round 5 this was the environment variable DIF_MC_GRID, read at every call.) */
 int dif_test_mc_grid_cap(int32_t n);
+/* TEST HOOK: how dif_mesh_cache_export_sdma behaves from now on (process-wide; returns the previous mode): 0 = default; 1 = leave the engine choice to
+ * the runtime (what happens under a HIP runtime other than the validated one); 2 = fail with DIF_ELAUNCH (what happens when the process's HSA runtime
+ * cannot be reached: the caller falls back to dif_mesh_cache_export_dma); 3 = count every export as slow (the engines are timed again after four). */
+int dif_test_sdma_mode(int32_t mode);
+/* out (host, int32[8]): HSA runtime reached (0/1), hipRuntimeGetVersion of the process, the version the engine selection was validated with,
+ * engine calibrations so far, exports so far, the three engines in use (-1: the runtime's choice). */
+int dif_sdma_info(int32_t* out);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,8 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "soak: long GPU runs of seeds / windows / modes that the default suite covers once — selected only when the "
+                                       "marker expression names them (`pytest -m soak`, tools/gpu_soak.sh); never part of `-m gpu` or `-m 'not gpu'`")
 
 
 def has_gpu():
@@ -23,8 +25,16 @@ def has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a machine without a GPU must fail loudly, not silently skip: the product has no CPU fallback.
-    pass
+    # (`-m gpu` on a machine without a GPU must fail loudly, not silently skip: the product has no CPU fallback.)
+    # soak tests run only when asked for by name: the driver's `-m gpu` step has a time limit, and `-m "not gpu"` runs without a GPU
+    if "soak" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("soak") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope="session")

@@ -51,7 +51,7 @@ def _frame_state(st, f):
 
 def _frame_extract(st, c):
     m = st.map
-    tens = st.last_tensors if st.last_tensors is not None else m._xbuf[1]     # (two queues: consecutive frames alternate between two buffer sets)
+    tens = st.last_tensors if st.last_tensors is not None else m._xbuf[1]
     K, B = int(c[_lib.C_K]), int(c[_lib.C_B])
     lo, hi = int(c[_lib.C_CACHE_KEPT]), int(c[_lib.C_CACHE_T])
     tri, tid, tstd, _ = m._cache
@@ -102,18 +102,16 @@ def _new_worst():
     return dict(lat_ref=0.0, lat_oracle=0.0, cube_ref=0.0, cube_oracle=0.0, flips=0, gated=0)
 
 
-@pytest.mark.parametrize("name,overlap", [("seq_c3_long", True), ("seq_c3_long", False), ("seq_c3_long", "split"), ("seq_c3_long", "scan"), ("seq_c2_long", True)])
+@pytest.mark.parametrize("name,overlap", [("seq_c3_long", True), pytest.param("seq_c3_long", False, marks=pytest.mark.soak),
+                                          pytest.param("seq_c2_long", True, marks=pytest.mark.soak)])
 def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model, oracle_net):
     """overlap: the bench's default — frame i+1's integrate front end on a second hardware queue beside frame i's extract
-    (`FusionStream.enable_overlap`); "split": also the frame's marching cubes on a third queue beside the next frame's decode; "scan": the frame's
-    two extract scans in its front end, before its fusion kernel (`scan_ahead`); False: every
-    frame's twelve launches on one queue."""
+    (`FusionStream.enable_overlap`); False: every frame's launches on one queue.  (`-m gpu` runs the default path on the driver's window;
+    the one-queue run and the C2 window with 64 % of the voxels past the 600-count gate are `-m soak`: tools/gpu_soak.sh.)"""
     from oracle import difusion_oracle as O
     g = np.load(GOLDEN / f"{name}.npz")
     F = int(g["n_frames"])
     st, scene, cfg, phase = _make(gpu_model, name, F)
-    st.split_mesh = overlap == "split"
-    st.scan_ahead = overlap == "scan"
     if overlap and not st.enable_overlap():
         pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
     om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
@@ -121,7 +119,6 @@ def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model,
     per_frame, delivered = [], []
     for f in range(F):
         out = _drive(st, f, "dma")
-        st.complete_frames()            # (two queues: the frame's marching cubes is otherwise enqueued behind the NEXT frame's integrate)
         torch.cuda.synchronize()
         if out is not None:
             delivered.append(tuple(x.clone() for x in out))
@@ -133,7 +130,7 @@ def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model,
     assert np.abs(st.map.latent_vecs[:n].cpu().numpy() - g["last_latent_vecs"]).max() < LATENT_TOL
     print(f"  {name}: {F} frames through step_direct(dma); vs reference: latents {worst['lat_ref']:.1e}, cubes {worst['cube_ref']:.1e}; vs oracle: latents "
           f"{worst['lat_oracle']:.1e}, cubes {worst['cube_oracle']:.1e}; {worst['flips']} samples at the refinement threshold; {worst['gated']} of {n} voxels past the gate")
-    assert worst["gated"] > 0.3 * n
+    assert worst["gated"] > 0.3 * n and st.map.n_deferred == 0
     # what the HOST received (pinned slot, by the copy beside the next frame) is the frame's log rows, bit for bit
     assert len(delivered) == F
     for f, (a, b) in enumerate(zip(per_frame, delivered)):
@@ -143,8 +140,6 @@ def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model,
     del st
     torch.cuda.empty_cache()
     st, _, _, _ = _make(gpu_model, name, F)
-    st.split_mesh = overlap == "split"
-    st.scan_ahead = overlap == "scan"
     if overlap:
         assert st.enable_overlap()
     got = []

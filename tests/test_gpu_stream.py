@@ -1,5 +1,5 @@
-"""GPU: the three ways `FusionStream` drives a frame (eager, software-pipelined, hipGraph replay through the device-resident frame
-descriptor) must leave bit-identical maps and hand back the same triangles."""
+"""GPU: the ways `FusionStream` drives a frame (eager, software-pipelined, direct launches through the device-readable frame descriptor on
+one and on two hardware queues, stream groups) must leave bit-identical maps and hand back the same triangles."""
 import numpy as np
 import pytest
 import torch
@@ -35,7 +35,7 @@ def same(a, b):
     assert a["tri"].shape[0] > 1000
 
 
-def test_eager_pipelined_and_graph_agree(gpu_model):
+def test_eager_pipelined_and_direct_agree(gpu_model):
     outs = {}
     st = make_stream(gpu_model)
     per_frame = []
@@ -59,30 +59,9 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     for a, b in zip(per_frame, got):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
 
-    st = make_stream(gpu_model)
-    got = []
-    st.step(0, d2h="new")                                   # sizes the buffers; the graph takes over from frame 1
-    torch.cuda.synchronize()
-    got.append(per_frame[0])
-    for i in range(1, N_FRAMES):
-        if i == 3:
-            st.map._gc_wanted = True                        # force a mesh-log compaction in mid-stream, with a frame still in flight
-        o = st.step_graph(i, d2h="new")
-        if o is not None:
-            torch.cuda.synchronize()
-            got.append(tuple(x.clone() for x in o))
-    o = st.flush()
-    got.append(tuple(x.clone() for x in o))
-    outs["graph"] = snapshot(st)
-    assert st.map._gc_epoch == 1 and st.n_captures == 1     # compacted once, and the captured graphs survived it
-    assert len(got) == N_FRAMES
-    for a, b in zip(per_frame[1:], got[1:]):
-        assert all(torch.equal(x, y) for x, y in zip(a, b))
-
     same(outs["eager"], outs["pipelined"])
-    same(outs["eager"], outs["graph"])
 
-    # direct launches through the frame descriptor (two C calls per frame, no graph), with a forced compaction and a tiny staging area
+    # direct launches through the frame descriptor (two C calls per frame), with a forced compaction
     st = make_stream(gpu_model)
     got = []
     st.step(0, d2h="new")
@@ -103,9 +82,8 @@ def test_eager_pipelined_and_graph_agree(gpu_model):
     same(outs["eager"], snapshot(st))
 
 
-@pytest.mark.parametrize("split", [False, True, "scan", "split+scan"])
 @pytest.mark.parametrize("d2h", ["dma", "none"])
-def test_two_queue_frames_are_bit_identical(d2h, split, gpu_model):
+def test_two_queue_frames_are_bit_identical(d2h, gpu_model):
     """`enable_overlap`: frame i+1's integrate front end (unproject ... encoder) on a second hardware queue beside frame i's extract, its
     fusion kernel behind that extract, every extract behind its frame's fusion kernel (device-side waits on words the kernels publish:
     dif_map_t.frame_seq).  Every frame's triangles and the final map equal the eager single-queue run bit for bit — with new voxels
@@ -121,8 +99,6 @@ def test_two_queue_frames_are_bit_identical(d2h, split, gpu_model):
     ref = snapshot(st)
     for rep in range(3):
         st = make_stream(gpu_model, initial_capacity=(1 << 13) if rep < 2 else None)
-        st.split_mesh = split in (True, "split+scan")       # (the frame's marching cubes + finish on a third queue beside the next frame's decode)
-        st.scan_ahead = split in ("scan", "split+scan")     # (the frame's two extract scans in its front end, before its fusion kernel)
         if not st.enable_overlap():
             pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
         got = []
@@ -152,54 +128,10 @@ def test_two_queue_frames_are_bit_identical(d2h, split, gpu_model):
             assert st.map._gc_epoch == 1
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_host_two_frames_ahead_hands_back_the_same_frames(overlap, gpu_model):
-    """`host_depth = 2`: step_direct(i) returns frame i-2 (normally complete already), so the host never waits for the frame in front of the
-    one it enqueues — what lets the two-queue mode queue the next front end in time.  Same triangles, same order, same final map as the eager
-    run; a forced log compaction and a map short of room (every frame first completes what is pending) included."""
-    st = make_stream(gpu_model)
-    F = N_FRAMES
-    per_frame = []
-    for i in range(F):
-        o = st.step(i, d2h="new")
-        torch.cuda.synchronize()
-        per_frame.append(tuple(x.clone() for x in o))
-    ref = snapshot(st)
-    for rep, cap in enumerate([None, 1 << 13]):
-        for d2h in ("dma", "none"):
-            st = make_stream(gpu_model, initial_capacity=cap)
-            st.host_depth = 2
-            st.split_mesh = bool(overlap)       # (the combination the split extract is meant for)
-            st.scan_ahead = bool(overlap and rep == 1)
-            if overlap and not st.enable_overlap():
-                pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
-            got = [per_frame[0]]
-            st.step(0, d2h="new")
-            torch.cuda.synchronize()
-            for i in range(1, F):
-                if i == 4:
-                    st.map._gc_wanted = True
-                o = st.step_direct(i, d2h=d2h)
-                if o is not None:
-                    if d2h == "none":
-                        torch.cuda.synchronize()
-                    got.append(tuple(x.clone() for x in o))
-            rest = st.backlog + st.flush_all(d2h)
-            st.backlog = []
-            torch.cuda.synchronize()
-            got += [tuple(x.clone() for x in o) for o in rest]
-            assert len(got) == F, (rep, d2h, len(got))
-            for f, (a, b) in enumerate(zip(per_frame, got)):
-                assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a, b)), f"cap {cap} d2h {d2h} frame {f}"
-            same(ref, snapshot(st))
-            assert st.map._gc_epoch == 1
-
-
-@pytest.mark.parametrize("mix", ["direct", "direct+graph"])
-def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
+def test_deferred_export_rides_with_the_next_frame(gpu_model):
     """`step_direct` with the stream's own capacity (room for the frames in flight, so the host never completes a frame early): a frame's new
-    triangles are copied to the pinned slot by the leading workgroups of the NEXT frame's point kernels (`dif_map_t.pending_export`), or —
-    mixed with `step_graph` frames — by a captured graph's first kernels; the last frame's by `dif_export_pending` at flush.  Every frame's
+    triangles are copied to the pinned slot by the leading workgroups of the NEXT frame's point kernels (`dif_map_t.pending_export`); the
+    last frame's by `dif_export_pending` at flush.  Every frame's
     triangles and the final map equal the eager stream's, bit for bit; no frame was exported by the fallback path in mid-stream."""
     st = make_stream(gpu_model)
     per_frame = []
@@ -223,7 +155,7 @@ def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
     torch.cuda.synchronize()
     got.append(per_frame[0])
     for i in range(1, N_FRAMES):
-        o = st.step_graph(i, d2h="new") if (mix == "direct+graph" and i % 2 == 0) else st.step_direct(i, d2h="new")
+        o = st.step_direct(i, d2h="new")
         if o is not None:
             torch.cuda.synchronize()
             got.append(tuple(x.clone() for x in o))
@@ -234,8 +166,7 @@ def test_deferred_export_rides_with_the_next_frame(mix, gpu_model):
     for f, (a, b) in enumerate(zip(per_frame[1:], got[1:])):
         assert all(torch.equal(x, y) for x, y in zip(a, b)), f"frame {f + 1}"
     same(want, snapshot(st))
-    if mix == "direct":
-        assert in_stream == 0 and early <= 1               # only the last frame (at flush) needed the stand-alone copy
+    assert in_stream == 0 and early <= 1                   # only the last frame (at flush) needed the stand-alone copy
 
 
 @pytest.mark.parametrize("grouped", [False, True], ids=["one_stream", "group_of_three"])
@@ -276,11 +207,11 @@ def test_copy_engine_delivery_equals_kernel_delivery(grouped, gpu_model):
             same(want_map[j], got_map[j])
 
 
-@pytest.mark.parametrize("other", ["graph", "pipelined", "eager"])
+@pytest.mark.parametrize("other", ["pipelined", "eager"])
 def test_compaction_with_a_deferred_export_pending(other, gpu_model):
     """A `step_direct` frame leaves its triangle export pending (absolute log rows); the NEXT frame is driven by another stepping mode on
     a frame where the mesh log is compacted.  The pending copy must be carried out before the compaction moves the rows (ADVICE r3:
-    `step_graph` / `step_pipelined` / `step` compacted first and the direct frame's triangles came out wrong)."""
+    `step_pipelined` / `step` compacted first and the direct frame's triangles came out wrong)."""
     ref = make_stream(gpu_model)
     want = [_eager(ref, i) for i in range(N_FRAMES)]
     want_state = snapshot(ref)
@@ -299,10 +230,7 @@ def test_compaction_with_a_deferred_export_pending(other, gpu_model):
             pending = i
         else:
             st.map._gc_wanted = True                        # the frame behind a direct frame compacts the log
-            if other == "graph":
-                take(st.step_graph(i, d2h="new"), pending)
-                pending = i
-            elif other == "pipelined":
+            if other == "pipelined":
                 take(st.step_pipelined(i, d2h="new"), pending)
                 pending = i
             else:
@@ -315,43 +243,16 @@ def test_compaction_with_a_deferred_export_pending(other, gpu_model):
     same(want_state, snapshot(st))
 
 
-def test_batched_graph_matches_frame_by_frame(gpu_model):
-    """F frames captured into one hipGraph (`step_batch`): every frame's mesh update and the final map must equal the eager run bit for
-    bit — with a tiny pinned staging area (fallback export for larger updates), mixed with a direct frame, and across a compaction."""
-    ref = make_stream(gpu_model)
-    want = [tuple(x.clone() for x in ref.step(i, d2h="new")) for i in range(N_FRAMES)]
-    torch.cuda.synchronize()
-    want_state = snapshot(ref)
-    st = make_stream(gpu_model)
-    st.BATCH_HOST_OUT_TRIANGLES = 512
-    got = [tuple(x.clone() for x in st.step(0, d2h="new"))]
-    outs = st.step_batch(1, 2, d2h="new")                       # frames 1, 2
-    outs += st.step_batch(3, 2, d2h="new")                      # frames 3, 4 (completes the first batch)
-    torch.cuda.synchronize()
-    got += [tuple(x.clone() for x in o) for o in outs]
-    st.map._gc_wanted = True
-    o = st.step_direct(5, d2h="new")                            # the compaction completes the pending batch first: its frames are in `backlog`
-    torch.cuda.synchronize()
-    assert o is None and len(st.backlog) == 2
-    got += [tuple(x.clone() for x in b) for b in st.backlog]
-    got += [tuple(x.clone() for x in b) for b in st.flush_all()]
-    assert len(got) == N_FRAMES
-    for a, b in zip(want, got):
-        assert all(torch.equal(x, y) for x, y in zip(a, b))
-    same(want_state, snapshot(st))
-
-
-def test_graph_mode_host_staging_overflow_falls_back(gpu_model):
-    """A frame with more new triangles than the pinned staging area of the captured graph holds must still hand back all of them
-    (through the side-stream export)."""
+def test_host_staging_overflow_falls_back(gpu_model):
+    """A frame with more new triangles than its pinned staging slot holds must still hand back all of them (through the side-stream export)."""
     ref = make_stream(gpu_model)
     want = [tuple(x.clone() for x in ref.step(i, d2h="new")) for i in range(4)]
     st = make_stream(gpu_model)
-    st.HOST_OUT_TRIANGLES = 64                               # instance attribute shadows the class default before the first capture
+    st.HOST_OUT_TRIANGLES = 64                               # instance attribute shadows the class default before the slots are made
     st.step(0, d2h="new")
     got = [want[0]]
     for i in range(1, 4):
-        o = st.step_graph(i, d2h="new")
+        o = st.step_direct(i, d2h="new")
         if o is not None:
             torch.cuda.synchronize()
             got.append(tuple(x.clone() for x in o))
@@ -389,7 +290,8 @@ def test_frame_descriptor_entry_point_bit_exact(gpu_model):
 def test_c3_full_size_invariants(gpu_model):
     """BASELINE config C3 at full size (128^3 grid, 640x480 frames): size-independent properties (the frame-by-frame comparison of the same
     stream with the reference and the oracle is tests/test_gpu_long.py): slot <-> voxel bijection, conservation of the observation count, idempotence of extract, vertices inside their voxel,
-    and bit-identity between an eager run and a hipGraph run (which walks the frame in 16x16 pixel tiles)."""
+    and bit-identity between an eager run and a directly launched run (which walks the frame in 16x16 pixel tiles) — with per-voxel extract
+    buffers far smaller than the map (`DenseIndexedMap._extract_rows`) and no extract deferred."""
     from di_fusion_amd.stream import FusionStream
     scene, cfg = S.config_c3()
     finals = []
@@ -397,8 +299,8 @@ def test_c3_full_size_invariants(gpu_model):
         st = FusionStream(gpu_model, scene, cfg, S.Intrinsic(), DEV, 5, deg_per_frame=0.5)
         rows = 0
         for i in range(5):
-            if rep == 1 and i >= 1:                     # second run: hipGraph replay through dif_integrate_frame (16x16 pixel tiles)
-                st.step_graph(i, d2h="none")
+            if rep == 1 and i >= 1:                     # second run: direct launches through dif_integrate_frame (16x16 pixel tiles)
+                st.step_direct(i, d2h="none")
             else:
                 st.step(i, d2h="none")
         st.flush("none")
@@ -406,6 +308,7 @@ def test_c3_full_size_invariants(gpu_model):
         m = st.map
         n = m.n_occupied
         assert n > 15000
+        assert m.n_deferred == 0 and m._xbuf[0][1] <= (1 << 16) < m._capacity      # <= 0.5 GB of per-voxel extract buffers for the 524,288-slot map
         pos = m.latent_vecs_pos[:n]
         idx = m.indexer.view(-1)
         assert torch.equal(idx[pos], torch.arange(n, device=DEV))                     # indexer[pos[s]] == s
@@ -599,7 +502,7 @@ def test_stream_group_rejects_maps_it_cannot_batch(gpu_model):
     assert all(st.map._capacity >= 8192 for st in small)
     a = FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, 2, deg_per_frame=6.0)
     b = FusionStream(gpu_model, S_.default_room(), cfg, intr, DEV, 2, deg_per_frame=6.0, phase_deg=45.0)
-    b.map.extract_buffer_bytes = 1 << 28                        # -> fewer rows per extract buffer than stream a
+    b.map.extract_buffer_bytes = 1 << 26                        # -> fewer rows per extract buffer than stream a
     for st in (a, b):
         st.step(0, "new")
     torch.cuda.synchronize()
@@ -714,3 +617,57 @@ def test_stream_group_argument_checks_and_mesh_left_in_hbm(gpu_model):
     with pytest.raises(ValueError):
         FusionStreamGroup([])
     torch.cuda.synchronize()
+
+
+def _by_voxel(snap):
+    """The mesh cache as a per-voxel multiset: rows in ascending voxel id (stable: a voxel's triangles keep their canonical order)."""
+    order = torch.sort(snap["tid"], stable=True).indices
+    return snap["tri"][order], snap["tid"][order], snap["tstd"][order]
+
+
+@pytest.mark.parametrize("overlap", [False, True], ids=["one_queue", "two_queues"])
+def test_extract_defers_instead_of_overflowing_and_catches_up(overlap, gpu_model):
+    """The per-voxel extract buffers of a stream are sized by what its frames decode, not by the map's capacity.  An extract whose dirty set
+    could need more rows than there are (min(7 K, n_occupied) > rows) changes NOTHING on the device — K = B = T = 0, the dirty set is kept,
+    counters[DIF_C_DEFERRED] says how many rows it wanted — the host grows the buffers when it sees that frame's counters, and the next
+    extract meshes everything that accumulated: the map is bit-identical to the eager run's throughout, and so is every voxel's mesh once the
+    stream has caught up.  The synchronous façade call (`extract_mesh_arrays`) grows and retries inside the call."""
+    ref = make_stream(gpu_model)
+    for i in range(N_FRAMES):
+        ref.step(i, d2h="none")
+    torch.cuda.synchronize()
+    want = snapshot(ref)
+
+    st = make_stream(gpu_model, initial_capacity=None)
+    if overlap and not st.enable_overlap():
+        pytest.skip("no second hardware queue to be had in this process (dif_queues_independent)")
+    st.step(0, d2h="none")
+    real = st.map._extract_rows
+    st.map._extract_rows = lambda res, no_cache=False: 256          # far too few rows for frames 1 and 2
+    empty = []
+    for i in range(1, N_FRAMES):
+        if i == 3:
+            st.map._extract_rows = real                             # the host has seen a deferral by now: the real sizing grows the buffers
+        o = st.step_direct(i, d2h="none")
+        if o is not None:
+            empty.append(int(o[0].shape[0]))
+    st.flush("none")
+    torch.cuda.synchronize()
+    assert st.map.n_deferred >= 2 and empty[0] == 0 and empty[1] == 0 and max(empty) > 0
+    assert st.map._xbuf[0][1] >= 2 * st.map._extract_rows_wanted > 512
+    got = snapshot(st)
+    assert got["n"] == want["n"]
+    for k in ("indexer", "latent", "obs"):
+        assert torch.equal(got[k], want[k]), k
+    for a, b in zip(_by_voxel(got), _by_voxel(want)):
+        assert torch.equal(a, b)
+    assert st.map.last_counters["deferred"] == 0 and int(st.map._dirty[:got["n"]].sum()) == 0
+
+    # the synchronous call: starts with 256 rows, finds them too few, grows, retries — one call, the whole mesh
+    st = make_stream(gpu_model, initial_capacity=None)
+    st.map.MIN_EXTRACT_ROWS = 256
+    for i in range(N_FRAMES):
+        st.step(i, d2h="none")
+    torch.cuda.synchronize()
+    assert st.map.n_deferred >= 1
+    same(want, snapshot(st))

@@ -2,6 +2,9 @@
 # a long seeded soak of the differential fuzzers (seeds the suite does not use) and the repeat-determinism check; the tails go to gpurun_out/soak/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/soak; mkdir -p $out
+# the tests the driver's `-m gpu` step leaves out (other fuzz seeds, the one-queue run of the 25-frame C3 window, the C2 window)
+timeout 1500 python -m pytest tests -m soak -x -q --durations=15 > $out/pytest_soak.log 2>&1; echo "pytest -m soak rc=$? $(tail -1 $out/pytest_soak.log)"
+timeout 900 python tools/soak_overlap.py ${SOAK_OVERLAP_RUNS:-12} 40 > $out/overlap.log 2>&1; echo "two-queue soak rc=$? $(tail -1 $out/overlap.log)"
 for seed in ${SOAK_SEEDS:-101 102 103}; do
   timeout 1200 python tools/fuzz_integrate.py --cases 120 --seed $seed > $out/integrate_$seed.log 2>&1; echo "integrate $seed rc=$? $(tail -1 $out/integrate_$seed.log)"
   timeout 900 python tools/fuzz_mc.py --cases 300 --seed $seed > $out/mc_$seed.log 2>&1; echo "mc $seed rc=$? $(tail -1 $out/mc_$seed.log)"

@@ -11,5 +11,5 @@ python - $out/bench_200.json $out/bench_k20.json <<'PY'
 import json,sys
 for f in sys.argv[1:]:
     d=json.loads(open(f).read().strip().splitlines()[-1]); r=d["roofline"]
-    print(f, d["value"], d["ms_per_step"], d["config"].get("frames_per_s_with_S_streams_per_gpu"), d["config"].get("frames_per_s_with_mesh_left_in_hbm"), d["config"].get("frames_per_s_with_5_frames_per_hipgraph"))
+    print(f, d["value"], d["ms_per_step"], d["config"].get("frames_per_s_with_S_streams_per_gpu"), d["config"].get("frames_per_s_with_mesh_left_in_hbm"))
 PY

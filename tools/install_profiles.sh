@@ -1,7 +1,7 @@
 # usage: bash tools/install_profiles.sh <gpurun_out tag> <profiles prefix>     copies the summaries of tools/refresh_profiles.sh into profiles/
 set -e
 S=gpurun_out/$1; P=profiles/$2
-for f in bench_n1 bench_graph bench_k20 bench_c1 bench_c2 bench_tiled_n1 bench_tiled_loopback8_delta bench_tiled_loopback8_full bench_tiled_loopback2_delta \
+for f in bench_n1 bench_k20 bench_c1 bench_c2 bench_tiled_n1 bench_tiled_loopback8_delta bench_tiled_loopback8_full bench_tiled_loopback2_delta \
          bench_cloud bench_query pmc_hbm pmc_hbm_k20 pmc_mfma_stream pmc_mfma_k20 bench_batch5 bench_rccl_1rank bench_rccl_1rank_before_clock bench_n1_one_queue \
          bench_k20_one_queue; do
   [ -s $S/$f.json ] && cp $S/$f.json ${P}_$f.json

@@ -29,7 +29,7 @@ def main():
     f = agg(sys.argv[1], "FETCH_SIZE")
     w = agg(sys.argv[2], "WRITE_SIZE")
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two SEPARATE passes of `python bench.py --no-cpu-baseline --steps 40 --warmup 4 "
-                   "--graph 0` (C3 workload); KB per launch averaged over the second half of the dispatches (or the last N with --last N: the timed frames of the driver's short run). hbm_bytes_per_launch = (2*FETCH_SIZE + "
+                   "` (C3 workload); KB per launch averaged over the second half of the dispatches (or the last N with --last N: the timed frames of the driver's short run). hbm_bytes_per_launch = (2*FETCH_SIZE + "
                    "WRITE_SIZE)*1024: FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md section HBM (gfx950 reports half of a wide "
                    "coalesced read); WRITE_SIZE uncalibrated.", "kernels": {}}
     for k in f:

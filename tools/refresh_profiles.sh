@@ -74,8 +74,6 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_t1 -o bench -- $B --mod
 python tools/rocpd_stats.py $(find $O/trace_t1 -name "*.db" | head -1) --after-nth k_prune_mark 14 --frames 100 > $O/kernel_stats_tiled_n1.md 2>&1
 rm -rf $O/trace_lb8 $O/trace_t1
 # ---- the rest ----
-timeout 300 $B --graph 1 --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
-timeout 300 $B --batch 5 --no-cpu-baseline --no-secondary > $O/bench_batch5.json 2> $O/bench_batch5.err
 for c in c1 c2; do timeout 300 $B --config $c --no-cpu-baseline --steps 50 > $O/bench_$c.json 2> $O/bench_$c.err; done
 DIF_FORCE_DIST=1 timeout 300 $B --no-cpu-baseline --no-secondary > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
 DIF_FORCE_DIST=1 timeout 300 $B --no-cpu-baseline --no-secondary --rccl-before-clock 1 > $O/bench_rccl_1rank_before_clock.json 2> $O/bench_rccl_1rank_before_clock.err

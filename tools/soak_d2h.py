@@ -30,11 +30,7 @@ def run(mode, frames):
     take(o)
     for i in range(1, frames):
         take(st.step_direct(i, d2h=mode))
-        for b in st.backlog:
-            take(b)
-        st.backlog = []
-    for o in st.flush_all(mode):
-        take(o)
+    take(st.flush(mode))
     m = st.map
     n = m.n_occupied
     final = (n, zlib.crc32(m.latent_vecs[:n].cpu().numpy().tobytes()), zlib.crc32(m.indexer.cpu().numpy().tobytes()))

@@ -1,5 +1,5 @@
 """Soak of the two-queue mode: the C3 stream (F frames) stepped R times on two queues — without any device drain, d2h dma and none alternating,
-host depth 1 and 2 alternating, the mesh half on the extracts' queue or on a third one, the host's steps delayed by random 0-100 / 0-300 us in two runs of three — against ONE single-queue run: every frame's triangles and the final map bit for bit.  A race between a frame's
+the host's steps delayed by random 0-100 / 0-300 us in two runs of three — against ONE single-queue run: every frame's triangles and the final map bit for bit.  A race between a frame's
 front end and its predecessor's extract would show up as a differing frame sooner or later.
 Usage: python tools/soak_overlap.py [R=20] [F=40]"""
 import gc, sys, time
@@ -20,11 +20,8 @@ scene, cfg = S.config_c3()
 import random
 
 
-def run(overlap, d2h, depth, jitter=0.0, seed=0, split=False, scan=False):
+def run(overlap, d2h, jitter=0.0, seed=0):
     st = FusionStream(model, scene, cfg, S.Intrinsic(), DEV, F, deg_per_frame=0.5)
-    st.host_depth = depth
-    st.split_mesh = split
-    st.scan_ahead = scan                                 # (the frame's extract scans in its front end, before its fusion kernel)
     if overlap:
         assert st.enable_overlap()
     outs = []
@@ -39,28 +36,27 @@ def run(overlap, d2h, depth, jitter=0.0, seed=0, split=False, scan=False):
             if d2h == "none" or i <= 2:
                 torch.cuda.synchronize()
             outs.append(tuple(x.clone().cpu() for x in o))
-    rest = st.backlog + st.flush_all(d2h)
-    st.backlog = []
+    o = st.flush(d2h)
     torch.cuda.synchronize()
-    outs += [tuple(x.clone().cpu() for x in o) for o in rest]
+    outs.append(tuple(x.clone().cpu() for x in o))
     n = st.map.n_occupied
     final = (st.map.indexer.clone().cpu(), st.map.latent_vecs[:n].clone().cpu(), st.map.voxel_obs_count[:n].clone().cpu())
     del st
-    gc.collect()                                         # (a stream's map and mesh cache refer to each other: 4-8 GB of extract buffers per run otherwise pile up)
+    gc.collect()                                         # (a stream's map and mesh cache refer to each other: their buffers otherwise pile up from run to run)
     return outs, final
 
 
-ref_outs, ref_final = run(False, "dma", 1)
+ref_outs, ref_final = run(False, "dma")
 assert len(ref_outs) == F
 bad = 0
 t0 = time.time()
 for r in range(R):
-    d2h, depth = ("dma", "none")[r & 1], 1 + ((r >> 1) & 1)
-    outs, final = run(True, d2h, depth, jitter=(0.0, 100e-6, 300e-6)[r % 3], seed=r, split=bool((r >> 2) & 1), scan=bool((r >> 3) & 1))
+    d2h = ("dma", "none")[r & 1]
+    outs, final = run(True, d2h, jitter=(0.0, 100e-6, 300e-6)[r % 3], seed=r)
     ok = len(outs) == F and all(all(torch.equal(x, y) for x, y in zip(a, b)) for a, b in zip(ref_outs, outs)) and all(torch.equal(x, y) for x, y in zip(ref_final, final))
     if not ok:
         bad += 1
         first = next((f for f, (a, b) in enumerate(zip(ref_outs, outs)) if not all(torch.equal(x, y) for x, y in zip(a, b))), None)
-        print(f"repeat {r} (d2h {d2h}, host depth {depth}): DIFFERS (first differing frame: {first}, frames {len(outs)})", flush=True)
+        print(f"repeat {r} (d2h {d2h}): DIFFERS (first differing frame: {first}, frames {len(outs)})", flush=True)
 print(f"two-queue soak: {R} runs of {F} C3 frames against the single-queue run: {bad} differ ({time.time() - t0:.0f} s)")
 sys.exit(1 if bad else 0)
