@@ -19,7 +19,7 @@ C_STAMP = 31
 SYNC_FUSED, SYNC_FRONT_DONE, SYNC_WORDS = 0, 32, 64      # dif_map_t.sync_words
 FC_COUNT = 32                                            # dif_map_t.frame_counters
 C_COUNT = 32
-PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge"]
+PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge", "decode_frame"]
 PROF_COUNT = 8
 LATENT_DIM = 29
 
@@ -143,6 +143,7 @@ SIGNATURES = {
     "dif_test_mc_grid_cap": (c_int32, [c_int32]),
     "dif_test_sdma_mode": (c_int32, [c_int32]),
     "dif_sdma_info": (c_int32, [POINTER(c_int32)]),
+    "dif_test_handoff": (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_int64)]),
     "dif_queues_independent": (c_int32, [c_void_p, c_void_p]),
     "dif_mesh_cache_export_sdma": (c_int32, [POINTER(DifExtractBuffers), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "dif_sdf_hg_workspace_bytes": (c_int64, [c_int64]),

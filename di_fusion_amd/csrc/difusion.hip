@@ -135,6 +135,7 @@ inline int grid_for(int64_t n, int per_block = DIF_BLOCK, int max_blocks = 4096)
 #include "kernels_cloud.hip.h"
 #include "kernels_optimize.hip.h"
 #include "kernels_track.hip.h"
+#include "kernels_litmus.hip.h"
 
 }  // namespace
 
@@ -978,9 +979,18 @@ static int voxel_decode_attributes() {
         if (hipFuncSetAttribute((const void*)k_decode_refine_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
         if (hipFuncSetAttribute((const void*)k_decode_voxels_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
         if (hipFuncSetAttribute((const void*)k_decode_refine_x6_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode_frame, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)k_decode_frame_batch, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
         attr_set[dev] = true;
     }
     return DIF_OK;
+}
+
+// measurement switch (read once): DIF_DECODE_LAUNCHES=2 runs the fast decode of the bf16 pipe as the two launches of rounds 2-5 (lattice, refine)
+// instead of the one persistent launch (k_decode_frame), for A/B runs on one box
+static bool decode_two_launches() {
+    static const bool two = [] { const char* e = getenv("DIF_DECODE_LAUNCHES"); return e && atoi(e) == 2; }();
+    return two;
 }
 
 static std::atomic<int> g_mc_grid_cap{0};
@@ -1077,6 +1087,16 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (voxel_decode_attributes() != DIF_OK) return DIF_ELAUNCH;
         int64_t blocks = (buf->max_voxels + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
+        if (x6 && !decode_two_launches()) {
+            // ONE persistent launch: lattice, hand-over, refine (kernels_extract.hip.h: k_decode_frame)
+            int64_t fblocks = (buf->max_voxels * (int64_t)(R3 / 32) + 7) / 8;
+            if (fblocks < blocks) fblocks = blocks;
+            if (fblocks > num_cus()) fblocks = num_cus();
+            ProfScope prof(DIF_PROF_DECODE_FRAME, s);
+            hipLaunchKernelGGL(k_decode_frame, dim3((int)fblocks), dim3(512), lds_bytes, s, V, refine_args_of(map, buf, e, true), (const float*)w->dec_x6_packed);
+            DIF_CHECK_LAUNCH();
+            return extract_mesh_part(map, buf, e, max_std, no_cache, scale_vertices, s);
+        }
         {
             ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
             if (x6) hipLaunchKernelGGL(k_decode_voxels<true>, dim3((int)blocks), dim3(512), lds_bytes, s, V, (const float*)w->dec_x6_packed);
@@ -1225,6 +1245,15 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
     DIF_CHECK_LAUNCH();
     if (launch_counted_scan_batch(occ, S, (int)((grid + 31) / 32), s) != DIF_OK) return DIF_ELAUNCH;
     if (voxel_decode_attributes() != DIF_OK) return DIF_ELAUNCH;
+    if (!decode_two_launches()) {
+        int64_t blocks = (max_voxels * S * (int64_t)(e.R3 / 32) + 7) / 8;
+        if (blocks < 1) blocks = 1;
+        if (blocks > num_cus()) blocks = num_cus();
+        ProfScope prof(DIF_PROF_DECODE_FRAME, s);
+        hipLaunchKernelGGL(k_decode_frame_batch, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4, s, vd, rf, (int)S,
+                           (const float*)w->dec_x6_packed);
+        DIF_CHECK_LAUNCH();
+    } else {
     {
         int64_t blocks = (max_voxels * S + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
@@ -1240,6 +1269,7 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
         ProfScope prof(DIF_PROF_DECODE_POINTS, s);
         hipLaunchKernelGGL(k_decode_refine_x6_batch, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, rf, (int)S, (const float*)w->dec_x6_packed);
         DIF_CHECK_LAUNCH();
+    }
     }
     {
         size_t lds_bytes; int grid1;
@@ -1495,6 +1525,76 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
         if (g_hsa.slow_calls >= 4) { g_hsa.engines[0] = -1; g_hsa.engine_us = 0.0; }
     }
     return DIF_OK;
+}
+
+// ---- TEST HOOK: litmus runs of the fence-free hand-overs (kernels_litmus.hip.h; tests/test_gpu_handoff.py) ------------------------------------
+int dif_test_handoff(int32_t mode, int32_t groups, int32_t iters, int32_t flags, int64_t* out) {
+    if (!out || mode < 0 || mode > 2 || groups < 1 || groups > 1024 || iters < 1 || iters > (1 << 22)) return DIF_EINVAL;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    hipStream_t s = nullptr, hs = nullptr;
+    int rc = DIF_ELAUNCH;
+    double* rec = nullptr; unsigned* counters = nullptr; unsigned long long* dout = nullptr; float4* hog = nullptr; double* box = nullptr;
+    const size_t hog_n = (size_t)64 << 20;                   // 1 GB of float4
+    do {
+        if (flags & 1) {            // a stream confined to every other CU (the hand-over must not depend on where the workgroups sit)
+            uint32_t mask[8];
+            for (auto& m : mask) m = 0x55555555u;
+            if (hipExtStreamCreateWithCUMask(&s, 8, mask) != hipSuccess) { (void)hipGetLastError(); break; }
+        } else if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        if (hipMalloc((void**)&dout, 64) != hipSuccess || hipMemsetAsync(dout, 0, 64, s) != hipSuccess) break;
+        if (flags & 2) {            // ... nor on a quiet memory system
+            if (hipStreamCreateWithFlags(&hs, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&hog, hog_n * sizeof(float4)) != hipSuccess ||
+                hipMemsetAsync(hog, 0, hog_n * sizeof(float4), hs) != hipSuccess || hipStreamSynchronize(hs) != hipSuccess) break;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (mode < 2) {
+            const size_t rec_bytes = (size_t)2 * groups * LIT_WORDS * sizeof(double), cnt_bytes = ((size_t)iters + 64) * sizeof(unsigned);
+            if (hipMalloc((void**)&rec, rec_bytes) != hipSuccess || hipMalloc((void**)&counters, cnt_bytes) != hipSuccess) break;
+            if (hipMemsetAsync(rec, 0, rec_bytes, s) != hipSuccess || hipMemsetAsync(counters, 0, cnt_bytes, s) != hipSuccess) break;
+            if (hipStreamSynchronize(s) != hipSuccess) break;
+            if (hog) hipLaunchKernelGGL(k_litmus_hog, dim3(128), dim3(256), 0, hs, hog, hog_n, (unsigned long long)20000000ull);      // <= 0.2 s
+            hipLaunchKernelGGL(k_litmus_device, dim3(groups), dim3(256), 0, s, rec, counters + 32, counters, iters, mode, dout);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
+        } else {
+            if (hipHostMalloc((void**)&box, (size_t)groups * 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) break;
+            memset(box, 0, (size_t)groups * 64 * sizeof(double));
+            if (hog) hipLaunchKernelGGL(k_litmus_hog, dim3(128), dim3(256), 0, hs, hog, hog_n, (unsigned long long)20000000ull);
+            hipLaunchKernelGGL(k_litmus_host, dim3(groups), dim3(64), 0, s, box, iters, dout);
+            if (hipGetLastError() != hipSuccess) break;
+            int64_t stale = 0, checked = 0, timeouts = 0;
+            for (int r = 1; r <= iters && !timeouts; ++r)
+                for (int m = 0; m < groups; ++m) {
+                    double* mine = box + (size_t)m * 64;
+                    long long* seq = reinterpret_cast<long long*>(mine + LIT_HOST_WORDS);
+                    const auto w0 = std::chrono::steady_clock::now();
+                    long spins = 0;
+                    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) < (long long)r)
+                        if ((++spins & 0xFFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 5.0) { ++timeouts; break; }
+                    if (timeouts) break;
+                    for (int j = 0; j < LIT_HOST_WORDS; ++j) {
+                        const double want = (double)(((unsigned long long)r << 20) ^ ((unsigned long long)m << 8) ^ (unsigned)j) + 0.5;
+                        if (__atomic_load_n(reinterpret_cast<long long*>(mine + j), __ATOMIC_RELAXED) != __builtin_bit_cast(long long, want)) ++stale;
+                    }
+                    ++checked;
+                    __atomic_store_n(seq + 1, (long long)r, __ATOMIC_RELEASE);
+                }
+            if (timeouts)           // let the workgroups run into their own time-out rather than wait for an answer that will not come
+                for (int m = 0; m < groups; ++m) __atomic_store_n(reinterpret_cast<long long*>(box + (size_t)m * 64 + LIT_HOST_WORDS) + 1, (long long)iters, __ATOMIC_RELEASE);
+            if (hipStreamSynchronize(s) != hipSuccess) break;
+            out[0] = stale; out[1] = checked; out[2] = timeouts;
+        }
+        out[3] = (int64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        unsigned long long host[3] = {0, 0, 0};
+        if (hipMemcpy(host, dout, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) break;
+        out[0] += (int64_t)host[0]; out[1] += (int64_t)host[1]; out[2] += (int64_t)host[2];
+        rc = DIF_OK;
+    } while (false);
+    if (hs) { (void)hipStreamSynchronize(hs); (void)hipStreamDestroy(hs); }
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    (void)hipFree(rec); (void)hipFree(counters); (void)hipFree(dout); (void)hipFree(hog);
+    if (box) (void)hipHostFree(box);
+    (void)hipGetLastError();
+    return rc;
 }
 
 // ---- are two streams on different hardware queues? ----------------------------------------------------------------------------------------

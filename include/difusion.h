@@ -499,7 +499,7 @@ int dif_merge_halo2(const dif_map_t* map, const int32_t* msg_a, int64_t max_a, c
 /* When enabled, a hipEvent pair is recorded around each launch of the named kernels ON THE STREAM THEY RUN ON. */
 enum { DIF_PROF_ENCODE = 0, DIF_PROF_DECODE_LATTICE = 1, DIF_PROF_DECODE_POINTS = 2, DIF_PROF_MC_COUNT = 3, DIF_PROF_MC_EMIT = 4,
        DIF_PROF_HALO_EXPORT = 5 /* the launches of one dif_export_halo* call */, DIF_PROF_HALO_MERGE = 6 /* of one dif_merge_halo* call */,
-       DIF_PROF_COUNT = 8 };
+       DIF_PROF_DECODE_FRAME = 7 /* the frame's ONE decoder launch: lattice + refine (B * l^3 + VH rows) */, DIF_PROF_COUNT = 8 };
 int dif_profile_enable(int32_t on);
 /* Sum of elapsed milliseconds and number of launches per kernel since the last reset; synchronises on the events. */
 int dif_profile_read(double* ms /* [DIF_PROF_COUNT], host */, int64_t* launches /* [DIF_PROF_COUNT], host */, int32_t reset);
@@ -530,6 +530,14 @@ int dif_test_mc_grid_cap(int32_t n);
  * the runtime (what happens under a HIP runtime other than the validated one); 2 = fail with DIF_ELAUNCH (what happens when the process's HSA runtime
  * cannot be reached: the caller falls back to dif_mesh_cache_export_dma); 3 = count every export as slow (the engines are timed again after four). */
 int dif_test_sdma_mode(int32_t mode);
+/* TEST HOOK: a litmus run of the fence-free hand-overs the product kernels use (write-through stores + s_waitcnt vmcnt(0) + word on the producer,
+ * sc1 loads on the consumer; csrc/kernels_litmus.hip.h).  mode 0: `groups` workgroups meet `iters` times through a counter every one polls, each then
+ * checks another workgroup's 29-double record (k_decode_frame's hand-over); mode 1: the last arriver of a ticket checks all records
+ * (k_sdf_hg_reduce's); mode 2: `groups` workgroups hand 44 doubles + a sequence word to the CPU through pinned memory `iters` times
+ * (k_sdf_hg_reduce's / k_extract_finish's hand-back).  flags bit 0: on a stream confined to every other CU; bit 1: beside a kernel that streams
+ * through 1 GB.  out (host, int64[4]): stale values seen, hand-overs checked, time-outs, microseconds.  Allocates and frees what it needs;
+ * synchronises. */
+int dif_test_handoff(int32_t mode, int32_t groups, int32_t iters, int32_t flags, int64_t* out);
 /* out (host, int32[8]): HSA runtime reached (0/1), hipRuntimeGetVersion of the process, the version the engine selection was validated with,
  * engine calibrations so far, exports so far, the three engines in use (-1: the runtime's choice). */
 int dif_sdma_info(int32_t* out);

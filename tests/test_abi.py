@@ -76,3 +76,43 @@ def test_no_gpu_means_loud_failure():
         DenseIndexedMap(model, syn.config_c1()[1].namespace(), 29, torch.device("cpu"))
     with pytest.raises(RuntimeError):
         model.decoder(torch.zeros((4, 32)))
+
+
+def _kernel_isa(names):
+    """Disassembly of the named kernels (substrings of the mangled names) of the built code object."""
+    import subprocess
+    import tempfile
+    from di_fusion_amd import _build
+    llvm = "/opt/rocm/lib/llvm/bin"
+    d = _build.build().read_bytes()
+    i = d.find(b"\x7fELF", d.find(b"__CLANG_OFFLOAD_BUNDLE__"))
+    with tempfile.NamedTemporaryFile(suffix=".o") as f:
+        f.write(d[i:]); f.flush()
+        syms = subprocess.run([f"{llvm}/llvm-readelf", "-s", "--wide", f.name], capture_output=True, text=True).stdout
+        out = {}
+        for n in names:
+            full = [ln.split()[-1] for ln in syms.splitlines() if n in ln and " FUNC " in ln]
+            assert full, f"kernel {n} not in the code object"
+            out[n] = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", f"--disassemble-symbols={full[0]}", f.name],
+                                    capture_output=True, text=True).stdout
+        return out
+
+
+def test_fence_free_handovers_compile_to_write_through_stores_and_sc1_loads():
+    """The hand-overs inside k_sdf_hg_reduce, k_decode_frame and k_extract_finish (and their litmus twin, csrc/kernels_litmus.hip.h) rest on what the
+    COMPILER makes of relaxed agent- / system-scope atomic stores and loads: write-through (sc1 / sc0 sc1) stores, sc1 loads, no cache write-back or
+    invalidate in between.  That is a property of the validated hipcc (di_fusion_amd/_build.py:VALIDATED_HIPCC), checked here in the built code object;
+    tests/test_gpu_handoff.py checks on the GPU that the hardware then does what the pattern assumes."""
+    isa = _kernel_isa(["k_litmus_device", "k_litmus_host", "k_sdf_hg_reduce", "14k_decode_frameE", "16k_extract_finishE"])
+    dev = isa["k_litmus_device"]
+    assert re.search(r"global_store_dwordx2 .* sc1", dev) and re.search(r"global_load_dwordx2 .* sc1", dev) and "s_waitcnt vmcnt(0)" in dev
+    host = isa["k_litmus_host"]
+    assert re.search(r"global_store_dwordx2 .* sc0 sc1", host) and re.search(r"global_load_dwordx2 .* sc0 sc1", host)
+    for k, text in isa.items():
+        assert "buffer_wbl2" not in text and "buffer_inv" not in text.replace("s_endpgm", ""), f"{k}: a cache write-back / invalidate inside the kernel body"
+    hg = isa["k_sdf_hg_reduce"]
+    assert re.search(r"global_store_dwordx2 .* sc1", hg) and re.search(r"global_load_dwordx2 .* sc1", hg) and re.search(r"global_store_dwordx2 .* sc0 sc1", hg)
+    frame = isa["14k_decode_frameE"]
+    # the lattice phase's fold records and refine-list entries leave write-through; the refine phase fetches them past the L2
+    assert re.search(r"global_store_dword .* sc1", frame) and re.search(r"buffer_load_dwordx4 .* sc1", frame) and re.search(r"global_load_dword .* sc1", frame)
+    assert re.search(r"global_store_dword .* sc0 sc1", isa["16k_extract_finishE"])
