@@ -210,6 +210,7 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
     int32_t* vbm;
     int* counters;
     int64_t max_voxels;
+    uint32_t* dec_sync;     // dif_map_t.sync_words or NULL: the decoder launch behind this scan claims its voxels through two of them (k_decode_frame)
     __device__ int count(int w) const { return __popc(bits[w]); }
     __device__ void emit(int w, int offset) const {
         uint32_t word = bits[w];
@@ -230,8 +231,7 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
         counters[DIF_C_B] = total;
         counters[DIF_C_VH] = 0;
         counters[DIF_C_WORK] = 0;
-        counters[DIF_C_DEC_TICKET] = 0;         // the decoder launch behind this scan claims its voxels through these two (k_decode_frame)
-        counters[DIF_C_DEC_DONE] = 0;
+        if (dec_sync) { dec_sync[DIF_SYNC_DEC_TICKET] = 0u; dec_sync[DIF_SYNC_DEC_DONE] = 0u; }
     }
 };
 
@@ -479,8 +479,8 @@ __global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArg
     }
 }
 
-// acc init from a per-lane record of the fold table that OTHER workgroups of the same launch have just written (k_decode_frame): 16-byte loads that
-// bypass the XCD's L2 (sc1: the eight L2s are not coherent with each other; the writers wrote through and waited for the acknowledgement)
+// acc init from a per-lane record of the fold table through 16-byte loads that bypass the XCD's L2 (sc1).  Measured and NOT used by k_decode_frame
+// (see decode_refine_x6_body); kept for experiments.
 struct FoldInitCoherent {
     __amdgpu_buffer_rsrc_t rsrc;    // the map's fold table
     unsigned rec;                   // byte offset of this lane's voxel record (256 floats)
@@ -541,11 +541,12 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
         const int b = e / res3, sb = e - b * res3;
         const float px = lat.coord(sb / (r * r)), py = lat.coord((sb / r) % r), pz = lat.coord(sb % r);
         float sdf, sd;
-        if constexpr (FUSED)
-            decoder_tile_folded_x6(lds, wfwd, FoldInitCoherent{__builtin_amdgcn_make_buffer_rsrc((void*)A.fold_table, 0, 0x7FFFFFFF, 0x00020000), (unsigned)b * 1024u},
-                                   px, py, pz, lane, sdf, sd);
-        else
-            decoder_tile_folded_x6(lds, wfwd, FoldInitGlobal{A.fold_table + (int64_t)b * 256}, px, py, pz, lane, sdf, sd);
+        // FUSED: the voxel's fold record was written through by a workgroup of THIS launch (possibly on another XCD) and acknowledged before the
+        // hand-over.  It is read with ORDINARY loads all the same — 32 KB per tile, 50 MB per frame, which as sc1 loads all went past the L2
+        // (profiles/r06_experiments.md 1): a record is eight whole 128-byte lines that no wave of this XCD has touched since the launch began
+        // (the launch starts with invalidated L1 / L2, phase one reads no fold record, and a workgroup writes only its own voxels' records), so the
+        // first load of a line misses to memory, where the data is, and later tiles of the same voxel hit.  Litmus mode 3 is this access pattern.
+        decoder_tile_folded_x6(lds, wfwd, FoldInitGlobal{A.fold_table + (int64_t)b * 256}, px, py, pz, lane, sdf, sd);
         if (live) {
             if (half == 0) A.out_sdf[e] = sign * sdf;
             else A.out_std[e] = sd;
@@ -654,6 +655,7 @@ struct VoxelDecodeArgs {
     int* counters;
     const float* fold_w;            // packing.py:pack_decoder_fold, or NULL (latent carried through the MFMAs)
     float* fold_table;              // [batch voxel][256] out, for the refine pass
+    uint32_t* sync;                 // k_decode_frame: dif_map_t.sync_words (DIF_SYNC_DEC_TICKET / DIF_SYNC_DEC_DONE, a 128-byte line each)
 };
 
 #define VD_MAX_L3 64
@@ -676,13 +678,13 @@ __device__ unsigned long long g_vd_trace[2048 * 8];
 // refine-list entries) is written through (sc1) and acknowledged before the workgroup reports its groups done; samples selected for the exact
 // re-decode are NOT written here (the second phase writes them: two XCDs' L2s must never both hold a dirty copy of one sample).
 // Hand-over to the second phase: a workgroup that finds the ticket exhausted waits for its own stores' acknowledgements (s_waitcnt vmcnt(0)), adds
-// the groups it decoded to counters[DIF_C_DEC_DONE] and polls that word until it equals the number of groups.  Only RUNNING workgroups hold groups,
+// the groups it decoded to sync_words[DIF_SYNC_DEC_DONE] and polls that word until it equals the number of groups.  Only RUNNING workgroups hold groups,
 // so the wait ends whether or not the whole grid is resident (a workgroup that starts late claims nothing and waits for the others); it gives up
 // after ~1 s with DIF_C_OVERFLOW = 10 instead of hanging the queue.  The batch scan in front of the launch returns ticket and count to 0.  No fence
 // anywhere: write-through stores + vmcnt(0) on the producers, sc1 loads on the consumers (as kernels_track.hip.h: a fence writes back and
 // invalidates the XCD's whole L2, ~4 us per workgroup; tests/test_gpu_handoff.py hammers exactly this pattern).
 template <bool X6, int NS, bool FUSED = false>
-__device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs, NS>& AB, int S, const float* __restrict__ wblob, int* __restrict__ sync = nullptr) {
+__device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs, NS>& AB, int S, const float* __restrict__ wblob, uint32_t* __restrict__ sync = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     VD_STAMP(0);
     constexpr int LDS_W = X6 ? X6_LDS_BYTES / 4 : ((DEC_LDS_FLOATS + 3) & ~3);
@@ -722,7 +724,7 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
     for (int round = 0; round < rounds; ++round) {
         int bg = first + round * n_pairs;                      // index in the concatenated range
         if (FUSED) {
-            if (threadIdx.x == 0) s_claim = atomicAdd(sync + DIF_C_DEC_TICKET, 1);
+            if (threadIdx.x == 0) s_claim = (int)atomicAdd(sync + DIF_SYNC_DEC_TICKET, 1u);
             __syncthreads();                                   // (the round's last barrier keeps the next claim behind every reader of this one)
             const int g = s_claim;
             if (g >= n_groups) break;
@@ -840,11 +842,13 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            if (mine) atomicAdd(sync + DIF_C_DEC_DONE, mine);
+            // (the polled word has a 128-byte line to itself: 256 pollers on the line of the refine-list reservations starved those — a line
+            // takes ~90 atomics per microsecond, profiles/r03 — and one poll per ~0.5 us and workgroup is all the hand-over needs)
+            if (mine) atomicAdd(sync + DIF_SYNC_DEC_DONE, (unsigned)mine);
             int spins = 0;
-            while (__hip_atomic_load(sync + DIF_C_DEC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_groups) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1 << 22)) { sync[DIF_C_OVERFLOW] = 10; break; }
+            while ((int)__hip_atomic_load(sync + DIF_SYNC_DEC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_groups) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1 << 21)) { AB.s[0].counters[DIF_C_OVERFLOW] = 10; break; }
             }
         }
         __syncthreads();
@@ -856,12 +860,12 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
 // weight image is staged once, one launch floor instead of two.  NS = 1: one map; NS = DIF_MAX_STREAMS: the maps of a stream group.
 __global__ void __launch_bounds__(512, 1) k_decode_frame(VoxelDecodeArgs A, DecodeArgs R, const float* __restrict__ wblob) {
     const BatchN<VoxelDecodeArgs, 1> AB{{A}};
-    decode_voxels_body<true, 1, true>(AB, 1, wblob, A.counters);
+    decode_voxels_body<true, 1, true>(AB, 1, wblob, A.sync);
     const BatchN<DecodeArgs, 1> RB{{R}};
     decode_refine_x6_body<1, true>(RB, 1, wblob);
 }
 __global__ void __launch_bounds__(512, 1) k_decode_frame_batch(Batch<VoxelDecodeArgs> AB, Batch<DecodeArgs> RB, int S, const float* __restrict__ wblob) {
-    decode_voxels_body<true, DIF_MAX_STREAMS, true>(AB, S, wblob, AB.s[0].counters);
+    decode_voxels_body<true, DIF_MAX_STREAMS, true>(AB, S, wblob, AB.s[0].sync);
     decode_refine_x6_body<DIF_MAX_STREAMS, true>(RB, S, wblob);
 }
 

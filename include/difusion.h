@@ -64,8 +64,6 @@ enum {
     DIF_C_DEFERRED = 23,    /* 0, or the rows the per-voxel extract buffers would have needed when the last streaming extract (dirty_tot set, untiled,
                              * capacity > 4096) found them too small for min(7 K, n_occupied) voxels: that extract then changed NOTHING (dirty set kept,
                              * K = B = T = 0) — the caller grows dif_extract_buffers_t.max_voxels and the next extract meshes the accumulated dirty set */
-    DIF_C_DEC_TICKET = 24,  /* idle 0: the persistent decoder's claim counter and its count of completed lattice groups (returned to 0 by the     */
-    DIF_C_DEC_DONE = 25,    /* batch scan in front of it)                                                                                        */
     DIF_C_STAMP = 31,       /* snapshots handed to the caller only (dif_extract_buffers_t.counters_out): the extract's `stamp`, written LAST        */
     DIF_C_COUNT = 32
 };
@@ -146,8 +144,9 @@ typedef struct dif_map {
 } dif_map_t;
 
 /* sync_words (each on a 128-byte line of its own): frame n's fusion kernel has completed (written by the first kernel of its extract); frame n's front
- * end has completed */
-enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_WORDS = 64 };
+ * end has completed; the claim counter of the frame's decoder launch and its count of completed lattice groups (k_decode_frame: both returned to 0 by
+ * the batch scan in front of it; polled words must not share a line with anything that is updated atomically) */
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_DEC_TICKET = 64, DIF_SYNC_DEC_DONE = 96, DIF_SYNC_WORDS = 128 };
 enum { DIF_FC_SHADOW = 4, DIF_FC_COUNT = 32 };
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
@@ -534,7 +533,9 @@ int dif_test_sdma_mode(int32_t mode);
  * sc1 loads on the consumer; csrc/kernels_litmus.hip.h).  mode 0: `groups` workgroups meet `iters` times through a counter every one polls, each then
  * checks another workgroup's 29-double record (k_decode_frame's hand-over); mode 1: the last arriver of a ticket checks all records
  * (k_sdf_hg_reduce's); mode 2: `groups` workgroups hand 44 doubles + a sequence word to the CPU through pinned memory `iters` times
- * (k_sdf_hg_reduce's / k_extract_finish's hand-back).  flags bit 0: on a stream confined to every other CU; bit 1: beside a kernel that streams
+ * (k_sdf_hg_reduce's / k_extract_finish's hand-back); mode 3: as mode 0 with
+ * record slots that are never reused inside a launch (iters <= 256) and ORDINARY loads on the consumer (k_decode_frame's fold records: lines its XCD has
+ * not touched since the launch began).  flags bit 0: on a stream confined to every other CU; bit 1: beside a kernel that streams
  * through 1 GB.  out (host, int64[4]): stale values seen, hand-overs checked, time-outs, microseconds.  Allocates and frees what it needs;
  * synchronises. */
 int dif_test_handoff(int32_t mode, int32_t groups, int32_t iters, int32_t flags, int64_t* out);

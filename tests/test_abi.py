@@ -113,6 +113,6 @@ def test_fence_free_handovers_compile_to_write_through_stores_and_sc1_loads():
     hg = isa["k_sdf_hg_reduce"]
     assert re.search(r"global_store_dwordx2 .* sc1", hg) and re.search(r"global_load_dwordx2 .* sc1", hg) and re.search(r"global_store_dwordx2 .* sc0 sc1", hg)
     frame = isa["14k_decode_frameE"]
-    # the lattice phase's fold records and refine-list entries leave write-through; the refine phase fetches them past the L2
-    assert re.search(r"global_store_dword .* sc1", frame) and re.search(r"buffer_load_dwordx4 .* sc1", frame) and re.search(r"global_load_dword .* sc1", frame)
+    # the lattice phase's fold records and refine-list entries leave write-through; the refine phase fetches the list entries and the row count past the L2
+    assert re.search(r"global_store_dword .* sc1", frame) and re.search(r"global_load_dword .* sc1", frame)
     assert re.search(r"global_store_dword .* sc0 sc1", isa["16k_extract_finishE"])

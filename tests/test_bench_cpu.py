@@ -122,7 +122,68 @@ def test_every_json_under_profiles_parses():
     assert not bad, bad
 
 
+def _scale_line(n, value, leg, **over):
+    tiled = leg == "tiled"
+    d = {"metric": "frames/s", "value": value, "n_gpus": n, "rccl_ranks": (n if n > 1 else 0), "rccl_probe": "test", "ms_per_step": 0.1,
+         "scaling": "strong" if tiled else "weak",
+         "config": {"rccl_before_clock": (leg in ("c4rccl", "tiled")) if n > 1 else None,
+                    "global_map_merge_after_the_clock": None if tiled else {"all_gather_and_fold_ms": 1.0}}}
+    d.update(over)
+    return d
+
+
+def test_scale_tool_dry_run_and_checks(tmp_path, capsys):
+    """tools/gpu_scale.py, the command of the 8-GPU day, without a GPU: `--dry` lists every launch line (all four legs x N = 1, 2, 4, 8, RCCL on
+    both sides of the clock, 127.0.0.1 rendezvous, one rank per GPU) and the predicted bands; `check()` accepts a curve inside the bands and fails on
+    an unobserved RCCL group, a failed map merge, RCCL on the wrong side of the clock, an N = 1 line that disagrees with the plain bench, and a curve
+    outside the prediction of DESIGN.md section 6."""
+    import json
+    sys.path.insert(0, str(ROOT / "tools"))
+    import gpu_scale
+    assert gpu_scale.main(["--dry", "--out", str(tmp_path)]) == 0
+    text = capsys.readouterr().out
+    for leg in ("c4", "c4rccl", "c4s4", "tiled"):
+        for n in (1, 2, 4, 8):
+            assert f"[{leg} N={n}]" in text
+    assert text.count("--rccl-before-clock 1") == 4 and text.count("--master-addr 127.0.0.1") == 12 and "HSA_ENABLE_IPC_MODE_LEGACY=0" in text
+    assert "rank 7: RANK=7 LOCAL_RANK=7 WORLD_SIZE=8 MASTER_ADDR=127.0.0.1" in text and "predicted bands" in text
+    cmds = gpu_scale.commands(tmp_path, 200, 8)
+    assert len(cmds) == 17 and len({str(c[3]) for c in cmds}) == 17
+    ports = [c[2][c[2].index("--master-port") + 1] for c in cmds if "--master-port" in c[2]]
+    assert len(set(ports)) == len(ports) == 12                                    # no two launches share a rendezvous port
+
+    def write(lines):
+        for f in tmp_path.glob("*.json"):
+            f.unlink()
+        (tmp_path / "ref_n1.json").write_text("banner\n" + json.dumps({"value": 7000.0}))
+        for (leg, n), d in lines.items():
+            (tmp_path / f"{leg}_n{n}.json").write_text(json.dumps(d))
+
+    good = {}
+    for leg in ("c4", "c4rccl", "c4s4"):
+        for n in (1, 2, 4, 8):
+            good[(leg, n)] = _scale_line(n, 7000.0 * n * (0.97 if n > 1 else 1.0) * (1.6 if leg == "c4s4" else 1.0), leg)
+    for n, sp in ((1, 1.0), (2, 1.1), (4, 1.25), (8, 1.33)):
+        good[("tiled", n)] = _scale_line(n, 5000.0 * sp, "tiled")
+    write(good)
+    out = []
+    assert gpu_scale.check(tmp_path, out.append) and out[-1] == "CHECKS ok"
+    for what, key, over in (("rccl_ranks=0", ("c4", 4), dict(rccl_ranks=0)),
+                            ("global map merge failed", ("c4", 2), dict(config={"rccl_before_clock": False, "global_map_merge_after_the_clock": {"error": "x"}})),
+                            ("rccl_before_clock=False, wanted True", ("c4rccl", 2), dict(config={"rccl_before_clock": False, "global_map_merge_after_the_clock": {}})),
+                            ("differs from the plain bench", ("c4", 1), dict(value=6000.0)),
+                            ("outside the predicted band", ("c4", 8), dict(value=7000.0 * 8 * 0.7)),
+                            ("outside the predicted band", ("tiled", 8), dict(value=5000.0 * 2.5))):
+        bad = dict(good)
+        bad[key] = {**good[key], **over}
+        write(bad)
+        out = []
+        assert not gpu_scale.check(tmp_path, out.append), what
+        assert any(what in ln for ln in out), (what, out)
+
+
 def test_scale_script_fails_on_unobserved_rccl():
-    """tools/gpu_scale.sh checks the OBSERVED rank count, the merge outcome and which side of the clock RCCL came up on."""
-    t = (ROOT / "tools" / "gpu_scale.sh").read_text()
+    """tools/gpu_scale.py checks the OBSERVED rank count, the merge outcome and which side of the clock RCCL came up on."""
+    t = (ROOT / "tools" / "gpu_scale.py").read_text()
     assert "rccl_ranks" in t and "rccl_probe" in t and "global map merge failed" in t and "rccl_before_clock" in t and "c4rccl" in t
+    assert "gpu_scale.py" in (ROOT / "tools" / "gpu_scale.sh").read_text()

@@ -35,6 +35,13 @@ def test_device_handovers_are_never_stale():
             assert r["stale"] == 0 and r["timeouts"] == 0 and r["handovers"] == groups * iters, (mode, groups, flags, r)
             total += r["handovers"]
     assert total >= 1_000_000
+    # k_decode_frame's fold records: write-through on the producer, ORDINARY loads of never-touched lines on the consumer (fresh slots per iteration)
+    fresh = 0
+    for rep in range(12):
+        r = _litmus(3, 256, 256, rep & 3)
+        assert r["stale"] == 0 and r["timeouts"] == 0 and r["handovers"] == 256 * 256, r
+        fresh += r["handovers"]
+    print(f"  mode 3 (ordinary loads of fresh lines): {fresh} hand-overs, none stale")
 
 
 def test_host_handovers_are_never_stale():
