@@ -1286,7 +1286,7 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
 }
 
 #ifdef DIF_TRACE
-int dif_trace_read(unsigned long long* out, int64_t n) {      // host copy of g_vd_trace (n <= 2048*8)
+int dif_trace_read(unsigned long long* out, int64_t n) {      // host copy of g_vd_trace (n <= 2048*16)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vd_trace), (size_t)n * 8) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }
 int dif_trace_read_encode(unsigned long long* out, int64_t n) {      // host copy of g_en_trace

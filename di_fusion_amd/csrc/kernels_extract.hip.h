@@ -479,6 +479,13 @@ __global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArg
     }
 }
 
+#ifdef DIF_TRACE            // tools/trace_decode.py: per-wave phase timestamps (100 MHz wall clock) of the last k_decode_voxels launch
+__device__ unsigned long long g_vd_trace[2048 * 16];
+#define VD_STAMP(slot) do { if (lane_id() == 0) g_vd_trace[((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define VD_STAMP(slot) do { } while (0)
+#endif
+
 // acc init from a per-lane record of the fold table through 16-byte loads that bypass the XCD's L2 (sc1).  Measured and NOT used by k_decode_frame
 // (see decode_refine_x6_body); kept for experiments.
 struct FoldInitCoherent {
@@ -539,6 +546,9 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
         rg.locate(T + nwaves, sm_n, lt_n, rows_n);
         e_next = (T + nwaves < n_tiles && lt_n * 32 + col < rows_n) ? entry(sm_n, lt_n * 32 + col) : 0;
         const int b = e / res3, sb = e - b * res3;
+#ifdef DIF_TRACE
+        if (FUSED && T == wave) { asm volatile("" :: "v"(b)); VD_STAMP(9); }
+#endif
         const float px = lat.coord(sb / (r * r)), py = lat.coord((sb / r) % r), pz = lat.coord(sb % r);
         float sdf, sd;
         // FUSED: the voxel's fold record was written through by a workgroup of THIS launch (possibly on another XCD) and acknowledged before the
@@ -551,7 +561,13 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
             if (half == 0) A.out_sdf[e] = sign * sdf;
             else A.out_std[e] = sd;
         }
+#ifdef DIF_TRACE
+        if (FUSED && T == wave) VD_STAMP(10);
+#endif
     }
+#ifdef DIF_TRACE
+    if (FUSED) VD_STAMP(11);
+#endif
 }
 
 __global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
@@ -662,12 +678,6 @@ struct VoxelDecodeArgs {
 #define VD_MAX_R2 64
 #define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3 + 2 * 256) /* per PAIR of waves: low sdf + low std + each wave's copy of the voxel's folded decoder constants */
 
-#ifdef DIF_TRACE            // tools/trace_decode.py: per-wave phase timestamps (100 MHz wall clock) of the last k_decode_voxels launch
-__device__ unsigned long long g_vd_trace[2048 * 8];
-#define VD_STAMP(slot) do { if (lane_id() == 0) g_vd_trace[((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define VD_STAMP(slot) do { } while (0)
-#endif
 
 // X6: the tiles run on the bf16 matrix pipe (decoder_tile_folded_x6; wblob = packing.py:pack_decoder_x6, folding required).
 // NS > 1: the decoded batches of S <= NS maps are walked as ONE range of voxels (map 0's, then map 1's, ...): weights staged once per
@@ -852,6 +862,7 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
             }
         }
         __syncthreads();
+        VD_STAMP(8);
     }
 }
 
