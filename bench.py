@@ -33,7 +33,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # /opt/skills/guides/MI355X_MICROARCH.md:42   
 # arithmetic is 2,500 / 6 TFLOP/s.  Matrix-pipe cycles one 32-row tile really occupies (per SIMD, 2.4 GHz), for the pipe-busy fraction:
 #   folded decoder tile: 480 bf16 MFMAs x 32 cycles + 16 f32 MFMAs x 64;   encoder tile: 312 x 32 + 3 x 64
 PEAK_X6_FP32_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-TILE_PIPE_CYCLES = {"bf16x6": {"encode": 312 * 32 + 3 * 64, "decode_lattice": 480 * 32 + 16 * 64, "decode_points": 480 * 32 + 16 * 64, "decode_frame": 480 * 32 + 16 * 64},
+TILE_PIPE_CYCLES = {"bf16x6": {"encode": 312 * 32 + 3 * 64, "decode_lattice": 480 * 32 + 16 * 64, "decode_points": 480 * 32 + 16 * 64},
                     "f32": {"encode": 419 * 64, "decode_lattice": 656 * 64, "decode_points": 656 * 64}}
 SIMDS, SHADER_HZ = 1024, 2.4e9
 
@@ -425,9 +425,8 @@ def halo_summary(stream, a):
 
 def roofline_of(records, sst):
     """records: [(kernel name, ms)] of the event-timed launches of the frames whose counters are `sst`."""
-    # (decode_frame: the frame's ONE decoder launch — the low lattice of every batch voxel AND the exact re-decode of the selected samples)
     rows = {"encode": (sum(s["M"] for s in sst), ENC_FLOP_PER_ROW), "decode_lattice": (sum(s["B"] * 64 for s in sst), DEC_FLOP_PER_ROW),
-            "decode_points": (sum(s["VH"] for s in sst), DEC_FLOP_PER_ROW), "decode_frame": (sum(s["B"] * 64 + s["VH"] for s in sst), DEC_FLOP_PER_ROW)}
+            "decode_points": (sum(s["VH"] for s in sst), DEC_FLOP_PER_ROW)}
     kern = {}
     for name, (n_rows, flop) in rows.items():
         ts = [ms for k, ms in records if k == name]
@@ -468,8 +467,7 @@ def roofline_block(per_frame, sst, pipe, short_run=False, streams=1):
         busy_pmc = json.loads(busy_file.read_text())["kernels"]
     except Exception:
         pass
-    kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode_refine_x6" if pipe == "bf16x6" else "k_decode<false>",
-             "decode_frame": "k_decode_frame"}[dom]
+    kname = {"encode": "k_encode", "decode_lattice": "k_decode_voxels", "decode_points": "k_decode_refine_x6" if pipe == "bf16x6" else "k_decode<false>"}[dom]
     if streams > 1:
         kname += "_batch"
     half = len(per_frame) // 2

@@ -25,7 +25,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # The compiler this tree was validated with (parity suite + tools/determinism_stress.py soak).  Two things in the kernels are properties of THIS
 # compiler rather than of the language: (1) the schedule of the bf16-pipe MLP tiles (below), and (2) the fence-free hand-overs — relaxed
 # agent-/system-scope atomic stores and loads must come out as write-through (sc1) stores and sc1 loads, with `s_waitcnt vmcnt(0)` in between
-# (csrc/kernels_litmus.hip.h; k_sdf_hg_reduce, k_decode_frame, k_extract_finish): tests/test_gpu_handoff.py hammers that pattern on every
+# (csrc/kernels_litmus.hip.h; k_sdf_hg_reduce, k_extract_finish): tests/test_gpu_handoff.py hammers that pattern on every
 # `pytest -m gpu`, and tests/test_abi.py checks the instructions in the built code object.  The bf16-pipe MLP kernels once showed a
 # schedule-dependent wrong tile with the SLP vectoriser on (see above): a different compiler means a different schedule, so its version is
 # part of the build id, and a build with another one says so loudly (DIF_ALLOW_OTHER_HIPCC=1 silences the warning once the GPU suite and

@@ -912,7 +912,7 @@ static VoxelDecodeArgs voxel_decode_args_of(const dif_map_t* map, const dif_weig
     VoxelDecodeArgs V = {};
     V.occ_slot = buf->occ_slot; V.latent = map->latent_vecs; V.cube_sdf = buf->cube_sdf; V.cube_std = buf->cube_std;
     V.counters = map->counters;          // B, VH of the frame
-    V.refine_list = buf->refine_list; V.R = e.R; V.sync = map->sync_words;
+    V.refine_list = buf->refine_list; V.R = e.R;
     V.fold_w = fold ? w->dec_fold_packed : nullptr; V.fold_table = buf->fold_table;
     V.low.res = e.l; V.low.a = (float)e.sample_a; V.low.vsize = (e.l > 1) ? (float)((e.sample_b - e.sample_a) / (e.l - 1)) : 0.0f;
     return V;
@@ -979,18 +979,9 @@ static int voxel_decode_attributes() {
         if (hipFuncSetAttribute((const void*)k_decode_refine_x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
         if (hipFuncSetAttribute((const void*)k_decode_voxels_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
         if (hipFuncSetAttribute((const void*)k_decode_refine_x6_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
-        if (hipFuncSetAttribute((const void*)k_decode_frame, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
-        if (hipFuncSetAttribute((const void*)k_decode_frame_batch, hipFuncAttributeMaxDynamicSharedMemorySize, x6_bytes) != hipSuccess) return DIF_ELAUNCH;
         attr_set[dev] = true;
     }
     return DIF_OK;
-}
-
-// measurement switch (read once): DIF_DECODE_LAUNCHES=2 runs the fast decode of the bf16 pipe as the two launches of rounds 2-5 (lattice, refine)
-// instead of the one persistent launch (k_decode_frame), for A/B runs on one box
-static bool decode_two_launches() {
-    static const bool two = [] { const char* e = getenv("DIF_DECODE_LAUNCHES"); return e && atoi(e) == 2; }();
-    return two;
 }
 
 static std::atomic<int> g_mc_grid_cap{0};
@@ -1072,7 +1063,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         }
     }
     {
-        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels, map->sync_words};
+        OccFunctor f{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, C, buf->max_voxels};
         if (launch_counted_scan(f, (int)((grid + 31) / 32), map->grid_tot, s) != DIF_OK) return DIF_ELAUNCH;      // the markers kept the block totals
     }
     int rc;
@@ -1087,16 +1078,6 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
         if (voxel_decode_attributes() != DIF_OK) return DIF_ELAUNCH;
         int64_t blocks = (buf->max_voxels + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
-        if (x6 && map->sync_words && !decode_two_launches()) {
-            // ONE persistent launch: lattice, hand-over, refine (kernels_extract.hip.h: k_decode_frame)
-            int64_t fblocks = (buf->max_voxels * (int64_t)(R3 / 32) + 7) / 8;
-            if (fblocks < blocks) fblocks = blocks;
-            if (fblocks > num_cus()) fblocks = num_cus();
-            ProfScope prof(DIF_PROF_DECODE_FRAME, s);
-            hipLaunchKernelGGL(k_decode_frame, dim3((int)fblocks), dim3(512), lds_bytes, s, V, refine_args_of(map, buf, e, true), (const float*)w->dec_x6_packed);
-            DIF_CHECK_LAUNCH();
-            return extract_mesh_part(map, buf, e, max_std, no_cache, scale_vertices, s);
-        }
         {
             ProfScope prof(DIF_PROF_DECODE_LATTICE, s);
             if (x6) hipLaunchKernelGGL(k_decode_voxels<true>, dim3((int)blocks), dim3(512), lds_bytes, s, V, (const float*)w->dec_x6_packed);
@@ -1226,7 +1207,7 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
             return DIF_EINVAL;
         if (!map->tri_start || !map->tri_n || !buf->fold_table || !buf->chunk_sum || !buf->mc_status || buf->max_voxels > ((int64_t)1 << 24)) return DIF_EINVAL;
         dirty.s[j] = DirtyScanArgs{dirty_set_of(map, buf, 0), map->counters + DIF_C_N_OCCUPIED, map->dirty_tot};
-        occ.f[j] = OccFunctor{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, map->counters, buf->max_voxels, map->sync_words};
+        occ.f[j] = OccFunctor{map->grid_bits, map->indexer, buf->occ_slot, map->vbm, map->counters, buf->max_voxels};
         occ.tot[j] = map->grid_tot;
         vd.s[j] = voxel_decode_args_of(map, w, buf, e, true);
         rf.s[j] = refine_args_of(map, buf, e, true);
@@ -1245,15 +1226,6 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
     DIF_CHECK_LAUNCH();
     if (launch_counted_scan_batch(occ, S, (int)((grid + 31) / 32), s) != DIF_OK) return DIF_ELAUNCH;
     if (voxel_decode_attributes() != DIF_OK) return DIF_ELAUNCH;
-    if (m0->sync_words && !decode_two_launches()) {
-        int64_t blocks = (max_voxels * S * (int64_t)(e.R3 / 32) + 7) / 8;
-        if (blocks < 1) blocks = 1;
-        if (blocks > num_cus()) blocks = num_cus();
-        ProfScope prof(DIF_PROF_DECODE_FRAME, s);
-        hipLaunchKernelGGL(k_decode_frame_batch, dim3((int)blocks), dim3(512), (size_t)X6_LDS_BYTES + 4 * VD_WAVE_LDS_FLOATS * 4, s, vd, rf, (int)S,
-                           (const float*)w->dec_x6_packed);
-        DIF_CHECK_LAUNCH();
-    } else {
     {
         int64_t blocks = (max_voxels * S + 3) / 4;
         if (blocks > num_cus()) blocks = num_cus();
@@ -1270,7 +1242,6 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
         hipLaunchKernelGGL(k_decode_refine_x6_batch, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, rf, (int)S, (const float*)w->dec_x6_packed);
         DIF_CHECK_LAUNCH();
     }
-    }
     {
         size_t lds_bytes; int grid1;
         const int rc = mc_onepass_setup(mc.s[0].a, lds_bytes, grid1, max_voxels);
@@ -1286,7 +1257,7 @@ int dif_extract_streams(const dif_stream_frame_t* st, int32_t S, const dif_weigh
 }
 
 #ifdef DIF_TRACE
-int dif_trace_read(unsigned long long* out, int64_t n) {      // host copy of g_vd_trace (n <= 2048*16)
+int dif_trace_read(unsigned long long* out, int64_t n) {      // host copy of g_vd_trace (n <= 2048*8)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vd_trace), (size_t)n * 8) == hipSuccess ? DIF_OK : DIF_ELAUNCH;
 }
 int dif_trace_read_encode(unsigned long long* out, int64_t n) {      // host copy of g_en_trace
@@ -1529,7 +1500,7 @@ int dif_mesh_cache_export_sdma(const dif_extract_buffers_t* buf, int64_t lo, int
 
 // ---- TEST HOOK: litmus runs of the fence-free hand-overs (kernels_litmus.hip.h; tests/test_gpu_handoff.py) ------------------------------------
 int dif_test_handoff(int32_t mode, int32_t groups, int32_t iters, int32_t flags, int64_t* out) {
-    if (!out || mode < 0 || mode > 3 || groups < 1 || groups > 1024 || iters < 1 || iters > (1 << 22) || (mode == 3 && iters > LIT_FRESH_ITERS)) return DIF_EINVAL;
+    if (!out || mode < 0 || mode > 2 || groups < 1 || groups > 1024 || iters < 1 || iters > (1 << 22)) return DIF_EINVAL;
     const bool host_mode = mode == 2;
     out[0] = out[1] = out[2] = out[3] = 0;
     hipStream_t s = nullptr, hs = nullptr;
@@ -1549,7 +1520,7 @@ int dif_test_handoff(int32_t mode, int32_t groups, int32_t iters, int32_t flags,
         }
         const auto t0 = std::chrono::steady_clock::now();
         if (!host_mode) {
-            const size_t rec_bytes = mode == 3 ? (size_t)iters * groups * LIT_FRESH_WORDS * sizeof(double) : (size_t)2 * groups * LIT_WORDS * sizeof(double), cnt_bytes = ((size_t)iters + 64) * sizeof(unsigned);
+            const size_t rec_bytes = (size_t)2 * groups * LIT_WORDS * sizeof(double), cnt_bytes = ((size_t)iters + 64) * sizeof(unsigned);
             if (hipMalloc((void**)&rec, rec_bytes) != hipSuccess || hipMalloc((void**)&counters, cnt_bytes) != hipSuccess) break;
             if (hipMemsetAsync(rec, 0, rec_bytes, s) != hipSuccess || hipMemsetAsync(counters, 0, cnt_bytes, s) != hipSuccess) break;
             if (hipStreamSynchronize(s) != hipSuccess) break;

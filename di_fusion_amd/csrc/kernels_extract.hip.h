@@ -210,7 +210,6 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
     int32_t* vbm;
     int* counters;
     int64_t max_voxels;
-    uint32_t* dec_sync;     // dif_map_t.sync_words or NULL: the decoder launch behind this scan claims its voxels through two of them (k_decode_frame)
     __device__ int count(int w) const { return __popc(bits[w]); }
     __device__ void emit(int w, int offset) const {
         uint32_t word = bits[w];
@@ -231,7 +230,6 @@ struct OccFunctor {         // bitmap -> occ_slot[b] in ascending lin order; vbm
         counters[DIF_C_B] = total;
         counters[DIF_C_VH] = 0;
         counters[DIF_C_WORK] = 0;
-        if (dec_sync) { dec_sync[DIF_SYNC_DEC_TICKET] = 0u; dec_sync[DIF_SYNC_DEC_DONE] = 0u; }
     }
 };
 
@@ -479,36 +477,9 @@ __global__ void __launch_bounds__(GRAD_X6_THREADS, 1) k_decode_grad_x6(DecodeArg
     }
 }
 
-#ifdef DIF_TRACE            // tools/trace_decode.py: per-wave phase timestamps (100 MHz wall clock) of the last k_decode_voxels launch
-__device__ unsigned long long g_vd_trace[2048 * 16];
-#define VD_STAMP(slot) do { if (lane_id() == 0) g_vd_trace[((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 16 + (slot)] = wall_clock64(); } while (0)
-#else
-#define VD_STAMP(slot) do { } while (0)
-#endif
-
-// acc init from a per-lane record of the fold table through 16-byte loads that bypass the XCD's L2 (sc1).  Measured and NOT used by k_decode_frame
-// (see decode_refine_x6_body); kept for experiments.
-struct FoldInitCoherent {
-    __amdgpu_buffer_rsrc_t rsrc;    // the map's fold table
-    unsigned rec;                   // byte offset of this lane's voxel record (256 floats)
-    __device__ __forceinline__ f16v load(int layer, int mb, int half) const {
-        const unsigned o = rec + (unsigned)(layer * 128 + mb * 32 + half * 16) * 4u;
-        const u4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 16), q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 16, 0, 16),
-                  q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 32, 0, 16), q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 48, 0, 16);
-        f16v r;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r[i] = __uint_as_float(q0[i]); r[4 + i] = __uint_as_float(q1[i]); r[8 + i] = __uint_as_float(q2[i]); r[12 + i] = __uint_as_float(q3[i]);
-        }
-        return r;
-    }
-};
-
 // Refine rows (mode 1 with the lattice pass's fold table) on the bf16 matrix pipe; wblob = packing.py:pack_decoder_x6.
 // NS > 1: the refine lists of S <= NS maps walked as one range of tiles (see encode_body); lattice and sign are those of map 0.
-// FUSED: the second phase of k_decode_frame — the weights are in LDS already, and list entries, row counts and fold records come from the launch's
-// own first phase on other XCDs: read with agent-scope (sc1) loads.
-template <int NS, bool FUSED = false>
+template <int NS>
 __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, NS>& B, int S, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), half = lane >> 5, col = lane & 31;
@@ -521,20 +492,16 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
     rg.pre[0] = 0;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        if (FUSED) rg.cnt[j] = (j < S) ? (int64_t)__hip_atomic_load(B.s[j].n_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        else rg.cnt[j] = (j < S) ? (B.s[j].n_ptr ? (int64_t)(*B.s[j].n_ptr) : B.s[j].n_static) : 0;
+        rg.cnt[j] = (j < S) ? (B.s[j].n_ptr ? (int64_t)(*B.s[j].n_ptr) : B.s[j].n_static) : 0;
         rg.pre[j + 1] = rg.pre[j] + (rg.cnt[j] + 31) / 32;
     }
     const int64_t n_tiles = rg.total();
-    auto entry = [&](int sm, int64_t row) -> int {
-        return FUSED ? __hip_atomic_load(B.s[sm].list + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : B.s[sm].list[row];
-    };
     // the first tile's list entries are requested before the weights are staged (one dependent hop off the critical path)
     int sm_n; int64_t lt_n, rows_n;
     rg.locate(wave, sm_n, lt_n, rows_n);
-    int e_next = (wave < n_tiles && lt_n * 32 + col < rows_n) ? entry(sm_n, lt_n * 32 + col) : 0;
+    int e_next = (wave < n_tiles && lt_n * 32 + col < rows_n) ? B.s[sm_n].list[lt_n * 32 + col] : 0;
     __builtin_amdgcn_sched_barrier(0);
-    if (!FUSED) stage_weights(lds, wblob, X6_LDS_BYTES / 4);
+    stage_weights(lds, wblob, X6_LDS_BYTES / 4);
     const __amdgpu_buffer_rsrc_t wfwd = make_rsrc(wblob, X6_BYTES / 4);
     for (int64_t T = wave; T < n_tiles; T += nwaves) {
         const int sm = sm_n;
@@ -544,30 +511,16 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
         const bool live = row < n_rows;
         const int e = e_next;
         rg.locate(T + nwaves, sm_n, lt_n, rows_n);
-        e_next = (T + nwaves < n_tiles && lt_n * 32 + col < rows_n) ? entry(sm_n, lt_n * 32 + col) : 0;
+        e_next = (T + nwaves < n_tiles && lt_n * 32 + col < rows_n) ? B.s[sm_n].list[lt_n * 32 + col] : 0;
         const int b = e / res3, sb = e - b * res3;
-#ifdef DIF_TRACE
-        if (FUSED && T == wave) { asm volatile("" :: "v"(b)); VD_STAMP(9); }
-#endif
         const float px = lat.coord(sb / (r * r)), py = lat.coord((sb / r) % r), pz = lat.coord(sb % r);
         float sdf, sd;
-        // FUSED: the voxel's fold record was written through by a workgroup of THIS launch (possibly on another XCD) and acknowledged before the
-        // hand-over.  It is read with ORDINARY loads all the same — 32 KB per tile, 50 MB per frame, which as sc1 loads all went past the L2
-        // (profiles/r06_experiments.md 1): a record is eight whole 128-byte lines that no wave of this XCD has touched since the launch began
-        // (the launch starts with invalidated L1 / L2, phase one reads no fold record, and a workgroup writes only its own voxels' records), so the
-        // first load of a line misses to memory, where the data is, and later tiles of the same voxel hit.  Litmus mode 3 is this access pattern.
         decoder_tile_folded_x6(lds, wfwd, FoldInitGlobal{A.fold_table + (int64_t)b * 256}, px, py, pz, lane, sdf, sd);
         if (live) {
             if (half == 0) A.out_sdf[e] = sign * sdf;
             else A.out_std[e] = sd;
         }
-#ifdef DIF_TRACE
-        if (FUSED && T == wave) VD_STAMP(10);
-#endif
     }
-#ifdef DIF_TRACE
-    if (FUSED) VD_STAMP(11);
-#endif
 }
 
 __global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
@@ -671,30 +624,25 @@ struct VoxelDecodeArgs {
     int* counters;
     const float* fold_w;            // packing.py:pack_decoder_fold, or NULL (latent carried through the MFMAs)
     float* fold_table;              // [batch voxel][256] out, for the refine pass
-    uint32_t* sync;                 // k_decode_frame: dif_map_t.sync_words (DIF_SYNC_DEC_TICKET / DIF_SYNC_DEC_DONE, a 128-byte line each)
 };
 
 #define VD_MAX_L3 64
 #define VD_MAX_R2 64
 #define VD_WAVE_LDS_FLOATS (2 * VD_MAX_L3 + 2 * 256) /* per PAIR of waves: low sdf + low std + each wave's copy of the voxel's folded decoder constants */
 
+#ifdef DIF_TRACE            // tools/trace_decode.py: per-wave phase timestamps (100 MHz wall clock) of the last k_decode_voxels launch
+__device__ unsigned long long g_vd_trace[2048 * 8];
+#define VD_STAMP(slot) do { if (lane_id() == 0) g_vd_trace[((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define VD_STAMP(slot) do { } while (0)
+#endif
 
 // X6: the tiles run on the bf16 matrix pipe (decoder_tile_folded_x6; wblob = packing.py:pack_decoder_x6, folding required).
 // NS > 1: the decoded batches of S <= NS maps are walked as ONE range of voxels (map 0's, then map 1's, ...): weights staged once per
 // workgroup, S frames' worth of pairs per launch.  A pair's voxel belongs to one map (scalar loads of that map's pointers from the
 // kernel-argument array); lattice, resolution and fold weights are those of map 0; refine-list space is reserved per map.
-// FUSED (k_decode_frame): the first phase of the frame's ONE decoder launch.  Voxels are CLAIMED, k per workgroup and claim, through a ticket — every
-// voxel of the phase is then held by a workgroup that runs, whatever else shares the GPU —; what the second phase reads on other XCDs (fold records,
-// refine-list entries) is written through (sc1) and acknowledged before the workgroup reports its groups done; samples selected for the exact
-// re-decode are NOT written here (the second phase writes them: two XCDs' L2s must never both hold a dirty copy of one sample).
-// Hand-over to the second phase: a workgroup that finds the ticket exhausted waits for its own stores' acknowledgements (s_waitcnt vmcnt(0)), adds
-// the groups it decoded to sync_words[DIF_SYNC_DEC_DONE] and polls that word until it equals the number of groups.  Only RUNNING workgroups hold groups,
-// so the wait ends whether or not the whole grid is resident (a workgroup that starts late claims nothing and waits for the others); it gives up
-// after ~1 s with DIF_C_OVERFLOW = 10 instead of hanging the queue.  The batch scan in front of the launch returns ticket and count to 0.  No fence
-// anywhere: write-through stores + vmcnt(0) on the producers, sc1 loads on the consumers (as kernels_track.hip.h: a fence writes back and
-// invalidates the XCD's whole L2, ~4 us per workgroup; tests/test_gpu_handoff.py hammers exactly this pattern).
-template <bool X6, int NS, bool FUSED = false>
-__device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs, NS>& AB, int S, const float* __restrict__ wblob, uint32_t* __restrict__ sync = nullptr) {
+template <bool X6, int NS>
+__device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs, NS>& AB, int S, const float* __restrict__ wblob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     VD_STAMP(0);
     constexpr int LDS_W = X6 ? X6_LDS_BYTES / 4 : ((DEC_LDS_FLOATS + 3) & ~3);
@@ -725,22 +673,10 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
     const int first = __builtin_amdgcn_readfirstlane(pair * (int)gridDim.x + (int)blockIdx.x);  // spread over CUs first
     // uniform trip count: the barriers below are workgroup-wide (the pair's hand-over, and the refine-list reservation: one global
     // atomic per workgroup, map and round instead of one per voxel — 900 same-address atomics at the end of the launch queued up for ~5 us)
-    __shared__ int s_tot[8], s_map[8], s_base[NS], s_claim;
-    // FUSED: k voxels per claim — as many as spread the batch over all workgroups (one pair per SIMD pair first), at most a pair each
-    const int k_claim = min(max((B + (int)gridDim.x - 1) / (int)gridDim.x, 1), pairs_per_block);
-    const int n_groups = (B + k_claim - 1) / k_claim;
-    const int rounds = FUSED ? 0x7FFFFFFF : (B + n_pairs - 1) / n_pairs;
-    int mine = 0;                                              // FUSED: groups this workgroup has decoded
+    __shared__ int s_tot[8], s_map[8], s_base[NS];
+    const int rounds = (B + n_pairs - 1) / n_pairs;
     for (int round = 0; round < rounds; ++round) {
-        int bg = first + round * n_pairs;                      // index in the concatenated range
-        if (FUSED) {
-            if (threadIdx.x == 0) s_claim = (int)atomicAdd(sync + DIF_SYNC_DEC_TICKET, 1u);
-            __syncthreads();                                   // (the round's last barrier keeps the next claim behind every reader of this one)
-            const int g = s_claim;
-            if (g >= n_groups) break;
-            ++mine;
-            bg = pair < k_claim ? g * k_claim + pair : B;
-        }
+        const int bg = first + round * n_pairs;                // index in the concatenated range
         int sm = 0, b = bg;                                    // map and index in that map's batch
 #pragma unroll
         for (int j = 1; j < NS; ++j)
@@ -763,10 +699,7 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 if (tsel == 0) {
                     float* rec = A.fold_table + (int64_t)b * 256;          // the refine pass picks the constants up from here
-                    for (int p = lane; p < 256; p += 64) {
-                        if (FUSED) __hip_atomic_store(rec + p, w_fold[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        else rec[p] = w_fold[p];
-                    }
+                    for (int p = lane; p < 256; p += 64) rec[p] = w_fold[p];
                 }
                 VD_STAMP(6);
 #if defined(DIF_VD_CUT) && DIF_VD_CUT == 2
@@ -805,12 +738,9 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
                 tri_axis(jz, l, scale, z0, z1, wz0, wz1);
                 float sv = tri_sample(w_low_sdf, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
                 float dv = tri_sample(w_low_std, l, x0, x1, y0, y1, z0, z1, wx0, wx1, wy0, wy1, wz0, wz1);
-                const bool pick = fabsf(sv) < 0.05f;
-                if (!(FUSED && pick)) {
-                    cube_sdf[e0 + jz] = -sv;
-                    cube_std[e0 + jz] = dv;
-                }
-                if (pick) sel |= 1u << jz;
+                cube_sdf[e0 + jz] = -sv;
+                cube_std[e0 + jz] = dv;
+                if (fabsf(sv) < 0.05f) sel |= 1u << jz;
             }
         }
         VD_STAMP(3);
@@ -839,45 +769,13 @@ __device__ __forceinline__ void decode_voxels_body(const BatchN<VoxelDecodeArgs,
             while (sel) {
                 const int jz = __ffs((int)sel) - 1;
                 sel &= sel - 1;
-                if (FUSED) __hip_atomic_store(refine_list + o, (int32_t)(e0 + jz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else refine_list[o] = (int32_t)(e0 + jz);
-                ++o;
+                refine_list[o++] = (int32_t)(e0 + jz);
             }
         }
         __syncthreads();                        // s_tot / s_base and the pair's LDS record are rewritten by the next round
         VD_STAMP(4);
     }
     VD_STAMP(5);
-    if (FUSED) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // (the polled word has a 128-byte line to itself: 256 pollers on the line of the refine-list reservations starved those — a line
-            // takes ~90 atomics per microsecond, profiles/r03 — and one poll per ~0.5 us and workgroup is all the hand-over needs)
-            if (mine) atomicAdd(sync + DIF_SYNC_DEC_DONE, (unsigned)mine);
-            int spins = 0;
-            while ((int)__hip_atomic_load(sync + DIF_SYNC_DEC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_groups) {
-                __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1 << 21)) { AB.s[0].counters[DIF_C_OVERFLOW] = 10; break; }
-            }
-        }
-        __syncthreads();
-        VD_STAMP(8);
-    }
-}
-
-// The frame's ONE decoder launch (fast two-level extract on the bf16 pipe): low lattice + trilinear x2 + threshold of every
-// batch voxel, the launch-wide hand-over, then the exact re-decode of the selected samples by the same persistent workgroups — the 146 KB
-// weight image is staged once, one launch floor instead of two.  NS = 1: one map; NS = DIF_MAX_STREAMS: the maps of a stream group.
-__global__ void __launch_bounds__(512, 1) k_decode_frame(VoxelDecodeArgs A, DecodeArgs R, const float* __restrict__ wblob) {
-    const BatchN<VoxelDecodeArgs, 1> AB{{A}};
-    decode_voxels_body<true, 1, true>(AB, 1, wblob, A.sync);
-    const BatchN<DecodeArgs, 1> RB{{R}};
-    decode_refine_x6_body<1, true>(RB, 1, wblob);
-}
-__global__ void __launch_bounds__(512, 1) k_decode_frame_batch(Batch<VoxelDecodeArgs> AB, Batch<DecodeArgs> RB, int S, const float* __restrict__ wblob) {
-    decode_voxels_body<true, DIF_MAX_STREAMS, true>(AB, S, wblob, AB.s[0].sync);
-    decode_refine_x6_body<DIF_MAX_STREAMS, true>(RB, S, wblob);
 }
 
 template <bool X6>

@@ -1,7 +1,8 @@
 // Litmus kernels for the fence-free hand-overs of the product kernels (dif_test_handoff; tests/test_gpu_handoff.py).  Part of libdifusion; included
 // by difusion.hip inside its anonymous namespace.  TEST INFRASTRUCTURE: nothing on the fusion path launches these.
 //
-// The pattern under test (kernels_track.hip.h:k_sdf_hg_reduce, kernels_extract.hip.h:k_decode_frame, kernels_mesh.hip.h:extract_finish_body):
+// The pattern under test (kernels_track.hip.h:k_sdf_hg_reduce, kernels_mesh.hip.h:extract_finish_body; a launch-wide meeting built on it was
+// measured as the frame's one-launch decoder in round 6 — profiles/r06_experiments.md 1 — and not kept):
 //   producer:  relaxed agent-scope (or system-scope) STORES of the payload — on gfx942 / gfx950 these are write-through stores (sc1 / sc0 sc1) —,
 //              s_waitcnt vmcnt(0) in the storing wave (every store acknowledged by the memory side), THEN the counter / ticket / sequence word;
 //   consumer:  sees the word through an agent-scope (system-scope: the CPU) load, THEN reads the payload with agent-scope loads (sc1: past the
@@ -18,50 +19,19 @@ __device__ __forceinline__ double lit_value(unsigned it, unsigned g, unsigned j)
     return (double)(((unsigned long long)it << 20) ^ ((unsigned long long)g << 8) ^ j) + 0.5;
 }
 
-// mode 0 — the decode launch's hand-over: every workgroup writes its record, waits for the acknowledgements, adds 1 to the iteration's counter, polls
+// mode 0 — a launch-wide meeting: every workgroup writes its record, waits for the acknowledgements, adds 1 to the iteration's counter, polls
 //          the counter until all G have arrived, then checks the record of ANOTHER workgroup (a different one every iteration, so that every pair of
 //          XCDs is crossed).  Two record slots: a workgroup rewrites slot (it & 1) only after it has passed iteration it + 1's counter, i.e. after
 //          every reader of iteration it has arrived there.
 // mode 1 — the tracker reduction's hand-over: same producers, but only the LAST arriver (ticket) reads — all G records — and then opens the next
 //          iteration through a second word.
-// mode 3 — k_decode_frame's fold records: as mode 0, but every iteration has record slots of its OWN (no address is written or read twice in a
-//          launch: iters <= LIT_FRESH_ITERS), a record is two whole 128-byte lines, and the consumer reads the other workgroup's record with ORDINARY
-//          loads: lines that no wave of its XCD has touched since the launch began (launches start with invalidated caches) must miss to memory,
-//          where the write-through data is.
 // G <= the number of workgroups the GPU (or the stream's CU mask) holds at once: the launch is a sequence of launch-wide meetings.
-#define LIT_FRESH_ITERS 256
-#define LIT_FRESH_WORDS 32      /* doubles per record in mode 3: 256 bytes */
 __global__ void __launch_bounds__(256) k_litmus_device(double* __restrict__ rec /* [2][G][LIT_WORDS] */, unsigned* __restrict__ counters /* [iters + 1] */,
                                                        unsigned* __restrict__ go /* mode 1: iterations released so far */, int iters, int mode,
                                                        unsigned long long* __restrict__ out /* [0] stale values seen, [1] hand-overs checked, [2] time-outs */) {
     const unsigned G = gridDim.x, g = blockIdx.x;
     __shared__ int s_last;
     unsigned long long bad = 0, seen = 0;
-    if (mode == 3) {
-        for (int it = 0; it < iters; ++it) {
-            double* mine = rec + ((size_t)it * G + g) * LIT_FRESH_WORDS;
-            if (threadIdx.x < LIT_FRESH_WORDS) __hip_atomic_store(mine + threadIdx.x, lit_value(it, g, threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (threadIdx.x == 0) {
-                __hip_atomic_fetch_add(counters + it, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int spins = 0;
-                while (__hip_atomic_load(counters + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 24)) { atomicAdd(out + 2, 1ull); break; }
-                }
-            }
-            __syncthreads();
-            const unsigned other = (g + 1u + (unsigned)it * 37u) % G;
-            if (other != g && threadIdx.x < LIT_FRESH_WORDS) {
-                const volatile double* src = rec + ((size_t)it * G + other) * LIT_FRESH_WORDS;       // an ordinary global load (volatile: not merged or hoisted)
-                if (src[threadIdx.x] != lit_value(it, other, threadIdx.x)) ++bad;
-            }
-            if (threadIdx.x == 0) ++seen;
-        }
-        if (bad) atomicAdd(out + 0, bad);
-        if (seen) atomicAdd(out + 1, seen);
-        return;
-    }
     for (int it = 0; it < iters; ++it) {
         double* mine = rec + ((size_t)(it & 1) * G + g) * LIT_WORDS;
         if (threadIdx.x < LIT_WORDS) __hip_atomic_store(mine + threadIdx.x, lit_value(it, g, threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

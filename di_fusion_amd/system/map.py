@@ -111,8 +111,7 @@ _OVERFLOW_WHAT = {8: "a delta halo message overflowed: the neighbours' halo copi
                      "parallel.exchange_halo(mode='full'), for streams that change this much per frame)",
                   1: "more voxels than latent rows", 2: "more dirty voxels than extract buffers", 3: "more decoded voxels than extract buffers",
                   5: "mesh-cache log full", 6: "more records than the export buffer",
-                  7: "marching cubes gave up waiting for an earlier workgroup (the GPU was shared with another kernel for seconds)",
-                  10: "the decoder launch gave up waiting for its lattice phase (the GPU was shared with another kernel for seconds)"}
+                  7: "marching cubes gave up waiting for an earlier workgroup (the GPU was shared with another kernel for seconds)"}
 
 
 class _NoSwitch:

@@ -144,9 +144,8 @@ typedef struct dif_map {
 } dif_map_t;
 
 /* sync_words (each on a 128-byte line of its own): frame n's fusion kernel has completed (written by the first kernel of its extract); frame n's front
- * end has completed; the claim counter of the frame's decoder launch and its count of completed lattice groups (k_decode_frame: both returned to 0 by
- * the batch scan in front of it; polled words must not share a line with anything that is updated atomically) */
-enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_DEC_TICKET = 64, DIF_SYNC_DEC_DONE = 96, DIF_SYNC_WORDS = 128 };
+ * end has completed */
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_WORDS = 64 };
 enum { DIF_FC_SHADOW = 4, DIF_FC_COUNT = 32 };
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
@@ -498,7 +497,7 @@ int dif_merge_halo2(const dif_map_t* map, const int32_t* msg_a, int64_t max_a, c
 /* When enabled, a hipEvent pair is recorded around each launch of the named kernels ON THE STREAM THEY RUN ON. */
 enum { DIF_PROF_ENCODE = 0, DIF_PROF_DECODE_LATTICE = 1, DIF_PROF_DECODE_POINTS = 2, DIF_PROF_MC_COUNT = 3, DIF_PROF_MC_EMIT = 4,
        DIF_PROF_HALO_EXPORT = 5 /* the launches of one dif_export_halo* call */, DIF_PROF_HALO_MERGE = 6 /* of one dif_merge_halo* call */,
-       DIF_PROF_DECODE_FRAME = 7 /* the frame's ONE decoder launch: lattice + refine (B * l^3 + VH rows) */, DIF_PROF_COUNT = 8 };
+       DIF_PROF_COUNT = 8 };
 int dif_profile_enable(int32_t on);
 /* Sum of elapsed milliseconds and number of launches per kernel since the last reset; synchronises on the events. */
 int dif_profile_read(double* ms /* [DIF_PROF_COUNT], host */, int64_t* launches /* [DIF_PROF_COUNT], host */, int32_t reset);
@@ -531,11 +530,9 @@ int dif_test_mc_grid_cap(int32_t n);
 int dif_test_sdma_mode(int32_t mode);
 /* TEST HOOK: a litmus run of the fence-free hand-overs the product kernels use (write-through stores + s_waitcnt vmcnt(0) + word on the producer,
  * sc1 loads on the consumer; csrc/kernels_litmus.hip.h).  mode 0: `groups` workgroups meet `iters` times through a counter every one polls, each then
- * checks another workgroup's 29-double record (k_decode_frame's hand-over); mode 1: the last arriver of a ticket checks all records
+ * checks another workgroup's 29-double record (a launch-wide meeting: the pattern of profiles/r06_experiments.md 1); mode 1: the last arriver of a ticket checks all records
  * (k_sdf_hg_reduce's); mode 2: `groups` workgroups hand 44 doubles + a sequence word to the CPU through pinned memory `iters` times
- * (k_sdf_hg_reduce's / k_extract_finish's hand-back); mode 3: as mode 0 with
- * record slots that are never reused inside a launch (iters <= 256) and ORDINARY loads on the consumer (k_decode_frame's fold records: lines its XCD has
- * not touched since the launch began).  flags bit 0: on a stream confined to every other CU; bit 1: beside a kernel that streams
+ * (k_sdf_hg_reduce's / k_extract_finish's hand-back).  flags bit 0: on a stream confined to every other CU; bit 1: beside a kernel that streams
  * through 1 GB.  out (host, int64[4]): stale values seen, hand-overs checked, time-outs, microseconds.  Allocates and frees what it needs;
  * synchronises. */
 int dif_test_handoff(int32_t mode, int32_t groups, int32_t iters, int32_t flags, int64_t* out);

@@ -44,9 +44,9 @@ def main():
         st.step(i, "none")
     torch.cuda.synchronize()
     B = st.stats[-1]["B"]
-    buf = (ctypes.c_ulonglong * (2048 * 16))()
-    assert lib.dif_trace_read(buf, 2048 * 16) == 0
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 16).astype(np.int64)
+    buf = (ctypes.c_ulonglong * (2048 * 8))()
+    assert lib.dif_trace_read(buf, 2048 * 8) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8).astype(np.int64)
     act = t[:, 2] > t[:, 0]                               # waves that decoded a voxel in the LAST launch (stamp 2 sits inside the b < B branch)
     t0 = t[:, 0][t[:, 0] > 0].min()
     us = lambda x: (x - t0) / 100.0
@@ -62,14 +62,6 @@ def main():
            "tiles_phase_of_last_voxel_us_median": float(np.median((t[act, 2] - t[act, 6]) / 100.0)),
            "upsample_us_median": float(np.median((t[act, 3] - t[act, 2]) / 100.0)),
            "list_us_median": float(np.median((t[act, 4] - t[act, 3]) / 100.0))}
-    if (t[:, 8] > 0).any():          # k_decode_frame: the hand-over and the refine phase (8 hand-over passed, 9 first list entries loaded, 10 first refine tile done, 11 exit)
-        ok = t[:, 8] >= t0
-        out["frame_kernel"] = {"lattice_loop_exit_us": [float(np.percentile(us(t[ok, 5]), q)) for q in (0, 50, 100)],
-                               "handover_passed_us": [float(np.percentile(us(t[ok, 8]), q)) for q in (0, 50, 100)],
-                               "first_entries_loaded_us": [float(np.percentile(us(t[ok, 9]), q)) for q in (0, 50, 100)],
-                               "first_refine_tile_done_us": [float(np.percentile(us(t[t[:, 10] >= t0, 10]), q)) for q in (0, 50, 100)] if (t[:, 10] >= t0).any() else None,
-                               "exit_us": [float(np.percentile(us(t[t[:, 11] >= t0, 11]), q)) for q in (0, 50, 100)],
-                               "waves_with_refine_tiles": int((t[:, 10] >= t0).sum())}
     print(json.dumps(out))
     # k_encode: 0 entry, 1 staged, 2 last tile's inputs gathered, 3 its MFMA chain done, 4 its records written, 5 exit
     buf = (ctypes.c_ulonglong * (4096 * 8))()          # (the x6 encoder runs 12 waves per workgroup: 3,072 of the 4,096 rows)
