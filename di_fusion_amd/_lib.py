@@ -16,7 +16,7 @@ LIB_PATH = Path(os.environ["DIF_LIB"]) if os.environ.get("DIF_LIB") else PKG / "
 # counters (difusion.h)
 C_N_OCCUPIED, C_OVERFLOW, C_ALLOC_NEW, C_M, C_C, C_ITEMS, C_K, C_B, C_VH, C_T, C_QUERY_M, C_N_KEPT, C_CACHE_T, C_CACHE_KEPT, C_EXPORT_N, C_WORK, C_CACHE_DEAD, C_CACHE_LIVE, C_OPT_ROWS, C_OPT_VOXELS, C_HALO_L, C_HALO_R, C_HALO_TICKET, C_DEFERRED = range(24)
 C_STAMP = 31
-SYNC_FUSED, SYNC_FRONT_DONE, SYNC_REFINING, SYNC_WORDS = 0, 32, 64, 96      # dif_map_t.sync_words
+SYNC_FUSED, SYNC_FRONT_DONE, SYNC_WORDS = 0, 32, 64      # dif_map_t.sync_words
 FC_COUNT = 32                                            # dif_map_t.frame_counters
 C_COUNT = 32
 PROF_NAMES = ["encode", "decode_lattice", "decode_points", "mc_count", "mc_emit", "halo_export", "halo_merge"]

@@ -479,16 +479,6 @@ static int integrate_plan(const dif_map_t* map, const dif_weights_t* w, const fl
     return DIF_OK;
 }
 
-// measurement switches of the two-queue arrangement (read once; defaults = the product): DIF_OV_ENC_WAIT=0 lets an overlapped frame's encoder start as
-// soon as its point kernels are done (rounds 5's order) instead of behind the START of the previous frame's refine kernel; DIF_OV_ENC_SLIM=0 runs it
-// as the 768-thread / 162 KB kernel instead of k_encode_slim
-static bool ov_flag(const char* name, bool dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) != 0 : dflt;
-}
-static bool ov_enc_wait() { static const bool v = ov_flag("DIF_OV_ENC_WAIT", true); return v; }
-static bool ov_enc_slim() { static const bool v = ov_flag("DIF_OV_ENC_SLIM", true); return v; }
-
 // workgroups (= CUs) of the encoder of an overlapped frame; DIF_OVERLAP_ENCODER_CUS (read once) for experiments
 static int overlap_encoder_cus() {
     static const int n = [] {
@@ -508,7 +498,6 @@ static int encoder_attributes() {
         if (hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_BYTES) != hipSuccess) return DIF_ELAUNCH;
         if (hipFuncSetAttribute((const void*)k_encode_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ENC_FLOATS * 4)) != hipSuccess) return DIF_ELAUNCH;
         if (hipFuncSetAttribute((const void*)k_encode_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_BYTES) != hipSuccess) return DIF_ELAUNCH;
-        if (hipFuncSetAttribute((const void*)k_encode_slim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E6_SLIM_LDS_BYTES) != hipSuccess) return DIF_ELAUNCH;
         attr_set[dev] = true;
     }
     return DIF_OK;
@@ -549,14 +538,7 @@ static int integrate_impl(const dif_map_t* map, const dif_weights_t* w, const fl
         // 96: 6,370, 64: 5,990, 32: 4,930 (it becomes the critical path: 74 us on 64 CUs), and the decode kernels take their 43-45 us beside ANY of
         // them — so it keeps all CUs.
         const int enc_grid = P.overlap ? overlap_encoder_cus() : num_cus();
-        // two queues: behind the START of the previous frame's refine kernel (its workgroups take every CU they need first; this encoder then moves in
-        // as they leave and runs beside that frame's marching cubes), and in the shape that fits a CU beside a marching-cubes workgroup
-        const bool dec_x6 = w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES && w->dec_fold_packed && w->dec_fold_packed_floats == DECF_FLOATS;
-        if (P.overlap && x6 && dec_x6 && ov_enc_wait() && wait_word(s, map->sync_words + DIF_SYNC_REFINING, map->frame_seq - 1) != DIF_OK) return DIF_ELAUNCH;
-        if (x6 && P.overlap && ov_enc_slim())
-            hipLaunchKernelGGL(k_encode_slim, dim3(enc_grid), dim3(512), (size_t)E6_SLIM_LDS_BYTES, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
-                               e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
-        else if (x6)
+        if (x6)
             hipLaunchKernelGGL(k_encode<true>, dim3(enc_grid), dim3(ENC_X6_THREADS), lds_bytes, s, e.g, (const float*)w->enc_x6_packed, e.src.xyz, e.src.normal, e.src.frame,
                                e.src.im, N, e.pair_list, e.rec_dir, e.rec_next, e.rec, e.upd_list, e.counters, e.dirty, e.dirty_tot);
         else
@@ -1055,12 +1037,6 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
     const ExtractGeo e = extract_geo(resolution);
     const int r = e.r, R = e.R, l = e.l, R3 = e.R3;
     if (buf->max_voxels * (int64_t)R3 >= ((int64_t)1 << 31)) return DIF_EINVAL;
-    // two queues: the NEXT frame's encoder waits for a word that this extract's refine kernel publishes (DIF_SYNC_REFINING) — whenever the weights carry
-    // the bf16-pipe decoder, which is how dif_integrate_frame decides to wait: such an extract must really run that kernel (refused before anything
-    // is enqueued: a frame that never publishes the word would leave the other queue waiting)
-    if (ov && w->dec_x6_packed && w->dec_x6_packed_bytes == X6_BYTES && w->dec_fold_packed && w->dec_fold_packed_floats == DECF_FLOATS &&
-        !(fast && l * l * l <= VD_MAX_L3 && R * R <= VD_MAX_R2 && buf->fold_table && w->dec_packed && w->dec_packed_floats == DEC_FLOATS))
-        return DIF_EINVAL;
     const double sample_a = e.sample_a, sample_b = e.sample_b;
 
     {   // dirty slots -> valid_blocks
@@ -1114,8 +1090,7 @@ static int extract_impl(const dif_map_t* map, const dif_weights_t* w, const dif_
             if (rblocks < 1) rblocks = 1;
             if (rblocks > num_cus()) rblocks = num_cus();
             ProfScope prof(DIF_PROF_DECODE_POINTS, s);
-            hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed,
-                               ov ? map->sync_words + DIF_SYNC_REFINING : nullptr, (uint32_t)map->frame_seq);
+            hipLaunchKernelGGL(k_decode_refine_x6, dim3((int)rblocks), dim3(512), (size_t)X6_LDS_BYTES, s, Rf, (const float*)w->dec_x6_packed);
             DIF_CHECK_LAUNCH();
             rc = DIF_OK;
         } else {

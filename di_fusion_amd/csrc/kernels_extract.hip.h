@@ -523,10 +523,7 @@ __device__ __forceinline__ void decode_refine_x6_body(const BatchN<DecodeArgs, N
     }
 }
 
-// refining_word (two queues): this kernel has STARTED — its workgroups hold the CUs they need — so the next frame's encoder may be let onto the
-// other queue (DIF_SYNC_REFINING; dif_integrate_frame waits for it in front of the encoder)
-__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob, uint32_t* __restrict__ refining_word, uint32_t seq) {
-    if (refining_word && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_store(refining_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ void __launch_bounds__(512, 1) k_decode_refine_x6(DecodeArgs A, const float* __restrict__ wblob) {
     const BatchN<DecodeArgs, 1> B{{A}};
     decode_refine_x6_body<1>(B, 1, wblob);
 }

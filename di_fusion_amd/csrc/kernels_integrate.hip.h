@@ -410,7 +410,7 @@ struct EncArgs {
 #ifndef ENC_X6_THREADS
 #define ENC_X6_THREADS 768        /* twelve waves per CU: 3,072 tile slots on the chip */
 #endif
-template <bool X6, int NS, bool SLIM = false>
+template <bool X6, int NS>
 __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S, const float* __restrict__ wblob, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     EN_STAMP(0);
@@ -472,9 +472,7 @@ __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S,
     rg.locate(wave, sm_n, lt_n, M_n);
     TileIn nxt = gather(wave < n_tiles, sm_n, lt_n, M_n);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SLIM) stage_encoder_slim(lds, wblob);
-    else stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
+    stage_weights(lds, wblob, X6 ? E6_BYTES / 4 : ENC_FLOATS);
     EN_STAMP(1);
     for (int T = wave; T < n_tiles; T += nwaves) {
         const TileIn cur = nxt;
@@ -502,7 +500,7 @@ __device__ __forceinline__ void encode_body(const BatchN<EncArgs, NS>& B, int S,
         int* dir = a.rec_dir + (int64_t)key * DIF_DIR_WORDS;
         if (pusher) dir_pos = atomicAdd(dir, 1);
         f16v out;
-        if constexpr (X6) out = encoder_tile_x6<SLIM>(lds, x0, x1, x2, lane, wrs);
+        if constexpr (X6) out = encoder_tile_x6(lds, x0, x1, x2, lane);
         else out = encoder_tile(lds, x0, x1, x2, lane);
         EN_STAMP(3);
         long long* p = a.rec + (int64_t)rec_id * DIF_REC_WORDS + half * 16;
@@ -536,17 +534,6 @@ k_encode(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, 
          int* __restrict__ upd_list, int* __restrict__ counters, uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
     const BatchN<EncArgs, 1> B{{EncArgs{g, PointSrc{xyz, normal, frame, im}, pair_list, rec_dir, rec_next, rec, upd_list, counters, dirty, dirty_tot}}};
     encode_body<X6, 1>(B, 1, wblob, N);
-}
-
-// The encoder of an overlapped frame (two queues): 512 threads, 125 KB of LDS, the register budget of THREE waves per SIMD (168) although the
-// workgroup brings only two — a workgroup then fits on a CU beside a workgroup of the previous frame's marching cubes (29 KB, one 96-register wave
-// per SIMD) instead of waiting for a CU of its own (EncSteps<true>).
-__global__ void __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(3, 3)))
-k_encode_slim(Geo g, const float* __restrict__ wblob, const float* __restrict__ xyz, const float* __restrict__ normal, const dif_frame_t* __restrict__ frame,
-              ImageGeo im, int64_t N, const uint2* __restrict__ pair_list, int* __restrict__ rec_dir, int* __restrict__ rec_next, long long* __restrict__ rec,
-              int* __restrict__ upd_list, int* __restrict__ counters, uint8_t* __restrict__ dirty, int* __restrict__ dirty_tot) {
-    const BatchN<EncArgs, 1> B{{EncArgs{g, PointSrc{xyz, normal, frame, im}, pair_list, rec_dir, rec_next, rec, upd_list, counters, dirty, dirty_tot}}};
-    encode_body<true, 1, true>(B, 1, wblob, N);
 }
 
 template <bool X6>

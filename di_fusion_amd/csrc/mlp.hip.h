@@ -601,52 +601,9 @@ __device__ __forceinline__ void decoder_tile_x6(const float* __restrict__ W /* L
 #define E6_L23 (E6_L1 + 12288)        // 48 steps of 3 KB                         147,456 B
 #define E6_BYTES (E6_L23 + 147456)    // 162,304 B
 
-// Where the 48 weight steps of lin2 / lin3 come from: all from LDS (the 162 KB image: a workgroup of its own per CU), or — SLIM — every fourth step
-// from L2 through a buffer resource, ENC_SLIM_RING such steps in flight (each issued 4 ENC_SLIM_RING steps before its use), the other 36 from
-// LDS in consumption order: 125,440 bytes, so that an encoder workgroup of 512 threads fits on a CU beside a marching-cubes workgroup (29 KB,
-// 96 registers) instead of waiting for a CU of its own (DESIGN.md section 3 "two queues").  Same steps, same order, same arithmetic.
-#define E6_SLIM_LDS_BYTES (E6_L23 + 36 * 3072)      /* 125,440 */
-#ifndef ENC_SLIM_RING
-#define ENC_SLIM_RING 1
-#endif
-template <bool SLIM>
-struct EncSteps {
-    const u4v* lds;                 // SLIM: step t (t % 4 != 3) at index t - t / 4; else step t at index t
-    __amdgpu_buffer_rsrc_t rsrc;    // SLIM: the whole blob
-    int base;                       // SLIM: byte offset of step 0 in the blob (E6_L23), opaque per tile
-    Tri ring[ENC_SLIM_RING];
-    __device__ __forceinline__ Tri from_l2(int t, int lane) const {
-        const int o = base + t * 3072;
-        return Tri{__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, o, 0), __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + 1024, o, 0),
-                   __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + 2048, o, 0)};
-    }
-    __device__ __forceinline__ void prime(int lane) {
-        if (SLIM) {
-#pragma unroll
-            for (int i = 0; i < ENC_SLIM_RING; ++i) ring[i] = from_l2(3 + 4 * i, lane);
-        }
-    }
-    // step t (a compile-time constant after unrolling); a streamed step hands its ring slot to the step eight further on
-    __device__ __forceinline__ Tri load(int t, int lane) {
-        if (SLIM && (t & 3) == 3) {
-            const Tri v = ring[(t >> 2) % ENC_SLIM_RING];
-            if (t + 4 * ENC_SLIM_RING < 48) ring[(t >> 2) % ENC_SLIM_RING] = from_l2(t + 4 * ENC_SLIM_RING, lane);
-            return v;
-        }
-        const u4v* q = lds + (SLIM ? t - (t >> 2) : t) * 192 + lane;
-        return Tri{q[0], q[64], q[128]};
-    }
-};
-
-template <bool SLIM = false>
-__device__ __forceinline__ f16v encoder_tile_x6(const float* __restrict__ W /* LDS */, float x0, float x1, float x2, int lane,
-                                                __amdgpu_buffer_rsrc_t Wg = __amdgpu_buffer_rsrc_t()) {
+__device__ __forceinline__ f16v encoder_tile_x6(const float* __restrict__ W /* LDS */, float x0, float x1, float x2, int lane) {
     const int half = lane >> 5;
     const char* Wb = reinterpret_cast<const char*>(W);
-    int goff = E6_L23;                          // opaque per tile (see decoder_tile: LICM would hoist the loop-invariant loads and spill)
-    if (SLIM) asm volatile("" : "+s"(goff) : : "memory");
-    EncSteps<SLIM> A{reinterpret_cast<const u4v*>(Wb + E6_L23), Wg, goff, {}};
-    A.prime(lane);
     f16v h0[1];
     {
         f16v acc = load_bias16(W + E6_B0, half);
@@ -665,6 +622,7 @@ __device__ __forceinline__ f16v encoder_tile_x6(const float* __restrict__ W /* L
     Tri xs[4];                                  // h1 sliced once: [kb][s]
 #pragma unroll
     for (int i = 0; i < 16; ++i) split_pair_into(h1[i >> 3], (i >> 2) & 1, i & 3, xs[i >> 2]);
+    const LdsX6 A{reinterpret_cast<const u4v*>(Wb + E6_L23)};
     int t = 0;
     Tri a = A.load(0, lane), an;
     f16v cur = load_bias16(W + E6_B2, half);
@@ -1118,19 +1076,6 @@ __device__ __forceinline__ void decoder_tile_nll_grad(const float* __restrict__ 
 
 // cooperative global -> LDS copy of `n_floats` (multiple of 4) by the whole block.  Eight 16-byte loads are in flight per thread before
 // the first LDS write: the copy is latency-bound (134 KB per CU is ~1 us of L2 bandwidth), so batching the loads is what shortens it.
-// SLIM encoder image: the fp32 auxiliary part and lin1 as they are, then the lin2 / lin3 steps with t % 4 != 3 (3 KB each) packed in order
-__device__ __forceinline__ void stage_encoder_slim(float* lds, const float* __restrict__ g) {
-    const f4v* __restrict__ src = reinterpret_cast<const f4v*>(g);
-    f4v* dst = reinterpret_cast<f4v*>(lds);
-    constexpr int HEAD4 = E6_L23 / 16, STEP4 = 3072 / 16;
-    for (int i = (int)threadIdx.x; i < HEAD4; i += (int)blockDim.x) dst[i] = src[i];
-    for (int i = (int)threadIdx.x; i < 36 * STEP4; i += (int)blockDim.x) {
-        const int c = i / STEP4, r = i - c * STEP4;         // packed chunk c holds step t = c + c / 3
-        dst[HEAD4 + i] = src[HEAD4 + (c + c / 3) * STEP4 + r];
-    }
-    __syncthreads();
-}
-
 __device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ g, int n_floats) {
     const f4v* __restrict__ src = reinterpret_cast<const f4v*>(g);
     f4v* dst = reinterpret_cast<f4v*>(lds);

@@ -144,9 +144,8 @@ typedef struct dif_map {
 } dif_map_t;
 
 /* sync_words (each on a 128-byte line of its own): frame n's fusion kernel has completed (written by the first kernel of its extract); frame n's front
- * end has completed; frame n's refine decode has STARTED (its last workgroup says so as it begins: frame n + 1's encoder is held back until then,
- * so that it runs beside frame n's marching cubes instead of taking the CUs between frame n's two decode kernels) */
-enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_REFINING = 64, DIF_SYNC_WORDS = 96 };
+ * end has completed */
+enum { DIF_SYNC_FUSED = 0, DIF_SYNC_FRONT_DONE = 32, DIF_SYNC_WORDS = 64 };
 enum { DIF_FC_SHADOW = 4, DIF_FC_COUNT = 32 };
 
 /* What a deferred export still has to copy: log rows [kept, kept + n) -> the caller's arrays (see dif_map_t.pending_export). */
