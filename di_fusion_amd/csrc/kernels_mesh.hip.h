@@ -330,15 +330,25 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 // a 30-bit value in one word, so there is no payload to order against the flag; it is published and polled with device-scope atomic
 // read-modify-writes only (the same coherence every other counter in this library relies on).
 // Which group a workgroup takes: with at most one group per workgroup (a stream frame: ~190 groups) simply its own index — workgroups
-// are dispatched in index order, so every predecessor is running or done (mc_onepass_direct).  Otherwise groups are handed out by a
-// ticket counter, lowest first (mc_onepass_ring): whatever the residency of the grid, a group's predecessors have all been claimed by
-// workgroups that are running (or done), and no look-back can wait for work nobody has started — no assumption about how many
-// workgroups of the grid are resident, or about what else shares the GPU.
+// are dispatched in index order, so every predecessor is running or done (mc_onepass_direct).  Otherwise groups are CLAIMED (mc_onepass_ring):
+// one ticket counter per XCD hands out that XCD's runs of MC_RUN consecutive groups (run q belongs to XCD q mod 8: consecutive groups are
+// z-, then y-neighbours, whose 27-neighbourhoods overlap — what one of them has pulled into the XCD's L2 the next ones find there), and a claim
+// is sealed by a compare-and-swap on the group's status word, so that a workgroup which waits for a group NOBODY has claimed (its XCD lags, or has
+// no workgroup resident) can take that very group itself.  Whatever the residency of the grid, a look-back therefore only ever waits for groups that
+// running workgroups have claimed — no assumption about how many workgroups of the grid are resident, or about what else shares the GPU.
 // A poll that does not succeed within MC_SPIN_LIMIT rounds gives up with DIF_C_OVERFLOW = 7 instead of hanging the queue.
 #define MC_ST_AGG 0x40000000u
 #define MC_ST_PREFIX 0x80000000u
+#define MC_ST_CLAIMED 0xC0000000u       /* claimed, not counted yet (value 0) */
 #define MC_ST_VALUE 0x3FFFFFFFu
 #define MC_SPIN_LIMIT (1 << 22)
+#define MC_RUN_MAX 128                  /* groups per XCD run at most (512 voxels: four z-rows of a 128^3 grid) */
+#define MC_PATIENCE 48                  /* polls a blocked look-back waits before it looks for an unclaimed group to take */
+#define MC_TICKET_STRIDE 32             /* words between the XCDs' ticket counters (a 128-byte line each) */
+#define MC_TICKET_WORDS (8 * MC_TICKET_STRIDE)
+__device__ __forceinline__ unsigned mc_state(unsigned st) { return st >> 30; }                      // 0 unknown, 1 AGG, 2 PREFIX, 3 CLAIMED
+__device__ __forceinline__ bool mc_published(unsigned st) { const unsigned q = st >> 30; return q == 1u || q == 2u; }
+__device__ __forceinline__ int mc_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }       // HW_REG_XCC_ID[3:0]
 // LDS of a wave: MC_RING sets of blended corners (ticket mode: groups that are counted and wait for their prefix; the direct mode uses the
 // first), the 27 neighbour batches, the edge vertices of the cells being evaluated
 #ifndef MC_RING
@@ -444,21 +454,24 @@ __device__ __forceinline__ void mc_emit_voxel(const McArgs& a, int lane, int r, 
 
 // One window of the look-back: the 64 groups idx, idx-1, ... (lane = distance).  Returns 1 when the window held a group that knows its
 // inclusive prefix (sum = everything from idx down to it), 0 when it held none (sum = all 64 counts: go on at idx - 64), -1 when a group
-// that is needed has not published anything yet and `block` is false (nothing consumed: ask again later).
-__device__ __forceinline__ int mc_lookback_window(const McArgs& a, unsigned* __restrict__ status, int idx, int lane, bool block, int& sum) {
+// that is needed has not published anything yet and `block` is false (nothing consumed: ask again later), -2 when `block` is true, `patience`
+// is given and the window still lacks a count after that many polls (nothing consumed: the caller looks for an unclaimed group to take).
+__device__ __forceinline__ int mc_lookback_window(const McArgs& a, unsigned* __restrict__ status, int idx, int lane, bool block, int& sum, int patience = 0) {
     const int i = idx - lane;
     unsigned st = (i >= 0) ? 0u : MC_ST_PREFIX;
     int spins = 0;
     unsigned long long pre;
     int p;
     while (true) {
-        if ((st & ~MC_ST_VALUE) == 0u) st = atomicOr(status + i, 0u);
-        pre = __ballot((st & MC_ST_PREFIX) != 0u);
+        if (!mc_published(st)) st = atomicOr(status + i, 0u);
+        pre = __ballot(mc_state(st) == 2u);
         p = pre ? (__ffsll((long long)pre) - 1) : 64;                          // nearest predecessor that knows its inclusive prefix
-        const unsigned long long missing = __ballot((st & ~MC_ST_VALUE) == 0u) & (p >= 63 ? ~0ull : ((2ull << p) - 1ull));
+        const unsigned long long missing = __ballot(!mc_published(st)) & (p >= 63 ? ~0ull : ((2ull << p) - 1ull));
         if (missing == 0ull) break;
         if (!block) return -1;
-        if (++spins > MC_SPIN_LIMIT) { if (lane == 0) a.log_counters[DIF_C_OVERFLOW] = 7; break; }
+        ++spins;
+        if (patience > 0 && spins > patience) return -2;
+        if (spins > MC_SPIN_LIMIT) { if (lane == 0) a.log_counters[DIF_C_OVERFLOW] = 7; break; }
         __builtin_amdgcn_s_sleep(2);
     }
     int v = (lane <= p) ? (int)(st & MC_ST_VALUE) : 0;
@@ -466,6 +479,23 @@ __device__ __forceinline__ int mc_lookback_window(const McArgs& a, unsigned* __r
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     sum = v;
     return pre ? 1 : 0;
+}
+
+// The lowest group at or below idx that NOBODY has claimed, among the groups above the nearest one that knows its prefix (scanned window by
+// window, read-only); -1 if every group up there is claimed (being counted by a running workgroup: it will publish without waiting for anyone).
+// Such a group can be completed at once by whoever takes it: everything between it and that prefix is counted or being counted.
+__device__ __forceinline__ int mc_find_unclaimed(unsigned* __restrict__ status, int idx, int lane) {
+    int best = -1;
+    for (; idx >= 0; idx -= 64) {
+        const int i = idx - lane;
+        const unsigned st = (i >= 0) ? atomicOr(status + i, 0u) : MC_ST_PREFIX;
+        const unsigned long long pre = __ballot(mc_state(st) == 2u);
+        const int p = pre ? (__ffsll((long long)pre) - 1) : 64;
+        const unsigned long long un = __ballot(st == 0u) & (p >= 63 ? ~0ull : ((2ull << p) - 1ull));
+        if (un) best = idx - (63 - __clzll((long long)un));                    // the farthest lane = the lowest group
+        if (pre) break;
+    }
+    return best;
 }
 
 // RC: the resolution as a compile-time constant (0: read it from the arguments).  The index arithmetic of the corners and cells divides by
@@ -537,18 +567,24 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
     }
 }
 
-// More groups than workgroups (a map with thousands of dirty voxels): groups are claimed through the ticket counter, and a workgroup does
-// not sit on a counted group until its prefix is known — it parks the group (its blended corners stay in LDS, MC_RING sets per wave) and
-// counts the next one; a parked group is emitted once its look-back succeeds (the cells are evaluated again from the parked corners:
-// cheaper than holding their edge vertices).  The ordered commit otherwise costs what the slowest of the ~1,000 groups in flight in front
-// of a group costs: measured, a third of the launch (profiles/r04_experiments.md).
-// No deadlock: a group's count is published right after counting and counting never waits; a workgroup only blocks on a look-back when
-// its ring is full or the tickets are gone, and what it waits for are counts of groups with lower tickets — held by workgroups that are
-// running (they took those tickets) and that publish them without waiting for anyone.
+// More groups than workgroups (a map with thousands of dirty voxels): groups are claimed — a ticket of the workgroup's XCD, sealed by a
+// compare-and-swap on the group's status word — and a workgroup does not sit on a counted group until its prefix is known: it parks the group
+// (its blended corners stay in LDS, up to MC_RING - 1 sets per wave) and counts the next one; a parked group is emitted once its look-back
+// succeeds (the cells are evaluated again from the parked corners: cheaper than holding their edge vertices).  The ordered commit otherwise costs
+// what the slowest of the ~1,000 groups in flight in front of a group costs: measured, a third of the launch (profiles/r04_experiments.md).
+// Runs per XCD: ticket n of XCD x is group ((n / R) 8 + x) R + n mod R — an XCD works through runs of R consecutive groups (R = MC_RUN_MAX, less
+// for few groups), so that the cubes its voxels share with their z- and y-neighbours are fetched into ITS L2 once (every XCD took every eighth
+// group until round 5: those neighbours sat in eight different L2s, and the counters showed the cubes fetched 3.3 times).  An XCD whose tickets
+// are used up helps the next one.
+// No deadlock, whatever the residency: a claimed group's count is published right after counting, and counting never waits.  A workgroup only
+// blocks in a look-back — when its ring holds MC_RING - 1 groups or the tickets are gone — and after MC_PATIENCE polls it asks whether a group
+// it waits for is UNCLAIMED (its XCD lags, or has no workgroup resident): the lowest such group above the nearest known prefix it claims itself
+// (mc_find_unclaimed) and completes at once in the ring's spare slot — everything between that group and the prefix is counted or being counted
+// by running workgroups.  The lowest group without a count is therefore always either being counted or about to be taken by whoever waits for it.
 template <int RC>
 __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __restrict__ status, unsigned* __restrict__ ticket, float* lds, int K,
                                                 int n_groups, int64_t log_n) {
-    __shared__ int s_g, s_res, s_excl;
+    __shared__ int s_g, s_res, s_excl, s_steal, s_hops;             // s_hops: ticket counters (this XCD's, the next one's, ...) found used up so far
     __shared__ int s_gid[MC_RING];                                   // parked groups (ring order: head .. head + cnt - 1)
     __shared__ int s_cnt[MC_RING][DIF_BLOCK / 64];                   // their voxels' triangle counts
     __shared__ int64_t s_vb[MC_RING][DIF_BLOCK / 64];                // ... and what the emit needs to know about each voxel
@@ -558,59 +594,112 @@ __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __res
     float* ring = lds + (size_t)wid * MC_ONEPASS_WAVE_LDS_FLOATS(nc);
     int* nb = reinterpret_cast<int*>(ring + MC_RING * MC_CORNER_FLOATS(nc));
     float* vl = reinterpret_cast<float*>(nb + 32) + lane;
+    if (threadIdx.x == 0) s_hops = 0;
     int head = 0, cnt = 0;
     bool exhausted = false;
     int lb_idx = -2, lb_excl = 0;                                    // wave 0: how far the oldest parked group's look-back has come (-2: not begun)
+
+    // count group g into ring slot `slot` (all waves): corners, cells, per-voxel bookkeeping
+    auto count_group = [&](int g, int slot) __attribute__((always_inline)) {
+        const int k = g * 4 + wid;
+        int ntri = 0;
+        bool crossing = false;
+        McVoxel v = {};
+        if (k < K) {
+            float* c_sdf = ring + slot * MC_CORNER_FLOATS(nc);
+            crossing = mc_load_voxel<RC>(a, k, lane, r, c_sdf, c_sdf + nc, nb, v);
+            unsigned long long tri_row;
+            unsigned ok;
+            if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_sdf + nc, vl, r, lane, tri_row, ok);
+        }
+        const int voxel_total = __shfl(wave_incl_scan(ntri), 63);
+        if (lane == 0) {
+            s_cnt[slot][wid] = voxel_total;
+            s_vb[slot][wid] = v.vb; s_slot[slot][wid] = v.slot; s_oldn[slot][wid] = v.old_n; s_olds[slot][wid] = v.old_s; s_cross[slot][wid] = crossing;
+            if (k < K) a.tri_count[k] = voxel_total;
+        }
+    };
+    // emit the group parked in `slot` at offset s_excl (all waves): the cells again from the parked corners, the same counts
+    auto emit_group = [&](int g, int slot) __attribute__((always_inline)) {
+        const int k = g * 4 + wid;
+        const int voxel_total = s_cnt[slot][wid];
+        if (k < K && voxel_total > 0) {
+            McVoxel v;
+            v.vb = s_vb[slot][wid]; v.slot = s_slot[slot][wid]; v.old_n = s_oldn[slot][wid]; v.old_s = s_olds[slot][wid];
+            mc_voxel_coords(a, v);
+            const float* c_sdf = ring + slot * MC_CORNER_FLOATS(nc);
+            int ntri = 0;
+            unsigned long long tri_row = ~0ull;
+            unsigned ok = 0u;
+            if (s_cross[slot][wid] && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_sdf + nc, vl, r, lane, tri_row, ok);
+            const int incl = wave_incl_scan(ntri);
+            int voxel_offset = s_excl;
+            for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[slot][w];
+            mc_emit_voxel(a, lane, r, v, voxel_total, voxel_offset, ntri, incl, tri_row, ok, vl, c_sdf + nc, log_n);
+        }
+    };
+
     while (true) {
-        const bool claim = cnt < MC_RING && !exhausted;
-        if (claim && threadIdx.x == 0) s_g = (int)atomicAdd(ticket, 1u);
+        const bool claim = cnt < MC_RING - 1 && !exhausted;          // (the ring's last slot stays free: a group taken over is completed there)
+        if (claim && threadIdx.x == 0) {
+            // run length: MC_RUN_MAX, shorter for few groups (every XCD should see several runs); a power of two
+            int run = MC_RUN_MAX;
+            while (run > 4 && run * 32 > n_groups) run >>= 1;
+            const int my_x = mc_xcc_id();
+            int g = -1, hops = s_hops;
+            while (hops < 8) {
+                const int x = (my_x + hops) & 7;
+                const unsigned n = atomicAdd(ticket + x * MC_TICKET_STRIDE, 1u);
+                const long long cand = ((long long)(n / (unsigned)run) * 8 + x) * run + (n % (unsigned)run);
+                if (cand >= n_groups) { ++hops; continue; }                     // this XCD's runs are used up (its tickets only grow): help the next one
+                if (atomicCAS(status + cand, 0u, MC_ST_CLAIMED) != 0u) continue; // somebody who waited for it has taken it
+                g = (int)cand;
+                break;
+            }
+            s_g = g;
+            s_hops = hops;
+        }
         __syncthreads();
         int g = -1;
         if (claim) {
             g = s_g;
-            if (g >= n_groups) { exhausted = true; g = -1; }
+            if (g < 0) exhausted = true;
         }
         const int tail = (head + cnt) % MC_RING;
-        if (g >= 0) {                                                // count group g, park it at the tail
-            const int k = g * 4 + wid;
-            int ntri = 0;
-            bool crossing = false;
-            McVoxel v = {};
-            if (k < K) {
-                float* c_sdf = ring + tail * MC_CORNER_FLOATS(nc);
-                crossing = mc_load_voxel<RC>(a, k, lane, r, c_sdf, c_sdf + nc, nb, v);
-                unsigned long long tri_row;
-                unsigned ok;
-                if (crossing && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_sdf + nc, vl, r, lane, tri_row, ok);
-            }
-            const int voxel_total = __shfl(wave_incl_scan(ntri), 63);
-            if (lane == 0) {
-                s_cnt[tail][wid] = voxel_total;
-                s_vb[tail][wid] = v.vb; s_slot[tail][wid] = v.slot; s_oldn[tail][wid] = v.old_n; s_olds[tail][wid] = v.old_s; s_cross[tail][wid] = crossing;
-                if (k < K) a.tri_count[k] = voxel_total;
-            }
-        }
+        if (g >= 0) count_group(g, tail);                            // park it at the tail
         __syncthreads();
         if (wid == 0) {
             if (g >= 0) {
                 const int agg = s_cnt[tail][0] + s_cnt[tail][1] + s_cnt[tail][2] + s_cnt[tail][3];
                 if (lane == 0) {
-                    if (g > 0) atomicExch(status + g, MC_ST_AGG | (unsigned)agg);
+                    atomicExch(status + g, MC_ST_AGG | (unsigned)agg);
                     s_gid[tail] = g;
                 }
             }
             const int npend = cnt + (g >= 0 ? 1 : 0);
-            int res = 0;
+            int res = 0, steal = -1;
             if (npend > 0) {
                 const int gh = cnt > 0 ? s_gid[head] : g;            // the oldest parked group
                 const int aggh = s_cnt[head][0] + s_cnt[head][1] + s_cnt[head][2] + s_cnt[head][3];
-                const bool block = npend == MC_RING || exhausted;    // nothing else to do but wait for it
+                const bool block = npend >= MC_RING - 1 || exhausted;  // nothing else to do but wait for it
                 if (lb_idx == -2) { lb_idx = gh - 1; lb_excl = 0; }
                 bool done = false;
+                int rounds = 0;
                 while (!done) {
                     if (lb_idx < 0) { done = true; break; }
                     int sum;
-                    const int found = mc_lookback_window(a, status, lb_idx, lane, block, sum);
+                    const int found = mc_lookback_window(a, status, lb_idx, lane, block, sum, MC_PATIENCE);
+                    if (found == -2) {                               // still waiting: is a group down there nobody's?  Take it.
+                        if (++rounds > MC_SPIN_LIMIT / MC_PATIENCE) { if (lane == 0) a.log_counters[DIF_C_OVERFLOW] = 7; done = true; break; }
+                        const int j = mc_find_unclaimed(status, lb_idx, lane);
+                        if (j >= 0) {
+                            unsigned old = 1u;
+                            if (lane == 0) old = atomicCAS(status + j, 0u, MC_ST_CLAIMED);
+                            if (__shfl((int)old, 0) == 0) steal = j;
+                        }
+                        if (steal >= 0) break;
+                        continue;                                    // (claimed by now, or being counted: poll on)
+                    }
                     if (found < 0) break;
                     lb_excl += sum;
                     if (found) done = true; else lb_idx -= 64;
@@ -625,29 +714,40 @@ __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __res
                     res = 1;
                 }
             }
-            if (lane == 0) s_res = res;
+            if (lane == 0) { s_res = res; s_steal = steal; }
         }
         __syncthreads();
         if (g >= 0) ++cnt;
         if (s_res) {                                                 // the oldest parked group has its offset: emit it
-            const int k = s_gid[head] * 4 + wid;
-            const int voxel_total = s_cnt[head][wid];
-            if (k < K && voxel_total > 0) {
-                McVoxel v;
-                v.vb = s_vb[head][wid]; v.slot = s_slot[head][wid]; v.old_n = s_oldn[head][wid]; v.old_s = s_olds[head][wid];
-                mc_voxel_coords(a, v);
-                const float* c_sdf = ring + head * MC_CORNER_FLOATS(nc);
-                int ntri = 0;
-                unsigned long long tri_row = ~0ull;
-                unsigned ok = 0u;
-                if (s_cross[head][wid] && lane < r3) ntri = mc_eval_cell(a, c_sdf, c_sdf + nc, vl, r, lane, tri_row, ok);     // (again: the same cells, the same counts)
-                const int incl = wave_incl_scan(ntri);
-                int voxel_offset = s_excl;
-                for (int w = 0; w < wid; ++w) voxel_offset += s_cnt[head][w];
-                mc_emit_voxel(a, lane, r, v, voxel_total, voxel_offset, ntri, incl, tri_row, ok, vl, c_sdf + nc, log_n);
-            }
+            emit_group(s_gid[head], head);
             head = (head + 1) % MC_RING;
             --cnt;
+        } else if (s_steal >= 0) {
+            // a group the head waits for was nobody's: count it in the spare slot, look back (everything between it and the nearest prefix is
+            // counted or being counted: this wait ends), emit, and go back to the head
+            const int j = s_steal, spare = (head + cnt) % MC_RING;
+            __syncthreads();                                         // (s_steal / s_res are rewritten below)
+            count_group(j, spare);
+            __syncthreads();
+            if (wid == 0) {
+                const int aggj = s_cnt[spare][0] + s_cnt[spare][1] + s_cnt[spare][2] + s_cnt[spare][3];
+                if (lane == 0) atomicExch(status + j, MC_ST_AGG | (unsigned)aggj);
+                int excl = 0;
+                for (int idx = j - 1; idx >= 0; idx -= 64) {
+                    int sum;
+                    const int found = mc_lookback_window(a, status, idx, lane, true, sum);
+                    excl += sum;
+                    if (found) break;
+                }
+                if (lane == 0) {
+                    atomicExch(status + j, MC_ST_PREFIX | ((unsigned)(excl + aggj) & MC_ST_VALUE));
+                    s_excl = excl;
+                    if (j == n_groups - 1) a.log_counters[DIF_C_T] = excl + aggj;
+                }
+            }
+            __syncthreads();
+            emit_group(j, spare);
+            __syncthreads();
         }
         if (exhausted && cnt == 0) break;
     }
@@ -758,7 +858,7 @@ __device__ __forceinline__ void extract_finish_body(const int32_t* __restrict__ 
     if (mc_status)                                  // the one-pass marching cubes' look-back words of this call: back to idle 0
     {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((Kd + 3) >> 2); i += gridDim.x * blockDim.x) mc_status[i] = 0u;
-        if (blockIdx.x == 0 && threadIdx.x == 0) *mc_ticket = 0u;
+        if (blockIdx.x == 0 && threadIdx.x < 8) mc_ticket[threadIdx.x * MC_TICKET_STRIDE] = 0u;      // one ticket counter per XCD
     }
     // every dirty flag has been consumed by this call: the block totals return to idle 0 (a DEFERRED extract consumed none: k_dirty_scan)
     if (dirty_tot && counters[DIF_C_DEFERRED] == 0)

@@ -677,7 +677,7 @@ class DenseIndexedMap:
                      tri_offset=torch.empty((max_vox,), dtype=torch.int32, device=dev),
                      block_tmp=torch.empty((4096,), dtype=torch.int32, device=dev),
                      chunk_sum=torch.zeros(((max_vox + 255) // 256 + (max_vox + 65535) // 65536,), dtype=torch.int32, device=dev),
-                     mc_status=torch.zeros(((max_vox + 3) // 4 + 1,), dtype=torch.int32, device=dev),
+                     mc_status=torch.zeros(((max_vox + 3) // 4 + 256,), dtype=torch.int32, device=dev),     # look-back words + 8 ticket counters, 32 words apart
                      fold_table=torch.empty((max_vox, 256), dtype=torch.float32, device=dev))
             self._xbuf = (key, t)
         t = self._xbuf[1]

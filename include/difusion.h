@@ -329,12 +329,12 @@ typedef struct dif_extract_buffers {
                                      * instead of count, scan, emit */
     float* fold_table;              /* optional [max_voxels][256]: per-voxel decoder constants handed from the lattice decode to the refine
                                      * decode (used when dif_weights_t.dec_fold_packed is set) */
-    uint32_t* mc_status;            /* optional [(max_voxels + 3) / 4 + 1], idle 0: with it (and chunk_sum, resolution <= 4) marching cubes is ONE launch:
+    uint32_t* mc_status;            /* optional [(max_voxels + 3) / 4 + 256], idle 0: with it (and chunk_sum, resolution <= 4) marching cubes is ONE launch:
                                      * a wave counts its voxel's triangles, learns its output offset by a decoupled look-back over groups of
                                      * four voxels and emits straight away (same canonical order).  A call with more groups than the launch has
-                                     * workgroups (thousands of dirty voxels) hands the groups out through the ticket word at the end of this
-                                     * array (dif_test_mc_grid_cap caps that launch, so that small maps take the ticket path
-                                     * in tests) */
+                                     * workgroups (thousands of dirty voxels) hands the groups out through eight ticket words (one per XCD, 32
+                                     * words apart) at the end of this array (dif_test_mc_grid_cap caps that launch, so that small maps take
+                                     * the ticket path in tests) */
     int32_t defer_export;           /* != 0 (with out_* and dif_map_t.pending_export): do not copy the new triangles to out_* now, leave a
                                      * dif_pending_export_t for the next dif_integrate_frame / dif_export_pending */
     /* Completion without stream events (an event record costs the queue ~5 us between two kernels; a frame has two):
