@@ -331,23 +331,29 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 // read-modify-writes only (the same coherence every other counter in this library relies on).
 // Which group a workgroup takes: with at most one group per workgroup (a stream frame: ~190 groups) simply its own index — workgroups
 // are dispatched in index order, so every predecessor is running or done (mc_onepass_direct).  Otherwise groups are CLAIMED (mc_onepass_ring):
-// one ticket counter per XCD hands out that XCD's runs of MC_RUN consecutive groups (run q belongs to XCD q mod 8: consecutive groups are
-// z-, then y-neighbours, whose 27-neighbourhoods overlap — what one of them has pulled into the XCD's L2 the next ones find there), and a claim
-// is sealed by a compare-and-swap on the group's status word, so that a workgroup which waits for a group NOBODY has claimed (its XCD lags, or has
-// no workgroup resident) can take that very group itself.  Whatever the residency of the grid, a look-back therefore only ever waits for groups that
-// running workgroups have claimed — no assumption about how many workgroups of the grid are resident, or about what else shares the GPU.
+// one ticket counter per XCD hands out that XCD's runs of consecutive groups, lowest first (run q belongs to XCD q mod 8: consecutive groups are
+// z-, then y-neighbours, whose 27-neighbourhoods overlap — what one of them has pulled into the XCD's L2 the next ones find there).  The groups
+// nobody has claimed are then exactly the ones at and beyond the eight counters, so a workgroup that waits for such a group (its XCD lags, or has
+// no workgroup resident) can take the lowest of them itself — by advancing that XCD's counter with a compare-and-swap.  Whatever the residency of
+// the grid, a look-back therefore only ever waits for groups that running workgroups have claimed — no assumption about how many workgroups of the
+// grid are resident, or about what else shares the GPU.
 // A poll that does not succeed within MC_SPIN_LIMIT rounds gives up with DIF_C_OVERFLOW = 7 instead of hanging the queue.
 #define MC_ST_AGG 0x40000000u
 #define MC_ST_PREFIX 0x80000000u
-#define MC_ST_CLAIMED 0xC0000000u       /* claimed, not counted yet (value 0) */
 #define MC_ST_VALUE 0x3FFFFFFFu
 #define MC_SPIN_LIMIT (1 << 22)
 #define MC_RUN_MAX 128                  /* groups per XCD run at most (512 voxels: four z-rows of a 128^3 grid) */
 #define MC_PATIENCE 48                  /* polls a blocked look-back waits before it looks for an unclaimed group to take */
 #define MC_TICKET_STRIDE 32             /* words between the XCDs' ticket counters (a 128-byte line each) */
 #define MC_TICKET_WORDS (8 * MC_TICKET_STRIDE)
-__device__ __forceinline__ unsigned mc_state(unsigned st) { return st >> 30; }                      // 0 unknown, 1 AGG, 2 PREFIX, 3 CLAIMED
-__device__ __forceinline__ bool mc_published(unsigned st) { const unsigned q = st >> 30; return q == 1u || q == 2u; }
+__device__ __forceinline__ bool mc_published(unsigned st) { return (st & ~MC_ST_VALUE) != 0u; }
+// ticket n of XCD x -> group: the XCD's runs are runs x, x + 8, x + 16, ... of `run` consecutive groups each (monotone in n)
+__device__ __forceinline__ long long mc_group_of_ticket(unsigned n, int x, int run) { return ((long long)(n / (unsigned)run) * 8 + x) * run + (n % (unsigned)run); }
+__device__ __forceinline__ int mc_run_length(int n_groups) {      // MC_RUN_MAX, shorter for few groups (every XCD should see several runs); a power of two
+    int run = MC_RUN_MAX;
+    while (run > 4 && run * 32 > n_groups) run >>= 1;
+    return run;
+}
 __device__ __forceinline__ int mc_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }       // HW_REG_XCC_ID[3:0]
 // LDS of a wave: MC_RING sets of blended corners (ticket mode: groups that are counted and wait for their prefix; the direct mode uses the
 // first), the 27 neighbour batches, the edge vertices of the cells being evaluated
@@ -464,7 +470,7 @@ __device__ __forceinline__ int mc_lookback_window(const McArgs& a, unsigned* __r
     int p;
     while (true) {
         if (!mc_published(st)) st = atomicOr(status + i, 0u);
-        pre = __ballot(mc_state(st) == 2u);
+        pre = __ballot((st & MC_ST_PREFIX) != 0u);
         p = pre ? (__ffsll((long long)pre) - 1) : 64;                          // nearest predecessor that knows its inclusive prefix
         const unsigned long long missing = __ballot(!mc_published(st)) & (p >= 63 ? ~0ull : ((2ull << p) - 1ull));
         if (missing == 0ull) break;
@@ -481,21 +487,31 @@ __device__ __forceinline__ int mc_lookback_window(const McArgs& a, unsigned* __r
     return pre ? 1 : 0;
 }
 
-// The lowest group at or below idx that NOBODY has claimed, among the groups above the nearest one that knows its prefix (scanned window by
-// window, read-only); -1 if every group up there is claimed (being counted by a running workgroup: it will publish without waiting for anyone).
-// Such a group can be completed at once by whoever takes it: everything between it and that prefix is counted or being counted.
-__device__ __forceinline__ int mc_find_unclaimed(unsigned* __restrict__ status, int idx, int lane) {
-    int best = -1;
-    for (; idx >= 0; idx -= 64) {
-        const int i = idx - lane;
-        const unsigned st = (i >= 0) ? atomicOr(status + i, 0u) : MC_ST_PREFIX;
-        const unsigned long long pre = __ballot(mc_state(st) == 2u);
-        const int p = pre ? (__ffsll((long long)pre) - 1) : 64;
-        const unsigned long long un = __ballot(st == 0u) & (p >= 63 ? ~0ull : ((2ull << p) - 1ull));
-        if (un) best = idx - (63 - __clzll((long long)un));                    // the farthest lane = the lowest group
-        if (pre) break;
+// The lowest group below `below` that NOBODY has claimed — the unclaimed groups are the ones at and beyond the XCDs' ticket counters, the lowest of
+// an XCD is the group of its very next ticket —, taken by advancing that XCD's counter by one with a compare-and-swap (so the taker holds exactly
+// that group, like a ticket holder).  Returns the group, or -1 if there is none (everything below is claimed: being counted by running workgroups,
+// which publish without waiting for anyone) or the counter moved meanwhile (the caller polls on and may ask again).
+// Such a group can be completed at once: it is the lowest unclaimed group anywhere, so everything below it is counted or being counted.
+__device__ __forceinline__ int mc_take_unclaimed(unsigned* __restrict__ ticket, int below, int run, int n_groups, int lane) {
+    unsigned n = 0u;
+    long long g = 0x7FFFFFFFll;
+    if (lane < 8) {
+        n = atomicOr(ticket + lane * MC_TICKET_STRIDE, 0u);
+        g = mc_group_of_ticket(n, lane, run);
+        if (g >= n_groups || g >= below) g = 0x7FFFFFFFll;
     }
-    return best;
+    int best = (int)g, who = lane;
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) {
+        const int ob = __shfl_xor(best, d), ow = __shfl_xor(who, d);
+        if (ob < best) { best = ob; who = ow; }
+    }
+    best = __shfl(best, 0); who = __shfl(who, 0);
+    if (best == 0x7FFFFFFF) return -1;
+    const unsigned nn = (unsigned)__shfl((int)n, who);
+    unsigned old = nn + 1u;
+    if (lane == 0) old = atomicCAS(ticket + who * MC_TICKET_STRIDE, nn, nn + 1u);
+    return (unsigned)__shfl((int)old, 0) == nn ? best : -1;
 }
 
 // RC: the resolution as a compile-time constant (0: read it from the arguments).  The index arithmetic of the corners and cells divides by
@@ -567,8 +583,8 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
     }
 }
 
-// More groups than workgroups (a map with thousands of dirty voxels): groups are claimed — a ticket of the workgroup's XCD, sealed by a
-// compare-and-swap on the group's status word — and a workgroup does not sit on a counted group until its prefix is known: it parks the group
+// More groups than workgroups (a map with thousands of dirty voxels): groups are claimed through a ticket of the workgroup's XCD — the
+// ticket holder is the only one that ever works on a group — and a workgroup does not sit on a counted group until its prefix is known: it parks the group
 // (its blended corners stay in LDS, up to MC_RING - 1 sets per wave) and counts the next one; a parked group is emitted once its look-back
 // succeeds (the cells are evaluated again from the parked corners: cheaper than holding their edge vertices).  The ordered commit otherwise costs
 // what the slowest of the ~1,000 groups in flight in front of a group costs: measured, a third of the launch (profiles/r04_experiments.md).
@@ -578,9 +594,10 @@ __device__ __forceinline__ void mc_onepass_direct(const McArgs& a, unsigned* __r
 // are used up helps the next one.
 // No deadlock, whatever the residency: a claimed group's count is published right after counting, and counting never waits.  A workgroup only
 // blocks in a look-back — when its ring holds MC_RING - 1 groups or the tickets are gone — and after MC_PATIENCE polls it asks whether a group
-// it waits for is UNCLAIMED (its XCD lags, or has no workgroup resident): the lowest such group above the nearest known prefix it claims itself
-// (mc_find_unclaimed) and completes at once in the ring's spare slot — everything between that group and the prefix is counted or being counted
-// by running workgroups.  The lowest group without a count is therefore always either being counted or about to be taken by whoever waits for it.
+// below its head is UNCLAIMED (its XCD lags, or has no workgroup resident): the lowest unclaimed group anywhere is the next ticket of some XCD,
+// and the waiting workgroup takes exactly that ticket (mc_take_unclaimed) and completes the group at once in the ring's spare slot — everything
+// below it is counted or being counted by running workgroups.  The lowest group without a count is therefore always either being counted or about
+// to be taken by whoever waits for it.
 template <int RC>
 __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __restrict__ status, unsigned* __restrict__ ticket, float* lds, int K,
                                                 int n_groups, int64_t log_n) {
@@ -642,17 +659,12 @@ __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __res
     while (true) {
         const bool claim = cnt < MC_RING - 1 && !exhausted;          // (the ring's last slot stays free: a group taken over is completed there)
         if (claim && threadIdx.x == 0) {
-            // run length: MC_RUN_MAX, shorter for few groups (every XCD should see several runs); a power of two
-            int run = MC_RUN_MAX;
-            while (run > 4 && run * 32 > n_groups) run >>= 1;
-            const int my_x = mc_xcc_id();
+            const int run = mc_run_length(n_groups), my_x = mc_xcc_id();
             int g = -1, hops = s_hops;
             while (hops < 8) {
                 const int x = (my_x + hops) & 7;
-                const unsigned n = atomicAdd(ticket + x * MC_TICKET_STRIDE, 1u);
-                const long long cand = ((long long)(n / (unsigned)run) * 8 + x) * run + (n % (unsigned)run);
+                const long long cand = mc_group_of_ticket(atomicAdd(ticket + x * MC_TICKET_STRIDE, 1u), x, run);
                 if (cand >= n_groups) { ++hops; continue; }                     // this XCD's runs are used up (its tickets only grow): help the next one
-                if (atomicCAS(status + cand, 0u, MC_ST_CLAIMED) != 0u) continue; // somebody who waited for it has taken it
                 g = (int)cand;
                 break;
             }
@@ -689,16 +701,11 @@ __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __res
                     if (lb_idx < 0) { done = true; break; }
                     int sum;
                     const int found = mc_lookback_window(a, status, lb_idx, lane, block, sum, MC_PATIENCE);
-                    if (found == -2) {                               // still waiting: is a group down there nobody's?  Take it.
+                    if (found == -2) {                               // still waiting: is a group below the head nobody's?  Take the lowest.
                         if (++rounds > MC_SPIN_LIMIT / MC_PATIENCE) { if (lane == 0) a.log_counters[DIF_C_OVERFLOW] = 7; done = true; break; }
-                        const int j = mc_find_unclaimed(status, lb_idx, lane);
-                        if (j >= 0) {
-                            unsigned old = 1u;
-                            if (lane == 0) old = atomicCAS(status + j, 0u, MC_ST_CLAIMED);
-                            if (__shfl((int)old, 0) == 0) steal = j;
-                        }
+                        steal = mc_take_unclaimed(ticket, gh, mc_run_length(n_groups), n_groups, lane);
                         if (steal >= 0) break;
-                        continue;                                    // (claimed by now, or being counted: poll on)
+                        continue;                                    // (all claimed: being counted — poll on)
                     }
                     if (found < 0) break;
                     lb_excl += sum;
