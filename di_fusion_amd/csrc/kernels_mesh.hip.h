@@ -342,8 +342,12 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_marching_cubes(McArgs a) {
 #define MC_ST_PREFIX 0x80000000u
 #define MC_ST_VALUE 0x3FFFFFFFu
 #define MC_SPIN_LIMIT (1 << 22)
+#ifndef MC_RUN_MAX
 #define MC_RUN_MAX 128                  /* groups per XCD run at most (512 voxels: four z-rows of a 128^3 grid) */
+#endif
+#ifndef MC_PATIENCE
 #define MC_PATIENCE 48                  /* polls a blocked look-back waits before it looks for an unclaimed group to take */
+#endif
 #define MC_TICKET_STRIDE 32             /* words between the XCDs' ticket counters (a 128-byte line each) */
 #define MC_TICKET_WORDS (8 * MC_TICKET_STRIDE)
 __device__ __forceinline__ bool mc_published(unsigned st) { return (st & ~MC_ST_VALUE) != 0u; }
