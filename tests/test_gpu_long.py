@@ -157,15 +157,17 @@ def test_direct_dma_stream_vs_reference_frame_by_frame(name, overlap, gpu_model,
     assert torch.equal(st.map.indexer, final[0]) and torch.equal(st.map.latent_vecs[:n], final[1]) and torch.equal(st.map.voxel_obs_count[:n], final[2])
 
 
-def test_stream_group_two_phases_vs_reference_frame_by_frame(gpu_model, oracle_net):
+@pytest.mark.parametrize("n_frames", [8, pytest.param(12, marks=pytest.mark.soak)])
+def test_stream_group_two_phases_vs_reference_frame_by_frame(n_frames, gpu_model, oracle_net):
     """S = 2: stream 0 fuses the bench's arc (fixture seq_c3_long), stream 1 the arc starting at 45 degrees (its own fixture): every frame of
     both streams against the reference and the oracle, through `dif_integrate_frames` + `dif_extract_streams`; then the same group again
-    without device synchronisation between its frames."""
+    without device synchronisation between its frames.  (`-m gpu`: the first 8 frames — the oracle stepped alongside is what takes the time —,
+    `-m soak`: all 12 of the second arc's fixture.)"""
     from di_fusion_amd.stream import FusionStreamGroup
     from oracle import difusion_oracle as O
     names = ["seq_c3_long", "seq_c3_long_p45"]
     gs = [np.load(GOLDEN / f"{nm}.npz") for nm in names]
-    F = min(int(g["n_frames"]) for g in gs)
+    F = min(n_frames, min(int(g["n_frames"]) for g in gs))
 
     def build():
         sts = []
