@@ -606,7 +606,6 @@ template <int RC>
 __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __restrict__ status, unsigned* __restrict__ ticket, float* lds, int K,
                                                 int n_groups, int64_t log_n) {
     __shared__ int s_g, s_res, s_excl, s_steal, s_hops;             // s_hops: ticket counters (this XCD's, the next one's, ...) found used up so far
-    __shared__ int s_gnext;                                          // a group claimed while the previous one was being emitted (-2: none)
     __shared__ int s_gid[MC_RING];                                   // parked groups (ring order: head .. head + cnt - 1)
     __shared__ int s_cnt[MC_RING][DIF_BLOCK / 64];                   // their voxels' triangle counts
     __shared__ int64_t s_vb[MC_RING][DIF_BLOCK / 64];                // ... and what the emit needs to know about each voxel
@@ -616,7 +615,7 @@ __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __res
     float* ring = lds + (size_t)wid * MC_ONEPASS_WAVE_LDS_FLOATS(nc);
     int* nb = reinterpret_cast<int*>(ring + MC_RING * MC_CORNER_FLOATS(nc));
     float* vl = reinterpret_cast<float*>(nb + 32) + lane;
-    if (threadIdx.x == 0) { s_hops = 0; s_gnext = -2; }
+    if (threadIdx.x == 0) s_hops = 0;
     int head = 0, cnt = 0;
     bool exhausted = false;
     int lb_idx = -2, lb_excl = 0;                                    // wave 0: how far the oldest parked group's look-back has come (-2: not begun)
@@ -663,10 +662,7 @@ __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __res
 
     while (true) {
         const bool claim = cnt < MC_RING - 1 && !exhausted;          // (the ring's last slot stays free: a group taken over is completed there)
-        if (claim && threadIdx.x == 0 && s_gnext != -2) {            // claimed behind the last emit: the ticket's round trip is already paid
-            s_g = s_gnext;
-            s_gnext = -2;
-        } else if (claim && threadIdx.x == 0) {
+        if (claim && threadIdx.x == 0) {
             const int run = mc_run_length(n_groups), my_x = mc_xcc_id();
             int g = -1, hops = s_hops;
             while (hops < 8) {
@@ -734,18 +730,7 @@ __device__ __forceinline__ void mc_onepass_ring(const McArgs& a, unsigned* __res
         __syncthreads();
         if (g >= 0) ++cnt;
         if (s_res) {                                                 // the oldest parked group has its offset: emit it
-            // ... and take the next ticket meanwhile (the slot this emit frees is the one it will need): the counter's answer — a round trip to
-            // the memory side, ~2 us of a ~20 us iteration — arrives while the triangles are written.  Only the plain case: a ticket beyond this
-            // XCD's runs is dropped and the next iteration claims the ordinary way (and moves on to the next XCD's counter).
-            unsigned n_next = 0u;
-            const bool ahead = threadIdx.x == 0 && !exhausted && s_hops == 0;
-            const int x_next = mc_xcc_id();
-            if (ahead) n_next = atomicAdd(ticket + x_next * MC_TICKET_STRIDE, 1u);
             emit_group(s_gid[head], head);
-            if (ahead) {
-                const long long cand = mc_group_of_ticket(n_next, x_next, mc_run_length(n_groups));
-                s_gnext = cand < n_groups ? (int)cand : -2;
-            }
             head = (head + 1) % MC_RING;
             --cnt;
         } else if (s_steal >= 0) {
