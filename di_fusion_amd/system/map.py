@@ -632,6 +632,15 @@ class DenseIndexedMap:
         return o[0][:n], o[1][:n], o[2][:n]
 
     MIN_EXTRACT_ROWS = 1 << 15
+    EXTRACT_ROWS_FLOOR = 1 << 12        # rows that `extract_buffer_bytes` never takes away
+
+    def _extract_rows_limit(self, resolution: int) -> int:
+        """The most rows `extract_buffer_bytes` allows a streaming map (a power of two, at least EXTRACT_ROWS_FLOOR)."""
+        per_voxel = ((2 * resolution) ** 3) * 12 + (resolution ** 3) * 8 + 1024 + 64
+        rows = self.EXTRACT_ROWS_FLOOR
+        while 2 * rows * per_voxel <= self.extract_buffer_bytes:
+            rows *= 2
+        return rows
 
     def _extract_rows(self, resolution: int, no_cache: bool = False) -> int:
         """Rows of the per-voxel extract buffers (~7.7 KB per row at resolution 4).
@@ -644,9 +653,7 @@ class DenseIndexedMap:
         R = 2 * resolution
         per_voxel = (R ** 3) * 12 + (resolution ** 3) * 8 + 1024 + 64
         if not no_cache and not self._tiled and self._capacity > 4096:
-            rows = _next_pow2(max(self.MIN_EXTRACT_ROWS, 4 * self._extract_high_water, 2 * self._extract_rows_wanted))
-            while rows > 4096 and rows * per_voxel > self.extract_buffer_bytes:
-                rows //= 2
+            rows = min(_next_pow2(max(self.MIN_EXTRACT_ROWS, 4 * self._extract_high_water, 2 * self._extract_rows_wanted)), self._extract_rows_limit(resolution))
         else:
             rows = _next_pow2(max(self._n_occ_ub, 1024))
             # Room to grow: four times the occupancy bound, at most the map's capacity and at most `extract_buffer_bytes` — re-allocating
@@ -731,6 +738,12 @@ class DenseIndexedMap:
         if c["deferred"] > 0:               # the extract found its buffers too small and changed nothing: the next one runs with more rows
             self._extract_rows_wanted = max(self._extract_rows_wanted, int(c["deferred"]))
             self.n_deferred += 1
+            limit = self._extract_rows_limit(self._xbuf[0][0])
+            if int(c["deferred"]) > min(limit, _next_pow2(self._capacity)):
+                # (growing cannot help: every later extract would defer as well and the dirty set would never be meshed)
+                raise RuntimeError(f"libdifusion: this extract needs {int(c['deferred'])} rows of per-voxel buffers, more than `extract_buffer_bytes` = "
+                                   f"{self.extract_buffer_bytes >> 20} MB allows ({limit} rows); it was deferred (nothing is lost: the dirty set is kept) — "
+                                   "raise the limit and extract again")
         if c["T"] >= handle["max_n_triangles"]:
             logging.warning(f"Warning from marching cube: the max triangle number is too small {c['T']} vs {handle['max_n_triangles']}")
         if c["K"] > 0:

@@ -669,3 +669,14 @@ def test_extract_defers_instead_of_overflowing_and_catches_up(overlap, gpu_model
     torch.cuda.synchronize()
     assert st.map.n_deferred >= 1
     same(snapshot(full), snapshot(st))
+    # a limit that no growth can satisfy is an error (with the dirty set kept), not an endless deferral
+    st = make_stream(gpu_model, initial_capacity=None)
+    st.map.MIN_EXTRACT_ROWS = st.map.EXTRACT_ROWS_FLOOR = 64
+    st.map.extract_buffer_bytes = 1 << 20                           # 128 rows
+    with pytest.raises(RuntimeError, match="extract_buffer_bytes"):
+        for i in range(N_FRAMES):
+            st.step(i, d2h="none")
+    torch.cuda.synchronize()
+    st.map.extract_buffer_bytes = 8 << 30
+    st.map.extract_mesh_arrays(4, int(4e6), max_std=0.15, to_host=False)           # nothing was lost
+    assert st.map.last_counters["K"] > 100 and st.map.last_counters["deferred"] == 0
