@@ -146,12 +146,14 @@ def _sphere_stream(gpu_model, frames):
     return st, scene, cfg
 
 
-@pytest.mark.parametrize("grid", [0, 7], ids=["group_per_workgroup", "ticket_mode"])
+@pytest.mark.parametrize("grid", [0, 7, 1, 2], ids=["group_per_workgroup", "ticket_mode", "ticket_mode_one_workgroup", "ticket_mode_two_workgroups"])
 def test_onepass_kernel_equals_flat_two_pass_kernels_on_the_extracts_own_cubes(gpu_model, grid, mc_grid_cap):
     """The stream's extract (one-pass marching cubes) and the flat HIP op (count pass, scan, emit pass) on the SAME decoded cubes, the same
     batch map and the same dirty list: identical triangles, ids and std — bit for bit (voxel units).  `ticket_mode`: the launch capped at
-    7 workgroups (dif_test_mc_grid_cap), so the > 25 groups of a frame are claimed through the ticket counter — the path of a map with thousands of
-    dirty voxels."""
+    7 workgroups (dif_test_mc_grid_cap), so the > 25 groups of a frame are claimed through the ticket counters — the path of a map with thousands of
+    dirty voxels.  With ONE or TWO workgroups at most two XCDs have a workgroup resident, while the groups belong to the runs of all eight: every other
+    XCD's groups must be taken over by whoever waits for them (or helped once the own tickets are used up) — the launch's guarantee that a look-back
+    only ever waits for groups a running workgroup has claimed, whatever the residency (csrc/kernels_mesh.hip.h: mc_onepass_ring)."""
     from di_fusion_amd.system import ext
     if grid:
         mc_grid_cap(grid)
