@@ -588,6 +588,70 @@ def tracker_fixtures(model):
     tracker_fixture(model, "track_c2", scene, cfg, syn.Intrinsic(), syn.Intrinsic().scaled(0.5), 2, 0.5, cases, iters, init_deg=0.4)
 
 
+VARIANTS = [("accumulated", dict(voxel_resolution=4, fast=True, no_cache=False)),      # two integrates, then ONE extract: the dirty sets accumulate (map.py:303-308)
+            ("exact_r4", dict(voxel_resolution=4, fast=False, no_cache=True)),           # every lattice sample decoded (map.py:683-685)
+            ("fast_r2", dict(voxel_resolution=2, fast=True, no_cache=True)),
+            ("fast_r3", dict(voxel_resolution=3, fast=True, no_cache=True)),
+            ("fast_r8", dict(voxel_resolution=8, fast=True, no_cache=True)),
+            ("exact_r2", dict(voxel_resolution=2, fast=False, no_cache=True)),
+            ("no_cache_r4", dict(voxel_resolution=4, fast=True, no_cache=True))]         # every allocated voxel re-meshed (map.py:614-616)
+
+
+def variants_fixture(model):
+    """`extract_mesh` AWAY from the call the tracking loop makes (resolution 4, fast, cached) and `integrate_keyframe` without pruning, run by the
+    REFERENCE on CPU: the 16^3 room map after two integrates WITHOUT an extract in between, then one extract per entry of VARIANTS (the argument
+    tuple handed to marching cubes: dirty list, batch map, B, a strided subset of the cubes), and a second map with `prune_min_vox_obs = 0`
+    (map.py:372-378: no mask is returned, every point's voxel is allocated).  -> extract_variants.npz"""
+    scene, cfg, intr = syn.default_room(), syn.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.4), syn.Intrinsic().scaled(0.25)
+    deg = 15.0
+    out = dict(deg_per_frame=np.float64(deg), n_frames=np.int64(2), names=np.asarray([n for n, _ in VARIANTS]))
+    m = ref_map.DenseIndexedMap(model, cfg.namespace(), 29, torch.device("cpu"))
+    for f in range(2):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg)
+        out[f"f{f}_xyz_sha"] = np.asarray(sha(xyz.numpy()))
+        m.integrate_keyframe(xyz, nrm)
+    for k, v in map_state(m).items():
+        out[f"int_{k}"] = v
+    for name, kw in VARIANTS:
+        RECORDED.clear()
+        m._make_mesh_from_cache = lambda: None
+        m.extract_mesh(kw["voxel_resolution"], int(4e6), fast=kw["fast"], max_std=0.15, extract_async=False, no_cache=kw["no_cache"], interpolate=True)
+        a = RECORDED["mc_args"]
+        B = a["cube_sdf"].size(0)
+        sel = np.arange(0, B, max(1, B // 24))
+        out[f"{name}_resolution"] = np.int64(kw["voxel_resolution"]); out[f"{name}_fast"] = np.int64(kw["fast"]); out[f"{name}_no_cache"] = np.int64(kw["no_cache"])
+        out[f"{name}_valid_blocks"] = a["valid_blocks"].numpy()
+        out[f"{name}_vec_batch_mapping"] = a["vec_batch_mapping"].numpy()
+        out[f"{name}_B"] = np.int64(B)
+        out[f"{name}_cube_sdf_sha"] = np.asarray(sha(a["cube_sdf"].numpy()))
+        out[f"{name}_cube_sel"] = sel.astype(np.int64)
+        out[f"{name}_cube_sdf"] = a["cube_sdf"].numpy()[sel]
+        out[f"{name}_cube_std"] = a["cube_std"].numpy()[sel]
+        out[f"{name}_updated_after"] = m.mesh_cache.updated_vec_id.numpy().copy()
+        print(f"  variant {name}: K={a['valid_blocks'].numel()} B={B} cube {tuple(a['cube_sdf'].shape[1:])}")
+    # pruning off
+    args = cfg.namespace()
+    args.prune_min_vox_obs = 0
+    m2 = ref_map.DenseIndexedMap(model, args, 29, torch.device("cpu"))
+    for f in range(2):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg)
+        unq = m2.integrate_keyframe(xyz, nrm)
+        assert unq is None
+        for k, v in map_state(m2).items():
+            out[f"noprune_f{f}_{k}"] = v
+    RECORDED.clear()
+    _extract(m2)
+    a = RECORDED["mc_args"]
+    out["noprune_valid_blocks"] = a["valid_blocks"].numpy()
+    out["noprune_B"] = np.int64(a["cube_sdf"].size(0))
+    sel = np.arange(0, a["cube_sdf"].size(0), max(1, a["cube_sdf"].size(0) // 24))
+    out["noprune_cube_sel"] = sel.astype(np.int64)
+    out["noprune_cube_sdf"] = a["cube_sdf"].numpy()[sel]
+    out["noprune_cube_std"] = a["cube_std"].numpy()[sel]
+    np.savez_compressed(HERE / "extract_variants.npz", **out)
+    print(f"extract_variants: saved ({(HERE / 'extract_variants.npz').stat().st_size / 1e6:.2f} MB), no-prune map {int(m2.n_occupied)} voxels against {int(m.n_occupied)}")
+
+
 def main():
     model, hyper = load_reference_model()
     if "--map-only" in sys.argv:
@@ -603,6 +667,8 @@ def main():
             tracker_fixtures(model)
         if "box_filter" in which:
             box_filter_fixture()
+        if "variants" in which:
+            variants_fixture(model)
         if "grads" in which:
             add_gradient_probes(model, "seq_small", syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.4),
                                 syn.Intrinsic().scaled(0.125), 3, 20.0)
@@ -629,6 +695,7 @@ def main():
     save_reference_map(model)
     full_size_sequences(model, ("seq_c2", "seq_c3"))
     optimize_sequence(model)
+    variants_fixture(model)
 
 
 if __name__ == "__main__":

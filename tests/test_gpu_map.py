@@ -457,6 +457,78 @@ def test_other_resolutions_and_exact_decode(resolution, fast, mc_grid, gpu_model
     assert np.abs(ntri.cpu().numpy() - want).max() < 1e-5
 
 
+def _variant_cubes(m, g, key, tol, oa):
+    K, B = m.last_counters["K"], m.last_counters["B"]
+    tens = m._xbuf[1]
+    assert np.array_equal(tens["valid_blocks"][:K].cpu().numpy(), g[f"{key}_valid_blocks"])
+    assert B == int(g[f"{key}_B"])
+    sel = torch.from_numpy(g[f"{key}_cube_sel"]).to(DEV)
+    cs, cd = tens["cube_sdf"][:B][sel].cpu().numpy(), tens["cube_std"][:B][sel].cpu().numpy()
+    want_s, want_d = g[f"{key}_cube_sdf"], g[f"{key}_cube_std"]
+    assert cs.shape == want_s.shape
+    # samples whose interpolated |sdf| sits within 1e-5 of the 0.05 refinement threshold may be refined on one side only: excluded, as everywhere
+    # (the oracle, stepped on the same inputs, says which)
+    thr = np.zeros((B, want_s[0].size), dtype=bool)
+    if len(oa["near_threshold"]):
+        thr[oa["near_threshold"][:, 0], oa["near_threshold"][:, 1]] = True
+    thr = thr.reshape((B,) + want_s.shape[1:])[g[f"{key}_cube_sel"]]
+    assert thr.mean() < 2e-3
+    d = max(np.abs(cs - want_s)[~thr].max(), np.abs(cd - want_d)[~thr].max())
+    assert d < tol, (key, d)
+    return d
+
+
+def test_extract_variants_vs_reference(gpu_model, oracle_net):
+    """`extract_mesh` away from the tracking loop's call, against the REFERENCE (tests/golden/extract_variants.npz): two integrates before ONE extract,
+    fast=False, resolutions 2 / 3 / 8, no_cache=True — dirty list, B and the cubes handed to marching cubes."""
+    from oracle import difusion_oracle as O
+    g = np.load(GOLDEN / "extract_variants.npz")
+    scene, cfg, intr = CASES["seq_room16"]
+    m = make_map(gpu_model, cfg)
+    om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size)
+    for f in range(int(g["n_frames"])):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=float(g["deg_per_frame"]))
+        m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV))
+        om.integrate_keyframe(xyz.numpy(), nrm.numpy())
+    n = m.n_occupied
+    assert n == int(g["int_n_occupied"])
+    assert np.array_equal(m.latent_vecs_pos[:n].cpu().numpy(), g["int_latent_vecs_pos"])
+    assert np.array_equal(m.voxel_obs_count[:n].cpu().numpy(), g["int_voxel_obs_count"])
+    assert np.abs(m.latent_vecs[:n].cpu().numpy() - g["int_latent_vecs"]).max() < 5e-6
+    for name in g["names"]:
+        r, fast, nc = int(g[f"{name}_resolution"]), bool(g[f"{name}_fast"]), bool(g[f"{name}_no_cache"])
+        out = m.extract_mesh_arrays(r, int(4e6), fast=fast, max_std=0.15, no_cache=nc)
+        d = _variant_cubes(m, g, name, SDF_TOL, om.extract_prepare(r, fast=fast, no_cache=nc))
+        print(f"  {name}: K={m.last_counters['K']} B={m.last_counters['B']} triangles {out[0].shape[0]} maxdiff {d:.2e}")
+        assert out[0].shape[0] > 1000
+
+
+def test_integrate_without_pruning_vs_reference(gpu_model, oracle_net):
+    """`prune_min_vox_obs = 0` (reference map.py:372-378): no mask comes back, every point's voxel is allocated; state and cubes against the reference."""
+    from di_fusion_amd.system.map import DenseIndexedMap
+    from oracle import difusion_oracle as O
+    g = np.load(GOLDEN / "extract_variants.npz")
+    scene, cfg, intr = CASES["seq_room16"]
+    args = cfg.namespace()
+    args.prune_min_vox_obs = 0
+    m = DenseIndexedMap(gpu_model, args, 29, DEV, initial_capacity=1024)
+    om = O.OracleMap(oracle_net, cfg.bound_min, cfg.bound_max, cfg.voxel_size, prune_min_vox_obs=0)
+    for f in range(int(g["n_frames"])):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=float(g["deg_per_frame"]))
+        assert m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV)) is None
+        om.integrate_keyframe(xyz.numpy(), nrm.numpy())
+        n = m.n_occupied
+        assert n == int(g[f"noprune_f{f}_n_occupied"])
+        idx = m.indexer.cpu().numpy()
+        nz = np.nonzero(idx != -1)[0]
+        assert np.array_equal(nz, g[f"noprune_f{f}_indexer_nz"]) and np.array_equal(idx[nz], g[f"noprune_f{f}_indexer_val"])
+        assert np.array_equal(m.latent_vecs_pos[:n].cpu().numpy(), g[f"noprune_f{f}_latent_vecs_pos"])
+        assert np.array_equal(m.voxel_obs_count[:n].cpu().numpy(), g[f"noprune_f{f}_voxel_obs_count"])
+        assert np.abs(m.latent_vecs[:n].cpu().numpy() - g[f"noprune_f{f}_latent_vecs"]).max() < 5e-6
+    m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+    _variant_cubes(m, g, "noprune", SDF_TOL, om.extract_prepare())
+
+
 def test_sdf_gauss_newton_pose_refinement(gpu_model):
     """The caller of the path: `SDFTracker.compute_sdf_Hg` (reference tracker.py:174-218) restated on top of `map.get_sdf` —
     residual sdf/std.detach(), Jacobian from autograd through the map, 6-DoF Gauss-Newton.  A perturbed camera pose must be
