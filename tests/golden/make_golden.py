@@ -14,6 +14,8 @@ Stubs injected before import:
     vector for everything up to marching cubes)
   * `torch.cuda.Stream/stream/synchronize` — no-ops (`map.py:232,625-626`)
   * `np.product` — removed in NumPy 2 (`map.py:201,407`)
+  * (mesh-cache fixture only, `--only mesh_cache`) `marching_cubes_interp` = the oracle's C restatement, `_get_valid_idx` handed a sentinel:
+    see mesh_cache_fixture
   * (tracker fixtures only, `--only track`) `pyquaternion` — the image has none: a `Quaternion` that keeps the rotation as a 3x3 matrix in
     float64 (`rotation_matrix`, `inverse`, `rotate`, `*`), enough for `utils/motion_util.Isometry` to run as written; the rest of
     `system.ext` the tracker imports (CUDA image / point-cloud kernels) as names that are never called; `Tensor.cuda()` = identity
@@ -652,6 +654,57 @@ def variants_fixture(model):
     print(f"extract_variants: saved ({(HERE / 'extract_variants.npz').stat().st_size / 1e6:.2f} MB), no-prune map {int(m2.n_occupied)} voxels against {int(m.n_occupied)}")
 
 
+def mesh_cache_fixture(model):
+    """The reference's OWN code behind marching cubes (map.py:698-714: `vertices * voxel_size + bound_min`, `_get_valid_idx`, the replace-by-voxel
+    concatenation of the mesh cache), run over four frames of the 16^3 room sequence.  The CUDA kernel cannot run here: for THIS fixture
+    `system.ext.marching_cubes_interp` is the oracle's C restatement (oracle/mc_oracle.c) on the cubes the reference hands it, so what the vectors pin is
+    the host-side rule, given triangles.  Stand-in stated: numba's `_get_valid_idx` (map.py:20-26) reads `query_idx[len]` unchecked when a cached id
+    lies above every new id (garbage that is != v: the triangle is kept); the identity `jit` would raise there, so the function is handed `query_idx`
+    with one int64-max sentinel appended (same answer, no out-of-range read).  -> mesh_cache.npz"""
+    from oracle import difusion_oracle as O
+    scene, cfg, intr = syn.default_room(), syn.MapConfig((-3.2, -3.2, -3.2), (3.2, 3.2, 3.2), 0.4), syn.Intrinsic().scaled(0.25)
+    deg, F = 15.0, 4
+    new = {}
+
+    def mc(indexer, valid_blocks, vec_batch_mapping, cube_sdf, cube_std, max_n, n_xyz, max_std):
+        t, i, d = O.marching_cubes_interp(indexer.numpy(), valid_blocks.numpy(), vec_batch_mapping.numpy(), cube_sdf.numpy(), cube_std.numpy(),
+                                          int(max_n), list(n_xyz), float(max_std))
+        new.update(tri=t, tid=i, tstd=d)
+        return torch.from_numpy(t), torch.from_numpy(i), torch.from_numpy(d)
+
+    real_valid = ref_map._get_valid_idx
+    sentinel_used = [0]
+
+    def valid_idx(base_idx, query_idx):
+        sentinel_used[0] += int(base_idx.max() > query_idx.max())
+        return real_valid(base_idx, np.concatenate([query_idx, np.asarray([np.iinfo(np.int64).max], dtype=query_idx.dtype)]))
+
+    out = dict(deg_per_frame=np.float64(deg), n_frames=np.int64(F))
+    _ext.marching_cubes_interp, ref_map._get_valid_idx = mc, valid_idx
+    try:
+        m = ref_map.DenseIndexedMap(model, cfg.namespace(), 29, torch.device("cpu"))
+        m._make_mesh_from_cache = lambda: None
+        for f in range(F):
+            xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=deg)
+            out[f"f{f}_xyz_sha"] = np.asarray(sha(xyz.numpy()))
+            m.integrate_keyframe(xyz, nrm)
+            m.extract_mesh(4, int(4e6), fast=True, max_std=0.15, extract_async=False, no_cache=False, interpolate=True)
+            c = m.mesh_cache
+            out[f"f{f}_new_id"] = new["tid"].copy()
+            out[f"f{f}_new_tri_voxel_units"] = new["tri"].copy()
+            out[f"f{f}_new_std"] = new["tstd"].copy()
+            out[f"f{f}_cache_id"] = c.vertices_flatten_id.copy()
+            out[f"f{f}_cache_vertices_sha"] = np.asarray(sha(c.vertices))
+            out[f"f{f}_cache_std_sha"] = np.asarray(sha(c.vertices_std))
+            assert c.vertices.dtype == np.float32 and c.vertices_flatten_id.dtype == np.int64
+            print(f"  mesh cache frame {f}: {new['tid'].shape[0]} new triangles over {len(np.unique(new['tid']))} voxels -> cache {c.vertices.shape[0]}")
+        out["final_vertices"], out["final_std"] = c.vertices.copy(), c.vertices_std.copy()
+    finally:
+        _ext.marching_cubes_interp, ref_map._get_valid_idx = _mc_record, real_valid
+    np.savez_compressed(HERE / "mesh_cache.npz", **out)
+    print(f"mesh_cache: saved ({(HERE / 'mesh_cache.npz').stat().st_size / 1e6:.2f} MB); cached ids above every new id in {sentinel_used[0]} of {F - 1} updates")
+
+
 def main():
     model, hyper = load_reference_model()
     if "--map-only" in sys.argv:
@@ -669,6 +722,8 @@ def main():
             box_filter_fixture()
         if "variants" in which:
             variants_fixture(model)
+        if "mesh_cache" in which:
+            mesh_cache_fixture(model)
         if "grads" in which:
             add_gradient_probes(model, "seq_small", syn.Scene(kind="sphere", radius=1.3), syn.MapConfig((-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), 0.4),
                                 syn.Intrinsic().scaled(0.125), 3, 20.0)
@@ -696,6 +751,7 @@ def main():
     full_size_sequences(model, ("seq_c2", "seq_c3"))
     optimize_sequence(model)
     variants_fixture(model)
+    mesh_cache_fixture(model)
 
 
 if __name__ == "__main__":

@@ -183,18 +183,36 @@ def test_mesh_cache_replace_by_voxel(gpu_model, oracle_net):
         cs, cd = m._xbuf[1]["cube_sdf"][:B].cpu().numpy(), m._xbuf[1]["cube_std"][:B].cpu().numpy()
         wt, oid, ostd = O.marching_cubes_interp(oa["indexer"], oa["valid_blocks"], oa["vec_batch_mapping"], cs, cd, int(4e6), om.n_xyz, 0.15)
         ov = (wt * np.float32(cfg.voxel_size)).astype(np.float32) + om.bound_min                  # map.py:698
-        if cache is None:
-            cache = [ov, oid, ostd]
-        else:                                                     # the reference's host-side rule, restated
-            keep = ~np.isin(cache[1], np.unique(oid))
-            replaced += int((~keep).sum())
-            cache = [np.concatenate([cache[0][keep], ov]), np.concatenate([cache[1][keep], oid]), np.concatenate([cache[2][keep], ostd])]
+        before = 0 if cache is None else cache[0].shape[0]
+        cache = O.mesh_cache_update(cache, ov, oid, ostd)         # the reference's host-side rule (pinned on its own code: mesh_cache.npz)
+        replaced += before + ov.shape[0] - cache[0].shape[0]
         assert v.shape[0] == vid.shape[0] == vs.shape[0] == cache[0].shape[0], (f, v.shape, cache[0].shape)
         assert np.array_equal(vid, cache[1])
         assert np.abs(v - cache[0]).max() < 1e-5 and np.abs(vs - cache[2]).max() < 1e-5
     assert replaced > 0 and len(np.unique(vid)) > 10
     mesh = m.extract_mesh(4, int(4e6), max_std=0.15)
     assert mesh is not None and mesh.triangles.shape[0] == v.shape[0]
+
+
+def test_mesh_cache_vs_reference(gpu_model):
+    """The mesh cache after each of four frames against the REFERENCE's own post-marching-cubes code (map.py:698-714; tests/golden/mesh_cache.npz, where
+    the CUDA marching cubes is played by the C oracle on the reference's cubes): the same triangles in the same order — voxel id at every position
+    of the cache —, the new triangles' ids per frame, the final vertices and stds within what the cubes' 1e-5 allows."""
+    g = np.load(GOLDEN / "mesh_cache.npz")
+    scene, cfg, intr = CASES["seq_room16"]
+    m = make_map(gpu_model, cfg)
+    for f in range(int(g["n_frames"])):
+        xyz, nrm = syn.frame_points(scene, f, intr, deg_per_frame=float(g["deg_per_frame"]))
+        m.integrate_keyframe(xyz.to(DEV), nrm.to(DEV))
+        v, vid, vs = m.extract_mesh_arrays(4, int(4e6), max_std=0.15)
+        ntri, nid, nstd = m.mesh_cache_tensors(new_only=True)
+        assert np.array_equal(nid.cpu().numpy(), g[f"f{f}_new_id"]), f
+        assert np.array_equal(vid, g[f"f{f}_cache_id"]), f
+        want = (g[f"f{f}_new_tri_voxel_units"] * np.float32(cfg.voxel_size)).astype(np.float32) + np.asarray(cfg.bound_min, dtype=np.float32)
+        d = np.abs(ntri.cpu().numpy() - want).max()
+        print(f"  frame {f}: {nid.shape[0]} new triangles, cache {vid.shape[0]}, new vertices within {d:.2e} m of the reference's")
+        assert d < 2e-4
+    assert np.abs(v - g["final_vertices"]).max() < 2e-4 and np.abs(vs - g["final_std"]).max() < 2e-4
 
 
 def test_edge_cases(gpu_model):
