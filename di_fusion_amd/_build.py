@@ -14,10 +14,13 @@ LIB = PKG / "libdifusion.so"
 SOURCES = [CSRC / "difusion.hip"]
 HEADERS = sorted(CSRC.glob("*.hip.h")) + [CSRC / "mc_tables.inc", PKG.parent / "include" / "difusion.h"]
 
-# -fno-slp-vectorize: the SLP vectoriser turns pairs of independent fp32 operations into v_pk_fma_f32 / v_pk_add_f32.  In the bf16-pipe
-# MLP kernels (two 250-register waves per SIMD) those packed operations returned wrong values for one 16-lane quarter of a wave now
-# and then (about one decoder tile in 10^5; tools/determinism_stress.py reproduces it within seconds), and beside MFMAs they are
-# slower than the scalar pair anyway (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of independent fp32 operations into v_pk_fma_f32 / v_pk_add_f32.  A v_pk_fma_f32 that runs
+# while other global loads of its wave are still outstanding loses, now and then, its write to the low register of the destination pair in lanes
+# 48..63 once other waves keep the CU's matrix pipes busy — the lattice kernel's fold constants, 5-13 voxels of 12,765 per launch with the round-6
+# kernels (tools/determinism_stress.py under DIF_LIB=<a build without this flag>: every repeat differs).  Reproduced outside this library by
+# tools/micro/pk_fma_fold.hip (never with v_fma_f32, never behind s_waitcnt vmcnt(0), never without MFMA waves on the CU;
+# profiles/r06_experiments.md 5).  The loop vectoriser makes the same instructions: csrc/common.hip.h:NO_PACKED_F32 marks those loops, and
+# tests/test_abi.py checks that the code object holds no packed fp32 arithmetic at all.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-Wno-unused-result", "-DNDEBUG"]
 

@@ -8,6 +8,13 @@
 #define DIF_WAVE 64
 #define DIF_BLOCK 256
 #define DIF_INVALID_KEY 0xFFFFFFFFu   // slot key of a (point, offset) pair that contributes to no voxel
+// No packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in this library.  On MI355X a v_pk_fma_f32 that runs while
+// other global loads of its wave are still outstanding (a counted s_waitcnt vmcnt(n > 0) in front of it) now and then loses its write to the LOW
+// register of the destination pair in lanes 48..63 once the CU's matrix pipes are kept busy by other waves: tools/micro/pk_fma_fold.hip reproduces
+// it on its own (0 wrong folds without MFMA waves, 5-13 in 2-3 M with six, up to 0.1 % with seven; never with v_fma_f32, never behind
+// s_waitcnt vmcnt(0); profiles/r06_experiments.md 5).  The SLP vectoriser is off for the whole build (di_fusion_amd/_build.py); the loops the LOOP
+// vectoriser would turn into packed pairs carry this pragma, and tests/test_abi.py checks that the built code object holds none.
+#define NO_PACKED_F32 _Pragma("clang loop vectorize(disable) interleave(disable)")
 
 #define DIF_CHECK_LAUNCH()                                   \
     do {                                                     \

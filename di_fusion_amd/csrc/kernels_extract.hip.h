@@ -579,6 +579,8 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_upsample_mark(const float* __rest
             const float* ls = low_sdf + (int64_t)b * l3;
             const float* ld = low_std + (int64_t)b * l3;
             e0 = (int64_t)b * R3 + (int64_t)jxy * R;
+            // (not vectorised: two iterations at a time come out as v_pk_fma_f32 / v_pk_mul_f32 on freshly loaded pairs — common.hip.h:NO_PACKED_F32)
+            NO_PACKED_F32
             for (int jz = 0; jz < R; ++jz) {
                 int z0, z1; float wz0, wz1;
                 tri_axis(jz, l, scale, z0, z1, wz0, wz1);

@@ -1014,6 +1014,7 @@ struct QueryFunctor {
 // d loss / d xyz of get_sdf for the caller's autograd: out[sel[m]] = grad[m] * g_sdf[m] (out zeroed by the caller; rows of invalid points stay 0)
 __global__ void __launch_bounds__(DIF_BLOCK) k_query_grad_scatter(const float* __restrict__ grad, const float* __restrict__ g_sdf, const int32_t* __restrict__ sel,
                                                                 int64_t M, float* __restrict__ out) {
+    NO_PACKED_F32
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M * 3; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = e / 3;
         out[(int64_t)sel[m] * 3 + (e - m * 3)] = grad[e] * g_sdf[m];

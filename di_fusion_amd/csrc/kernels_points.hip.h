@@ -326,6 +326,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_pbf_finish(const long long* __res
                                                         float* __restrict__ out_nrm, uint32_t* __restrict__ bits, const float* __restrict__ pts, int64_t N,
                                                         float vs, const unsigned* __restrict__ mm, const int* __restrict__ status) {
     const int nb = n_boxes[0];
+    NO_PACKED_F32
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)nb * 3; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = e / 3; int a = (int)(e - r * 3);
         const float cnt = (float)sums[r * 8 + 6];
@@ -334,6 +335,7 @@ __global__ void __launch_bounds__(DIF_BLOCK) k_pbf_finish(const long long* __res
     }
     if (status[0]) return;
     const BoxGrid G = pbf_grid(mm, vs);                      // restore the bitmap to all-zero for the next call
+    NO_PACKED_F32
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t c = pbf_cell(G, pts + i * 3, vs);
         bits[c >> 5] = 0u;

@@ -98,6 +98,24 @@ def _kernel_isa(names):
         return out
 
 
+def test_no_packed_fp32_arithmetic_in_the_code_object():
+    """v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 beside outstanding global loads lose a write now and then on MI355X once the CU's matrix pipes are
+    busy (tools/micro/pk_fma_fold.hip reproduces it standalone; csrc/common.hip.h:NO_PACKED_F32): the library is built without the SLP vectoriser and
+    the loops the loop vectoriser would pair are marked, so that NO kernel holds one."""
+    import subprocess
+    import tempfile
+    from di_fusion_amd import _build
+    d = _build.build().read_bytes()
+    i = d.find(b"\x7fELF", d.find(b"__CLANG_OFFLOAD_BUNDLE__"))
+    with tempfile.NamedTemporaryFile(suffix=".o") as f:
+        f.write(d[i:]); f.flush()
+        txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True).stdout
+    assert txt.count("v_mfma_f32_32x32x16_bf16") > 1000                      # (the disassembly is the device code)
+    found = re.findall(r"^\s*(v_pk_(?:fma|mul|add)_f32)\b", txt, flags=re.M)
+    assert not found, f"{len(found)} packed fp32 instructions in libdifusion.so"
+    assert "-fno-slp-vectorize" in _build.HIPCC_FLAGS
+
+
 def test_fence_free_handovers_compile_to_write_through_stores_and_sc1_loads():
     """The hand-overs inside k_sdf_hg_reduce and k_extract_finish (and their litmus twin, csrc/kernels_litmus.hip.h) rest on what the
     COMPILER makes of relaxed agent- / system-scope atomic stores and loads: write-through (sc1 / sc0 sc1) stores, sc1 loads, no cache write-back or
