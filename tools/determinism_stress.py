@@ -1,8 +1,9 @@
 """Repeat frame 0 of the C3 stream (12.8k decoded voxels: 25k lattice tiles + 24k refine tiles + 74k encoder tiles per repeat) on a
 fresh map and compare every repeat with the first one, bit for bit: latents, the fold table, both cube arrays and the counters.
     python tools/determinism_stress.py [repeats]            (DIF_DECODER_PIPE=f32 for the f32-input MFMA kernels)
-Found the one flaky build of the round: with the SLP vectoriser on (v_pk_fma_f32 in decoder_fold_consts) about one lattice tile in
-10^5 came out with 16 wrong fold constants; see di_fusion_amd/_build.py."""
+Found the one flaky build of round 2: with the SLP vectoriser on (v_pk_fma_f32 in decoder_fold_consts) lattice tiles come out with 16 wrong
+fold constants — with the round-6 kernels 5-13 voxels per launch, every repeat (DIF_LIB=<a build without -fno-slp-vectorize>); the cause is
+reproduced on its own by tools/micro/pk_fma_fold.hip (di_fusion_amd/_build.py, profiles/r06_experiments.md 5)."""
 import sys
 from pathlib import Path
 
